@@ -1,0 +1,231 @@
+/*
+ * ratilqr.h -- C ABI of libratilqr_hip.so: the MI355X (gfx950) implementation of RATiLQR.jl's
+ * iLEQG solve and of the Cross-Entropy loop over theta that wraps it.
+ *
+ * The reference (pure Julia) has no FFI boundary; its operator API for this path is the set of
+ * exported functions in /root/reference/src/RATiLQR.jl:20-53.  Each entry point below names the
+ * reference function it replaces (file:line into /root/reference/src).  The Julia-side `ccall`
+ * bindings a maintainer would add are in INTEGRATION.md and julia/RATiLQRAMD.jl.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all floating point is fp64 (Float64), counters int32/int64;
+ *   - matrices are COLUMN-MAJOR (Julia native), time is the slowest index: a Vector{Matrix}
+ *     `L_array` of N (m x n) gains is the flat buffer L[i + m*j + m*n*t];
+ *   - the caller owns every host buffer; the library copies in/out and retains no pointer after
+ *     return (exception: the standard-normal stream registered with rat_ce_set_stream);
+ *   - no exceptions cross the ABI: functions return a rat_rc (API misuse / HIP errors), and every
+ *     trajectory carries a per-sample status (RAT_ST_*) with value = +Inf where the reference
+ *     would have thrown (cross_entropy_bilevel_optimization.jl:161-165);
+ *   - call from one host thread per handle; a handle owns one HIP device and one stream.
+ *   - user closures f/c/h/W cannot cross the ABI: problems are instances of compiled-in model
+ *     families (rat_problem_desc.model).
+ */
+#ifndef RATILQR_H
+#define RATILQR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAT_VERSION 100
+
+/* ---- return codes (API level) ---------------------------------------------------------------- */
+typedef int32_t rat_rc;
+#define RAT_OK               0
+#define RAT_ERR_ARG          1   /* bad argument / option out of the reference's @assert ranges */
+#define RAT_ERR_UNSUPPORTED  2   /* problem size or model outside the compiled kernels (n<=12, m<=4) */
+#define RAT_ERR_HIP          3   /* HIP runtime error (see rat_last_error) */
+#define RAT_ERR_NO_PROBLEM   4   /* rat_problem_set was not called */
+#define RAT_ERR_STREAM_DRY   5   /* injected N(0,1) stream exhausted */
+#define RAT_ERR_DIVERGED     6   /* a loop the reference would spin in forever was cut (App. B.11/B.15) */
+
+/* ---- per-trajectory status (what the reference's exceptions become) -------------------------- */
+#define RAT_ST_RUNNING          (-1)
+#define RAT_ST_OK                 0  /* converged: d > d_current && mu <= mu_min  (ileqg.jl:642)            */
+#define RAT_ST_M_NOT_PD_INIT      1  /* @assert isposdef(M) in initialize!        (ileqg.jl:234,440) -> Inf */
+#define RAT_ST_M_NOT_PD_GAIN      2  /* @assert isposdef(M) in solve_approximate_dp! (ileqg.jl:366)  -> Inf */
+#define RAT_ST_ITER_MAX           3  /* iter_max reached (ileqg.jl:648); value is valid                     */
+#define RAT_ST_DOMAIN             4  /* DomainError / non-finite in rollout or linearisation         -> Inf */
+#define RAT_ST_MU_DIVERGED        5  /* mu-restart loop cut                                         -> Inf */
+#define RAT_ST_SINGULAR           6  /* reserved (SingularException)                                 -> Inf */
+#define RAT_ST_LS_DIVERGED        7  /* line search cut after 4000 DP-failed candidates (App. B.5)  -> Inf */
+
+/* ---- model families --------------------------------------------------------------------------- */
+#define RAT_MODEL_LQ        1  /* f = A x + B u + kappa x.^3 ; c_k, h quadratic (tables below)                */
+#define RAT_MODEL_POWERLAW  2  /* f = x.^a + u.^b (n == m) ; c = cx sum(x.^p) + cu sum(u.^pu) ; h = pl_h   */
+
+/* Replaces FiniteHorizonRiskSensitiveOptimalControlProblem(f, c, h, W, N)
+ * (optimal_control_problems.jl:67-73).  Field order is shared with oracle/ratilqr_oracle.h. */
+typedef struct rat_problem_desc {
+    int32_t model;
+    int32_t n, m, N;
+    int32_t cost_tv;          /* 1: Q,R,P,qv,rv,q0 hold N entries (k = 0..N-1), else one entry */
+    int32_t W_tv;             /* 1: W holds N entries, else one entry                            */
+    const double *A;          /* n*n                */
+    const double *B;          /* n*m                */
+    const double *Q;          /* n*n [*N]  c_xx     */
+    const double *R;          /* m*m [*N]  c_uu     */
+    const double *P;          /* m*n [*N]  c_ux     */
+    const double *qv;         /* n   [*N]           */
+    const double *rv;         /* m   [*N]           */
+    const double *q0;         /* 1   [*N]           */
+    const double *Qf;         /* n*n  h_xx          */
+    const double *qvf;        /* n                  */
+    double q0f;
+    double kappa;
+    double pl_a, pl_b, pl_p, pl_pu, pl_cx, pl_cu, pl_h;
+    const double *W;          /* n*n [*N]  noise covariance W(k) */
+} rat_problem_desc;
+
+/* Replaces the keyword arguments of ILEQGSolver(problem; ...)  (ileqg.jl:191-201). */
+typedef struct rat_ileqg_opts {
+    double mu_min, delta_0, lambda, d;
+    int64_t iter_max;
+    double eps_init, eps_min;
+    int32_t adaptive_eps_init;
+} rat_ileqg_opts;
+
+typedef struct rat_handle_s *rat_handle;
+
+int32_t     rat_version(void);
+const char *rat_last_error(void);
+void        rat_default_ileqg_opts(rat_ileqg_opts *o);                      /* defaults of ileqg.jl:191-194 */
+
+/* Create a solver context on HIP device `device`.
+ *   max_batch : largest number of theta-samples one batch call will carry (device buffers are sized once)
+ *   spec_eps  : E >= 1, number of line-search step sizes eps_k = eps*lambda^k evaluated speculatively
+ *               per (sample, iteration); results are identical for every E.
+ * Replaces the ILEQGSolver constructor (ileqg.jl:191-208); option ranges are validated as its @asserts. */
+rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int32_t spec_eps, int32_t device, rat_handle *out);
+void   rat_destroy(rat_handle h);
+rat_rc rat_set_ileqg_opts(rat_handle h, const rat_ileqg_opts *opts);
+
+/* Upload a problem (tables are copied).  Replaces passing `problem` to every call. */
+rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *desc);
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+
+/* Batched iLEQG: one complete solve!(ileqg, problem, x0, u0; theta_i) per sample, all samples at once.
+ * Replaces the fan-out of compute_value_worker (cross_entropy_bilevel_optimization.jl:144-167,186-191):
+ * value[i] = solve!(...)[4], or +Inf where the reference would throw.  Optional outputs (may be NULL):
+ * status[i] (RAT_ST_*), iters[i] (iLEQG iterations), ls_evals[i] (line-search candidates consumed by the
+ * sequential rule of line_search!, ileqg.jl:504-581). x0[n], u0[m*N], theta[B]: host buffers. */
+rat_rc rat_ileqg_solve_batch(rat_handle h, const double *x0, const double *u0, const double *theta, int64_t B,
+                             double *value, int32_t *status, int32_t *iters, int32_t *ls_evals);
+
+/* Same with theta / value / status / iters / ls_evals resident in device (HBM) memory; x0/u0 are taken
+ * from the last rat_set_initial() call.  Asynchronous w.r.t. the host except for the per-round counter
+ * read-back; returns after the batch has finished on the handle's stream. */
+rat_rc rat_set_initial(rat_handle h, const double *x0, const double *u0);
+rat_rc rat_ileqg_solve_batch_dev(rat_handle h, const double *theta_dev, int64_t B, double *value_dev,
+                                 int32_t *status_dev, int32_t *iters_dev, int32_t *ls_evals_dev);
+
+/* Single solve with the full policy returned.  Replaces solve!(ileqg, problem, x_0, u_array; theta)
+ * (ileqg.jl:635-659): x[n*(N+1)], l[m*N], L[m*n*N], value, eps_history as (eps, new-current) pairs
+ * (eps_hist holds 2*hist_cap doubles; *hist_n receives the number of pairs produced). */
+rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *u0, double theta,
+                       double *x, double *l, double *L, double *value, int32_t *status, int32_t *iters,
+                       double *eps_hist, int64_t hist_cap, int64_t *hist_n);
+
+/* ---- individual operators (unit parity with test/ileqg_test.jl) -------------------------------- */
+
+/* simulate_dynamics(problem, x_0, u_array)                     ileqg.jl:18-38   -> x[n*(N+1)]; *domain_fail = 1 on DomainError */
+rat_rc rat_rollout_open(rat_handle h, const double *x0, const double *u, double *x, int32_t *domain_fail);
+/* simulate_dynamics(problem, x_array, l_array, L_array)        ileqg.jl:62-87   -> x_new, u_new */
+rat_rc rat_rollout_feedback(rat_handle h, const double *xbar, const double *l, const double *L,
+                            double *x_new, double *u_new, int32_t *domain_fail);
+/* integrate_cost(problem, x_array, u_array)                    ileqg.jl:115-124 */
+rat_rc rat_integrate_cost(rat_handle h, const double *x, const double *u, double *cost);
+/* approximate_model(problem, u_array, x_array)                 ileqg.jl:258-322
+ * -> q[N+1], qv[n*(N+1)], Q[n*n*(N+1)], r[m*N], R[m*m*N], P[m*n*N], A[n*n*N], B[n*m*N], W[n*n*N] */
+rat_rc rat_approximate_model(rat_handle h, const double *u, const double *x,
+                             double *q, double *qv, double *Q, double *r, double *R, double *P,
+                             double *A, double *B, double *W, int32_t *domain_fail);
+/* solve_approximate_dp!(ileqg, approx; theta)                  ileqg.jl:341-406
+ * in : the ApproximationResult arrays above (W is taken from the problem),  theta, mu, delta (in/out)
+ * out: L[m*n*N], dl[m*N], updated mu / delta (regularisation restarts), status (0 / RAT_ST_M_NOT_PD_GAIN / ...),
+ *      and the DynamicProgrammingResult dumps (any may be NULL): s[N+1], sv[n*(N+1)], S[n*n*(N+1)],
+ *      g[m*N], G[m*n*N], H[m*m*N]. */
+rat_rc rat_dp_gain_sweep(rat_handle h, const double *q, const double *qv, const double *Q, const double *r,
+                         const double *R, const double *P, const double *A, const double *B,
+                         double theta, double *mu, double *delta, double *L, double *dl, int32_t *status,
+                         double *s, double *sv, double *S, double *g, double *G, double *H);
+/* solve_approximate_dp(approx, L_array, dl_array; theta, mu)    ileqg.jl:412-465 ; dl may be NULL (zeros);
+ * *status = 0 or RAT_ST_M_NOT_PD_GAIN (the @assert at :440). */
+rat_rc rat_dp_policy_eval(rat_handle h, const double *q, const double *qv, const double *Q, const double *r,
+                          const double *R, const double *P, const double *A, const double *B,
+                          const double *L, const double *dl, double theta, double mu, int32_t *status,
+                          double *s, double *sv, double *S, double *g, double *G, double *H);
+
+/* ---- Cross-Entropy loop over theta (RAT iLQR) -------------------------------------------------- */
+
+/* Replaces CrossEntropyBilevelOptimizationSolver (cross_entropy_bilevel_optimization.jl:70-127).
+ * The struct is caller-owned plain data: mu_init/sigma_init persist across solves as in the reference. */
+typedef struct rat_ce_solver {
+    /* parameters */
+    int64_t num_samples, num_elite, iter_max;
+    double  lambda;
+    int32_t use_theta_max;
+    /* mutable state */
+    double  mu_init, sigma_init, mu, sigma, theta_max, theta_min;
+    int64_t iter_current;
+    /* bookkeeping (not in the reference) */
+    int64_t n_solves, n_redraws;
+} rat_ce_solver;
+
+void   rat_ce_default(rat_ce_solver *c);                                     /* ctor defaults :100-127 */
+void   rat_ce_initialize(rat_ce_solver *c);                                  /* initialize!   :133-138 */
+
+/* Source of randomness replacing `rng::AbstractRNG`: theta = mu + sigma*z with z drawn in order from a
+ * standard-normal stream.  Either inject one (parity runs; the pointer must stay valid while in use) or
+ * seed the built-in generator (SplitMix64-seeded xoshiro256++ with Box-Muller; documented in DESIGN.md). */
+rat_rc rat_ce_set_stream(rat_handle h, const double *z, int64_t nz);
+rat_rc rat_ce_seed(rat_handle h, uint64_t seed);
+int64_t rat_ce_stream_pos(rat_handle h);
+
+/* get_positive_samples(mu, sigma, num_samples, rng)             :233-246 */
+rat_rc rat_ce_get_positive_samples(rat_handle h, double mu, double sigma, int64_t num, double *theta);
+/* compute_cost(ce_solver, problem, x, u_array, theta_array, kl_bound)  :173-195  (cost = value + kl/theta) */
+rat_rc rat_ce_compute_cost(rat_handle h, const double *x0, const double *u0, const double *theta, int64_t B,
+                           double kl_bound, double *cost);
+/* The bookkeeping half of step! (:291-334) for hosts that evaluate costs themselves (multi-GPU: the
+ * host all-gathers cost shards between rat_ce_draw and rat_ce_update).
+ *   rat_ce_draw   : theta[num_samples] for the current iteration (uses mu_init/sigma_init in iteration 1)
+ *   rat_ce_update : consumes the costs; *redraw = 1 when the reference would loop and redraw (:293-298, :306) */
+rat_rc rat_ce_begin_step(rat_ce_solver *c);
+rat_rc rat_ce_draw(rat_handle h, const rat_ce_solver *c, double *theta);
+rat_rc rat_ce_update(rat_ce_solver *c, const double *theta, const double *cost, int32_t *redraw);
+/* handle-free form of rat_ce_draw over an explicit stream (pure host code; usable before any device exists):
+ * consumes z[*zpos..] and advances *zpos. */
+rat_rc rat_ce_draw_stream(const rat_ce_solver *c, const double *z, int64_t nz, int64_t *zpos, double *theta);
+/* step!(ce_solver, problem, x, u_array, kl_bound, rng)          :252-335 ; theta_out/cost_out may be NULL */
+rat_rc rat_ce_step(rat_handle h, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
+                   double *theta_out, double *cost_out);
+/* solve!(ce_solver, problem, x_0, u_array, rng; kl_bound)       :364-415 */
+rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
+                    double *theta_opt, double *x, double *l, double *L, double *value,
+                    double *theta_min, double *theta_max);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
+#define RAT_K_ROLLOUT   0
+#define RAT_K_LINEARIZE 1
+#define RAT_K_SWEEP_EVAL 2
+#define RAT_K_SWEEP_GAIN 3
+#define RAT_K_SELECT    4
+#define RAT_K_COUNT     5
+/* When enabled, every kernel launch is bracketed by HIP events on the handle's stream. */
+rat_rc rat_profile_enable(rat_handle h, int32_t on);
+rat_rc rat_profile_reset(rat_handle h);
+/* launches[k], trajectories[k] (units processed), total_ms[k] for k < RAT_K_COUNT */
+rat_rc rat_profile_get(rat_handle h, int64_t *launches, int64_t *trajectories, double *total_ms);
+/* the handle's HIP stream as an opaque pointer (hipStream_t), and its device index */
+void  *rat_stream(rat_handle h);
+/* bytes of one trajectory's tile bundle as laid out in HBM, and of the per-trajectory L/x/u arrays */
+rat_rc rat_layout_info(rat_handle h, int64_t *tile_bytes, int64_t *L_bytes, int64_t *x_bytes, int64_t *u_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -10,3 +10,30 @@ from .problems import (  # noqa: F401
     PowerLawRiskSensitiveProblem,
     synthetic_lq_problem,
 )
+from ._native import RatError, SO_PATH  # noqa: F401,E402
+from . import _native as native  # noqa: F401,E402
+from .ileqg import (  # noqa: F401,E402
+    Context,
+    ILEQGSolver,
+    ApproximationResult,
+    DynamicProgrammingResult,
+    simulate_dynamics,
+    integrate_cost,
+    approximate_model,
+    solve_approximate_dp,
+    solve_approximate_dp_,
+    increase_mu_and_delta_,
+    decrease_mu_and_delta_,
+    line_search_,
+    step_,
+    solve_,
+    solve_stepwise_,
+)
+from .ileqg import initialize_ as initialize_ileqg_  # noqa: F401,E402
+from . import ileqg, cross_entropy  # noqa: F401,E402
+from .cross_entropy import (  # noqa: F401,E402
+    CrossEntropyBilevelOptimizationSolver,
+    compute_cost,
+    compute_cost_serial,
+    get_positive_samples,
+)

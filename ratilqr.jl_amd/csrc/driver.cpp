@@ -1,0 +1,943 @@
+// driver.cpp -- host side of libratilqr_hip.so: the C ABI of include/ratilqr.h.
+//
+// Owns the device buffers of a handle, packs problems into the padded MFMA-native tables of layout.h,
+// drives the batched iLEQG state machine (solve!/step!/line_search! of ileqg.jl:494-659 for many theta
+// at once, with E speculative line-search step sizes per sample) and restates the Cross-Entropy loop of
+// cross_entropy_bilevel_optimization.jl:233-415 on top of it.  There is no CPU fallback: every numeric
+// result is produced by the kernels of kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ratilqr.h"
+#include "kernels.h"
+#include "layout.h"
+
+static thread_local std::string g_err;
+static rat_rc fail(rat_rc rc, const std::string &msg) { g_err = msg; return rc; }
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+struct EvRec { hipEvent_t a, b; int kind; int64_t ntraj; };
+
+struct rat_handle_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    rat_ileqg_opts opts;
+    OptsDev opd;
+    int Bmax = 0, E = 1;
+    bool have_problem = false;
+    int n = 0, m = 0, N = 0;
+    ProblemDev pb;
+    std::vector<void *> pb_allocs, st_allocs;
+    std::vector<double> hW;          // host copy of W (col-major, N entries) for rat_approximate_model
+    int W_tv = 0;
+    StateDev st;
+    double *d_x0 = nullptr, *d_u0 = nullptr, *d_theta = nullptr, *d_val = nullptr, *d_opout = nullptr, *d_dump = nullptr,
+           *d_dlin = nullptr;
+    int *d_ist = nullptr, *d_iit = nullptr, *d_ils = nullptr;
+    int *h_counters = nullptr;       // pinned
+    bool have_initial = false;
+    // profiling
+    bool prof = false;
+    std::vector<EvRec> evs;
+    size_t ev_used = 0;
+    int64_t p_launch[RAT_K_COUNT] = {0}, p_traj[RAT_K_COUNT] = {0};
+    double p_ms[RAT_K_COUNT] = {0};
+    // CE randomness
+    const double *z = nullptr;
+    int64_t nz = 0, zpos = 0;
+    bool internal_rng = false;
+    uint64_t rs[4] = {0, 0, 0, 0};
+    bool have_spare = false;
+    double spare = 0;
+};
+
+extern "C" int32_t rat_version(void) { return RAT_VERSION; }
+extern "C" const char *rat_last_error(void) { return g_err.c_str(); }
+
+extern "C" void rat_default_ileqg_opts(rat_ileqg_opts *o) {          // ileqg.jl:191-194
+    o->mu_min = 1e-6; o->delta_0 = 2.0; o->lambda = 0.5; o->d = 1e-2; o->iter_max = 100;
+    o->eps_init = 1.0; o->eps_min = 1e-6; o->adaptive_eps_init = 0;
+}
+
+static bool opts_ok(const rat_ileqg_opts *o) {                       // the @assert block ileqg.jl:195-201
+    return (0 < o->lambda && o->lambda < 1) && (o->d > 0) && (o->mu_min > 0) && (o->delta_0 > 0) &&
+           (0 < o->eps_init && o->eps_init <= 1) && (o->eps_init > o->eps_min) && (0 < o->eps_min && o->eps_min < 1) &&
+           o->iter_max >= 1;
+}
+static void set_opd(rat_handle h) {
+    h->opd.mu_min = h->opts.mu_min; h->opd.delta_0 = h->opts.delta_0; h->opd.lambda = h->opts.lambda;
+    h->opd.d = h->opts.d; h->opd.eps_init = h->opts.eps_init; h->opd.eps_min = h->opts.eps_min;
+    h->opd.iter_max = (int)std::min<int64_t>(h->opts.iter_max, 1 << 30); h->opd.adaptive = h->opts.adaptive_eps_init;
+}
+
+extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int32_t spec_eps, int32_t device, rat_handle *out) {
+    if (!out || max_batch < 1 || spec_eps < 1 || spec_eps > 64) return fail(RAT_ERR_ARG, "rat_create: bad batch / spec_eps");
+    rat_ileqg_opts o;
+    if (opts) o = *opts; else rat_default_ileqg_opts(&o);
+    if (!opts_ok(&o)) return fail(RAT_ERR_ARG, "rat_create: ILEQGSolver option out of range (ileqg.jl:195-201)");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(RAT_ERR_HIP, "rat_create: no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RAT_ERR_ARG, "rat_create: bad device index");
+    HIPCHK(hipSetDevice(device));
+    rat_handle h = new rat_handle_s();
+    h->device = device; h->opts = o; h->Bmax = max_batch; h->E = spec_eps;
+    set_opd(h);
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * sizeof(int), hipHostMallocDefault));
+    memset(&h->st, 0, sizeof(h->st));
+    memset(&h->pb, 0, sizeof(h->pb));
+    *out = h;
+    return RAT_OK;
+}
+
+static void free_list(std::vector<void *> &v) {
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+extern "C" void rat_destroy(rat_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_list(h->pb_allocs);
+    free_list(h->st_allocs);
+    for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (h->h_counters) (void)hipHostFree(h->h_counters);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" rat_rc rat_set_ileqg_opts(rat_handle h, const rat_ileqg_opts *opts) {
+    if (!h || !opts) return fail(RAT_ERR_ARG, "null");
+    if (!opts_ok(opts)) return fail(RAT_ERR_ARG, "ILEQGSolver option out of range (ileqg.jl:195-201)");
+    h->opts = *opts;
+    set_opd(h);
+    return RAT_OK;
+}
+
+template <class T>
+static rat_rc dev_alloc(std::vector<void *> &list, T **p, size_t count) {
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    list.push_back(q);
+    *p = (T *)q;
+    return RAT_OK;
+}
+template <class T>
+static rat_rc dev_upload(rat_handle h, std::vector<void *> &list, const T **p, const std::vector<T> &v) {
+    T *q = nullptr;
+    rat_rc rc = dev_alloc(list, &q, v.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *p = q;
+    (void)h;
+    return RAT_OK;
+}
+
+// LU inverse with partial pivoting (host, tiny): stands for inv(W), ileqg.jl:365
+static bool host_inv(int n, const double *A, double *Ainv) {
+    std::vector<double> a(A, A + n * n), b(n * n, 0.0);
+    for (int i = 0; i < n; ++i) b[i + n * i] = 1.0;
+    for (int k = 0; k < n; ++k) {
+        int p = k; double best = std::fabs(a[k + n * k]);
+        for (int i = k + 1; i < n; ++i) if (std::fabs(a[i + n * k]) > best) { best = std::fabs(a[i + n * k]); p = i; }
+        if (best == 0.0 || best != best) return false;
+        if (p != k) for (int j = 0; j < n; ++j) { std::swap(a[k + n * j], a[p + n * j]); std::swap(b[k + n * j], b[p + n * j]); }
+        const double d = a[k + n * k];
+        for (int i = k + 1; i < n; ++i) {
+            const double f = a[i + n * k] / d;
+            if (f == 0.0) continue;
+            for (int j = k; j < n; ++j) a[i + n * j] -= f * a[k + n * j];
+            for (int j = 0; j < n; ++j) b[i + n * j] -= f * b[k + n * j];
+        }
+    }
+    for (int j = 0; j < n; ++j)
+        for (int k = n - 1; k >= 0; --k) {
+            double v = b[k + n * j];
+            for (int i = k + 1; i < n; ++i) v -= a[k + n * i] * Ainv[i + n * j];
+            Ainv[k + n * j] = v / a[k + n * k];
+        }
+    return true;
+}
+
+static rat_rc alloc_state(rat_handle h) {
+    free_list(h->st_allocs);
+    StateDev &st = h->st;
+    const int N = h->N, E = h->E, B = h->Bmax;
+    st.B = B; st.E = E; st.N = N;
+    st.tile_stride = (long)N * TSTRIDE + TTERM;
+    st.x_stride = (long)(N + 1) * XSTR;
+    st.u_stride = (long)N * USTR;
+    const size_t slots = (size_t)B * (E + 1);
+    rat_rc rc;
+#define AL(ptr, cnt) if ((rc = dev_alloc(h->st_allocs, &(ptr), (cnt)))) return rc
+    AL(st.tiles, slots * st.tile_stride);
+    AL(st.xs, slots * st.x_stride);
+    AL(st.us, slots * st.u_stride);
+    AL(st.L, (size_t)B * N * LSTR);
+    AL(st.dl, (size_t)B * N * USTR);
+    AL(st.theta, B); AL(st.mu, B); AL(st.delta, B); AL(st.value, B); AL(st.d_cur, B); AL(st.eps_init, B); AL(st.ls_eps, B);
+    AL(st.status, B); AL(st.iter, B); AL(st.ls_active, B); AL(st.ls_count, B); AL(st.slot_nom, B); AL(st.n_ls, B); AL(st.hist_n, B);
+    AL(st.value_c, (size_t)B * E); AL(st.d_c, (size_t)B * E); AL(st.flag_c, (size_t)B * E);
+    AL(st.counters, 2);
+    st.hist = nullptr; st.hist_cap = 0;
+    AL(h->d_x0, XSTR); AL(h->d_u0, (size_t)N * USTR); AL(h->d_theta, B); AL(h->d_val, B);
+    AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);
+    AL(h->d_opout, 2); AL(h->d_dump, (size_t)(N + 1) * DUMP_STRIDE); AL(h->d_dlin, (size_t)N * USTR);
+#undef AL
+    // padded lanes of the slot pools must be exact zeros
+    HIPCHK(hipMemsetAsync(st.xs, 0, slots * st.x_stride * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st.us, 0, slots * st.u_stride * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st.L, 0, (size_t)B * N * LSTR * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st.dl, 0, (size_t)B * N * USTR * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st.flag_c, 0, (size_t)B * E * sizeof(int), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
+    if (!h || !d) return fail(RAT_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(h->device));
+    const int n = d->n, m = d->m, N = d->N;
+    if (n < 1 || m < 1 || N < 1) return fail(RAT_ERR_ARG, "rat_problem_set: n, m, N must be positive");
+    if (n > RAT_NP || m > RAT_MP)
+        return fail(RAT_ERR_UNSUPPORTED, "rat_problem_set: kernels are compiled for n <= 12, m <= 4");
+    if (d->model != RAT_MODEL_LQ && d->model != RAT_MODEL_POWERLAW) return fail(RAT_ERR_UNSUPPORTED, "unknown model family");
+    if (d->model == RAT_MODEL_POWERLAW && n != m) return fail(RAT_ERR_ARG, "power-law family needs n == m");
+    if (!d->W) return fail(RAT_ERR_ARG, "W missing");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_list(h->pb_allocs);
+    ProblemDev pb;
+    memset(&pb, 0, sizeof(pb));
+    pb.model = d->model; pb.n = n; pb.m = m; pb.N = N; pb.cost_tv = d->cost_tv ? 1 : 0; pb.W_tv = d->W_tv ? 1 : 0;
+    pb.q0f = d->q0f; pb.kappa = d->kappa;
+    pb.pl_a = d->pl_a; pb.pl_b = d->pl_b; pb.pl_p = d->pl_p; pb.pl_pu = d->pl_pu; pb.pl_cx = d->pl_cx; pb.pl_cu = d->pl_cu; pb.pl_h = d->pl_h;
+    const int Nc = pb.cost_tv ? N : 1, Nw = pb.W_tv ? N : 1;
+    std::vector<double> Zt(192, 0.0), Ctab((size_t)Nc * 256, 0.0), lin((size_t)Nc * 16, 0.0), q0(Nc, 0.0), Qf(144, 0.0), qvf(16, 0.0);
+    if (d->model == RAT_MODEL_LQ) {
+        if (!d->A || !d->B || !d->Q || !d->R || !d->P || !d->qv || !d->rv || !d->q0 || !d->Qf || !d->qvf)
+            return fail(RAT_ERR_ARG, "LQ family: a table pointer is null");
+        for (int i = 0; i < n; ++i) {
+            for (int jj = 0; jj < n; ++jj) Zt[i * 16 + jj] = d->A[i + n * jj];
+            for (int g = 0; g < m; ++g) Zt[i * 16 + 12 + g] = d->B[i + n * g];
+        }
+        for (int k = 0; k < Nc; ++k) {
+            double *C = &Ctab[(size_t)k * 256];
+            const double *Q = d->Q + (size_t)k * n * n, *R = d->R + (size_t)k * m * m, *P = d->P + (size_t)k * m * n;
+            for (int i = 0; i < n; ++i)
+                for (int jj = 0; jj < n; ++jj) C[i * 16 + jj] = (i <= jj) ? Q[i + n * jj] : Q[jj + n * i];   // Symmetric(c_xx) :270
+            for (int g = 0; g < m; ++g)
+                for (int g2 = 0; g2 < m; ++g2) C[(12 + g) * 16 + 12 + g2] = (g <= g2) ? R[g + m * g2] : R[g2 + m * g];   // :271
+            for (int g = 0; g < m; ++g)
+                for (int jj = 0; jj < n; ++jj) { C[(12 + g) * 16 + jj] = P[g + m * jj]; C[jj * 16 + 12 + g] = P[g + m * jj]; }
+            for (int g = m; g < RAT_MP; ++g) C[(12 + g) * 16 + 12 + g] = 1.0;
+            for (int i = 0; i < n; ++i) lin[(size_t)k * 16 + i] = d->qv[(size_t)k * n + i];
+            for (int g = 0; g < m; ++g) lin[(size_t)k * 16 + 12 + g] = d->rv[(size_t)k * m + g];
+            q0[k] = d->q0[k];
+        }
+        for (int i = 0; i < n; ++i) {
+            for (int jj = 0; jj < n; ++jj) Qf[i * 12 + jj] = (i <= jj) ? d->Qf[i + n * jj] : d->Qf[jj + n * i];
+            qvf[i] = d->qvf[i];
+        }
+    }
+    std::vector<double> Winv((size_t)Nw * 192, 0.0), Wp((size_t)Nw * 192, 0.0), epiv((size_t)Nw * 16, 1.0), ldw(Nw, 0.0);
+    h->hW.assign(d->W, d->W + (size_t)Nw * n * n);
+    h->W_tv = pb.W_tv;
+    for (int k = 0; k < Nw; ++k) {
+        const double *W = d->W + (size_t)k * n * n;
+        std::vector<double> wi(n * n);
+        if (!host_inv(n, W, wi.data())) return fail(RAT_ERR_ARG, "rat_problem_set: W(k) is singular (inv(W) would throw, ileqg.jl:365)");
+        double *wo = &Winv[(size_t)k * 192], *wq = &Wp[(size_t)k * 192];
+        for (int i = 0; i < RAT_NP; ++i)
+            for (int jj = 0; jj < RAT_NP; ++jj) {
+                if (i < n && jj < n) {
+                    wo[i * 16 + jj] = (i <= jj) ? wi[i + n * jj] : wi[jj + n * i];   // Symmetric(inv(W) - ...) reads the upper triangle
+                    wq[i * 16 + jj] = W[i + n * jj];
+                } else if (i == jj) wo[i * 16 + jj] = 1.0;
+            }
+        // elimination pivots e_k of the padded inv(W): logdet(W M) = sum log(d_k / e_k)
+        double a[12][12];
+        for (int i = 0; i < 12; ++i) for (int jj = 0; jj < 12; ++jj) a[i][jj] = wo[i * 16 + jj];
+        for (int p = 0; p < 12; ++p) {
+            const double piv = a[p][p];
+            epiv[(size_t)k * 16 + p] = piv;
+            ldw[k] -= std::log(piv);
+            for (int i = p + 1; i < 12; ++i) {
+                const double f = a[i][p] / piv;
+                for (int jj = p; jj < 12; ++jj) a[i][jj] -= f * a[p][jj];
+            }
+        }
+    }
+    rat_rc rc;
+#define UP(field, vec) if ((rc = dev_upload(h, h->pb_allocs, &pb.field, vec))) return rc
+    UP(Zt, Zt); UP(Ctab, Ctab); UP(lin, lin); UP(q0, q0); UP(Qf, Qf); UP(qvf, qvf);
+    UP(Winv, Winv); UP(Wp, Wp); UP(epiv, epiv); UP(logdetW, ldw);
+#undef UP
+    const bool realloc_state = !h->have_problem || h->N != N;
+    h->pb = pb; h->n = n; h->m = m; h->N = N;
+    h->have_problem = true; h->have_initial = false;
+    if (realloc_state && (rc = alloc_state(h))) return rc;
+    return RAT_OK;
+}
+
+// ---- profiling helpers -----------------------------------------------------------------------------
+static void prof_begin(rat_handle h, int kind, int64_t ntraj) {
+    if (!h->prof) return;
+    if (h->ev_used == h->evs.size()) {
+        EvRec e;
+        (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+        h->evs.push_back(e);
+    }
+    EvRec &e = h->evs[h->ev_used];
+    e.kind = kind; e.ntraj = ntraj;
+    (void)hipEventRecord(e.a, h->stream);
+}
+static void prof_end(rat_handle h) {
+    if (!h->prof) return;
+    (void)hipEventRecord(h->evs[h->ev_used].b, h->stream);
+    h->ev_used++;
+}
+static void prof_flush(rat_handle h) {
+    if (!h->ev_used) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->evs[i].a, h->evs[i].b);
+        h->p_launch[h->evs[i].kind]++; h->p_traj[h->evs[i].kind] += h->evs[i].ntraj; h->p_ms[h->evs[i].kind] += ms;
+    }
+    h->ev_used = 0;
+}
+extern "C" rat_rc rat_profile_enable(rat_handle h, int32_t on) { if (!h) return RAT_ERR_ARG; prof_flush(h); h->prof = on != 0; return RAT_OK; }
+extern "C" rat_rc rat_profile_reset(rat_handle h) {
+    if (!h) return RAT_ERR_ARG;
+    prof_flush(h);
+    for (int k = 0; k < RAT_K_COUNT; ++k) { h->p_launch[k] = 0; h->p_traj[k] = 0; h->p_ms[k] = 0; }
+    return RAT_OK;
+}
+extern "C" rat_rc rat_profile_get(rat_handle h, int64_t *launches, int64_t *traj, double *ms) {
+    if (!h) return RAT_ERR_ARG;
+    prof_flush(h);
+    for (int k = 0; k < RAT_K_COUNT; ++k) { if (launches) launches[k] = h->p_launch[k]; if (traj) traj[k] = h->p_traj[k]; if (ms) ms[k] = h->p_ms[k]; }
+    return RAT_OK;
+}
+extern "C" void *rat_stream(rat_handle h) { return h ? (void *)h->stream : nullptr; }
+extern "C" rat_rc rat_layout_info(rat_handle h, int64_t *tile_bytes, int64_t *L_bytes, int64_t *x_bytes, int64_t *u_bytes) {
+    if (!h || !h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "no problem set");
+    if (tile_bytes) *tile_bytes = h->st.tile_stride * 8;
+    if (L_bytes) *L_bytes = (int64_t)h->N * LSTR * 8;
+    if (x_bytes) *x_bytes = h->st.x_stride * 8;
+    if (u_bytes) *u_bytes = h->st.u_stride * 8;
+    return RAT_OK;
+}
+
+// ---- the batched solve state machine ------------------------------------------------------------------
+static rat_rc read_counters(rat_handle h, int *c0, int *c1) {
+    HIPCHK(hipMemcpyAsync(h->h_counters, h->st.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *c0 = h->h_counters[0]; *c1 = h->h_counters[1];
+    return RAT_OK;
+}
+
+static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
+    SweepArgs a;
+    a.st = st; a.pb = h->pb; a.op = h->opd; a.mode = mode; a.dl_in = nullptr; a.mu_op = 0.0; a.op_out = nullptr; a.dump = nullptr;
+    return a;
+}
+
+// line-search rounds for the samples flagged ls_active; returns the number of samples still running
+static rat_rc line_search_rounds(rat_handle h, const StateDev &st, int *running) {
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    LinArgs la; la.st = st; la.pb = h->pb; la.mode = 1;
+    const int64_t nc = (int64_t)st.B * st.E;
+    for (;;) {
+        prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollout(ra, h->stream); prof_end(h);
+        prof_begin(h, RAT_K_LINEARIZE, nc); launch_linearize(la, h->stream); prof_end(h);
+        prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(sweep_args(h, st, 1), (int)nc, false, false, h->stream); prof_end(h);
+        HIPCHK(hipMemsetAsync(st.counters, 0, 2 * sizeof(int), h->stream));
+        prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, h->stream); prof_end(h);
+        int more = 0;
+        rat_rc rc = read_counters(h, &more, running);
+        if (rc) return rc;
+        if (more == 0) break;
+    }
+    return RAT_OK;
+}
+
+static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
+    if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
+    if (!h->have_initial) return fail(RAT_ERR_ARG, "rat_set_initial was not called");
+    if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");
+    HIPCHK(hipSetDevice(h->device));
+    StateDev st = h->st;
+    st.B = B;
+    launch_init_state(st, h->opd, theta_dev, h->stream);
+    // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    LinArgs la; la.st = st; la.pb = h->pb; la.mode = 0;
+    prof_begin(h, RAT_K_ROLLOUT, B); launch_rollout(ra, h->stream); prof_end(h);
+    prof_begin(h, RAT_K_LINEARIZE, B); launch_linearize(la, h->stream); prof_end(h);
+    prof_begin(h, RAT_K_SWEEP_EVAL, B); launch_sweep(sweep_args(h, st, 2), B, false, false, h->stream); prof_end(h);
+    HIPCHK(hipMemsetAsync(st.counters, 0, 2 * sizeof(int), h->stream));
+    launch_count_running(st, h->stream);
+    int more = 0, running = 0;
+    rat_rc rc = read_counters(h, &more, &running);
+    if (rc) return rc;
+    // while true: step!; convergence / iter_max test   (ileqg.jl:640-654)
+    int64_t guard = 0;
+    while (running > 0) {
+        if (++guard > (int64_t)h->opd.iter_max + 2) return fail(RAT_ERR_DIVERGED, "iteration guard tripped");
+        // step! (:598-613): the accepted candidate's tiles are the re-linearisation of :604 (App. B.1)
+        prof_begin(h, RAT_K_SWEEP_GAIN, running); launch_sweep(sweep_args(h, st, 0), B, true, false, h->stream); prof_end(h);
+        launch_ls_begin(st, h->stream);
+        if ((rc = line_search_rounds(h, st, &running))) return rc;
+    }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_set_initial(rat_handle h, const double *x0, const double *u0) {
+    if (!h || !x0 || !u0) return fail(RAT_ERR_ARG, "null");
+    if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> xp(XSTR, 0.0), up((size_t)h->N * USTR, 0.0);
+    for (int i = 0; i < h->n; ++i) xp[i] = x0[i];
+    for (int t = 0; t < h->N; ++t) for (int g = 0; g < h->m; ++g) up[(size_t)t * USTR + g] = u0[(size_t)t * h->m + g];
+    HIPCHK(hipMemcpyAsync(h->d_x0, xp.data(), xp.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_u0, up.data(), up.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_initial = true;
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_ileqg_solve_batch_dev(rat_handle h, const double *theta_dev, int64_t B, double *value_dev,
+                                            int32_t *status_dev, int32_t *iters_dev, int32_t *ls_evals_dev) {
+    if (!h || !theta_dev) return fail(RAT_ERR_ARG, "null");
+    rat_rc rc = run_batch(h, theta_dev, (int)B);
+    if (rc) return rc;
+    StateDev st = h->st; st.B = (int)B;
+    launch_gather(st, value_dev, status_dev, iters_dev, ls_evals_dev, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_ileqg_solve_batch(rat_handle h, const double *x0, const double *u0, const double *theta, int64_t B,
+                                        double *value, int32_t *status, int32_t *iters, int32_t *ls_evals) {
+    if (!h || !theta || !value) return fail(RAT_ERR_ARG, "null");
+    if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");
+    rat_rc rc = rat_set_initial(h, x0, u0);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_theta, theta, B * 8, hipMemcpyHostToDevice, h->stream));
+    rc = rat_ileqg_solve_batch_dev(h, h->d_theta, B, h->d_val, h->d_ist, h->d_iit, h->d_ils);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(value, h->d_val, B * 8, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, h->d_ist, B * 4, hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(hipMemcpy(iters, h->d_iit, B * 4, hipMemcpyDeviceToHost));
+    if (ls_evals) HIPCHK(hipMemcpy(ls_evals, h->d_ils, B * 4, hipMemcpyDeviceToHost));
+    return RAT_OK;
+}
+
+// ---- host <-> padded layout helpers -------------------------------------------------------------------
+static void pad_x(const rat_handle h, const double *x, std::vector<double> &xp) {       // [n*(N+1)] -> [(N+1)*12]
+    xp.assign((size_t)(h->N + 1) * XSTR, 0.0);
+    for (int t = 0; t <= h->N; ++t) for (int i = 0; i < h->n; ++i) xp[(size_t)t * XSTR + i] = x[(size_t)t * h->n + i];
+}
+static void pad_u(const rat_handle h, const double *u, std::vector<double> &up) {
+    up.assign((size_t)h->N * USTR, 0.0);
+    for (int t = 0; t < h->N; ++t) for (int g = 0; g < h->m; ++g) up[(size_t)t * USTR + g] = u[(size_t)t * h->m + g];
+}
+static void pad_L(const rat_handle h, const double *L, std::vector<double> &Lp) {        // col-major m x n x N -> [N][4][12]
+    Lp.assign((size_t)h->N * LSTR, 0.0);
+    for (int t = 0; t < h->N; ++t)
+        for (int g = 0; g < h->m; ++g)
+            for (int jj = 0; jj < h->n; ++jj) Lp[(size_t)t * LSTR + g * 12 + jj] = L[(size_t)t * h->m * h->n + g + h->m * jj];
+}
+static void unpad_x(const rat_handle h, const std::vector<double> &xp, double *x) {
+    for (int t = 0; t <= h->N; ++t) for (int i = 0; i < h->n; ++i) x[(size_t)t * h->n + i] = xp[(size_t)t * XSTR + i];
+}
+static void unpad_u(const rat_handle h, const std::vector<double> &up, double *u) {
+    for (int t = 0; t < h->N; ++t) for (int g = 0; g < h->m; ++g) u[(size_t)t * h->m + g] = up[(size_t)t * USTR + g];
+}
+static void unpad_L(const rat_handle h, const std::vector<double> &Lp, double *L) {
+    for (int t = 0; t < h->N; ++t)
+        for (int g = 0; g < h->m; ++g)
+            for (int jj = 0; jj < h->n; ++jj) L[(size_t)t * h->m * h->n + g + h->m * jj] = Lp[(size_t)t * LSTR + g * 12 + jj];
+}
+
+static rat_rc fetch_slot(rat_handle h, int slot, std::vector<double> *xp, std::vector<double> *up, std::vector<double> *tp) {
+    const StateDev &st = h->st;
+    if (xp) { xp->resize(st.x_stride); HIPCHK(hipMemcpy(xp->data(), st.xs + (size_t)slot * st.x_stride, st.x_stride * 8, hipMemcpyDeviceToHost)); }
+    if (up) { up->resize(st.u_stride); HIPCHK(hipMemcpy(up->data(), st.us + (size_t)slot * st.u_stride, st.u_stride * 8, hipMemcpyDeviceToHost)); }
+    if (tp) { tp->resize(st.tile_stride); HIPCHK(hipMemcpy(tp->data(), st.tiles + (size_t)slot * st.tile_stride, st.tile_stride * 8, hipMemcpyDeviceToHost)); }
+    return RAT_OK;
+}
+
+// one-sample state for the operator forms: status RUNNING, slot_nom 0, given theta/mu/delta
+static rat_rc op_prepare(rat_handle h, double theta, double mu, double delta, StateDev *out) {
+    if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
+    HIPCHK(hipSetDevice(h->device));
+    StateDev st = h->st; st.B = 1;
+    HIPCHK(hipMemcpyAsync(h->d_theta, &theta, 8, hipMemcpyHostToDevice, h->stream));
+    launch_init_state(st, h->opd, h->d_theta, h->stream);
+    HIPCHK(hipMemcpyAsync(st.mu, &mu, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(st.delta, &delta, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = st;
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *u0, double theta, double *x, double *l, double *L,
+                                  double *value, int32_t *status, int32_t *iters, double *eps_hist, int64_t hist_cap, int64_t *hist_n) {
+    if (!h || !x0 || !u0) return fail(RAT_ERR_ARG, "null");
+    rat_rc rc = rat_set_initial(h, x0, u0);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_theta, &theta, 8, hipMemcpyHostToDevice, h->stream));
+    double *d_hist = nullptr;
+    const int cap = (int)std::min<int64_t>(std::max<int64_t>(hist_cap, 0), 1 << 20);
+    if (eps_hist && cap > 0) { HIPCHK(hipMalloc((void **)&d_hist, (size_t)cap * 16)); }
+    h->st.hist = d_hist; h->st.hist_cap = cap;
+    rc = run_batch(h, h->d_theta, 1);
+    h->st.hist = nullptr; h->st.hist_cap = 0;
+    if (rc) { if (d_hist) (void)hipFree(d_hist); return rc; }
+    int st_h = 0, it_h = 0, nom = 0, hn = 0; double val = 0;
+    HIPCHK(hipMemcpy(&st_h, h->st.status, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&it_h, h->st.iter, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&nom, h->st.slot_nom, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&hn, h->st.hist_n, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&val, h->st.value, 8, hipMemcpyDeviceToHost));
+    if (status) *status = st_h;
+    if (iters) *iters = it_h;
+    if (value) *value = (st_h == 0 || st_h == 3) ? val : INFINITY;
+    if (hist_n) *hist_n = hn;
+    if (d_hist) {
+        HIPCHK(hipMemcpy(eps_hist, d_hist, (size_t)std::min(hn, cap) * 16, hipMemcpyDeviceToHost));
+        (void)hipFree(d_hist);
+    }
+    std::vector<double> xp, up, Lp((size_t)h->N * LSTR);
+    if ((rc = fetch_slot(h, nom, &xp, &up, nullptr))) return rc;
+    HIPCHK(hipMemcpy(Lp.data(), h->st.L, Lp.size() * 8, hipMemcpyDeviceToHost));
+    if (x) unpad_x(h, xp, x);
+    if (l) unpad_u(h, up, l);
+    if (L) unpad_L(h, Lp, L);
+    return RAT_OK;
+}
+
+// ---- operator forms ------------------------------------------------------------------------------------
+extern "C" rat_rc rat_rollout_open(rat_handle h, const double *x0, const double *u, double *x, int32_t *domain_fail) {
+    if (!h || !x0 || !u || !x) return fail(RAT_ERR_ARG, "null");
+    rat_rc rc = rat_set_initial(h, x0, u);
+    if (rc) return rc;
+    StateDev st;
+    if ((rc = op_prepare(h, 0.0, 0.0, h->opts.delta_0, &st))) return rc;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    launch_rollout(ra, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> xp;
+    if ((rc = fetch_slot(h, 0, &xp, nullptr, nullptr))) return rc;
+    unpad_x(h, xp, x);
+    int st_h = 0;
+    HIPCHK(hipMemcpy(&st_h, h->st.status, 4, hipMemcpyDeviceToHost));
+    if (domain_fail) *domain_fail = (st_h == RAT_ST_DOMAIN);
+    return RAT_OK;
+}
+
+static rat_rc put_slot0(rat_handle h, const double *x, const double *u) {
+    std::vector<double> xp, up;
+    if (x) { pad_x(h, x, xp); HIPCHK(hipMemcpy(h->st.xs, xp.data(), xp.size() * 8, hipMemcpyHostToDevice)); }
+    if (u) { pad_u(h, u, up); HIPCHK(hipMemcpy(h->st.us, up.data(), up.size() * 8, hipMemcpyHostToDevice)); }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_rollout_feedback(rat_handle h, const double *xbar, const double *l, const double *L,
+                                       double *x_new, double *u_new, int32_t *domain_fail) {
+    if (!h || !xbar || !l || !L) return fail(RAT_ERR_ARG, "null");
+    StateDev st;
+    rat_rc rc = op_prepare(h, 0.0, 0.0, h->opts.delta_0, &st);
+    if (rc) return rc;
+    if ((rc = put_slot0(h, xbar, l))) return rc;
+    std::vector<double> Lp;
+    pad_L(h, L, Lp);
+    HIPCHK(hipMemcpy(st.L, Lp.data(), Lp.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(st.dl, 0, (size_t)h->N * USTR * 8));
+    const int one = 1;
+    HIPCHK(hipMemcpy(st.ls_active, &one, 4, hipMemcpyHostToDevice));
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    launch_rollout(ra, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> xp, up;
+    if ((rc = fetch_slot(h, 1, &xp, &up, nullptr))) return rc;        // candidate 0 of sample 0 lives in slot 1
+    if (x_new) unpad_x(h, xp, x_new);
+    if (u_new) unpad_u(h, up, u_new);
+    int fl = 0;
+    HIPCHK(hipMemcpy(&fl, st.flag_c, 4, hipMemcpyDeviceToHost));
+    if (domain_fail) *domain_fail = (fl == 2);
+    return RAT_OK;
+}
+
+static rat_rc linearize_slot0(rat_handle h, const double *u, const double *x, std::vector<double> *tiles, int32_t *domain_fail) {
+    StateDev st;
+    rat_rc rc = op_prepare(h, 0.0, 0.0, h->opts.delta_0, &st);
+    if (rc) return rc;
+    if ((rc = put_slot0(h, x, u))) return rc;
+    LinArgs la; la.st = st; la.pb = h->pb; la.mode = 0;
+    launch_linearize(la, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = fetch_slot(h, 0, nullptr, nullptr, tiles))) return rc;
+    int st_h = 0;
+    HIPCHK(hipMemcpy(&st_h, h->st.status, 4, hipMemcpyDeviceToHost));
+    if (domain_fail) *domain_fail = (st_h == RAT_ST_DOMAIN);
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_integrate_cost(rat_handle h, const double *x, const double *u, double *cost) {
+    if (!h || !x || !u || !cost) return fail(RAT_ERR_ARG, "null");
+    std::vector<double> tp;
+    int32_t dom = 0;
+    rat_rc rc = linearize_slot0(h, u, x, &tp, &dom);
+    if (rc) return rc;
+    double acc = 0.0;                                                   // ileqg.jl:118-123
+    for (int t = 0; t < h->N; ++t) acc += tp[(size_t)t * TSTRIDE + TS_q];
+    acc += tp[(size_t)h->N * TSTRIDE + TT_q];
+    *cost = dom ? NAN : acc;
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_approximate_model(rat_handle h, const double *u, const double *x, double *q, double *qv, double *Q,
+                                        double *r, double *R, double *P, double *A, double *B, double *W, int32_t *domain_fail) {
+    if (!h || !x || !u) return fail(RAT_ERR_ARG, "null");
+    std::vector<double> tp;
+    rat_rc rc = linearize_slot0(h, u, x, &tp, domain_fail);
+    if (rc) return rc;
+    const int n = h->n, m = h->m, N = h->N;
+    for (int t = 0; t < N; ++t) {
+        const double *ts = &tp[(size_t)t * TSTRIDE];
+        if (q) q[t] = ts[TS_q];
+        for (int i = 0; i < n; ++i) {
+            if (qv) qv[(size_t)t * n + i] = ts[TS_QR + i];
+            for (int jj = 0; jj < n; ++jj) {
+                if (Q) Q[(size_t)t * n * n + i + n * jj] = ts[TS_Q + i * 12 + jj];
+                if (A) A[(size_t)t * n * n + i + n * jj] = ts[TS_Z + i * 16 + jj];
+            }
+            for (int g = 0; g < m; ++g) if (B) B[(size_t)t * n * m + i + n * g] = ts[TS_Z + i * 16 + 12 + g];
+        }
+        for (int g = 0; g < m; ++g) {
+            if (r) r[(size_t)t * m + g] = ts[TS_QR + 12 + g];
+            for (int jj = 0; jj < n; ++jj) if (P) P[(size_t)t * m * n + g + m * jj] = ts[TS_PR + g * 16 + jj];
+            for (int g2 = 0; g2 < m; ++g2) if (R) R[(size_t)t * m * m + g + m * g2] = ts[TS_PR + g * 16 + 12 + g2];
+        }
+        if (W) memcpy(W + (size_t)t * n * n, h->hW.data() + (h->W_tv ? (size_t)t * n * n : 0), sizeof(double) * n * n);   // :312
+    }
+    const double *tt = &tp[(size_t)N * TSTRIDE];
+    if (q) q[N] = tt[TT_q];
+    for (int i = 0; i < n; ++i) {
+        if (qv) qv[(size_t)N * n + i] = tt[TT_QV + i];
+        for (int jj = 0; jj < n; ++jj) if (Q) Q[(size_t)N * n * n + i + n * jj] = tt[TT_Q + i * 12 + jj];
+    }
+    return RAT_OK;
+}
+
+// ApproximationResult arrays (reference layout) -> one padded tile bundle
+static void pack_tiles(const rat_handle h, const double *q, const double *qv, const double *Q, const double *r, const double *R,
+                       const double *P, const double *A, const double *B, std::vector<double> &tp) {
+    const int n = h->n, m = h->m, N = h->N;
+    tp.assign(h->st.tile_stride, 0.0);
+    for (int t = 0; t < N; ++t) {
+        double *ts = &tp[(size_t)t * TSTRIDE];
+        ts[TS_q] = q[t];
+        for (int i = 0; i < n; ++i) {
+            ts[TS_QR + i] = qv[(size_t)t * n + i];
+            for (int jj = 0; jj < n; ++jj) {
+                ts[TS_Q + i * 12 + jj] = Q[(size_t)t * n * n + i + n * jj];
+                ts[TS_Z + i * 16 + jj] = A[(size_t)t * n * n + i + n * jj];
+            }
+            for (int g = 0; g < m; ++g) ts[TS_Z + i * 16 + 12 + g] = B[(size_t)t * n * m + i + n * g];
+        }
+        for (int g = 0; g < m; ++g) {
+            ts[TS_QR + 12 + g] = r[(size_t)t * m + g];
+            for (int jj = 0; jj < n; ++jj) ts[TS_PR + g * 16 + jj] = P[(size_t)t * m * n + g + m * jj];
+            for (int g2 = 0; g2 < m; ++g2) ts[TS_PR + g * 16 + 12 + g2] = R[(size_t)t * m * m + g + m * g2];
+        }
+        for (int g = m; g < RAT_MP; ++g) ts[TS_PR + g * 16 + 12 + g] = 1.0;
+    }
+    double *tt = &tp[(size_t)N * TSTRIDE];
+    tt[TT_q] = q[N];
+    for (int i = 0; i < n; ++i) {
+        tt[TT_QV + i] = qv[(size_t)N * n + i];
+        for (int jj = 0; jj < n; ++jj) tt[TT_Q + i * 12 + jj] = Q[(size_t)N * n * n + i + n * jj];
+    }
+}
+
+static rat_rc unpack_dump(rat_handle h, double *s, double *sv, double *S, double *g, double *G, double *H) {
+    const int n = h->n, m = h->m, N = h->N;
+    std::vector<double> dp((size_t)(N + 1) * DUMP_STRIDE);
+    HIPCHK(hipMemcpy(dp.data(), h->d_dump, dp.size() * 8, hipMemcpyDeviceToHost));
+    for (int t = 0; t <= N; ++t) {
+        const double *d = &dp[(size_t)t * DUMP_STRIDE];
+        if (s) s[t] = d[DUMP_s];
+        for (int i = 0; i < n; ++i) {
+            if (sv) sv[(size_t)t * n + i] = d[DUMP_SV + i];
+            // Symmetric(S): upper triangle mirrored (ileqg.jl:391)
+            for (int jj = 0; jj < n; ++jj) if (S) S[(size_t)t * n * n + i + n * jj] = (i <= jj) ? d[DUMP_S + i * 12 + jj] : d[DUMP_S + jj * 12 + i];
+        }
+        if (t == N) continue;
+        for (int a = 0; a < m; ++a) {
+            if (g) g[(size_t)t * m + a] = d[DUMP_g + a];
+            for (int jj = 0; jj < n; ++jj) if (G) G[(size_t)t * m * n + a + m * jj] = d[DUMP_G + a * 12 + jj];
+            for (int a2 = 0; a2 < m; ++a2) if (H) H[(size_t)t * m * m + a + m * a2] = d[DUMP_H + a * 4 + a2];
+        }
+    }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_dp_gain_sweep(rat_handle h, const double *q, const double *qv, const double *Q, const double *r,
+                                    const double *R, const double *P, const double *A, const double *B, double theta,
+                                    double *mu, double *delta, double *L, double *dl, int32_t *status,
+                                    double *s, double *sv, double *S, double *g, double *G, double *H) {
+    if (!h || !q || !qv || !Q || !r || !R || !P || !A || !B || !mu || !delta) return fail(RAT_ERR_ARG, "null");
+    StateDev st;
+    rat_rc rc = op_prepare(h, theta, *mu, *delta, &st);
+    if (rc) return rc;
+    std::vector<double> tp;
+    pack_tiles(h, q, qv, Q, r, R, P, A, B, tp);
+    HIPCHK(hipMemcpy(st.tiles, tp.data(), tp.size() * 8, hipMemcpyHostToDevice));
+    SweepArgs a = sweep_args(h, st, 0);
+    a.op_out = h->d_opout; a.dump = h->d_dump;
+    launch_sweep(a, 1, true, true, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double oo[2];
+    HIPCHK(hipMemcpy(oo, h->d_opout, 16, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mu, st.mu, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(delta, st.delta, 8, hipMemcpyDeviceToHost));
+    if (status) *status = (int32_t)oo[1];
+    std::vector<double> Lp((size_t)h->N * LSTR), dlp((size_t)h->N * USTR);
+    HIPCHK(hipMemcpy(Lp.data(), st.L, Lp.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dlp.data(), st.dl, dlp.size() * 8, hipMemcpyDeviceToHost));
+    if (L) unpad_L(h, Lp, L);
+    if (dl) unpad_u(h, dlp, dl);
+    return unpack_dump(h, s, sv, S, g, G, H);
+}
+
+extern "C" rat_rc rat_dp_policy_eval(rat_handle h, const double *q, const double *qv, const double *Q, const double *r,
+                                     const double *R, const double *P, const double *A, const double *B, const double *L,
+                                     const double *dl, double theta, double mu, int32_t *status,
+                                     double *s, double *sv, double *S, double *g, double *G, double *H) {
+    if (!h || !q || !qv || !Q || !r || !R || !P || !A || !B || !L) return fail(RAT_ERR_ARG, "null");
+    StateDev st;
+    rat_rc rc = op_prepare(h, theta, mu, h->opts.delta_0, &st);
+    if (rc) return rc;
+    std::vector<double> tp, Lp, dlp;
+    pack_tiles(h, q, qv, Q, r, R, P, A, B, tp);
+    HIPCHK(hipMemcpy(st.tiles, tp.data(), tp.size() * 8, hipMemcpyHostToDevice));
+    pad_L(h, L, Lp);
+    HIPCHK(hipMemcpy(st.L, Lp.data(), Lp.size() * 8, hipMemcpyHostToDevice));
+    SweepArgs a = sweep_args(h, st, 3);
+    if (dl) { pad_u(h, dl, dlp); HIPCHK(hipMemcpy(h->d_dlin, dlp.data(), dlp.size() * 8, hipMemcpyHostToDevice)); a.dl_in = h->d_dlin; }
+    a.mu_op = mu; a.op_out = h->d_opout; a.dump = h->d_dump;
+    launch_sweep(a, 1, false, true, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double oo[2];
+    HIPCHK(hipMemcpy(oo, h->d_opout, 16, hipMemcpyDeviceToHost));
+    if (status) *status = (int32_t)oo[1];
+    return unpack_dump(h, s, sv, S, g, G, H);
+}
+
+// ---- Cross-Entropy loop -----------------------------------------------------------------------------------
+extern "C" void rat_ce_default(rat_ce_solver *c) {                       // :100-127
+    memset(c, 0, sizeof(*c));
+    c->num_samples = 10; c->num_elite = 3; c->iter_max = 5; c->lambda = 0.5; c->use_theta_max = 0;
+    c->mu_init = 1.0; c->sigma_init = 2.0; c->mu = c->mu_init; c->sigma = c->sigma_init;
+    c->theta_max = 0.0; c->theta_min = INFINITY; c->iter_current = 0;
+}
+extern "C" void rat_ce_initialize(rat_ce_solver *c) {                    // :133-138
+    c->iter_current = 0; c->mu = c->mu_init; c->sigma = c->sigma_init; c->theta_max = 0.0; c->theta_min = INFINITY;
+}
+extern "C" rat_rc rat_ce_set_stream(rat_handle h, const double *z, int64_t nz) {
+    if (!h) return RAT_ERR_ARG;
+    h->z = z; h->nz = nz; h->zpos = 0; h->internal_rng = false;
+    return RAT_OK;
+}
+static uint64_t splitmix64(uint64_t &x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+extern "C" rat_rc rat_ce_seed(rat_handle h, uint64_t seed) {
+    if (!h) return RAT_ERR_ARG;
+    uint64_t x = seed;
+    for (int i = 0; i < 4; ++i) h->rs[i] = splitmix64(x);
+    h->internal_rng = true; h->have_spare = false; h->z = nullptr; h->nz = 0; h->zpos = 0;
+    return RAT_OK;
+}
+extern "C" int64_t rat_ce_stream_pos(rat_handle h) { return h ? h->zpos : -1; }
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static double next_uniform(rat_handle h) {                              // xoshiro256++, 53-bit mantissa in (0,1]
+    uint64_t *s = h->rs;
+    const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+    return ((double)(result >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+}
+static bool next_normal(rat_handle h, double *z) {
+    if (!h->internal_rng) {
+        if (!h->z || h->zpos >= h->nz) return false;
+        *z = h->z[h->zpos++];
+        return true;
+    }
+    h->zpos++;
+    if (h->have_spare) { h->have_spare = false; *z = h->spare; return true; }
+    const double u1 = next_uniform(h), u2 = next_uniform(h);           // Box-Muller
+    const double rr = std::sqrt(-2.0 * std::log(u1)), ang = 6.283185307179586476925286766559 * u2;
+    h->spare = rr * std::sin(ang); h->have_spare = true;
+    *z = rr * std::cos(ang);
+    return true;
+}
+
+extern "C" rat_rc rat_ce_get_positive_samples(rat_handle h, double mu, double sigma, int64_t num, double *theta) {   // :233-246
+    if (!h || !theta) return fail(RAT_ERR_ARG, "null");
+    int64_t k = 0, guard = 0;
+    while (true) {
+        double z;
+        if (!next_normal(h, &z)) return fail(RAT_ERR_STREAM_DRY, "standard-normal stream exhausted");
+        const double th = mu + sigma * z;                               // rand(rng, Normal(mu, sigma))
+        if (th > 0.0) theta[k++] = th;
+        if (k >= num) break;
+        if (++guard > (int64_t)1 << 40) return fail(RAT_ERR_DIVERGED, "get_positive_samples did not terminate");
+    }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_ce_compute_cost(rat_handle h, const double *x0, const double *u0, const double *theta, int64_t B,
+                                      double kl_bound, double *cost) {   // :173-195
+    rat_rc rc = rat_ileqg_solve_batch(h, x0, u0, theta, B, cost, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    for (int64_t i = 0; i < B; ++i) cost[i] = cost[i] + kl_bound / theta[i];   // :193
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_ce_begin_step(rat_ce_solver *c) { if (!c) return RAT_ERR_ARG; c->iter_current += 1; return RAT_OK; }   // :259
+
+extern "C" rat_rc rat_ce_draw(rat_handle h, const rat_ce_solver *c, double *theta) {   // :266-279
+    if (!h || !c) return fail(RAT_ERR_ARG, "null");
+    if (c->iter_current == 1) return rat_ce_get_positive_samples(h, c->mu_init, c->sigma_init, c->num_samples, theta);
+    return rat_ce_get_positive_samples(h, c->mu, c->sigma, c->num_samples, theta);
+}
+
+extern "C" rat_rc rat_ce_draw_stream(const rat_ce_solver *c, const double *z, int64_t nz, int64_t *zpos, double *theta) {
+    if (!c || !z || !zpos || !theta) return fail(RAT_ERR_ARG, "null");
+    const double mu = (c->iter_current == 1) ? c->mu_init : c->mu, sigma = (c->iter_current == 1) ? c->sigma_init : c->sigma;
+    int64_t k = 0;
+    while (k < c->num_samples) {                                          // get_positive_samples :233-246
+        if (*zpos >= nz) return fail(RAT_ERR_STREAM_DRY, "standard-normal stream exhausted");
+        const double th = mu + sigma * z[(*zpos)++];
+        if (th > 0.0) theta[k++] = th;
+    }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_ce_update(rat_ce_solver *c, const double *theta, const double *cost, int32_t *redraw) {   // :291-334
+    if (!c || !theta || !cost || !redraw) return fail(RAT_ERR_ARG, "null");
+    const int64_t B = c->num_samples;
+    if (c->num_elite < 1 || c->num_elite > B) return fail(RAT_ERR_ARG, "num_elite out of range");
+    int64_t num_inf = 0;
+    for (int64_t i = 0; i < B; ++i) num_inf += std::isinf(cost[i]) ? 1 : 0;       // :291
+    const int64_t num_valid = B - num_inf;
+    const double thresh = std::max((double)c->num_elite, (double)B * c->lambda);
+    *redraw = 1;
+    if (c->iter_current == 1 && (double)num_valid < thresh) {                      // :293-298
+        c->mu_init *= c->lambda; c->sigma_init *= c->lambda;
+        return RAT_OK;
+    } else if (c->iter_current == 1 && num_valid == B) {                           // :299-305
+        c->mu_init /= c->lambda; c->sigma_init /= c->lambda;
+    } else if ((double)num_valid >= thresh) {                                      // :306
+    } else {
+        return RAT_OK;                                                              // redraw with unchanged parameters
+    }
+    *redraw = 0;
+    for (int64_t i = 0; i < B; ++i) {                                              // :314-324 (if / elseif)
+        if (std::isinf(cost[i])) continue;
+        if (theta[i] < c->theta_min) c->theta_min = theta[i];
+        else if (theta[i] > c->theta_max) c->theta_max = theta[i];
+    }
+    std::vector<int64_t> idx(B);
+    for (int64_t i = 0; i < B; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {          // sort(by = cost), isless: NaN last
+        const double x = cost[a], y = cost[b];
+        if (x != x) return false;
+        if (y != y) return true;
+        return x < y;
+    });
+    double sum = 0;
+    for (int64_t i = 0; i < c->num_elite; ++i) sum += theta[idx[i]];
+    const double mu_new = sum / (double)c->num_elite;                              // :329
+    double ss = 0;
+    for (int64_t i = 0; i < c->num_elite; ++i) ss += (theta[idx[i]] - mu_new) * (theta[idx[i]] - mu_new);
+    c->mu = mu_new; c->sigma = std::sqrt(ss / (double)c->num_elite);              // :330-334 (population std)
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_ce_step(rat_handle h, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
+                              double *theta_out, double *cost_out) {              // :252-335
+    if (!h || !c) return fail(RAT_ERR_ARG, "null");
+    if (c->num_samples > h->Bmax) return fail(RAT_ERR_ARG, "num_samples exceeds max_batch of rat_create");
+    std::vector<double> theta(c->num_samples), cost(c->num_samples);
+    rat_ce_begin_step(c);
+    for (int redraws = 0;; ++redraws) {
+        if (redraws > 1000) return fail(RAT_ERR_DIVERGED, "CE redraw loop cut after 1000 redraws (reference would spin, App. B.11)");
+        rat_rc rc = rat_ce_draw(h, c, theta.data());
+        if (rc) return rc;
+        if ((rc = rat_ce_compute_cost(h, x0, u0, theta.data(), c->num_samples, kl_bound, cost.data()))) return rc;
+        c->n_solves += c->num_samples;
+        if (redraws) c->n_redraws++;
+        int32_t redraw = 0;
+        if ((rc = rat_ce_update(c, theta.data(), cost.data(), &redraw))) return rc;
+        if (!redraw) break;
+    }
+    if (theta_out) memcpy(theta_out, theta.data(), theta.size() * 8);
+    if (cost_out) memcpy(cost_out, cost.data(), cost.size() * 8);
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
+                               double *theta_opt, double *x, double *l, double *L, double *value,
+                               double *theta_min, double *theta_max) {             // :364-415
+    if (!h || !c || !theta_opt || !value) return fail(RAT_ERR_ARG, "null");
+    if (!(kl_bound >= 0)) return fail(RAT_ERR_ARG, "KL Divergence Bound must be non-negative (:368)");
+    rat_ce_initialize(c);                                                           // :369
+    double th_opt, tmin = 0.0, tmax = 0.0;
+    if (kl_bound > 0) {
+        while (c->iter_current < c->iter_max) {                                     // :371-373
+            rat_rc rc = rat_ce_step(h, c, x0, u0, kl_bound, nullptr, nullptr);
+            if (rc) return rc;
+        }
+        tmin = c->theta_min; tmax = c->theta_max;                                   // :374
+        th_opt = c->use_theta_max ? tmax : c->mu;                                   // :375-382
+    } else {
+        th_opt = 0.0;                                                               // :388
+    }
+    for (int tries = 0;; ++tries) {                                                 // :390-414
+        if (tries > 10000) return fail(RAT_ERR_DIVERGED, "final-solve retry loop cut (reference would spin, App. B.15)");
+        int32_t st = 0; double val = 0;
+        rat_rc rc = rat_ileqg_solve(h, x0, u0, th_opt, x, l, L, &val, &st, nullptr, nullptr, 0, nullptr);
+        if (rc) return rc;
+        if (st == RAT_ST_OK || st == RAT_ST_ITER_MAX) {
+            *theta_opt = th_opt;
+            if (kl_bound > 0) { *value = val + kl_bound / th_opt; if (theta_min) *theta_min = tmin; if (theta_max) *theta_max = tmax; }   // :406
+            else { *value = val; if (theta_min) *theta_min = 0.0; if (theta_max) *theta_max = 0.0; }                                    // :408
+            return RAT_OK;
+        }
+        th_opt = std::max(0.0, th_opt - c->sigma);                                   // :412
+    }
+}

@@ -1,0 +1,42 @@
+// kernels.h -- argument blocks and launchers of kernels.hip (host side: driver.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+struct SweepArgs {
+    StateDev st;
+    ProblemDev pb;
+    OptsDev op;
+    int mode;              // 0 gain sweep on nominal slots; 1 policy evaluation of line-search candidates;
+                           // 2 policy evaluation of nominal slots with L = 0, mu = 0 (initialize!);
+                           // 3 operator form of policy evaluation (sample 0, L/dl given, mu = mu_op)
+    const double *dl_in;   // mode 3: dl_array or null
+    double mu_op;          // mode 3
+    double *op_out;        // modes 0/3 operator forms: [0] = s_1, [1] = status ; else null
+    double *dump;          // DUMP instantiations: [N+1][DUMP_STRIDE]
+};
+
+struct RolloutArgs {
+    StateDev st;
+    ProblemDev pb;
+    OptsDev op;
+    int mode;              // 0 open loop from (x0, u0) into the nominal slots; 1 closed loop candidates
+    const double *x0;      // [12]
+    const double *u0;      // [N*4]
+};
+
+struct LinArgs {
+    StateDev st;
+    ProblemDev pb;
+    int mode;              // 0 nominal slots, 1 candidate slots
+};
+
+void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s);
+void launch_rollout(const RolloutArgs &a, hipStream_t s);
+void launch_linearize(const LinArgs &a, hipStream_t s);
+void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
+void launch_ls_begin(const StateDev &st, hipStream_t s);
+void launch_ls_select(const StateDev &st, const OptsDev &op, hipStream_t s);
+void launch_count_running(const StateDev &st, hipStream_t s);
+void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, hipStream_t s);

@@ -1,0 +1,743 @@
+// kernels.hip -- gfx950 (CDNA4) kernels of the iLEQG hot path.
+//
+//   rollout_kernel    simulate_dynamics, open loop and closed loop        (ileqg.jl:18-38, 62-87) + d_current reduction (:539)
+//   linearize_kernel  approximate_model -> tile bundles in HBM            (ileqg.jl:258-322)
+//   sweep_kernel      risk-sensitive Riccati sweep, gain / policy-eval    (ileqg.jl:341-406 / 412-465)
+//   ls_begin_kernel / ls_select_kernel / init_state_kernel                 per-sample control flow of step!/line_search!/solve!
+//                                                                          (ileqg.jl:494-592, 598-613, 635-659) replayed on device
+//
+// sweep_kernel: ONE WAVEFRONT PER TRAJECTORY.  The value function is carried as the augmented
+// symmetric matrix V = [[S, s_vec], [s_vec', 2 s]] (13 x 13 inside a 16 x 16 tile) held in the
+// accumulator layout of v_mfma_f64_16x16x4_f64 (4 doubles per lane: col = lane & 15,
+// row = 4*reg + (lane >> 4)).  In that layout register s of a matrix X is at once
+//   - the B operand of K-slice s of  (.) * X, and
+//   - the A operand of K-slice s of  X' * (.)
+// so every product of one backward step chains through registers with no data movement:
+//     Y  = M^-1 V             3 MFMA      (M = W^-1 - theta S, inverted by a 12-step symmetric sweep)
+//     V~ = V + V (theta Y)    3 MFMA      (V~ = [[D S, D s_vec],[., 2s + theta s' M^-1 s]])
+//     T  = V~ [A|B]           3 MFMA      (row 12 of T is s~'[A|B])
+//     F  = [A|B]' T + C       3 MFMA      (C = [[Q,P'],[P,R]] enters as the accumulator input)
+//     V  = Fx + La' Ua + Ga' La   2 MFMA  (La = [L|dl], Ga = [G|g], Ua = H La + Ga: 4 x 16 "natural" rows)
+// The 4x4 system H X = -[G|g] is solved redundantly by every lane for its own column (LDL').
+// logdet(W M) is accumulated per lane as sum_k log(d_k / e_k) (pivots of M over pivots of W^-1) and
+// reduced once per sweep.  See tools/mfma_step_model.py for the NumPy model of this step.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "layout.h"
+#include "kernels.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ d4 mm3(const d4 &a, const d4 &b, d4 acc) {     // acc += A' B over K-slices 0..2 (rows 0..11)
+    acc = MFMA(a[0], b[0], acc);
+    acc = MFMA(a[1], b[1], acc);
+    acc = MFMA(a[2], b[2], acc);
+    return acc;
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+__device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base.isapprox, rtol = sqrt(eps), atol = 0
+    if (x == y) return true;
+    if (!isfinite(x) || !isfinite(y)) return false;
+    return fabs(x - y) <= 1.4901161193847656e-8 * fmax(fabs(x), fabs(y));
+}
+
+// =====================================================================================================
+// sweep_kernel
+// =====================================================================================================
+struct TileRegs {
+    d4 z, c, lc;
+    double qr, q;
+};
+
+template <bool GAIN>
+__device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict__ tp, const int (&offC)[4], int l, int j,
+                                          const double *__restrict__ Lp, const double *__restrict__ dlp, bool haveL) {
+    tr.z[0] = tp[TS_Z + l];
+    tr.z[1] = tp[TS_Z + 64 + l];
+    tr.z[2] = tp[TS_Z + 128 + l];
+    tr.z[3] = 0.0;
+    tr.c[0] = tp[offC[0]];
+    tr.c[1] = tp[offC[1]];
+    tr.c[2] = tp[offC[2]];
+    tr.c[3] = tp[offC[3]];
+    tr.qr = tp[TS_QR + j];
+    tr.q = tp[TS_q];
+    if (!GAIN) {
+        tr.lc = (d4){0.0, 0.0, 0.0, 0.0};
+        if (haveL) {
+            if (j < 12) {
+                tr.lc[0] = Lp[j];
+                tr.lc[1] = Lp[12 + j];
+                tr.lc[2] = Lp[24 + j];
+                tr.lc[3] = Lp[36 + j];
+            } else if (j == 12 && dlp) {
+                tr.lc[0] = dlp[0];
+                tr.lc[1] = dlp[1];
+                tr.lc[2] = dlp[2];
+                tr.lc[3] = dlp[3];
+            }
+        }
+    }
+}
+
+template <bool GAIN, bool DUMP>
+__global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
+    const int l = threadIdx.x, g = l >> 4, j = l & 15;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    const int tid = blockIdx.x;
+    int b, slot, cidx = -1;
+    if (a.mode == 1) {
+        b = tid / st.E;
+        const int k = tid - b * st.E;
+        if (!st.ls_active[b]) return;
+        cidx = tid;
+        if (st.flag_c[cidx] == 2) return;
+        slot = cand_slot(b, k, st.slot_nom[b], st.E);
+    } else {
+        b = tid;
+        if (st.status[b] != ST_RUNNING) return;
+        slot = b * (st.E + 1) + st.slot_nom[b];
+    }
+    const double theta = st.theta[b];
+    double mu = (a.mode == 2) ? 0.0 : (a.mode == 3 ? a.mu_op : st.mu[b]);
+    double delta = st.delta[b];
+    const int N = st.N;
+    const double *__restrict__ tile0 = st.tiles + (long)slot * st.tile_stride;
+    const bool haveL = (a.mode == 1 || a.mode == 3);
+    const double *__restrict__ Lb = st.L + (long)b * N * LSTR;
+    double *__restrict__ Lout = st.L + (long)b * N * LSTR;
+    double *__restrict__ dlout = st.dl + (long)b * N * USTR;
+
+    __shared__ double rowbuf[2][16];
+    __shared__ double hbuf[4][16];
+    __shared__ double fbuf[16];
+
+    int offC[4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int i = 4 * r + g;
+        offC[r] = (j < 12) ? (TS_Q + i * 12 + j) : (TS_PR + (j - 12) * 16 + i);
+    }
+    offC[3] = TS_PR + g * 16 + j;
+
+    // noise tables (time-invariant case is hoisted out of the time loop)
+    d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
+    double ep = 1.0;
+    if (!pb.W_tv) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            winv[r] = pb.Winv[64 * r + l];
+            wp[r] = pb.Wp[64 * r + l];
+        }
+        ep = pb.epiv[j];
+    }
+    const double coef = (theta != 0.0) ? -1.0 / (2.0 * theta) : 0.5;
+
+    int restarts = 0;
+    int fail = 0;         // 1: M not PD, 5: mu diverged
+    d4 v;
+    double racc;
+    while (true) {        // mu-regularisation restart loop (ileqg.jl:359); runs once for policy evaluation
+        // terminal condition (ileqg.jl:352-354 / 429-431)
+        const double *__restrict__ tt = tile0 + (long)N * TSTRIDE;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = 4 * r + g;
+            v[r] = (j < 12) ? tt[TT_Q + i * 12 + j] : (j == 12 ? tt[TT_QV + i] : 0.0);
+        }
+        v[3] = (g == 0) ? (j < 12 ? tt[TT_QV + j] : (j == 12 ? 2.0 * tt[TT_q] : 0.0)) : 0.0;
+        racc = 0.0;
+        if (DUMP) {
+            double *dp = a.dump + (long)N * DUMP_STRIDE;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int i = 4 * r + g;
+                if (j < 12) dp[DUMP_S + i * 12 + j] = v[r];
+                if (j == 12) dp[DUMP_SV + i] = v[r];
+            }
+            if (l == 12) dp[DUMP_s] = 0.5 * v[3];
+        }
+        TileRegs nx;
+        load_tile<GAIN>(nx, tile0 + (long)(N - 1) * TSTRIDE, offC, l, j, Lb + (long)(N - 1) * LSTR,
+                        a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, haveL);
+        bool h_not_pd = false;
+        for (int t = N - 1; t >= 0; --t) {
+            const TileRegs cur = nx;
+            if (t > 0)          // software prefetch of step t-1 (a full step of latency hiding)
+                load_tile<GAIN>(nx, tile0 + (long)(t - 1) * TSTRIDE, offC, l, j, Lb + (long)(t - 1) * LSTR,
+                                a.dl_in ? a.dl_in + (long)(t - 1) * USTR : nullptr, haveL);
+            if (pb.W_tv) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    winv[r] = pb.Winv[(long)t * 192 + 64 * r + l];
+                    wp[r] = pb.Wp[(long)t * 192 + 64 * r + l];
+                }
+                ep = pb.epiv[(long)t * 16 + j];
+            }
+            d4 vt;
+            if (theta != 0.0) {
+                // M = Symmetric(inv(W) - theta S)   (ileqg.jl:365)
+                d4 m;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) m[r] = (j < 12) ? (winv[r] - theta * v[r]) : 0.0;
+                m[3] = 0.0;
+                // symmetric sweep operator on pivots 0..11: m <- -M^-1 ; pivots d_k > 0 <=> isposdef(M) (:366)
+                bool pd = true;
+                double piv = 1.0;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const int kr = k >> 2, kg = k & 3;
+                    if (g == kg) rowbuf[k & 1][j] = m[kr];
+                    __syncthreads();
+                    const double vj = rowbuf[k & 1][j];
+                    const double p = rowbuf[k & 1][k];
+                    const double vi0 = rowbuf[k & 1][g], vi1 = rowbuf[k & 1][4 + g], vi2 = rowbuf[k & 1][8 + g];
+                    pd = pd && (p > 0.0);
+                    if (l == k) piv = p;
+                    const double ip = 1.0 / p;
+                    const double w = vj * ip;
+                    {
+                        const int i = g;
+                        m[0] = (i == k) ? ((j == k) ? -ip : w) : ((j == k) ? vi0 * ip : fma(-vi0, w, m[0]));
+                    }
+                    {
+                        const int i = 4 + g;
+                        m[1] = (i == k) ? ((j == k) ? -ip : w) : ((j == k) ? vi1 * ip : fma(-vi1, w, m[1]));
+                    }
+                    {
+                        const int i = 8 + g;
+                        m[2] = (i == k) ? ((j == k) ? -ip : w) : ((j == k) ? vi2 * ip : fma(-vi2, w, m[2]));
+                    }
+                }
+                if (!pd) { fail = 1; break; }
+                d4 minv;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) minv[r] = (j < 12) ? -m[r] : 0.0;
+                minv[3] = 0.0;
+                // logdet(W M) = sum_k log(d_k / e_k)   (ileqg.jl:387), reduced once per sweep
+                if (l < 12) racc += log(piv / ep);
+                // Y = M^-1 [S | s_vec]
+                d4 y = mm3(minv, v, (d4){0, 0, 0, 0});
+                y *= theta;
+                // V~ = V + V[:, 0:12] (theta Y)  ->  D S, D s_vec, 2 s + theta s_vec' M^-1 s_vec   (:367, :387)
+                vt = mm3(v, y, v);
+            } else {
+                // theta == 0: D = I ; 0.5 tr(W S)   (ileqg.jl:385)
+                if (j < 12) racc += wp[0] * v[0] + wp[1] * v[1] + wp[2] * v[2];
+                vt = v;
+            }
+            // T = V~[:, 0:12] [A|B] : rows 0..11 = (D S)[A|B], row 12 = (D s_vec)'[A|B]
+            const d4 tm = mm3(vt, cur.z, (d4){0, 0, 0, 0});
+            // F = [A|B]' T + [[Q,P'],[P,R]]  (:369-370 and the Q + A'DSA term of :390)
+            d4 f = mm3(cur.z, tm, cur.c);
+            // H block: rows 12..15 of F live in register 3;  + mu I  (:370)
+            const double gh = f[3] + ((j == 12 + g) ? mu : 0.0);
+            const double fv = tm[3] + cur.qr;      // lanes g == 0: [q_vec + A' D s_vec | r + B' D s_vec]  (:368, :389)
+            hbuf[g][j] = gh;
+            if (g == 0) fbuf[j] = fv;
+            __syncthreads();
+            // H = Symmetric(H): upper triangle   (:371)
+            const double h00 = hbuf[0][12], h01 = hbuf[0][13], h02 = hbuf[0][14], h03 = hbuf[0][15];
+            const double h11 = hbuf[1][13], h12 = hbuf[1][14], h13 = hbuf[1][15];
+            const double h22 = hbuf[2][14], h23 = hbuf[2][15], h33 = hbuf[3][15];
+            // column j of [G | g | 0]
+            double g0, g1, g2, g3;
+            if (j < 12) { g0 = hbuf[0][j]; g1 = hbuf[1][j]; g2 = hbuf[2][j]; g3 = hbuf[3][j]; }
+            else if (j == 12) { g0 = fbuf[12]; g1 = fbuf[13]; g2 = fbuf[14]; g3 = fbuf[15]; }
+            else { g0 = g1 = g2 = g3 = 0.0; }
+            double x0, x1, x2, x3;
+            if (GAIN) {
+                // LDL' of H; all pivots > 0 <=> isposdef(H)   (:372)
+                const double d0 = h00, i0 = 1.0 / d0;
+                const double l10 = h01 * i0, l20 = h02 * i0, l30 = h03 * i0;
+                const double d1 = h11 - l10 * h01, i1 = 1.0 / d1;
+                const double l21 = (h12 - l20 * h01) * i1, l31 = (h13 - l30 * h01) * i1;
+                const double d2 = h22 - l20 * h02 - l21 * (l21 * d1), i2 = 1.0 / d2;
+                const double l32 = (h23 - l30 * h02 - l31 * (l21 * d1)) * i2;
+                const double d3 = h33 - l30 * h03 - l31 * (l31 * d1) - l32 * (l32 * d2), i3 = 1.0 / d3;
+                if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) { h_not_pd = true; break; }
+                // X = -H \ [G | g]   (:379-382)
+                const double y0 = -g0;
+                const double y1 = -g1 - l10 * y0;
+                const double y2 = -g2 - l20 * y0 - l21 * y1;
+                const double y3 = -g3 - l30 * y0 - l31 * y1 - l32 * y2;
+                x3 = y3 * i3;
+                x2 = y2 * i2 - l32 * x3;
+                x1 = y1 * i1 - l21 * x2 - l31 * x3;
+                x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+            } else {
+                x0 = cur.lc[0]; x1 = cur.lc[1]; x2 = cur.lc[2]; x3 = cur.lc[3];
+            }
+            const double la = (g == 0) ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));     // [L | dl] natural rows
+            const double ga = (g == 0) ? g0 : (g == 1 ? g1 : (g == 2 ? g2 : g3));     // [G | g]  natural rows
+            const double hg0 = (g == 0) ? h00 : (g == 1 ? h01 : (g == 2 ? h02 : h03));
+            const double hg1 = (g == 0) ? h01 : (g == 1 ? h11 : (g == 2 ? h12 : h13));
+            const double hg2 = (g == 0) ? h02 : (g == 1 ? h12 : (g == 2 ? h22 : h23));
+            const double hg3 = (g == 0) ? h03 : (g == 1 ? h13 : (g == 2 ? h23 : h33));
+            const double ua = hg0 * x0 + hg1 * x1 + hg2 * x2 + hg3 * x3 + ga;         // H [L|dl] + [G|g]
+            if (GAIN) {
+                if (j < 12) Lout[(long)t * LSTR + g * 12 + j] = la;
+                else if (j == 12) dlout[(long)t * USTR + g] = la;
+            }
+            // Fx = [[Q + A'DSA, f_x], [f_x', 2q + 2s + theta s'M^-1 s]]
+            d4 fx;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) fx[r] = (j < 12) ? f[r] : (j == 12 ? fbuf[4 * r + g] : 0.0);
+            fx[3] = (g == 0) ? (j < 12 ? fv : (j == 12 ? 2.0 * cur.q + vt[3] : 0.0)) : 0.0;
+            // V = Fx + La' Ua + Ga' La    (:383, :389, :390)
+            d4 vn = MFMA(la, ua, fx);
+            vn = MFMA(ga, la, vn);
+            v = vn;
+            if (DUMP) {
+                double *dp = a.dump + (long)t * DUMP_STRIDE;
+                const double tot = wave_sum(racc);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int i = 4 * r + g;
+                    if (j < 12) dp[DUMP_S + i * 12 + j] = v[r];
+                    if (j == 12) dp[DUMP_SV + i] = v[r];
+                }
+                if (l == 12) dp[DUMP_s] = 0.5 * v[3] + coef * tot;
+                if (l < 4) dp[DUMP_g + l] = fbuf[12 + l];
+                if (j < 12) dp[DUMP_G + g * 12 + j] = hbuf[g][j];
+                else dp[DUMP_H + g * 4 + (j - 12)] = (g <= j - 12) ? hbuf[g][j] : hbuf[j - 12][12 + g];
+            }
+            __syncthreads();      // hbuf / fbuf are rewritten next step
+        }
+        if (GAIN && h_not_pd) {
+            // increase_mu_and_delta!  (ileqg.jl:471-474), then restart the whole sweep (:373-378)
+            delta = fmax(a.op.delta_0, delta * a.op.delta_0);
+            mu = fmax(a.op.mu_min, mu * delta);
+            if (++restarts > 400 || !isfinite(mu)) { fail = 5; break; }
+            __syncthreads();
+            continue;
+        }
+        break;
+    }
+    const double tot = wave_sum(racc);
+    if (l == 12) {
+        const double s0 = 0.5 * v[3] + coef * tot;
+        if (a.mode == 1) {
+            st.value_c[cidx] = s0;
+            st.flag_c[cidx] = fail ? 1 : 0;
+        } else if (a.mode == 2) {
+            st.value[b] = fail ? INFINITY : s0;
+            if (fail) st.status[b] = 1;                      // RAT_ST_M_NOT_PD_INIT
+        } else if (a.mode == 3) {
+            a.op_out[0] = s0;
+            a.op_out[1] = (double)(fail ? 2 : 0);
+        } else {
+            st.mu[b] = mu;
+            st.delta[b] = delta;
+            if (fail) { st.status[b] = (fail == 1) ? 2 : 5; st.value[b] = INFINITY; st.iter[b] += 1; }   // M_NOT_PD_GAIN / MU_DIVERGED
+            if (a.op_out) { a.op_out[0] = s0; a.op_out[1] = (double)(fail ? (fail == 1 ? 2 : 5) : 0); }
+        }
+    }
+}
+
+void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s) {
+    if (ntraj <= 0) return;
+    dim3 grid(ntraj), block(64);
+    if (gain) {
+        if (dump) hipLaunchKernelGGL((sweep_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((sweep_kernel<true, false>), grid, block, 0, s, a);
+    } else {
+        if (dump) hipLaunchKernelGGL((sweep_kernel<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((sweep_kernel<false, false>), grid, block, 0, s, a);
+    }
+}
+
+// =====================================================================================================
+// rollout_kernel: four trajectories per wavefront (one per 16-lane row).  Lane j < 12 owns state
+// component j, lanes j < 4 additionally own control component j.
+// =====================================================================================================
+__device__ __forceinline__ double powchk(double bse, double e, int &dom) {
+    const double r = pow(bse, e);
+    if (r != r && bse == bse) dom = 1;        // Julia: DomainError for a negative base with a fractional exponent
+    return r;
+}
+
+__global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
+    const int row = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    const int N = st.N;
+    const int ncand = (a.mode == 0) ? st.B : st.B * st.E;
+    int c = blockIdx.x * 4 + row;
+    bool live = c < ncand;
+    int b = 0, k = 0;
+    if (live) {
+        if (a.mode == 0) { b = c; live = (st.status[b] == ST_RUNNING); }
+        else { b = c / st.E; k = c - b * st.E; live = st.ls_active[b] != 0; }
+    }
+    __shared__ double shdx[4][12];
+    __shared__ double shxu[4][16];
+    __shared__ double shq[4][4];
+
+    const int nom = live ? st.slot_nom[b] : 0;
+    const int slot_n = b * (st.E + 1) + nom;
+    const int slot_o = (a.mode == 0) ? slot_n : cand_slot(b, k, nom, st.E);
+    const double *__restrict__ xbar = st.xs + (long)slot_n * st.x_stride;
+    const double *__restrict__ lnom = (a.mode == 0) ? a.u0 : st.us + (long)slot_n * st.u_stride;
+    double *__restrict__ xo = st.xs + (long)slot_o * st.x_stride;
+    double *__restrict__ uo = st.us + (long)slot_o * st.u_stride;
+    const double *__restrict__ Lb = st.L + (long)b * N * LSTR;
+    const double *__restrict__ dlb = st.dl + (long)b * N * USTR;
+
+    double eps = 0.0;
+    if (live && a.mode == 1) {
+        eps = st.ls_eps[b];
+        for (int q = 0; q < k; ++q) eps *= a.op.lambda;        // eps_k = eps * lambda^k by repeated multiplication (:530,:557)
+    }
+    // row j of [A|B] (time-invariant dynamics: f has no time argument in the reference)
+    double zr[16];
+    if (pb.model == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zr[q] = (j < 12) ? pb.Zt[j * 16 + q] : 0.0;
+    }
+    double x = 0.0;
+    if (j < 12) x = (a.mode == 0) ? a.x0[j] : xbar[j];
+    if (live && j < 12) xo[j] = x;
+    double dmax = -INFINITY;
+    bool dnan = false;
+    int dom = 0;
+    for (int t = 0; t < N; ++t) {
+        double u = 0.0;
+        if (a.mode == 1) {
+            if (j < 12) shdx[row][j] = x - xbar[(long)t * XSTR + j];
+            __syncthreads();
+            if (j < 4 && live) {
+                const double *Lr = Lb + (long)t * LSTR + j * 12;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) acc += Lr[q] * shdx[row][q];          // L_t (x_t - xbar_t)   (:82)
+                const double lt = lnom[(long)t * USTR + j];
+                const double lnew = lt + eps * dlb[(long)t * USTR + j];               // l + eps dl           (:509)
+                u = lnew + acc;
+                const double du = lt - u;
+                shq[row][j] = du * du;
+            }
+        } else if (j < 4) {
+            u = lnom[(long)t * USTR + j];
+        }
+        if (j < 12) shxu[row][j] = x;
+        if (j < 4) shxu[row][12 + j] = u;
+        __syncthreads();
+        double xn = 0.0;
+        if (j < 12) {
+            if (pb.model == 1) {
+                double acc = 0.0, accb = 0.0;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) acc += zr[q] * shxu[row][q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) accb += zr[12 + q] * shxu[row][12 + q];
+                acc += accb;
+                if (pb.kappa != 0.0) acc += pb.kappa * (x * x * x);
+                xn = acc;
+            } else if (j < pb.n) {
+                xn = powchk(x, pb.pl_a, dom) + powchk(shxu[row][12 + j], pb.pl_b, dom);
+            }
+        }
+        if (a.mode == 1 && j == 0) {
+            const double dn = sqrt(shq[row][0] + shq[row][1] + shq[row][2] + shq[row][3]);
+            if (dn != dn) dnan = true;                      // maximum() propagates NaN
+            else if (dn > dmax) dmax = dn;
+        }
+        if (live) {
+            if (j < 12) xo[(long)(t + 1) * XSTR + j] = xn;
+            if (j < 4) uo[(long)t * USTR + j] = u;
+        }
+        x = xn;
+        __syncthreads();
+    }
+    // any lane of the row saw a DomainError?
+    const unsigned long long bal = __ballot(dom != 0);
+    const int rowdom = ((bal >> (row * 16)) & 0xFFFFull) != 0;
+    if (live && j == 0) {
+        if (a.mode == 1) {
+            st.d_c[c] = dnan ? NAN : dmax;
+            st.flag_c[c] = rowdom ? 2 : 0;
+        } else if (rowdom) {
+            st.status[b] = 4;               // RAT_ST_DOMAIN
+            st.value[b] = INFINITY;
+        }
+    }
+}
+
+void launch_rollout(const RolloutArgs &a, hipStream_t s) {
+    const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
+    if (ncand <= 0) return;
+    hipLaunchKernelGGL(rollout_kernel, dim3((ncand + 3) / 4), dim3(64), 0, s, a);
+}
+
+// =====================================================================================================
+// linearize_kernel: one wavefront per (trajectory, time step); writes the 417-double tile.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    const int N = st.N;
+    const int nchunk = (N + 1 + 3) / 4;
+    const int c = blockIdx.x / nchunk;
+    const int t = (blockIdx.x - c * nchunk) * 4 + w;
+    if (t > N) return;
+    int b, slot;
+    if (a.mode == 0) {
+        b = c;
+        if (st.status[b] != ST_RUNNING) return;
+        slot = b * (st.E + 1) + st.slot_nom[b];
+    } else {
+        b = c / st.E;
+        const int k = c - b * st.E;
+        if (!st.ls_active[b]) return;
+        slot = cand_slot(b, k, st.slot_nom[b], st.E);
+    }
+    const double *__restrict__ xp = st.xs + (long)slot * st.x_stride + (long)t * XSTR;
+    const double *__restrict__ up = st.us + (long)slot * st.u_stride + (long)t * USTR;
+    double *__restrict__ tp = st.tiles + (long)slot * st.tile_stride + (long)t * TSTRIDE;
+    int dom = 0;
+    if (t == N) {                                                    // terminal: h, h_x, h_xx   (ileqg.jl:314-316)
+        if (pb.model == 1) {
+            for (int e = l; e < 144; e += 64) tp[TT_Q + e] = pb.Qf[e];
+            double part = 0.0;
+            if (l < 12) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) acc += pb.Qf[l * 12 + q] * xp[q];
+                const double qv = acc + pb.qvf[l];
+                tp[TT_QV + l] = qv;
+                part = xp[l] * (0.5 * acc + pb.qvf[l]);
+            }
+            const double tot = wave_sum(part);
+            if (l == 0) tp[TT_q] = tot + pb.q0f;
+        } else {
+            for (int e = l; e < 144; e += 64) tp[TT_Q + e] = 0.0;
+            if (l < 12) tp[TT_QV + l] = 0.0;
+            if (l == 0) tp[TT_q] = pb.pl_h;
+        }
+        return;
+    }
+    const int kc = pb.cost_tv ? t : 0;
+    if (pb.model == 1) {
+        // f_x = A + diag(3 kappa x^2), f_u = B    (:303, :308)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = 64 * r + l, i = e >> 4;
+            double val = pb.Zt[e];
+            if (pb.kappa != 0.0 && (e & 15) == i) val += 3.0 * pb.kappa * (xp[i] * xp[i]);
+            tp[TS_Z + e] = val;
+        }
+        const double *__restrict__ C = pb.Ctab + (long)kc * 256;
+        for (int e = l; e < 144; e += 64) {                          // c_xx   (:298)
+            const int i = e / 12, jj = e - i * 12;
+            tp[TS_Q + e] = C[i * 16 + jj];
+        }
+        tp[TS_PR + l] = C[(12 + (l >> 4)) * 16 + j];                 // [c_ux | c_uu]   (:300-301)
+        double part = 0.0;
+        if (l < 16) {                                                // [c_x | c_u] = C [x;u] + [qv;rv]   (:297, :299)
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) acc += C[l * 16 + q] * xp[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += C[l * 16 + 12 + q] * up[q];
+            const double lin = pb.lin[(long)kc * 16 + l];
+            tp[TS_QR + l] = acc + lin;
+            const double xu = (l < 12) ? xp[l] : up[l - 12];
+            part = xu * (0.5 * acc + lin);
+        }
+        const double tot = wave_sum(part);
+        if (l == 0) tp[TS_q] = tot + pb.q0[kc];                      // c   (:296)
+    } else {
+        // power-law family: every derivative is diagonal
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = 64 * r + l, i = e >> 4, cc = e & 15;
+            double val = 0.0;
+            if (i < pb.n) {
+                if (cc == i) val = pb.pl_a * powchk(xp[i], pb.pl_a - 1.0, dom);
+                else if (cc == 12 + i) val = pb.pl_b * powchk(up[i], pb.pl_b - 1.0, dom);
+            }
+            tp[TS_Z + e] = val;
+        }
+        for (int e = l; e < 144; e += 64) {
+            const int i = e / 12, jj = e - i * 12;
+            double val = 0.0;
+            if (i == jj && i < pb.n) val = pb.pl_cx * pb.pl_p * (pb.pl_p - 1.0) * powchk(xp[i], pb.pl_p - 2.0, dom);
+            tp[TS_Q + e] = val;
+        }
+        {
+            const int gg = l >> 4;
+            double val = 0.0;
+            if (j == 12 + gg) val = (gg < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(up[gg], pb.pl_pu - 2.0, dom) : 1.0;
+            tp[TS_PR + l] = val;
+        }
+        double part = 0.0;
+        if (l < 16) {
+            double val = 0.0;
+            if (l < pb.n) {
+                val = pb.pl_cx * pb.pl_p * powchk(xp[l], pb.pl_p - 1.0, dom);
+                part = pb.pl_cx * powchk(xp[l], pb.pl_p, dom);
+            } else if (l >= 12 && l - 12 < pb.m) {
+                val = pb.pl_cu * pb.pl_pu * powchk(up[l - 12], pb.pl_pu - 1.0, dom);
+                part = pb.pl_cu * powchk(up[l - 12], pb.pl_pu, dom);
+            }
+            tp[TS_QR + l] = val;
+        }
+        const double tot = wave_sum(part);
+        if (l == 0) tp[TS_q] = tot;
+    }
+    if (__ballot(dom != 0) != 0ull && l == 0) {
+        if (a.mode == 0) { st.status[b] = 4; st.value[b] = INFINITY; }
+        else st.flag_c[c] = 2;
+    }
+}
+
+void launch_linearize(const LinArgs &a, hipStream_t s) {
+    const int ntraj = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
+    if (ntraj <= 0) return;
+    const int nchunk = (a.st.N + 1 + 3) / 4;
+    hipLaunchKernelGGL(linearize_kernel, dim3(ntraj * nchunk), dim3(256), 0, s, a);
+}
+
+// =====================================================================================================
+// per-sample control flow (one thread per sample)
+// =====================================================================================================
+__global__ void init_state_kernel(StateDev st, OptsDev op, const double *theta_in) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    st.theta[b] = theta_in[b];
+    st.mu[b] = 0.0;                       // initialize! sets mu = 0.0, Delta = Delta_0   (ileqg.jl:216)
+    st.delta[b] = op.delta_0;
+    st.value[b] = INFINITY;
+    st.d_cur[b] = INFINITY;               // :217
+    st.eps_init[b] = op.eps_init;         // :219
+    st.ls_eps[b] = op.eps_init;
+    st.status[b] = ST_RUNNING;
+    st.iter[b] = 0;                       // :218
+    st.ls_active[b] = 0;
+    st.ls_count[b] = 0;
+    st.slot_nom[b] = 0;
+    st.n_ls[b] = 0;
+    st.hist_n[b] = 0;
+    if (b == 0) { st.counters[0] = 0; st.counters[1] = 0; }
+}
+
+// start of step! for every running sample (ileqg.jl:598-613): iter += 1, line search starts at eps_init (:502)
+__global__ void ls_begin_kernel(StateDev st) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    if (st.status[b] != ST_RUNNING) { st.ls_active[b] = 0; return; }
+    st.iter[b] += 1;
+    st.ls_eps[b] = st.eps_init[b];
+    st.ls_count[b] = 0;
+    st.ls_active[b] = 1;
+}
+
+// Replays the sequential rule of line_search! (ileqg.jl:504-581) over the E speculatively evaluated
+// candidates of each sample, then the convergence test of solve! (:642-653).
+__global__ void ls_select_kernel(StateDev st, OptsDev op) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    if (!st.ls_active[b]) {
+        return;
+    }
+    double eps = st.ls_eps[b];
+    const double cur = st.value[b];
+    int count = st.ls_count[b];
+    int chosen = -1;
+    bool failed = false;
+    for (int k = 0; k < st.E; ++k) {
+        const int c = b * st.E + k;
+        count++;                                               // :505
+        const int fl = st.flag_c[c];
+        if (fl == 2) { failed = true; break; }                 // exception outside the try (App. B.8)
+        if (fl == 1) { eps *= op.lambda; continue; }           // :529-535
+        const double nv = st.value_c[c];
+        if (st.hist) {
+            const int hn = st.hist_n[b];
+            if (hn < st.hist_cap) {
+                st.hist[((long)b * st.hist_cap + hn) * 2] = eps;
+                st.hist[((long)b * st.hist_cap + hn) * 2 + 1] = nv - cur;          // :537
+            }
+            st.hist_n[b] = hn + 1;
+        }
+        if (isapprox_default(nv, cur) || nv < cur) { chosen = k; break; }           // :538
+        eps *= op.lambda;                                      // :557
+        if (eps < op.eps_min) { chosen = k; break; }           // :558 forced accept of the candidate just evaluated
+    }
+    st.n_ls[b] += (chosen >= 0 || failed) ? (count - st.ls_count[b]) : st.E;
+    if (failed) {
+        st.status[b] = 4; st.value[b] = INFINITY; st.ls_active[b] = 0;
+        return;
+    }
+    if (chosen < 0) {
+        if (count > 4000) { st.status[b] = 7; st.value[b] = INFINITY; st.ls_active[b] = 0; return; }
+        st.ls_eps[b] = eps;
+        st.ls_count[b] = count;
+        atomicAdd(&st.counters[0], 1);
+        atomicAdd(&st.counters[1], 1);
+        return;
+    }
+    // accept (:539-555 / :559-575)
+    const int c = b * st.E + chosen;
+    const int nom = st.slot_nom[b];
+    st.d_cur[b] = st.d_c[c];
+    st.value[b] = st.value_c[c];
+    st.slot_nom[b] = (chosen < nom) ? chosen : chosen + 1;     // x_array, l_array (and their tiles) <- candidate
+    st.ls_active[b] = 0;
+    if (op.adaptive) {                                         // :582-591
+        if (count == 1) st.eps_init[b] = fmin(op.eps_init, eps / op.lambda);
+        else {
+            while (eps < op.eps_min) eps = eps / op.lambda;
+            st.eps_init[b] = eps;
+        }
+    }
+    if (op.d > st.d_cur[b] && st.mu[b] <= op.mu_min) st.status[b] = 0;              // converged  (:642)
+    else if (st.iter[b] == op.iter_max) st.status[b] = 3;                           // iter_max   (:648)
+    else atomicAdd(&st.counters[1], 1);
+}
+
+void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s) {
+    hipLaunchKernelGGL(init_state_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, op, theta_dev);
+}
+void launch_ls_begin(const StateDev &st, hipStream_t s) {
+    hipLaunchKernelGGL(ls_begin_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st);
+}
+void launch_ls_select(const StateDev &st, const OptsDev &op, hipStream_t s) {
+    hipLaunchKernelGGL(ls_select_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, op);
+}
+
+// count samples still running after the init sweep (solve! enters its loop only for those)
+__global__ void count_running_kernel(StateDev st) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    if (st.status[b] == ST_RUNNING) atomicAdd(&st.counters[1], 1);
+}
+void launch_count_running(const StateDev &st, hipStream_t s) {
+    hipLaunchKernelGGL(count_running_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st);
+}
+
+// gather the outputs of a batch: value (Inf for failures), status, iters, ls_evals
+__global__ void gather_kernel(StateDev st, double *value, int *status, int *iters, int *ls_evals) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    const int s = st.status[b];
+    if (value) value[b] = (s == 0 || s == 3) ? st.value[b] : INFINITY;
+    if (status) status[b] = s;
+    if (iters) iters[b] = st.iter[b];
+    if (ls_evals) ls_evals[b] = st.n_ls[b];
+}
+void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, hipStream_t s) {
+    hipLaunchKernelGGL(gather_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, value, status, iters, ls_evals);
+}

@@ -1,0 +1,89 @@
+// layout.h -- HBM data layout shared by the HIP kernels and the host driver.
+//
+// The kernels are specialised for the padded size NP = 12 states, MP = 4 controls (n <= 12, m <= 4):
+// NP + MP = 16 is exactly the edge of one v_mfma_f64_16x16x4_f64 tile, so [A|B] is a 12x16 operand and
+// the Q-function Hessian [[Q,P'],[P,R]] is one 16x16 accumulator.  Smaller problems are embedded with
+// zero padding (identity on the padded diagonals of W^-1 and R, which leaves every result unchanged).
+//
+// Tile bundle of one trajectory (what approximate_model, ileqg.jl:258-322, produces), doubles:
+//   step t = 0..N-1, stride TSTRIDE = 417 = n^2 + nm + n^2 + m^2 + mn + n + m + 1 at n=12, m=4:
+//     [TS_Z  .. +192)  Z  = [A | B]   12 x 16 row-major        (f_x | f_u)
+//     [TS_Q  .. +144)  Q  = c_xx      12 x 12 row-major (symmetric)
+//     [TS_PR .. + 64)  PR = [P | R]    4 x 16 row-major        (c_ux | c_uu)
+//     [TS_QR .. + 16)  qr = [q_vec | r]                        (c_x | c_u)
+//     [TS_q]           q  = c
+//   terminal block at N*TSTRIDE: Qf 12x12 row-major (144), q_vec (12), q (1)  -> TTERM = 157
+//   total = N*417 + 157 doubles = 21,007 doubles = 168,056 B at N = 50.
+// Row-major 16-wide blocks make every MFMA operand / accumulator register one coalesced 512-B load:
+// lane l of a wave reads element 64*r + l of the block into register r.
+#pragma once
+
+#define RAT_NP 12
+#define RAT_MP 4
+#define RAT_PD 16
+#define RAT_AUG 12          /* index of the homogeneous coordinate in the augmented value matrix */
+
+#define TS_Z   0
+#define TS_Q   192
+#define TS_PR  336
+#define TS_QR  400
+#define TS_q   416
+#define TSTRIDE 417
+#define TT_Q   0
+#define TT_QV  144
+#define TT_q   156
+#define TTERM  157
+
+#define XSTR 12             /* doubles per time step of a state history   */
+#define USTR 4              /* doubles per time step of a control history */
+#define LSTR 48             /* doubles per time step of a gain history: L_t as 4 x 12 row-major */
+
+#define DUMP_S   0          /* per-step debug dump (rat_dp_* operators): S 12x12 row-major */
+#define DUMP_SV  144
+#define DUMP_s   156
+#define DUMP_g   157
+#define DUMP_G   161        /* 4 x 12 row-major */
+#define DUMP_H   209        /* 4 x 4 row-major  */
+#define DUMP_STRIDE 225
+
+#define ST_RUNNING (-1)
+
+struct ProblemDev {
+    int model, n, m, N, cost_tv, W_tv;
+    const double *Zt;    // [192]      [A|B] 12x16 row-major, zero padded
+    const double *Ctab;  // [Nc][256]  [[Q,P'],[P,R]] 16x16 row-major, padded R diagonal = 1
+    const double *lin;   // [Nc][16]   [qv | rv]
+    const double *q0;    // [Nc]
+    const double *Qf;    // [144]      12x12 row-major
+    const double *qvf;   // [16]
+    double q0f, kappa;
+    double pl_a, pl_b, pl_p, pl_pu, pl_cx, pl_cu, pl_h;
+    const double *Winv;  // [Nw][192]  inv(W(k)) 12x16 row-major, padded diagonal = 1
+    const double *Wp;    // [Nw][192]  W(k), zero padded
+    const double *epiv;  // [Nw][16]   elimination pivots of the padded inv(W(k)) (logdet pairing)
+    const double *logdetW; // [Nw]
+};
+
+// All per-sample / per-slot device state of one handle.
+struct StateDev {
+    int B, E, N;
+    long tile_stride, x_stride, u_stride;      // doubles per slot
+    double *tiles, *xs, *us;                   // slot pools: B*(E+1) slots
+    double *L, *dl;                            // [B][N*48], [B][N*4]
+    double *theta, *mu, *delta, *value, *d_cur, *eps_init, *ls_eps;
+    int *status, *iter, *ls_active, *ls_count, *slot_nom, *n_ls, *hist_n;
+    double *value_c, *d_c;                     // [B*E]
+    int *flag_c;                               // [B*E] 0 ok, 1 DP failed (M not PD), 2 domain failure
+    double *hist; int hist_cap;                // [B][2*hist_cap] or null
+    int *counters;                             // [0] samples still in line search, [1] samples running
+};
+
+struct OptsDev {
+    double mu_min, delta_0, lambda, d, eps_init, eps_min;
+    int iter_max, adaptive;
+};
+
+__host__ __device__ inline int cand_slot(int b, int k, int nom, int E) {
+    int s = (k < nom) ? k : k + 1;
+    return b * (E + 1) + s;
+}
