@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- iLEQG solves/sec (N=50, n=12, m=4) at CE batch = 1024 per GPU.
+
+A "step" is one compute_cost-equivalent pass (cross_entropy_bilevel_optimization.jl:173-195) over a CE batch of
+1024 theta-samples on every rank: 1024 complete iLEQG solves (initialize! + iterations with line search) on the
+synthetic LQ-plus-noise problem of SURVEY.md section 8(d), followed -- when N > 1 -- by the all-gather of the
+per-sample costs (RCCL).  theta, x0, u0 and the problem tables are resident in HBM before the timed region.
+Weak scaling: every rank owns its own 1024-sample CE batch; value = N * 1024 * K / max-over-ranks time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--spec-eps E] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def draw_theta(B, seed):
+    """Positive samples of N(1, 2) -- the CE solver's first-iteration distribution (mu_init=1, sigma_init=2)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < B:
+        z = 1.0 + 2.0 * rng.standard_normal(B)
+        out.extend(z[z > 0.0].tolist())
+    return np.array(out[:B])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--spec-eps", type=int, default=1, help="E speculative line-search step sizes per sample")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import ratilqr.jl_amd as rat
+
+    B, E, K, W = args.batch, args.spec_eps, args.steps, args.warmup
+    prob, x0, u0 = rat.synthetic_lq_problem(n=12, m=4, N=50, seed=0)
+    ctx = rat.Context(prob, max_batch=B, spec_eps=E, device=local_rank)
+    ctx.set_initial(x0, u0)
+    kl_bound = 0.1
+    theta_h = draw_theta(B, seed=1000 + rank)
+    theta = torch.as_tensor(theta_h, dtype=torch.float64, device=dev)
+    value = torch.empty(B, dtype=torch.float64, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+    ls = torch.empty(B, dtype=torch.int32, device=dev)
+    cost_all = torch.empty(world * B, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.solve_batch_dev(theta.data_ptr(), B, value.data_ptr(), status.data_ptr(), iters.data_ptr(), ls.data_ptr())
+        cost = value + kl_bound / theta                       # cost = value + kl/theta  (:193)
+        if world > 1:
+            dist.all_gather_into_tensor(cost_all, cost)       # per-sample costs to every rank (RCCL)
+        else:
+            cost_all.copy_(cost)
+
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    ctx.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st_h, it_h, ls_h = status.cpu().numpy(), iters.cpu().numpy(), ls.cpu().numpy()
+    feasible = float(np.mean((st_h == 0) | (st_h == 3)))
+
+    if rank == 0:
+        lay = ctx.layout_info()
+        # algorithmic bytes of the dominant kernel (policy-evaluation sweep of line-search candidates):
+        # tile bundle + gains read, one value written -- SURVEY.md section 8(d): 187.3 KB per candidate.
+        bytes_per_traj = lay["tile_bytes"] + lay["L_bytes"] + 8
+        pe = prof["sweep_eval"]
+        avg_ms = pe["ms"] / max(pe["launches"], 1)
+        traj_per_launch = pe["trajectories"] / max(pe["launches"], 1)
+        achieved = bytes_per_traj * traj_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"sweep_eval_E{E}_B{B}", None)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "iLEQG solves/sec (N=50, n=12, m=4) at CE batch=1024",
+            "value": world * B * K / elapsed,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "batched iLEQG solves of one CE batch (compute_cost): synthetic LQ-plus-noise, N=50, n=12, m=4, "
+                            "W=1e-3 I, theta ~ N(1,2)>0, kl=0.1, iLEQG defaults",
+                "ce_batch_per_gpu": B, "global_batch": world * B, "spec_eps": E,
+                "parallelism": f"theta-shards x{world}, cost all-gather" if world > 1 else "single GPU",
+                "feasible_fraction": feasible, "mean_iters": float(it_h.mean()), "mean_ls_evals": float(ls_h.mean()),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "sweep_kernel<eval> (policy-evaluation Riccati sweep of line-search candidates)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_trajectory": bytes_per_traj, "trajectories_per_launch": traj_per_launch,
+                "avg_launch_ms": avg_ms, "launches": pe["launches"],
+            },
+            "kernel_ms_per_step": {k: v["ms"] / K for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu:
+            from oracle import oracle as orc
+
+            P = orc.Problem(prob)
+            cores = os.cpu_count() or 1
+            n_done, t_cpu = 0, 0.0
+            chunk = max(64, 32 * cores)
+            while t_cpu < args.cpu_seconds:
+                th = draw_theta(chunk, seed=77 + n_done)
+                t1 = time.perf_counter()
+                orc.compute_value_batch(P, x0, u0, th, nthreads=cores)
+                t_cpu += time.perf_counter() - t1
+                n_done += chunk
+            out["cpu_baseline"] = {
+                "value": n_done / t_cpu, "unit": "solves/s", "cores": cores, "kind": "port",
+                "sample": f"{n_done} solves of the same workload (theta ~ N(1,2)>0) by the C oracle, OpenMP one sample per "
+                          f"thread on {cores} threads, {t_cpu:.1f} s; the Julia reference is not runnable (no julia binary)",
+            }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,7 +214,8 @@ rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0, const doub
 #define RAT_K_SWEEP_EVAL 2
 #define RAT_K_SWEEP_GAIN 3
 #define RAT_K_SELECT    4
-#define RAT_K_COUNT     5
+#define RAT_K_SWEEP_INIT 5   /* open-loop policy evaluation of initialize! (no gains read) */
+#define RAT_K_COUNT     6
 /* When enabled, every kernel launch is bracketed by HIP events on the handle's stream. */
 rat_rc rat_profile_enable(rat_handle h, int32_t on);
 rat_rc rat_profile_reset(rat_handle h);

@@ -390,7 +390,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
     LinArgs la; la.st = st; la.pb = h->pb; la.mode = 0;
     prof_begin(h, RAT_K_ROLLOUT, B); launch_rollout(ra, h->stream); prof_end(h);
     prof_begin(h, RAT_K_LINEARIZE, B); launch_linearize(la, h->stream); prof_end(h);
-    prof_begin(h, RAT_K_SWEEP_EVAL, B); launch_sweep(sweep_args(h, st, 2), B, false, false, h->stream); prof_end(h);
+    prof_begin(h, RAT_K_SWEEP_INIT, B); launch_sweep(sweep_args(h, st, 2), B, false, false, h->stream); prof_end(h);
     HIPCHK(hipMemsetAsync(st.counters, 0, 2 * sizeof(int), h->stream));
     launch_count_running(st, h->stream);
     int more = 0, running = 0;

@@ -151,9 +151,10 @@ class Context:
         nv.check(nv.lib().rat_profile_reset(self.h))
 
     def profile_get(self):
-        la = (C.c_int64 * 5)(); tr = (C.c_int64 * 5)(); ms = (C.c_double * 5)()
+        nk = len(nv.K_NAMES)
+        la = (C.c_int64 * nk)(); tr = (C.c_int64 * nk)(); ms = (C.c_double * nk)()
         nv.check(nv.lib().rat_profile_get(self.h, la, tr, ms))
-        return {nv.K_NAMES[k]: dict(launches=la[k], trajectories=tr[k], ms=ms[k]) for k in range(5)}
+        return {nv.K_NAMES[k]: dict(launches=la[k], trajectories=tr[k], ms=ms[k]) for k in range(nk)}
 
     def layout_info(self):
         v = [C.c_int64() for _ in range(4)]

@@ -1,0 +1,109 @@
+"""CPU-side checks of the product library: it loads without a GPU, exports exactly what include/ratilqr.h
+declares, validates options like the reference's @asserts, refuses to compute without a device (no CPU
+fallback), and its host-side CE bookkeeping (rat_ce_draw_stream / rat_ce_update) replays the oracle's
+step! decisions when fed the same costs."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ratilqr.jl_amd as rat
+from ratilqr.jl_amd import _native as nv
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_GPU = torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ratilqr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rat_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = nv.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ratilqr.h but not exported"
+    assert declared == set(nv.EXPORTS)
+    assert lib.rat_version() == 100
+
+
+def test_defaults_match_reference_constructor():                    # ileqg.jl:191-194, ce.jl:100-116
+    o = nv.IleqgOpts()
+    nv.lib().rat_default_ileqg_opts(C.byref(o))
+    assert (o.mu_min, o.delta_0, o.lam, o.d, o.iter_max, o.eps_init, o.eps_min, o.adaptive_eps_init) == \
+           (1e-6, 2.0, 0.5, 1e-2, 100, 1.0, 1e-6, 0)
+    c = nv.CeSolver()
+    nv.lib().rat_ce_default(C.byref(c))
+    assert (c.num_samples, c.num_elite, c.iter_max, c.lam, c.mu_init, c.sigma_init) == (10, 3, 5, 0.5, 1.0, 2.0)
+    assert c.theta_max == 0.0 and np.isinf(c.theta_min)
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_fallback():
+    prob, x0, u = rat.synthetic_lq_problem()
+    with pytest.raises(rat.RatError):
+        rat.Context(prob)
+
+
+def test_option_asserts_on_host():                                  # ileqg.jl:195-201
+    for bad in (dict(lam=0.0), dict(d=-1.0), dict(mu_min=0.0), dict(Delta_0=-2.0), dict(eps_init=0.0),
+                dict(eps_init=0.5, eps_min=0.6), dict(eps_min=0.0)):
+        with pytest.raises(AssertionError):
+            rat.ileqg.make_opts(**bad)
+
+
+def test_problem_tables_are_column_major():
+    prob, _, _ = rat.synthetic_lq_problem(n=3, m=2, N=4, seed=2)
+    t = prob.c_tables()
+    assert np.array_equal(t["A"].reshape(3, 3).T, prob.A) and np.array_equal(t["B"].reshape(2, 3).T, prob.B)
+    d, keep = nv.make_desc(prob)
+    assert (d.n, d.m, d.N, d.model) == (3, 2, 4, 1)
+
+
+def test_ce_host_bookkeeping_replays_oracle_step():
+    """rat_ce_begin_step / rat_ce_draw_stream / rat_ce_update (pure host code in the .so) against orc_ce_step."""
+    L = nv.lib()
+    prob, x0, u = rat.synthetic_lq_problem(n=4, m=2, N=20, seed=1)
+    P = orc.Problem(prob)
+    z = np.random.default_rng(3).standard_normal(20000)
+    for kw in (dict(num_samples=16, num_elite=4), dict(num_samples=16, num_elite=4, mu_init=30.0, sigma_init=8.0)):
+        oc = orc.CrossEntropyBilevelOptimizationSolver(z, nthreads=4, **kw)
+        oc.initialize()
+        c = nv.CeSolver()
+        L.rat_ce_default(C.byref(c))
+        c.num_samples, c.num_elite = kw["num_samples"], kw["num_elite"]
+        c.mu_init, c.sigma_init = kw.get("mu_init", 1.0), kw.get("sigma_init", 2.0)
+        L.rat_ce_initialize(C.byref(c))
+        zpos = C.c_int64(0)
+        for it in range(3):
+            rc, tho, costo = oc.step(P, x0, u, 0.1)
+            assert rc == 0
+            nv.check(L.rat_ce_begin_step(C.byref(c)))
+            theta = np.zeros(c.num_samples)
+            while True:
+                nv.check(L.rat_ce_draw_stream(C.byref(c), nv.P(z), C.c_int64(z.size), C.byref(zpos), nv.P(theta)))
+                val, _, _, _ = orc.compute_value_batch(P, x0, u, theta, nthreads=4)
+                cost = val + 0.1 / theta
+                redraw = C.c_int32()
+                nv.check(L.rat_ce_update(C.byref(c), nv.P(theta), nv.P(cost), C.byref(redraw)))
+                if not redraw.value:
+                    break
+            assert np.array_equal(theta, tho) and zpos.value == oc.c.zpos
+            assert c.mu == oc.c.mu and c.sigma == oc.c.sigma
+            assert c.mu_init == oc.c.mu_init and c.sigma_init == oc.c.sigma_init
+            assert c.theta_min == oc.c.theta_min and c.theta_max == oc.c.theta_max and c.iter_current == oc.c.iter_current
+
+
+def test_stream_exhaustion_is_an_error():
+    L = nv.lib()
+    c = nv.CeSolver()
+    L.rat_ce_default(C.byref(c))
+    L.rat_ce_begin_step(C.byref(c))
+    z = -np.ones(50)
+    th = np.zeros(10)
+    zp = C.c_int64(0)
+    rc = L.rat_ce_draw_stream(C.byref(c), nv.P(z), C.c_int64(z.size), C.byref(zp), nv.P(th))
+    assert rc == 5 and b"exhausted" in L.rat_last_error()

@@ -1,0 +1,84 @@
+"""world_size-2 gloo test of the theta-sharding layer (ratilqr.jl_amd.distributed): contiguous shards,
+one all-gather of per-sample costs, replicated elite selection.  The cost evaluator is injected: on the
+GPU box it is Context.solve_batch_dev (tests/test_gpu_distributed.py); here (CPU, no GPU) the oracle stands
+in as the evaluator so that the sharding / gather / CE bookkeeping logic itself is what is under test."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ratilqr.jl_amd as rat
+from ratilqr.jl_amd import distributed as rd
+from oracle import oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    return rat.synthetic_lq_problem(n=4, m=2, N=20, seed=1)
+
+
+def _worker(rank, world, port, B, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob, x0, u = _problem()
+    P = orc.Problem(prob)
+    calls = []
+
+    def evaluate(th):
+        calls.append(th.numel())
+        v, _, _, _ = orc.compute_value_batch(P, x0, u, th.numpy(), nthreads=1)
+        return torch.as_tensor(v, dtype=torch.float64)
+
+    def final(theta):
+        s = orc.ILEQGSolver(P)
+        rc = s.solve(x0, u, theta)
+        return rc in (0, 3), s.x_array, s.l_array, s.L_array, s.s.value_current
+
+    z = np.random.default_rng(99).standard_normal(20000)
+    solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=B, num_elite=4)
+    res = rd.solve_sharded(solver, 0.1, z, evaluate, final)
+    lo, hi = rd.shard_bounds(B, world, rank)
+    assert all(c == hi - lo for c in calls)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([res[0], res[4], res[5], res[6], solver.c.mu, solver.c.sigma,
+                                                             solver.c.mu_init, solver.c.n_solves]))
+    dist.destroy_process_group()
+
+
+def _run(world, B, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    return [np.load(os.path.join(str(tmp_path), f"r{r}.npy")) for r in range(world)]
+
+
+def test_shard_bounds_cover_everything():
+    for B in (1, 7, 13, 1024):
+        for G in (1, 2, 3, 8):
+            spans = [rd.shard_bounds(B, G, r) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_ce_matches_single_process_oracle(tmp_path):
+    B = 13                                   # ragged: 7 + 6
+    got = _run(2, B, tmp_path)
+    assert np.array_equal(got[0], got[1])    # replicated decisions: every rank ends with identical state
+    prob, x0, u = _problem()
+    z = np.random.default_rng(99).standard_normal(20000)
+    oc = orc.CrossEntropyBilevelOptimizationSolver(z, num_samples=B, num_elite=4)
+    rc, th, x, l, L, val, tmin, tmax = oc.solve(orc.Problem(prob), x0, u, 0.1)
+    assert rc == 0
+    ref = np.array([th, val, tmin, tmax, oc.c.mu, oc.c.sigma, oc.c.mu_init, oc.c.n_solves])
+    assert np.array_equal(got[0], ref)       # same evaluator, same stream -> bitwise the same CE trajectory

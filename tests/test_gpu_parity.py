@@ -1,0 +1,262 @@
+"""GPU parity of the batched iLEQG hot path against the CPU oracle and the committed golden vectors.
+
+Tolerances: values 1e-9 relative, trajectories/gains 1e-9*(1+|.|inf) absolute, identical
+status / iteration count / line-search count, identical results for every speculation width E."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ratilqr.jl_amd as rat
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
+VT = 1e-9
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def check_batch(ctx, P, x0, u, theta, **opts):
+    vo, so, io, lo = orc.compute_value_batch(P, x0, u, theta, nthreads=8, **opts)
+    vg, sg, ig, lg = ctx.solve_batch(x0, u, theta)
+    assert np.array_equal(sg, so), (sg, so)
+    assert np.array_equal(ig, io) and np.array_equal(lg, lo), (ig, io, lg, lo)
+    fin = np.isfinite(vo)
+    assert np.array_equal(fin, np.isfinite(vg))
+    assert np.all(np.isposinf(vg[~fin]))
+    if fin.any():
+        assert np.all(np.abs(vg[fin] - vo[fin]) <= VT * np.abs(vo[fin]))
+    return vg, sg, ig, lg
+
+
+def test_config2_golden_256_thetas():
+    """BASELINE config 2: 256 theta = linspace(0.01, 0.8 theta_max), N=50, n=12, m=4, one compute_cost batch."""
+    g = GOLD["config2"]
+    prob, x0, u = rat.synthetic_lq_problem()
+    ctx = rat.Context(prob, max_batch=256, spec_eps=1)
+    v, st, it, ls = ctx.solve_batch(x0, u, np.array(g["theta"]))
+    assert np.array_equal(st, g["status"]) and np.array_equal(it, g["iters"]) and np.array_equal(ls, g["ls"])
+    assert np.all(np.abs(v - np.array(g["value"])) <= VT * np.abs(g["value"]))
+    assert np.all(np.diff(v) > 0)                  # value is increasing in theta on this problem
+    # edges: theta = 0 (iLQG branch), just below / above the breakdown theta of initialize!
+    e = GOLD["config2_edge"]
+    v, st, _, _ = ctx.solve_batch(x0, u, np.array(e["theta"]))
+    assert np.array_equal(st, e["status"])
+    for a, b in zip(v, e["value"]):
+        assert (b is None and np.isposinf(a)) or abs(a - b) <= VT * abs(b)
+
+
+def test_first_gain_sweep_policy_against_oracle():
+    """config 2: L, dl of the first gain sweep and the converged policy of single solves."""
+    prob, x0, u = rat.synthetic_lq_problem()
+    P = orc.Problem(prob)
+    ctx = rat.Context(prob)
+    for theta in (0.0, 0.3, 6.0, 10.0):
+        so = orc.ILEQGSolver(P)
+        assert so.solve(x0, u, theta) == 0
+        r = ctx.solve(x0, u, theta)
+        assert r["status"] == 0 and r["iters"] == so.s.iter_current and r["hist_n"] == so.s.n_hist
+        assert abs(r["value"] - so.s.value_current) <= VT * abs(so.s.value_current)
+        for k, ref in (("x", so.x_array), ("l", so.l_array), ("L", so.L_array)):
+            assert np.abs(r[k] - ref).max() <= VT * (1 + np.abs(ref).max())
+        assert np.array_equal(r["eps_history"][:, 0], so.eps_history[:, 0])
+
+
+@pytest.mark.parametrize("E", [1, 2, 4, 8])
+def test_speculation_width_does_not_change_results(E):
+    """App. B.17: evaluating E step sizes at once and replaying the sequential rule is result-identical."""
+    prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
+    P = orc.Problem(prob)
+    theta = np.array([0.0, 1.0, 2.0, 4.0, 5.0, 5.9, 6.3, 6.6, 9.0])
+    ctx = rat.Context(prob, max_batch=theta.size, spec_eps=E)
+    vg, sg, ig, lg = check_batch(ctx, P, x0, u, theta)
+    g = GOLD["cubic_backtracking"]
+    sel = [0, 2, 4]
+    assert np.all(np.abs(vg[sel] - np.array(g["value"])[[0, 1, 2]]) <= VT * np.abs(np.array(g["value"])[[0, 1, 2]]))
+    assert lg[4] == 6 and ig[4] == 4           # theta = 5: eps = 1, 1, 1, 1, 1/2, 1/4
+
+
+def test_batch_composition_independence():
+    """App. B.16: a sample's result must not depend on what else is in the batch (fresh solver per sample)."""
+    prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
+    theta = np.array([0.0, 3.0, 5.0, 6.2, 30.0, 1.0, 6.45])
+    ctx = rat.Context(prob, max_batch=theta.size, spec_eps=4)
+    v_all, s_all, i_all, l_all = ctx.solve_batch(x0, u, theta)
+    perm = np.random.default_rng(0).permutation(theta.size)
+    v_p, s_p, i_p, l_p = ctx.solve_batch(x0, u, theta[perm])
+    assert np.array_equal(v_all[perm], v_p) and np.array_equal(s_all[perm], s_p) and np.array_equal(l_all[perm], l_p)
+    for k in range(theta.size):
+        v1, s1, i1, l1 = ctx.solve_batch(x0, u, theta[k:k + 1])
+        assert (v1[0] == v_all[k] or (np.isinf(v1[0]) and np.isinf(v_all[k]))) and s1[0] == s_all[k] and i1[0] == i_all[k]
+
+
+def test_config1_small_problems_golden():
+    """BASELINE config 1: N=20, n=4, m=2 LQ plumbing instance (padded into the 12/4 kernels)."""
+    g = GOLD["config1_n4"]
+    prob, x0, u = rat.synthetic_lq_problem(n=4, m=2, N=20, seed=1)
+    ctx = rat.Context(prob, max_batch=4, spec_eps=2)
+    v, st, it, ls = ctx.solve_batch(x0, u, np.array(g["theta"]))
+    assert np.array_equal(st, g["status"]) and np.array_equal(it, g["iters"])
+    for a, b in zip(v, g["value"]):
+        assert (b is None and np.isposinf(a)) or abs(a - b) <= VT * abs(b)
+    r = ctx.solve(x0, u, 0.5)
+    assert rel(r["L"][0], g["L0"]) < VT and rel(r["x"][-1], g["x_end"]) < 1e-8
+
+
+def test_nonlinear_powerlaw_golden():
+    g = GOLD["nonlinear_test"]
+    prob = rat.PowerLawRiskSensitiveProblem(2, 10, 0.01 * np.eye(2))
+    ctx = rat.Context(prob, max_batch=5, spec_eps=3)
+    theta = np.array([0.0, 0.1, 0.3, 0.43, 0.5])
+    v, st, it, ls = ctx.solve_batch(np.zeros(2), 0.1 * np.ones((10, 2)), theta)
+    for k, th in enumerate(theta):
+        e = g[repr(float(th))]
+        assert st[k] == e["rc"] and it[k] == e["iters"] and ls[k] == e["ls"] and abs(v[k] - e["value"]) <= VT * e["value"]
+
+
+def test_domain_error_maps_to_status_and_inf():
+    """x < 0 with a fractional exponent throws DomainError in the reference -> status 4, value Inf."""
+    prob = rat.PowerLawRiskSensitiveProblem(2, 10, 0.01 * np.eye(2))
+    P = orc.Problem(prob)
+    ctx = rat.Context(prob, max_batch=2)
+    x0, u = np.array([-0.2, 0.1]), 0.1 * np.ones((10, 2))
+    vo, so, _, _ = orc.compute_value_batch(P, x0, u, [0.0, 0.3])
+    vg, sg, _, _ = ctx.solve_batch(x0, u, np.array([0.0, 0.3]))
+    assert np.array_equal(so, sg) and np.all(sg == 4) and np.all(np.isposinf(vg))
+
+
+def stress_problem(seed, kappa=0.03, qs=-0.2, rw=0.1):
+    rng = np.random.default_rng(seed)
+    n, m, N = 12, 4, 50
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A, B, x0 = 0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), rng.standard_normal(n)
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=qs * np.eye(n), R=rw * np.eye(m), N=N, W=1e-3 * np.eye(n), Qf=np.eye(n), kappa=kappa)
+    return prob, x0, np.zeros((N, m))
+
+
+@pytest.mark.parametrize("seed,kappa", [(1, 0.0), (2, 0.0)])
+def test_mu_regularisation_restarts_and_iter_max(seed, kappa):
+    """Indefinite stage cost: H not PD -> increase_mu_and_delta!, sweep restarts (ileqg.jl:372-378); mu then stays
+    above mu_min so the solve runs to iter_max.  Same decisions as the oracle."""
+    prob, x0, u = stress_problem(seed, kappa)
+    P = orc.Problem(prob)
+    ctx = rat.Context(prob, rat.ileqg.make_opts(iter_max=8), max_batch=3, spec_eps=2)
+    vg, sg, ig, lg = check_batch(ctx, P, x0, u, np.array([0.0, 1.0, 4.0]), iter_max=8)
+    assert np.all(sg == 3) and np.all(ig == 8)
+    # operator form reports the regularisation it ended with
+    xs = ctx.rollout_open(x0, u)
+    ap = ctx.approximate_model(u, xs)
+    _, ap_o = orc.approximate_model(P, u, xs)
+    st, L, dl, dp, mu, delta = ctx.dp_gain_sweep(ap, 1.0, 0.0, 2.0)
+    rc, Lo, dlo, dpo, muo, deo = orc.dp_gain(P, ap_o, 1.0)
+    assert st == 0 and rc == 0 and mu == muo and delta == deo and mu > 1e-6
+    assert rel(L, Lo) < 1e-9 and rel(dl, dlo) < 1e-9 and rel(dp.s_array, dpo["s"]) < 1e-9
+
+
+def test_time_varying_cost_and_noise_tables():
+    """c(k, x, u) and W(k) depend on k (docs example: c = k/2 x'x + k/2 u'u, optimal_control_problems.jl:50-55)."""
+    rng = np.random.default_rng(11)
+    n, m, N = 6, 3, 25
+    A = 0.95 * np.linalg.qr(rng.standard_normal((n, n)))[0]
+    B = rng.standard_normal((n, m)) / np.sqrt(n)
+    k = np.arange(N, dtype=float)[:, None, None]
+    Q = (0.5 + 0.1 * k) * np.eye(n)
+    R = (0.2 + 0.05 * k) * np.eye(m)
+    Pm = 0.05 * rng.standard_normal((N, m, n))
+    Wk = np.stack([(1e-3 * (1 + 0.5 * np.sin(t))) * np.eye(n) + 1e-4 * np.outer(v, v)
+                   for t, v in zip(range(N), rng.standard_normal((N, n)))])
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=Q, R=R, P=Pm, qv=0.1 * rng.standard_normal((N, n)), rv=0.1 * rng.standard_normal((N, m)),
+                                      q0=k.ravel(), N=N, W=Wk, Qf=2 * np.eye(n), qvf=0.3 * rng.standard_normal(n), q0f=1.5)
+    x0, u = rng.standard_normal(n), 0.1 * rng.standard_normal((N, m))
+    P = orc.Problem(prob)
+    ctx = rat.Context(prob, max_batch=6, spec_eps=2)
+    check_batch(ctx, P, x0, u, np.array([0.0, 0.5, 2.0, 5.0, 20.0, 200.0]))
+    # operator-level parity on the same problem
+    _, xo = orc.simulate_open(P, x0, u)
+    assert rel(ctx.rollout_open(x0, u), xo) < 1e-12
+    ap = ctx.approximate_model(u, xo)
+    _, ap_o = orc.approximate_model(P, u, xo)
+    a = ap_o.arrays()
+    for kk, name in (("q", "q_array"), ("qv", "q_vec_array"), ("Q", "Q_array"), ("r", "r_array"), ("R", "R_array"),
+                     ("P", "P_array"), ("A", "A_array"), ("B", "B_array"), ("W", "W_array")):
+        assert rel(getattr(ap, name), a[kk]) < 1e-12, kk
+    for theta in (0.0, 2.0):
+        st, L, dl, dp, _, _ = ctx.dp_gain_sweep(ap, theta, 0.0, 2.0)
+        _, Lo, dlo, dpo, _, _ = orc.dp_gain(P, ap_o, theta)
+        assert st == 0
+        for got, ref in ((L, Lo), (dl, dlo), (dp.s_array, dpo["s"]), (dp.S_array, dpo["S"]), (dp.s_vec_array, dpo["sv"]),
+                         (dp.g_array, dpo["g"]), (dp.G_array, dpo["G"]), (dp.H_array, dpo["H"])):
+            assert rel(got, ref) < 1e-10
+
+
+def test_adaptive_eps_init_and_custom_options():
+    prob, x0, u = rat.synthetic_lq_problem(seed=11, kappa=0.05)
+    P = orc.Problem(prob)
+    theta = np.array([0.0, 2.0, 6.0, 8.5])
+    for kw in (dict(adaptive_eps_init=True), dict(lam=0.3, eps_init=0.7, d=1e-3), dict(eps_min=0.3, iter_max=3)):
+        ctx = rat.Context(prob, rat.ileqg.make_opts(**kw), max_batch=4, spec_eps=3)
+        okw = {("adaptive_eps_init" if k == "adaptive_eps_init" else k): (int(v) if k == "adaptive_eps_init" else v) for k, v in kw.items()}
+        check_batch(ctx, P, x0, u, theta, **okw)
+
+
+def test_full_size_batch_properties():
+    """BASELINE sizes (B = 1024, E = 8): size-independent properties instead of an oracle run."""
+    prob, x0, u = rat.synthetic_lq_problem()
+    rng = np.random.default_rng(4)
+    theta = np.abs(1.0 + 2.0 * rng.standard_normal(1024))
+    theta[::97] = 40.0 + rng.random(theta[::97].size)            # sprinkle infeasible samples
+    ctx = rat.Context(prob, max_batch=1024, spec_eps=8)
+    v, st, it, ls = ctx.solve_batch(x0, u, theta)
+    bad = theta > 12.6
+    assert np.all(st[bad] == 1) and np.all(np.isposinf(v[bad])) and np.all(it[bad] == 0)
+    ok = theta < 12.5
+    assert np.all(st[ok] == 0) and np.all(it[ok] == 2) and np.all(ls[ok] == 2)
+    order = np.argsort(theta[ok])
+    assert np.all(np.diff(v[ok][order]) >= -1e-9)               # monotone in theta
+    # a random subset agrees with the oracle
+    idx = rng.choice(1024, 48, replace=False)
+    vo, so, _, _ = orc.compute_value_batch(orc.Problem(prob), x0, u, theta[idx], nthreads=8)
+    assert np.array_equal(so, st[idx])
+    fin = np.isfinite(vo)
+    assert np.all(np.abs(v[idx][fin] - vo[fin]) <= VT * np.abs(vo[fin]))
+    # E = 1 gives bitwise the same batch
+    ctx1 = rat.Context(prob, max_batch=1024, spec_eps=1)
+    v1, st1, it1, ls1 = ctx1.solve_batch(x0, u, theta)
+    assert np.array_equal(v1, v) and np.array_equal(st1, st) and np.array_equal(ls1, ls)
+
+
+def test_api_misuse_is_reported():
+    prob, x0, u = rat.synthetic_lq_problem()
+    ctx = rat.Context(prob, max_batch=4)
+    with pytest.raises(rat.RatError):
+        ctx.solve_batch(x0, u, np.ones(5))                       # exceeds max_batch
+    big = rat.LQRiskSensitiveProblem(np.eye(13), np.ones((13, 2)), Q=np.eye(13), R=np.eye(2), N=5, W=np.eye(13), Qf=np.eye(13))
+    with pytest.raises(rat.RatError):
+        rat.Context(big)                                         # n > 12: unsupported, fails loudly
+
+
+@pytest.mark.parametrize("seed,theta", [(1, 1.0), (2, 1.0), (2, 4.0)])
+def test_dp_failed_line_search_candidates(seed, theta):
+    """Indefinite cost + cubic drift: some line-search candidates fail the DP (M not PD / non-finite) and are skipped
+    without an eps_history entry or eps_min test (ileqg.jl:529-535, App. B.5); E = 1, 3, 8 replay the same sequence."""
+    prob, x0, u = stress_problem(seed, kappa=0.03)
+    P = orc.Problem(prob)
+    so = orc.ILEQGSolver(P, iter_max=8)
+    rc = so.solve(x0, u, theta)
+    assert so.s.n_ls_evals > so.s.n_hist            # the oracle did see DP-failed candidates
+    ref = None
+    for E in (1, 3, 8):
+        ctx = rat.Context(prob, rat.ileqg.make_opts(iter_max=8), max_batch=1, spec_eps=E)
+        v, st, it, ls = ctx.solve_batch(x0, u, np.array([theta]))
+        r = ctx.solve(x0, u, theta)
+        assert st[0] == rc and it[0] == so.s.iter_current and ls[0] == so.s.n_ls_evals and r["hist_n"] == so.s.n_hist
+        assert np.array_equal(r["eps_history"][:, 0], so.eps_history[:, 0])
+        assert abs(v[0] - so.s.value_current) <= 1e-7 * abs(so.s.value_current)
+        if ref is None:
+            ref = v[0]
+        assert v[0] == ref
