@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libratilqr_hip.so")
+SO_PATH = os.environ.get("RATILQR_SO", os.path.join(_HERE, "csrc", "libratilqr_hip.so"))   # override: diagnostic builds only
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

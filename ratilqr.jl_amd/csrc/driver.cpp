@@ -272,15 +272,18 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
         // elimination pivots e_k of the padded inv(W): logdet(W M) = sum log(d_k / e_k)
         double a[12][12];
         for (int i = 0; i < 12; ++i) for (int jj = 0; jj < 12; ++jj) a[i][jj] = wo[i * 16 + jj];
+        double pivs[12];
         for (int p = 0; p < 12; ++p) {
             const double piv = a[p][p];
-            epiv[(size_t)k * 16 + p] = piv;
+            pivs[p] = piv;
             ldw[k] -= std::log(piv);
             for (int i = p + 1; i < 12; ++i) {
                 const double f = a[i][p] / piv;
                 for (int jj = p; jj < 12; ++jj) a[i][jj] -= f * a[p][jj];
             }
         }
+        // the kernels eliminate 2x2 blocks {p, p+1}: lane p (even) multiplies det(P) by 1 / (e_p e_{p+1})
+        for (int p = 0; p < 12; p += 2) { epiv[(size_t)k * 16 + p] = 1.0 / (pivs[p] * pivs[p + 1]); epiv[(size_t)k * 16 + p + 1] = 1.0; }
     }
     rat_rc rc;
 #define UP(field, vec) if ((rc = dev_upload(h, h->pb_allocs, &pb.field, vec))) return rc
@@ -334,6 +337,12 @@ extern "C" rat_rc rat_profile_get(rat_handle h, int64_t *launches, int64_t *traj
     for (int k = 0; k < RAT_K_COUNT; ++k) { if (launches) launches[k] = h->p_launch[k]; if (traj) traj[k] = h->p_traj[k]; if (ms) ms[k] = h->p_ms[k]; }
     return RAT_OK;
 }
+#ifdef RAT_DIAG
+extern "C" rat_rc rat_diag_read(rat_handle h, double *out64) {
+    HIPCHK(hipMemcpy(out64, h->d_dump, 64 * 8, hipMemcpyDeviceToHost));
+    return RAT_OK;
+}
+#endif
 extern "C" void *rat_stream(rat_handle h) { return h ? (void *)h->stream : nullptr; }
 extern "C" rat_rc rat_layout_info(rat_handle h, int64_t *tile_bytes, int64_t *L_bytes, int64_t *x_bytes, int64_t *u_bytes) {
     if (!h || !h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "no problem set");
@@ -355,6 +364,9 @@ static rat_rc read_counters(rat_handle h, int *c0, int *c1) {
 static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     SweepArgs a;
     a.st = st; a.pb = h->pb; a.op = h->opd; a.mode = mode; a.dl_in = nullptr; a.mu_op = 0.0; a.op_out = nullptr; a.dump = nullptr;
+#ifdef RAT_DIAG
+    a.dump = h->d_dump;
+#endif
     return a;
 }
 

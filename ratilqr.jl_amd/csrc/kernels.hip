@@ -38,6 +38,36 @@ __device__ __forceinline__ d4 mm3(const d4 &a, const d4 &b, d4 acc) {     // acc
     return acc;
 }
 
+// Single-wavefront workgroups: LDS operations of one wave complete in issue order, so a cross-lane exchange
+// through LDS needs no s_barrier and -- unlike __syncthreads() -- must not drain vmcnt (that would serialise the
+// software-prefetched tile loads of the next time step).  This only stops the compiler from reordering.
+#define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/p: v_rcp_f64 seed + two Newton steps (relative error ~1e-16; the full IEEE divide sequence is ~2x longer and sits
+// on the serial pivot chain of the elimination)
+__device__ __forceinline__ double fast_rcp(double p) {
+    double x = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-p, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+
+// pivot-chain variant: one Newton step (measured max relative error 2.1e-15, tools/ubench/mfma_rcp.hip)
+__device__ __forceinline__ double fast_rcp1(double p) {
+    double x = __builtin_amdgcn_rcp(p);
+    const double e = fma(-p, x, 1.0);
+    return fma(x, e, x);
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
@@ -50,6 +80,19 @@ __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base
     return fabs(x - y) <= 1.4901161193847656e-8 * fmax(fabs(x), fabs(y));
 }
 
+// Diagnostic build only (make diag): s_memtime stamps per segment of the time step; shares of one wave's cycles are
+// written to the dump buffer.  Never compiled into the product library.
+#ifdef RAT_DIAG
+#define DIAG_DECL unsigned long long dg_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long dg_prev = 0;
+#define DIAG_START() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dg_prev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DIAG_STAMP(i, val) do { asm volatile("" :: "v"(val)); __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        { unsigned long long now_ = __builtin_readcyclecounter(); dg_acc[i] += now_ - dg_prev; dg_prev = now_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DIAG_DECL
+#define DIAG_START() do {} while (0)
+#define DIAG_STAMP(i, val) do {} while (0)
+#endif
+
 // =====================================================================================================
 // sweep_kernel
 // =====================================================================================================
@@ -58,7 +101,11 @@ struct TileRegs {
     double qr, q;
 };
 
-template <bool GAIN>
+// All loads are unconditional and branch-free (clamped lane offsets + selects): the number of loads in flight is then a
+// compile-time constant, so the prefetch of step t-1 can stay outstanding across the whole of step t behind a counted
+// s_waitcnt vmcnt(N).  (A lane-conditional load makes the count path-dependent and degrades the wait to ~vmcnt(0),
+// which exposes a full HBM latency per time step.)
+template <bool GAIN, bool DUMP>
 __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict__ tp, const int (&offC)[4], int l, int j,
                                           const double *__restrict__ Lp, const double *__restrict__ dlp, bool haveL) {
     tr.z[0] = tp[TS_Z + l];
@@ -72,26 +119,26 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
     tr.qr = tp[TS_QR + j];
     tr.q = tp[TS_q];
     if (!GAIN) {
-        tr.lc = (d4){0.0, 0.0, 0.0, 0.0};
-        if (haveL) {
-            if (j < 12) {
-                tr.lc[0] = Lp[j];
-                tr.lc[1] = Lp[12 + j];
-                tr.lc[2] = Lp[24 + j];
-                tr.lc[3] = Lp[36 + j];
-            } else if (j == 12 && dlp) {
-                tr.lc[0] = dlp[0];
-                tr.lc[1] = dlp[1];
-                tr.lc[2] = dlp[2];
-                tr.lc[3] = dlp[3];
-            }
+        const int jc = (j < 12) ? j : 11;
+        const bool use = haveL && (j < 12);
+        const double l0 = Lp[jc], l1 = Lp[12 + jc], l2 = Lp[24 + jc], l3 = Lp[36 + jc];
+        tr.lc[0] = use ? l0 : 0.0;
+        tr.lc[1] = use ? l1 : 0.0;
+        tr.lc[2] = use ? l2 : 0.0;
+        tr.lc[3] = use ? l3 : 0.0;
+        if (DUMP && dlp && j == 12) {           // operator form only (rat_dp_policy_eval with a dl_array)
+            tr.lc[0] = dlp[0];
+            tr.lc[1] = dlp[1];
+            tr.lc[2] = dlp[2];
+            tr.lc[3] = dlp[3];
         }
     }
 }
 
-template <bool GAIN, bool DUMP>
+template <bool GAIN, bool DUMP, bool WTV>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
-    const int l = threadIdx.x, g = l >> 4, j = l & 15;
+    const int l_ = threadIdx.x, g_ = l_ >> 4, j_ = l_ & 15;
+    const int l = l_, g = g_, j = j_;
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
     const int tid = blockIdx.x;
@@ -118,7 +165,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     double *__restrict__ Lout = st.L + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)b * N * USTR;
 
-    __shared__ double rowbuf[2][16];
+    __shared__ double rowbuf[2][2][16];
     __shared__ double hbuf[4][16];
     __shared__ double fbuf[16];
 
@@ -132,21 +179,23 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
 
     // noise tables (time-invariant case is hoisted out of the time loop)
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
-    double ep = 1.0;
-    if (!pb.W_tv) {
+    double epinv = 1.0;
+    if (!WTV) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             winv[r] = pb.Winv[64 * r + l];
             wp[r] = pb.Wp[64 * r + l];
         }
-        ep = pb.epiv[j];
+        epinv = pb.epiv[j];                 // host stores the reciprocal pivots 1/e_k
     }
     const double coef = (theta != 0.0) ? -1.0 / (2.0 * theta) : 0.5;
 
+    DIAG_DECL
     int restarts = 0;
     int fail = 0;         // 1: M not PD, 5: mu diverged
     d4 v;
-    double racc;
+    double racc, rprod;
+    int rexp;
     while (true) {        // mu-regularisation restart loop (ileqg.jl:359); runs once for policy evaluation
         // terminal condition (ileqg.jl:352-354 / 429-431)
         const double *__restrict__ tt = tile0 + (long)N * TSTRIDE;
@@ -157,6 +206,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
         }
         v[3] = (g == 0) ? (j < 12 ? tt[TT_QV + j] : (j == 12 ? 2.0 * tt[TT_q] : 0.0)) : 0.0;
         racc = 0.0;
+        rprod = 1.0;
+        rexp = 0;
         if (DUMP) {
             double *dp = a.dump + (long)N * DUMP_STRIDE;
 #pragma unroll
@@ -168,21 +219,30 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             if (l == 12) dp[DUMP_s] = 0.5 * v[3];
         }
         TileRegs nx;
-        load_tile<GAIN>(nx, tile0 + (long)(N - 1) * TSTRIDE, offC, l, j, Lb + (long)(N - 1) * LSTR,
+        load_tile<GAIN, DUMP>(nx, tile0 + (long)(N - 1) * TSTRIDE, offC, l, j, Lb + (long)(N - 1) * LSTR,
                         a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, haveL);
         bool h_not_pd = false;
         for (int t = N - 1; t >= 0; --t) {
+            // opaque per-step copies of the lane indices: keeps the (lane == const) masks as one v_cmp at their use
+            // instead of ~40 loop-invariant SGPR pairs (which spill: the kernel is SGPR-bound, not VGPR-bound)
+            int l = l_, g = g_, j = j_;
+            asm volatile("" : "+v"(l), "+v"(g), "+v"(j));
+            DIAG_START();
             const TileRegs cur = nx;
-            if (t > 0)          // software prefetch of step t-1 (a full step of latency hiding)
-                load_tile<GAIN>(nx, tile0 + (long)(t - 1) * TSTRIDE, offC, l, j, Lb + (long)(t - 1) * LSTR,
-                                a.dl_in ? a.dl_in + (long)(t - 1) * USTR : nullptr, haveL);
-            if (pb.W_tv) {
+            {                   // software prefetch of step t-1 (a full step of latency hiding).  Unconditional (index
+                                // clamped at 0) so that the loads stay in straight-line code and the compiler can
+                                // wait with a counted vmcnt(N) instead of vmcnt(0) at the join of a branch.
+                const int tn = (t > 0) ? t - 1 : 0;
+                load_tile<GAIN, DUMP>(nx, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR,
+                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, haveL);
+            }
+            if (WTV) {          // time-varying W(k): separate instantiation, so that the common case keeps a static load count
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     winv[r] = pb.Winv[(long)t * 192 + 64 * r + l];
                     wp[r] = pb.Wp[(long)t * 192 + 64 * r + l];
                 }
-                ep = pb.epiv[(long)t * 16 + j];
+                epinv = pb.epiv[(long)t * 16 + j];
             }
             d4 vt;
             if (theta != 0.0) {
@@ -191,46 +251,63 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) m[r] = (j < 12) ? (winv[r] - theta * v[r]) : 0.0;
                 m[3] = 0.0;
-                // symmetric sweep operator on pivots 0..11: m <- -M^-1 ; pivots d_k > 0 <=> isposdef(M) (:366)
+                DIAG_STAMP(0, m[0]);
+                // symmetric sweep operator with 2x2 block pivots K = {k, k+1}, k = 0, 2, .., 10:  m <- -M^-1.
+                // With P = M_KK, Bk = P^-1:  M'_KK = -Bk, M'_Kj = Bk M_Kj, M'_iK = M_iK Bk, M'_ij = M_ij - M_iK Bk M_Kj.
+                // Rows k, k+1 are exchanged through LDS with -I in their pivot slots, so that every lane runs the one formula
+                //   m'_ij = base_ij - vi1 U1_j - vi2 U2_j,   U_j = Bk [v1_j; v2_j],   base = 0 on pivot rows/columns, m elsewhere.
+                // Leading minors p11 > 0, det P > 0 for every block  <=>  isposdef(M)  (:366); det P = d_k d_{k+1}.
                 bool pd = true;
-                double piv = 1.0;
+                double pivdet = 1.0;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    const int kr = k >> 2, kg = k & 3;
-                    if (g == kg) rowbuf[k & 1][j] = m[kr];
-                    __syncthreads();
-                    const double vj = rowbuf[k & 1][j];
-                    const double p = rowbuf[k & 1][k];
-                    const double vi0 = rowbuf[k & 1][g], vi1 = rowbuf[k & 1][4 + g], vi2 = rowbuf[k & 1][8 + g];
-                    pd = pd && (p > 0.0);
-                    if (l == k) piv = p;
-                    const double ip = 1.0 / p;
-                    const double w = vj * ip;
-                    {
-                        const int i = g;
-                        m[0] = (i == k) ? ((j == k) ? -ip : w) : ((j == k) ? vi0 * ip : fma(-vi0, w, m[0]));
+                for (int kb = 0; kb < 6; ++kb) {
+                    const int k = 2 * kb, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
+                    const double p11 = readlane_f64(m[kr], kg * 16 + k);
+                    const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
+                    const double p22 = readlane_f64(m[kr], (kg + 1) * 16 + k + 1);
+                    if (g == kg || g == kg + 1) {
+                        const bool own = (j == k + (g - kg));                // my row's own pivot slot -> -1, the other -> 0
+                        const bool oth = (j == k + 1 - (g - kg));
+                        rowbuf[kb & 1][g - kg][j] = own ? -1.0 : (oth ? 0.0 : m[kr]);
                     }
-                    {
-                        const int i = 4 + g;
-                        m[1] = (i == k) ? ((j == k) ? -ip : w) : ((j == k) ? vi1 * ip : fma(-vi1, w, m[1]));
-                    }
-                    {
-                        const int i = 8 + g;
-                        m[2] = (i == k) ? ((j == k) ? -ip : w) : ((j == k) ? vi2 * ip : fma(-vi2, w, m[2]));
-                    }
+                    const double det = fma(p11, p22, -(p12 * p12));
+                    const double idet = fast_rcp1(det);                      // overlaps the LDS row exchange
+                    const double b11 = p22 * idet, b12 = -(p12 * idet), b22 = p11 * idet;
+                    WAVE_SYNC();
+                    const double v1 = rowbuf[kb & 1][0][j], v2 = rowbuf[kb & 1][1][j];
+                    const double a10 = rowbuf[kb & 1][0][g], a20 = rowbuf[kb & 1][1][g];
+                    const double a11 = rowbuf[kb & 1][0][4 + g], a21 = rowbuf[kb & 1][1][4 + g];
+                    const double a12 = rowbuf[kb & 1][0][8 + g], a22 = rowbuf[kb & 1][1][8 + g];
+                    pd = pd && (p11 > 0.0) && (det > 0.0);
+                    pivdet = (l == k) ? det : pivdet;
+                    const double u1 = fma(b12, v2, b11 * v1), u2 = fma(b22, v2, b12 * v1);
+                    const bool colk = (j == k) || (j == k + 1), rowk = (g == kg) || (g == kg + 1);
+                    const double b0 = (colk || (kr == 0 && rowk)) ? 0.0 : m[0];
+                    const double b1 = (colk || (kr == 1 && rowk)) ? 0.0 : m[1];
+                    const double b2 = (colk || (kr == 2 && rowk)) ? 0.0 : m[2];
+                    m[0] = fma(-a20, u2, fma(-a10, u1, b0));
+                    m[1] = fma(-a21, u2, fma(-a11, u1, b1));
+                    m[2] = fma(-a22, u2, fma(-a12, u1, b2));
                 }
+                DIAG_STAMP(1, m[0]);
                 if (!pd) { fail = 1; break; }
+                // theta M^-1 (the sweep left -M^-1); padded columns cleared
                 d4 minv;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) minv[r] = (j < 12) ? -m[r] : 0.0;
+                for (int r = 0; r < 3; ++r) minv[r] = (j < 12) ? -theta * m[r] : 0.0;
                 minv[3] = 0.0;
-                // logdet(W M) = sum_k log(d_k / e_k)   (ileqg.jl:387), reduced once per sweep
-                if (l < 12) racc += log(piv / ep);
-                // Y = M^-1 [S | s_vec]
-                d4 y = mm3(minv, v, (d4){0, 0, 0, 0});
-                y *= theta;
+                // logdet(W M) = sum over blocks of log(det P_k / (e_k e_k+1))   (ileqg.jl:387), reduced once per sweep
+                // (kept as a normalised running product: one log() per sweep instead of one per step)
+                if ((l & 1) == 0 && l < 12) {
+                    rprod *= pivdet * epinv;
+                    rexp += __builtin_amdgcn_frexp_exp(rprod);
+                    rprod = __builtin_amdgcn_frexp_mant(rprod);
+                }
+                // Y = theta M^-1 [S | s_vec]
+                const d4 y = mm3(minv, v, (d4){0, 0, 0, 0});
                 // V~ = V + V[:, 0:12] (theta Y)  ->  D S, D s_vec, 2 s + theta s_vec' M^-1 s_vec   (:367, :387)
                 vt = mm3(v, y, v);
+                DIAG_STAMP(2, vt[0]);
             } else {
                 // theta == 0: D = I ; 0.5 tr(W S)   (ileqg.jl:385)
                 if (j < 12) racc += wp[0] * v[0] + wp[1] * v[1] + wp[2] * v[2];
@@ -243,9 +320,10 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             // H block: rows 12..15 of F live in register 3;  + mu I  (:370)
             const double gh = f[3] + ((j == 12 + g) ? mu : 0.0);
             const double fv = tm[3] + cur.qr;      // lanes g == 0: [q_vec + A' D s_vec | r + B' D s_vec]  (:368, :389)
+            DIAG_STAMP(3, gh);
             hbuf[g][j] = gh;
             if (g == 0) fbuf[j] = fv;
-            __syncthreads();
+            WAVE_SYNC();
             // H = Symmetric(H): upper triangle   (:371)
             const double h00 = hbuf[0][12], h01 = hbuf[0][13], h02 = hbuf[0][14], h03 = hbuf[0][15];
             const double h11 = hbuf[1][13], h12 = hbuf[1][14], h13 = hbuf[1][15];
@@ -258,13 +336,13 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             double x0, x1, x2, x3;
             if (GAIN) {
                 // LDL' of H; all pivots > 0 <=> isposdef(H)   (:372)
-                const double d0 = h00, i0 = 1.0 / d0;
+                const double d0 = h00, i0 = fast_rcp(d0);
                 const double l10 = h01 * i0, l20 = h02 * i0, l30 = h03 * i0;
-                const double d1 = h11 - l10 * h01, i1 = 1.0 / d1;
+                const double d1 = h11 - l10 * h01, i1 = fast_rcp(d1);
                 const double l21 = (h12 - l20 * h01) * i1, l31 = (h13 - l30 * h01) * i1;
-                const double d2 = h22 - l20 * h02 - l21 * (l21 * d1), i2 = 1.0 / d2;
+                const double d2 = h22 - l20 * h02 - l21 * (l21 * d1), i2 = fast_rcp(d2);
                 const double l32 = (h23 - l30 * h02 - l31 * (l21 * d1)) * i2;
-                const double d3 = h33 - l30 * h03 - l31 * (l31 * d1) - l32 * (l32 * d2), i3 = 1.0 / d3;
+                const double d3 = h33 - l30 * h03 - l31 * (l31 * d1) - l32 * (l32 * d2), i3 = fast_rcp(d3);
                 if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) { h_not_pd = true; break; }
                 // X = -H \ [G | g]   (:379-382)
                 const double y0 = -g0;
@@ -285,6 +363,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             const double hg2 = (g == 0) ? h02 : (g == 1 ? h12 : (g == 2 ? h22 : h23));
             const double hg3 = (g == 0) ? h03 : (g == 1 ? h13 : (g == 2 ? h23 : h33));
             const double ua = hg0 * x0 + hg1 * x1 + hg2 * x2 + hg3 * x3 + ga;         // H [L|dl] + [G|g]
+            DIAG_STAMP(4, ua);
             if (GAIN) {
                 if (j < 12) Lout[(long)t * LSTR + g * 12 + j] = la;
                 else if (j == 12) dlout[(long)t * USTR + g] = la;
@@ -298,9 +377,10 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             d4 vn = MFMA(la, ua, fx);
             vn = MFMA(ga, la, vn);
             v = vn;
+            DIAG_STAMP(5, v[0]);
             if (DUMP) {
                 double *dp = a.dump + (long)t * DUMP_STRIDE;
-                const double tot = wave_sum(racc);
+                const double tot = wave_sum(racc + ((theta != 0.0 && (l & 1) == 0 && l < 12) ? (log(rprod) + (double)rexp * 0.6931471805599453094) : 0.0));
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int i = 4 * r + g;
@@ -312,19 +392,23 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                 if (j < 12) dp[DUMP_G + g * 12 + j] = hbuf[g][j];
                 else dp[DUMP_H + g * 4 + (j - 12)] = (g <= j - 12) ? hbuf[g][j] : hbuf[j - 12][12 + g];
             }
-            __syncthreads();      // hbuf / fbuf are rewritten next step
+            WAVE_SYNC();          // hbuf / fbuf are rewritten next step
         }
         if (GAIN && h_not_pd) {
             // increase_mu_and_delta!  (ileqg.jl:471-474), then restart the whole sweep (:373-378)
             delta = fmax(a.op.delta_0, delta * a.op.delta_0);
             mu = fmax(a.op.mu_min, mu * delta);
             if (++restarts > 400 || !isfinite(mu)) { fail = 5; break; }
-            __syncthreads();
+            WAVE_SYNC();
             continue;
         }
         break;
     }
-    const double tot = wave_sum(racc);
+#ifdef RAT_DIAG
+    if (l_ == 0 && blockIdx.x < 8 && a.dump)
+        for (int q = 0; q < 6; ++q) a.dump[blockIdx.x * 8 + q] = (double)dg_acc[q];
+#endif
+    const double tot = wave_sum(racc + ((theta != 0.0 && (l & 1) == 0 && l < 12) ? (log(rprod) + (double)rexp * 0.6931471805599453094) : 0.0));
     if (l == 12) {
         const double s0 = 0.5 * v[3] + coef * tot;
         if (a.mode == 1) {
@@ -345,15 +429,21 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     }
 }
 
+template <bool GAIN, bool DUMP>
+static void launch_sweep_w(const SweepArgs &a, dim3 grid, hipStream_t s) {
+    if (a.pb.W_tv) hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, true>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, false>), grid, dim3(64), 0, s, a);
+}
+
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s) {
     if (ntraj <= 0) return;
-    dim3 grid(ntraj), block(64);
+    dim3 grid(ntraj);
     if (gain) {
-        if (dump) hipLaunchKernelGGL((sweep_kernel<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((sweep_kernel<true, false>), grid, block, 0, s, a);
+        if (dump) launch_sweep_w<true, true>(a, grid, s);
+        else launch_sweep_w<true, false>(a, grid, s);
     } else {
-        if (dump) hipLaunchKernelGGL((sweep_kernel<false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((sweep_kernel<false, false>), grid, block, 0, s, a);
+        if (dump) launch_sweep_w<false, true>(a, grid, s);
+        else launch_sweep_w<false, false>(a, grid, s);
     }
 }
 
@@ -415,7 +505,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         double u = 0.0;
         if (a.mode == 1) {
             if (j < 12) shdx[row][j] = x - xbar[(long)t * XSTR + j];
-            __syncthreads();
+            WAVE_SYNC();
             if (j < 4 && live) {
                 const double *Lr = Lb + (long)t * LSTR + j * 12;
                 double acc = 0.0;
@@ -432,7 +522,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         }
         if (j < 12) shxu[row][j] = x;
         if (j < 4) shxu[row][12 + j] = u;
-        __syncthreads();
+        WAVE_SYNC();
         double xn = 0.0;
         if (j < 12) {
             if (pb.model == 1) {
@@ -458,7 +548,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
             if (j < 4) uo[(long)t * USTR + j] = u;
         }
         x = xn;
-        __syncthreads();
+        WAVE_SYNC();
     }
     // any lane of the row saw a DomainError?
     const unsigned long long bal = __ballot(dom != 0);

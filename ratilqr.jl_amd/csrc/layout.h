@@ -60,7 +60,7 @@ struct ProblemDev {
     double pl_a, pl_b, pl_p, pl_pu, pl_cx, pl_cu, pl_h;
     const double *Winv;  // [Nw][192]  inv(W(k)) 12x16 row-major, padded diagonal = 1
     const double *Wp;    // [Nw][192]  W(k), zero padded
-    const double *epiv;  // [Nw][16]   elimination pivots of the padded inv(W(k)) (logdet pairing)
+    const double *epiv;  // [Nw][16]   even k: 1/(e_k e_k+1), e = elimination pivots of the padded inv(W(k)); odd k: 1 (logdet pairing)
     const double *logdetW; // [Nw]
 };
 
