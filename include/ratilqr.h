@@ -216,7 +216,9 @@ rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0, const doub
 #define RAT_K_SELECT    4
 #define RAT_K_SWEEP_INIT 5   /* open-loop policy evaluation of initialize! (no gains read) */
 #define RAT_K_COUNT     6
-/* When enabled, every kernel launch is bracketed by HIP events on the handle's stream. */
+/* When enabled, kernel launches are bracketed by HIP events on the handle's stream.
+ * on = 0: off; on = 1: every kernel kind; otherwise on = (mask << 1) | 1 with bit k of mask selecting kind RAT_K_k.
+ * Launches of a surplus round (no live sample left) are not counted. */
 rat_rc rat_profile_enable(rat_handle h, int32_t on);
 rat_rc rat_profile_reset(rat_handle h);
 /* launches[k], trajectories[k] (units processed), total_ms[k] for k < RAT_K_COUNT */

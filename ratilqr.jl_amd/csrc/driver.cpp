@@ -47,10 +47,12 @@ struct rat_handle_s {
     double *d_x0 = nullptr, *d_u0 = nullptr, *d_theta = nullptr, *d_val = nullptr, *d_opout = nullptr, *d_dump = nullptr,
            *d_dlin = nullptr;
     int *d_ist = nullptr, *d_iit = nullptr, *d_ils = nullptr;
-    int *h_counters = nullptr;       // pinned
+    int *h_counters = nullptr;       // pinned, [CTR_RING][2]
+    hipEvent_t round_ev[CTR_RING] = {};
     bool have_initial = false;
     // profiling
-    bool prof = false;
+    bool prof = false, prof_cur = false;
+    unsigned prof_mask = 0xFFFFFFFFu;   // bit k: record kernel kind k
     std::vector<EvRec> evs;
     size_t ev_used = 0;
     int64_t p_launch[RAT_K_COUNT] = {0}, p_traj[RAT_K_COUNT] = {0};
@@ -97,7 +99,8 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     h->device = device; h->opts = o; h->Bmax = max_batch; h->E = spec_eps;
     set_opd(h);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < CTR_RING; ++i) HIPCHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->pb, 0, sizeof(h->pb));
     *out = h;
@@ -117,6 +120,7 @@ extern "C" void rat_destroy(rat_handle h) {
     free_list(h->st_allocs);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->h_counters) (void)hipHostFree(h->h_counters);
+    for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
     (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -193,7 +197,7 @@ static rat_rc alloc_state(rat_handle h) {
     AL(st.theta, B); AL(st.mu, B); AL(st.delta, B); AL(st.value, B); AL(st.d_cur, B); AL(st.eps_init, B); AL(st.ls_eps, B);
     AL(st.status, B); AL(st.iter, B); AL(st.ls_active, B); AL(st.ls_count, B); AL(st.slot_nom, B); AL(st.n_ls, B); AL(st.hist_n, B);
     AL(st.value_c, (size_t)B * E); AL(st.d_c, (size_t)B * E); AL(st.flag_c, (size_t)B * E);
-    AL(st.counters, 2);
+    AL(st.counters, 2 * CTR_RING);
     st.hist = nullptr; st.hist_cap = 0;
     AL(h->d_x0, XSTR); AL(h->d_u0, (size_t)N * USTR); AL(h->d_theta, B); AL(h->d_val, B);
     AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);
@@ -299,7 +303,8 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
 
 // ---- profiling helpers -----------------------------------------------------------------------------
 static void prof_begin(rat_handle h, int kind, int64_t ntraj) {
-    if (!h->prof) return;
+    h->prof_cur = h->prof && ((h->prof_mask >> kind) & 1u);
+    if (!h->prof_cur) return;
     if (h->ev_used == h->evs.size()) {
         EvRec e;
         (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
@@ -310,7 +315,7 @@ static void prof_begin(rat_handle h, int kind, int64_t ntraj) {
     (void)hipEventRecord(e.a, h->stream);
 }
 static void prof_end(rat_handle h) {
-    if (!h->prof) return;
+    if (!h->prof_cur) return;
     (void)hipEventRecord(h->evs[h->ev_used].b, h->stream);
     h->ev_used++;
 }
@@ -320,11 +325,18 @@ static void prof_flush(rat_handle h) {
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, h->evs[i].a, h->evs[i].b);
+        if (h->evs[i].kind < 0) continue;                 // launches of a surplus round (no live sample)
         h->p_launch[h->evs[i].kind]++; h->p_traj[h->evs[i].kind] += h->evs[i].ntraj; h->p_ms[h->evs[i].kind] += ms;
     }
     h->ev_used = 0;
 }
-extern "C" rat_rc rat_profile_enable(rat_handle h, int32_t on) { if (!h) return RAT_ERR_ARG; prof_flush(h); h->prof = on != 0; return RAT_OK; }
+extern "C" rat_rc rat_profile_enable(rat_handle h, int32_t on) {
+    if (!h) return RAT_ERR_ARG;
+    prof_flush(h);
+    h->prof = on != 0;
+    h->prof_mask = (on == 1 || on == 0) ? 0xFFFFFFFFu : ((unsigned)on >> 1);   // on = 1: all kinds; else (mask << 1) | 1
+    return RAT_OK;
+}
 extern "C" rat_rc rat_profile_reset(rat_handle h) {
     if (!h) return RAT_ERR_ARG;
     prof_flush(h);
@@ -354,13 +366,6 @@ extern "C" rat_rc rat_layout_info(rat_handle h, int64_t *tile_bytes, int64_t *L_
 }
 
 // ---- the batched solve state machine ------------------------------------------------------------------
-static rat_rc read_counters(rat_handle h, int *c0, int *c1) {
-    HIPCHK(hipMemcpyAsync(h->h_counters, h->st.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    *c0 = h->h_counters[0]; *c1 = h->h_counters[1];
-    return RAT_OK;
-}
-
 static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     SweepArgs a;
     a.st = st; a.pb = h->pb; a.op = h->opd; a.mode = mode; a.dl_in = nullptr; a.mu_op = 0.0; a.op_out = nullptr; a.dump = nullptr;
@@ -370,22 +375,24 @@ static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     return a;
 }
 
-// line-search rounds for the samples flagged ls_active; returns the number of samples still running
-static rat_rc line_search_rounds(rat_handle h, const StateDev &st, int *running) {
+// One ROUND advances every sample by one stage of its own solve!/step!/line_search! sequence (ileqg.jl:494-659):
+//   gain sweep   for samples that are running and not inside a line search (step!: re-linearisation = the accepted
+//                candidate's tiles, App. B.1; solve_approximate_dp!; then line_search! starts: epilogue of the kernel)
+//   rollout, linearise, policy-evaluation sweep of E candidates for every sample inside a line search
+//   select       replays the sequential accept rule, convergence / iter_max tests, counts the samples still running
+// Samples never wait for each other: one that needs another line-search round simply skips the next gain sweep.
+static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
+    const int slot = round % CTR_RING;
+    const int64_t nc = (int64_t)st.B * st.E;
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
     LinArgs la; la.st = st; la.pb = h->pb; la.mode = 1;
-    const int64_t nc = (int64_t)st.B * st.E;
-    for (;;) {
-        prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollout(ra, h->stream); prof_end(h);
-        prof_begin(h, RAT_K_LINEARIZE, nc); launch_linearize(la, h->stream); prof_end(h);
-        prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(sweep_args(h, st, 1), (int)nc, false, false, h->stream); prof_end(h);
-        HIPCHK(hipMemsetAsync(st.counters, 0, 2 * sizeof(int), h->stream));
-        prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, h->stream); prof_end(h);
-        int more = 0;
-        rat_rc rc = read_counters(h, &more, running);
-        if (rc) return rc;
-        if (more == 0) break;
-    }
+    prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
+    prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollout(ra, h->stream); prof_end(h);
+    prof_begin(h, RAT_K_LINEARIZE, nc); launch_linearize(la, h->stream); prof_end(h);
+    prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(sweep_args(h, st, 1), (int)nc, false, false, h->stream); prof_end(h);
+    prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
+    HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
     return RAT_OK;
 }
 
@@ -403,19 +410,21 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
     prof_begin(h, RAT_K_ROLLOUT, B); launch_rollout(ra, h->stream); prof_end(h);
     prof_begin(h, RAT_K_LINEARIZE, B); launch_linearize(la, h->stream); prof_end(h);
     prof_begin(h, RAT_K_SWEEP_INIT, B); launch_sweep(sweep_args(h, st, 2), B, false, false, h->stream); prof_end(h);
-    HIPCHK(hipMemsetAsync(st.counters, 0, 2 * sizeof(int), h->stream));
-    launch_count_running(st, h->stream);
-    int more = 0, running = 0;
-    rat_rc rc = read_counters(h, &more, &running);
-    if (rc) return rc;
-    // while true: step!; convergence / iter_max test   (ileqg.jl:640-654)
-    int64_t guard = 0;
-    while (running > 0) {
-        if (++guard > (int64_t)h->opd.iter_max + 2) return fail(RAT_ERR_DIVERGED, "iteration guard tripped");
-        // step! (:598-613): the accepted candidate's tiles are the re-linearisation of :604 (App. B.1)
-        prof_begin(h, RAT_K_SWEEP_GAIN, running); launch_sweep(sweep_args(h, st, 0), B, true, false, h->stream); prof_end(h);
-        launch_ls_begin(st, h->stream);
-        if ((rc = line_search_rounds(h, st, &running))) return rc;
+    // while true: step!; convergence / iter_max test   (ileqg.jl:640-654).  The host runs one round ahead of the counter
+    // it polls, so the GPU never idles on a host round trip; the one surplus round at the end finds no live sample.
+    const int64_t max_rounds = ((int64_t)h->opd.iter_max + 1) * (4000 / st.E + 2);
+    rat_rc rc;
+    if ((rc = enqueue_round(h, st, 0))) return rc;
+    for (int64_t r = 0;; ++r) {
+        if (r + 1 > max_rounds) return fail(RAT_ERR_DIVERGED, "round guard tripped");
+        const size_t ev0 = h->ev_used;
+        if ((rc = enqueue_round(h, st, (int)((r + 1) % (2 * CTR_RING))))) return rc;
+        const int slot = (int)(r % (2 * CTR_RING)) % CTR_RING;
+        HIPCHK(hipEventSynchronize(h->round_ev[slot]));
+        if (h->h_counters[2 * slot + 1] == 0) {
+            for (size_t i = ev0; i < h->ev_used; ++i) h->evs[i].kind = -1;    // the round just enqueued has no live sample
+            break;
+        }
     }
     return RAT_OK;
 }

@@ -36,7 +36,5 @@ void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream
 void launch_rollout(const RolloutArgs &a, hipStream_t s);
 void launch_linearize(const LinArgs &a, hipStream_t s);
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
-void launch_ls_begin(const StateDev &st, hipStream_t s);
-void launch_ls_select(const StateDev &st, const OptsDev &op, hipStream_t s);
-void launch_count_running(const StateDev &st, hipStream_t s);
+void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
 void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, hipStream_t s);

@@ -3,7 +3,7 @@
 //   rollout_kernel    simulate_dynamics, open loop and closed loop        (ileqg.jl:18-38, 62-87) + d_current reduction (:539)
 //   linearize_kernel  approximate_model -> tile bundles in HBM            (ileqg.jl:258-322)
 //   sweep_kernel      risk-sensitive Riccati sweep, gain / policy-eval    (ileqg.jl:341-406 / 412-465)
-//   ls_begin_kernel / ls_select_kernel / init_state_kernel                 per-sample control flow of step!/line_search!/solve!
+//   ls_select_kernel / init_state_kernel (+ the epilogue of the gain sweep)  per-sample control flow of step!/line_search!/solve!
 //                                                                          (ileqg.jl:494-592, 598-613, 635-659) replayed on device
 //
 // sweep_kernel: ONE WAVEFRONT PER TRAJECTORY.  The value function is carried as the augmented
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     } else {
         b = tid;
         if (st.status[b] != ST_RUNNING) return;
+        if (a.mode == 0 && st.ls_active[b]) return;      // still inside line_search! of its current iteration
         slot = b * (st.E + 1) + st.slot_nom[b];
     }
     const double theta = st.theta[b];
@@ -423,7 +424,13 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
         } else {
             st.mu[b] = mu;
             st.delta[b] = delta;
-            if (fail) { st.status[b] = (fail == 1) ? 2 : 5; st.value[b] = INFINITY; st.iter[b] += 1; }   // M_NOT_PD_GAIN / MU_DIVERGED
+            st.iter[b] += 1;                                  // step!: iter_current += 1   (ileqg.jl:599)
+            if (fail) { st.status[b] = (fail == 1) ? 2 : 5; st.value[b] = INFINITY; }   // M_NOT_PD_GAIN / MU_DIVERGED
+            else {                                            // line_search! starts at eps_init   (ileqg.jl:502)
+                st.ls_eps[b] = st.eps_init[b];
+                st.ls_count[b] = 0;
+                st.ls_active[b] = 1;
+            }
             if (a.op_out) { a.op_out[0] = s0; a.op_out[1] = (double)(fail ? (fail == 1 ? 2 : 5) : 0); }
         }
     }
@@ -470,6 +477,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         if (a.mode == 0) { b = c; live = (st.status[b] == ST_RUNNING); }
         else { b = c / st.E; k = c - b * st.E; live = st.ls_active[b] != 0; }
     }
+    if (__ballot(live) == 0ull) return;              // whole wave idle (finished samples, no-op rounds)
     __shared__ double shdx[4][12];
     __shared__ double shxu[4][16];
     __shared__ double shq[4][4];
@@ -495,48 +503,73 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) zr[q] = (j < 12) ? pb.Zt[j * 16 + q] : 0.0;
     }
+    const int jx = (j < 12) ? j : 11, ju = j & 3;          // clamped lane offsets: every load below is unconditional
     double x = 0.0;
     if (j < 12) x = (a.mode == 0) ? a.x0[j] : xbar[j];
     if (live && j < 12) xo[j] = x;
     double dmax = -INFINITY;
     bool dnan = false;
     int dom = 0;
+    // software prefetch of the step-(t+1) operands (static load count: see load_tile)
+    double n_xb = xbar[jx], n_l = lnom[ju], n_dl = dlb[ju];
+    double n_L[12];
+    if (a.mode == 1) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) n_L[q] = Lb[ju * 12 + q];
+    }
     for (int t = 0; t < N; ++t) {
+        const double c_xb = n_xb, c_l = n_l, c_dl = n_dl;
+        double c_L[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) c_L[q] = n_L[q];
+        {
+            const int tn = (t + 1 < N) ? t + 1 : t;
+            n_xb = xbar[(long)tn * XSTR + jx];
+            n_l = lnom[(long)tn * USTR + ju];
+            n_dl = dlb[(long)tn * USTR + ju];
+            if (a.mode == 1) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) n_L[q] = Lb[(long)tn * LSTR + ju * 12 + q];
+            }
+        }
         double u = 0.0;
         if (a.mode == 1) {
-            if (j < 12) shdx[row][j] = x - xbar[(long)t * XSTR + j];
+            if (j < 12) shdx[row][j] = x - c_xb;
             WAVE_SYNC();
-            if (j < 4 && live) {
-                const double *Lr = Lb + (long)t * LSTR + j * 12;
-                double acc = 0.0;
+            {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
-                for (int q = 0; q < 12; ++q) acc += Lr[q] * shdx[row][q];          // L_t (x_t - xbar_t)   (:82)
-                const double lt = lnom[(long)t * USTR + j];
-                const double lnew = lt + eps * dlb[(long)t * USTR + j];               // l + eps dl           (:509)
-                u = lnew + acc;
-                const double du = lt - u;
-                shq[row][j] = du * du;
+                for (int q = 0; q < 4; ++q) {                      // L_t (x_t - xbar_t)   (:82)
+                    a0 = fma(c_L[q], shdx[row][q], a0);
+                    a1 = fma(c_L[4 + q], shdx[row][4 + q], a1);
+                    a2 = fma(c_L[8 + q], shdx[row][8 + q], a2);
+                }
+                const double lnew = c_l + eps * c_dl;                 // l + eps dl           (:509)
+                u = lnew + ((a0 + a1) + a2);
+                const double du = c_l - u;
+                if (j < 4) shq[row][j] = du * du;
             }
-        } else if (j < 4) {
-            u = lnom[(long)t * USTR + j];
+        } else {
+            u = c_l;
         }
         if (j < 12) shxu[row][j] = x;
         if (j < 4) shxu[row][12 + j] = u;
         WAVE_SYNC();
         double xn = 0.0;
-        if (j < 12) {
-            if (pb.model == 1) {
-                double acc = 0.0, accb = 0.0;
+        if (pb.model == 1) {
+            double acc = 0.0, acc2 = 0.0, acc3 = 0.0, accb = 0.0;
 #pragma unroll
-                for (int q = 0; q < 12; ++q) acc += zr[q] * shxu[row][q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) accb += zr[12 + q] * shxu[row][12 + q];
-                acc += accb;
-                if (pb.kappa != 0.0) acc += pb.kappa * (x * x * x);
-                xn = acc;
-            } else if (j < pb.n) {
-                xn = powchk(x, pb.pl_a, dom) + powchk(shxu[row][12 + j], pb.pl_b, dom);
+            for (int q = 0; q < 4; ++q) {
+                acc = fma(zr[q], shxu[row][q], acc);
+                acc2 = fma(zr[4 + q], shxu[row][4 + q], acc2);
+                acc3 = fma(zr[8 + q], shxu[row][8 + q], acc3);
+                accb = fma(zr[12 + q], shxu[row][12 + q], accb);
             }
+            acc = ((acc + acc2) + acc3) + accb;
+            if (pb.kappa != 0.0) acc += pb.kappa * (x * x * x);
+            xn = (j < 12) ? acc : 0.0;
+        } else if (j < pb.n) {
+            xn = powchk(x, pb.pl_a, dom) + powchk(shxu[row][12 + j], pb.pl_b, dom);
         }
         if (a.mode == 1 && j == 0) {
             const double dn = sqrt(shq[row][0] + shq[row][1] + shq[row][2] + shq[row][3]);
@@ -705,6 +738,7 @@ void launch_linearize(const LinArgs &a, hipStream_t s) {
 // =====================================================================================================
 __global__ void init_state_kernel(StateDev st, OptsDev op, const double *theta_in) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < 2 * CTR_RING) st.counters[b] = 0;
     if (b >= st.B) return;
     st.theta[b] = theta_in[b];
     st.mu[b] = 0.0;                       // initialize! sets mu = 0.0, Delta = Delta_0   (ileqg.jl:216)
@@ -720,28 +754,21 @@ __global__ void init_state_kernel(StateDev st, OptsDev op, const double *theta_i
     st.slot_nom[b] = 0;
     st.n_ls[b] = 0;
     st.hist_n[b] = 0;
-    if (b == 0) { st.counters[0] = 0; st.counters[1] = 0; }
-}
-
-// start of step! for every running sample (ileqg.jl:598-613): iter += 1, line search starts at eps_init (:502)
-__global__ void ls_begin_kernel(StateDev st) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= st.B) return;
-    if (st.status[b] != ST_RUNNING) { st.ls_active[b] = 0; return; }
-    st.iter[b] += 1;
-    st.ls_eps[b] = st.eps_init[b];
-    st.ls_count[b] = 0;
-    st.ls_active[b] = 1;
 }
 
 // Replays the sequential rule of line_search! (ileqg.jl:504-581) over the E speculatively evaluated
 // candidates of each sample, then the convergence test of solve! (:642-653).
-__global__ void ls_select_kernel(StateDev st, OptsDev op) {
+// Counters of round `slot`: [2*slot] samples still inside their line search, [2*slot+1] samples still running.
+__global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= st.B) return;
-    if (!st.ls_active[b]) {
-        return;
+    if (b == 0) {                          // clear the ring entry two rounds ahead (stream order makes this race-free)
+        const int z = (slot + 2) % CTR_RING;
+        st.counters[2 * z] = 0;
+        st.counters[2 * z + 1] = 0;
     }
+    if (b >= st.B) return;
+    if (!st.ls_active[b]) return;
+    int *ctr = st.counters + 2 * slot;
     double eps = st.ls_eps[b];
     const double cur = st.value[b];
     int count = st.ls_count[b];
@@ -775,8 +802,8 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op) {
         if (count > 4000) { st.status[b] = 7; st.value[b] = INFINITY; st.ls_active[b] = 0; return; }
         st.ls_eps[b] = eps;
         st.ls_count[b] = count;
-        atomicAdd(&st.counters[0], 1);
-        atomicAdd(&st.counters[1], 1);
+        atomicAdd(&ctr[0], 1);
+        atomicAdd(&ctr[1], 1);
         return;
     }
     // accept (:539-555 / :559-575)
@@ -795,27 +822,15 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op) {
     }
     if (op.d > st.d_cur[b] && st.mu[b] <= op.mu_min) st.status[b] = 0;              // converged  (:642)
     else if (st.iter[b] == op.iter_max) st.status[b] = 3;                           // iter_max   (:648)
-    else atomicAdd(&st.counters[1], 1);
+    else atomicAdd(&ctr[1], 1);
 }
 
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s) {
-    hipLaunchKernelGGL(init_state_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, op, theta_dev);
+    const int n = st.B > 2 * CTR_RING ? st.B : 2 * CTR_RING;
+    hipLaunchKernelGGL(init_state_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, op, theta_dev);
 }
-void launch_ls_begin(const StateDev &st, hipStream_t s) {
-    hipLaunchKernelGGL(ls_begin_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st);
-}
-void launch_ls_select(const StateDev &st, const OptsDev &op, hipStream_t s) {
-    hipLaunchKernelGGL(ls_select_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, op);
-}
-
-// count samples still running after the init sweep (solve! enters its loop only for those)
-__global__ void count_running_kernel(StateDev st) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= st.B) return;
-    if (st.status[b] == ST_RUNNING) atomicAdd(&st.counters[1], 1);
-}
-void launch_count_running(const StateDev &st, hipStream_t s) {
-    hipLaunchKernelGGL(count_running_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st);
+void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s) {
+    hipLaunchKernelGGL(ls_select_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, op, slot);
 }
 
 // gather the outputs of a batch: value (Inf for failures), status, iters, ls_evals

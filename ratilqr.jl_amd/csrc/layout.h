@@ -47,6 +47,7 @@
 #define DUMP_STRIDE 225
 
 #define ST_RUNNING (-1)
+#define CTR_RING 8          /* per-round counter pairs kept in a ring (host polls one round behind) */
 
 struct ProblemDev {
     int model, n, m, N, cost_tv, W_tv;
@@ -75,7 +76,7 @@ struct StateDev {
     double *value_c, *d_c;                     // [B*E]
     int *flag_c;                               // [B*E] 0 ok, 1 DP failed (M not PD), 2 domain failure
     double *hist; int hist_cap;                // [B][2*hist_cap] or null
-    int *counters;                             // [0] samples still in line search, [1] samples running
+    int *counters;                             // [CTR_RING][2]: per round {samples still in line search, samples running}
 };
 
 struct OptsDev {

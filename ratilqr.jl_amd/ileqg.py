@@ -144,8 +144,15 @@ class Context:
                                                     C.c_void_p(status_ptr), C.c_void_p(iters_ptr), C.c_void_p(ls_ptr)))
 
     # ---- measurement -----------------------------------------------------------------------------
-    def profile(self, on=True):
-        nv.check(nv.lib().rat_profile_enable(self.h, int(on)))
+    def profile(self, on=True, kinds=None):
+        """HIP-event timing of kernel launches; ``kinds`` (names from _native.K_NAMES) restricts what is recorded."""
+        flag = int(bool(on))
+        if on and kinds is not None:
+            mask = 0
+            for k in kinds:
+                mask |= 1 << nv.K_NAMES.index(k)
+            flag = (mask << 1) | 1
+        nv.check(nv.lib().rat_profile_enable(self.h, flag))
 
     def profile_reset(self):
         nv.check(nv.lib().rat_profile_reset(self.h))
