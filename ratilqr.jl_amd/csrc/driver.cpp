@@ -387,8 +387,8 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
     LinArgs la; la.st = st; la.pb = h->pb; la.mode = 1;
     prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
-    prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollout(ra, h->stream); prof_end(h);
-    prof_begin(h, RAT_K_LINEARIZE, nc); launch_linearize(la, h->stream); prof_end(h);
+    (void)la;
+    prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);        // fused rollout + linearise
     prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(sweep_args(h, st, 1), (int)nc, false, false, h->stream); prof_end(h);
     prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
     HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -407,8 +407,8 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
     // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
     LinArgs la; la.st = st; la.pb = h->pb; la.mode = 0;
-    prof_begin(h, RAT_K_ROLLOUT, B); launch_rollout(ra, h->stream); prof_end(h);
-    prof_begin(h, RAT_K_LINEARIZE, B); launch_linearize(la, h->stream); prof_end(h);
+    (void)la;
+    prof_begin(h, RAT_K_ROLLOUT, B); launch_rollin(ra, h->stream); prof_end(h);         // fused rollout + linearise
     prof_begin(h, RAT_K_SWEEP_INIT, B); launch_sweep(sweep_args(h, st, 2), B, false, false, h->stream); prof_end(h);
     // while true: step!; convergence / iter_max test   (ileqg.jl:640-654).  The host runs one round ahead of the counter
     // it polls, so the GPU never idles on a host round trip; the one surplus round at the end finds no live sample.

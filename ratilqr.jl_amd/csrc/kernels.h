@@ -34,6 +34,7 @@ struct LinArgs {
 
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s);
 void launch_rollout(const RolloutArgs &a, hipStream_t s);
+void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout + linearise (solver hot loop)
 void launch_linearize(const LinArgs &a, hipStream_t s);
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);

@@ -604,6 +604,254 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 }
 
 // =====================================================================================================
+// rollin_kernel: fused simulate_dynamics + approximate_model for the solver's hot loop.  ONE wavefront per
+// trajectory: lanes 0..15 run the (sequential, latency-bound) rollout step, then all 64 lanes stream the 417-double
+// tile of that step to HBM, so the tile writes ride in the rollout's idle issue slots and x_t, u_t never make a
+// round trip through HBM between the two reference functions (ileqg.jl:62-87 then :258-322).  Same arithmetic as
+// rollout_kernel + linearize_kernel (which remain for the operator entry points).
+// =====================================================================================================
+__global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
+    const int l = threadIdx.x, j = l & 15, g = l >> 4;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    const int N = st.N;
+    const int c = blockIdx.x;
+    int b, k = 0;
+    if (a.mode == 0) { b = c; if (st.status[b] != ST_RUNNING) return; }
+    else { b = c / st.E; k = c - b * st.E; if (!st.ls_active[b]) return; }
+    __shared__ double shdx[12];
+    __shared__ double shxu[16];
+    __shared__ double shq[4];
+
+    const int nom = st.slot_nom[b];
+    const int slot_n = b * (st.E + 1) + nom;
+    const int slot_o = (a.mode == 0) ? slot_n : cand_slot(b, k, nom, st.E);
+    const double *__restrict__ xbar = st.xs + (long)slot_n * st.x_stride;
+    const double *__restrict__ lnom = (a.mode == 0) ? a.u0 : st.us + (long)slot_n * st.u_stride;
+    double *__restrict__ xo = st.xs + (long)slot_o * st.x_stride;
+    double *__restrict__ uo = st.us + (long)slot_o * st.u_stride;
+    double *__restrict__ tile0 = st.tiles + (long)slot_o * st.tile_stride;
+    const double *__restrict__ Lb = st.L + (long)b * N * LSTR;
+    const double *__restrict__ dlb = st.dl + (long)b * N * USTR;
+    const bool lq = (pb.model == 1);
+
+    double eps = 0.0;
+    if (a.mode == 1) {
+        eps = st.ls_eps[b];
+        for (int q = 0; q < k; ++q) eps *= a.op.lambda;        // eps_k = eps * lambda^k by repeated multiplication (:530,:557)
+    }
+    // per-lane constants of the LQ family (dynamics are time-invariant; cost tables only when !cost_tv)
+    double zr[16], crow[16];
+    double zt0 = 0, zt1 = 0, zt2 = 0, cq0 = 0, cq1 = 0, cq2 = 0, cpr = 0, clin = 0, cq00 = 0;
+    const int e2 = (l + 128 < 144) ? l + 128 : 0;              // Q element handled by the third (partial) store
+    const int jx = (j < 12) ? j : 11, ju = j & 3;
+    if (lq) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zr[q] = pb.Zt[jx * 16 + q];
+        zt0 = pb.Zt[l]; zt1 = pb.Zt[64 + l]; zt2 = pb.Zt[128 + l];
+        if (!pb.cost_tv) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) crow[q] = pb.Ctab[j * 16 + q];
+            cq0 = pb.Ctab[(l / 12) * 16 + l % 12];
+            cq1 = pb.Ctab[((l + 64) / 12) * 16 + (l + 64) % 12];
+            cq2 = pb.Ctab[(e2 / 12) * 16 + e2 % 12];
+            cpr = pb.Ctab[(12 + g) * 16 + j];
+            clin = pb.lin[j];
+            cq00 = pb.q0[0];
+        }
+    }
+    double x = 0.0;
+    if (j < 12) x = (a.mode == 0) ? a.x0[j] : xbar[j];
+    if (l < 12) xo[l] = x;
+    double dmax = -INFINITY;
+    bool dnan = false;
+    int dom = 0;
+    double n_xb = xbar[jx], n_l = lnom[ju], n_dl = dlb[ju];
+    double n_L[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) n_L[q] = 0.0;
+    if (a.mode == 1) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) n_L[q] = Lb[ju * 12 + q];
+    }
+    for (int t = 0; t < N; ++t) {
+        const double c_xb = n_xb, c_l = n_l, c_dl = n_dl;
+        double c_L[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) c_L[q] = n_L[q];
+        {
+            const int tn = (t + 1 < N) ? t + 1 : t;             // unconditional prefetch of step t+1 (static load count)
+            n_xb = xbar[(long)tn * XSTR + jx];
+            n_l = lnom[(long)tn * USTR + ju];
+            n_dl = dlb[(long)tn * USTR + ju];
+            if (a.mode == 1) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) n_L[q] = Lb[(long)tn * LSTR + ju * 12 + q];
+            }
+        }
+        double u = c_l;
+        if (a.mode == 1) {
+            if (l < 12) shdx[l] = x - c_xb;
+            WAVE_SYNC();
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                          // L_t (x_t - xbar_t)   (:82)
+                a0 = fma(c_L[q], shdx[q], a0);
+                a1 = fma(c_L[4 + q], shdx[4 + q], a1);
+                a2 = fma(c_L[8 + q], shdx[8 + q], a2);
+            }
+            const double lnew = c_l + eps * c_dl;                     // l + eps dl           (:509)
+            u = lnew + ((a0 + a1) + a2);
+            const double du = c_l - u;
+            if (l < 4) shq[l] = du * du;
+        }
+        if (l < 12) shxu[l] = x;
+        if (l < 4) shxu[12 + l] = u;
+        WAVE_SYNC();
+        double xu[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xu[q] = shxu[q];
+        // ---- x_{t+1} = f(x_t, u_t) ------------------------------------------------------------------
+        double xn = 0.0;
+        if (lq) {
+            double acc = 0.0, acc2 = 0.0, acc3 = 0.0, accb = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = fma(zr[q], xu[q], acc);
+                acc2 = fma(zr[4 + q], xu[4 + q], acc2);
+                acc3 = fma(zr[8 + q], xu[8 + q], acc3);
+                accb = fma(zr[12 + q], xu[12 + q], accb);
+            }
+            acc = ((acc + acc2) + acc3) + accb;
+            if (pb.kappa != 0.0) acc += pb.kappa * (x * x * x);
+            xn = (j < 12) ? acc : 0.0;
+        } else if (j < pb.n) {
+            xn = powchk(x, pb.pl_a, dom) + powchk(xu[12 + (j & 3)], pb.pl_b, dom);
+        }
+        if (a.mode == 1 && l == 0) {
+            const double dn = sqrt(shq[0] + shq[1] + shq[2] + shq[3]);
+            if (dn != dn) dnan = true;                          // maximum() propagates NaN
+            else if (dn > dmax) dmax = dn;
+        }
+        if (l < 12) xo[(long)(t + 1) * XSTR + l] = xn;
+        if (l < 4) uo[(long)t * USTR + l] = u;
+        // ---- tile of step t: approximate_model at (x_t, u_t)   (ileqg.jl:294-313) ---------------------
+        double *__restrict__ tp = tile0 + (long)t * TSTRIDE;
+        if (lq) {
+            const int kc = pb.cost_tv ? t : 0;
+            if (pb.cost_tv) {
+                const double *__restrict__ C = pb.Ctab + (long)kc * 256;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) crow[q] = C[j * 16 + q];
+                cq0 = C[(l / 12) * 16 + l % 12];
+                cq1 = C[((l + 64) / 12) * 16 + (l + 64) % 12];
+                cq2 = C[(e2 / 12) * 16 + e2 % 12];
+                cpr = C[(12 + g) * 16 + j];
+                clin = pb.lin[(long)kc * 16 + j];
+                cq00 = pb.q0[kc];
+            }
+            // f_x = A + diag(3 kappa x^2) | f_u = B
+            double z0 = zt0, z1 = zt1, z2 = zt2;
+            if (pb.kappa != 0.0) {
+                const int i0 = l >> 4, i1 = (64 + l) >> 4, i2 = (128 + l) >> 4;
+                if (j == i0) z0 += 3.0 * pb.kappa * (xu[i0 & 15] * xu[i0 & 15]);
+                if (j == i1) z1 += 3.0 * pb.kappa * (xu[i1 & 15] * xu[i1 & 15]);
+                if (j == i2) z2 += 3.0 * pb.kappa * (xu[i2 & 15] * xu[i2 & 15]);
+            }
+            tp[TS_Z + l] = z0; tp[TS_Z + 64 + l] = z1; tp[TS_Z + 128 + l] = z2;
+            tp[TS_Q + l] = cq0; tp[TS_Q + 64 + l] = cq1;
+            if (l < 16) tp[TS_Q + 128 + l] = cq2;
+            tp[TS_PR + l] = cpr;
+            double acc = 0.0;                                       // [c_x | c_u] = C [x;u] + [qv;rv]
+#pragma unroll
+            for (int q = 0; q < 12; ++q) acc += crow[q] * xu[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += crow[12 + q] * xu[12 + q];
+            if (l < 16) tp[TS_QR + l] = acc + clin;
+            double part = (l < 16) ? xu[j] * (0.5 * acc + clin) : 0.0;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (l == 0) tp[TS_q] = part + cq00;                     // c
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int e = 64 * r + l, i = e >> 4, cc = e & 15;
+                double val = 0.0;
+                if (i < pb.n) {
+                    if (cc == i) val = pb.pl_a * powchk(xu[i & 15], pb.pl_a - 1.0, dom);
+                    else if (cc == 12 + i) val = pb.pl_b * powchk(xu[12 + (i & 3)], pb.pl_b - 1.0, dom);
+                }
+                tp[TS_Z + e] = val;
+            }
+            for (int e = l; e < 144; e += 64) {
+                const int i = e / 12, jj = e - i * 12;
+                double val = 0.0;
+                if (i == jj && i < pb.n) val = pb.pl_cx * pb.pl_p * (pb.pl_p - 1.0) * powchk(xu[i & 15], pb.pl_p - 2.0, dom);
+                tp[TS_Q + e] = val;
+            }
+            {
+                double val = 0.0;
+                if (j == 12 + g) val = (g < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(xu[12 + g], pb.pl_pu - 2.0, dom) : 1.0;
+                tp[TS_PR + l] = val;
+            }
+            double part = 0.0, val = 0.0;
+            if (l < pb.n) {
+                val = pb.pl_cx * pb.pl_p * powchk(xu[l & 15], pb.pl_p - 1.0, dom);
+                part = pb.pl_cx * powchk(xu[l & 15], pb.pl_p, dom);
+            } else if (l >= 12 && l - 12 < pb.m) {
+                val = pb.pl_cu * pb.pl_pu * powchk(xu[l & 15], pb.pl_pu - 1.0, dom);
+                part = pb.pl_cu * powchk(xu[l & 15], pb.pl_pu, dom);
+            }
+            if (l < 16) tp[TS_QR + l] = val;
+            if (l >= 16) part = 0.0;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (l == 0) tp[TS_q] = part;
+        }
+        x = xn;
+        WAVE_SYNC();
+    }
+    // ---- terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316) ------------------------------------------
+    {
+        if (l < 12) shxu[l] = x;
+        WAVE_SYNC();
+        double *__restrict__ tp = tile0 + (long)N * TSTRIDE;
+        if (lq) {
+            for (int e = l; e < 144; e += 64) tp[TT_Q + e] = pb.Qf[e];
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) acc += pb.Qf[jx * 12 + q] * shxu[q];
+            const double qvf = pb.qvf[jx];
+            if (l < 12) tp[TT_QV + l] = acc + qvf;
+            double part = (l < 12) ? shxu[jx] * (0.5 * acc + qvf) : 0.0;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (l == 0) tp[TT_q] = part + pb.q0f;
+        } else {
+            for (int e = l; e < 144; e += 64) tp[TT_Q + e] = 0.0;
+            if (l < 12) tp[TT_QV + l] = 0.0;
+            if (l == 0) tp[TT_q] = pb.pl_h;
+        }
+    }
+    const bool anydom = __ballot(dom != 0) != 0ull;
+    if (l == 0) {
+        if (a.mode == 1) {
+            st.d_c[c] = dnan ? NAN : dmax;
+            st.flag_c[c] = anydom ? 2 : 0;
+        } else if (anydom) {
+            st.status[b] = 4;               // RAT_ST_DOMAIN
+            st.value[b] = INFINITY;
+        }
+    }
+}
+
+void launch_rollin(const RolloutArgs &a, hipStream_t s) {
+    const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
+    if (ncand <= 0) return;
+    hipLaunchKernelGGL(rollin_kernel, dim3(ncand), dim3(64), 0, s, a);
+}
+
+// =====================================================================================================
 // linearize_kernel: one wavefront per (trajectory, time step); writes the 417-double tile.
 // =====================================================================================================
 __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
