@@ -74,6 +74,18 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
+// sum over each 16-lane row with DPP row rotations (VALU speed; no trip through the LDS crossbar like ds_bpermute)
+__device__ __forceinline__ double row_sum16(double x) {
+#define ROW_ROR(v, n) __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + (n), 0xF, 0xF, false), \
+                                       __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + (n), 0xF, 0xF, false))
+    x += ROW_ROR(x, 8);
+    x += ROW_ROR(x, 4);
+    x += ROW_ROR(x, 2);
+    x += ROW_ROR(x, 1);
+#undef ROW_ROR
+    return x;
+}
+
 __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base.isapprox, rtol = sqrt(eps), atol = 0
     if (x == y) return true;
     if (!isfinite(x) || !isfinite(y)) return false;
@@ -768,9 +780,7 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc += crow[12 + q] * xu[12 + q];
             if (l < 16) tp[TS_QR + l] = acc + clin;
-            double part = (l < 16) ? xu[j] * (0.5 * acc + clin) : 0.0;
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+            const double part = row_sum16(xu[j] * (0.5 * acc + clin));    // every 16-lane row holds the same sum
             if (l == 0) tp[TS_q] = part + cq00;                     // c
         } else {
 #pragma unroll
@@ -804,8 +814,7 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
             }
             if (l < 16) tp[TS_QR + l] = val;
             if (l >= 16) part = 0.0;
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+            part = row_sum16(part);
             if (l == 0) tp[TS_q] = part;
         }
         x = xn;
@@ -823,9 +832,7 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
             for (int q = 0; q < 12; ++q) acc += pb.Qf[jx * 12 + q] * shxu[q];
             const double qvf = pb.qvf[jx];
             if (l < 12) tp[TT_QV + l] = acc + qvf;
-            double part = (l < 12) ? shxu[jx] * (0.5 * acc + qvf) : 0.0;
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+            const double part = row_sum16((j < 12) ? shxu[jx] * (0.5 * acc + qvf) : 0.0);
             if (l == 0) tp[TT_q] = part + pb.q0f;
         } else {
             for (int e = l; e < 144; e += 64) tp[TT_Q + e] = 0.0;
