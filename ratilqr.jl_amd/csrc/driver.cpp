@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,6 +35,9 @@ struct EvRec { hipEvent_t a, b; int kind; int64_t ntraj; };
 struct rat_handle_s {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // speculative gain sweeps run here, concurrently with the evaluation sweep
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
     rat_ileqg_opts opts;
     OptsDev opd;
     int Bmax = 0, E = 1;
@@ -99,6 +103,10 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     h->device = device; h->opts = o; h->Bmax = max_batch; h->E = spec_eps;
     set_opd(h);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
+    if (const char *e = getenv("RATILQR_SPECULATE")) h->speculate = (e[0] == '1');
     HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
     for (int i = 0; i < CTR_RING; ++i) HIPCHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
     memset(&h->st, 0, sizeof(h->st));
@@ -121,6 +129,9 @@ extern "C" void rat_destroy(rat_handle h) {
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
+    if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+    if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -192,8 +203,11 @@ static rat_rc alloc_state(rat_handle h) {
     AL(st.tiles, slots * st.tile_stride);
     AL(st.xs, slots * st.x_stride);
     AL(st.us, slots * st.u_stride);
-    AL(st.L, (size_t)B * N * LSTR);
-    AL(st.dl, (size_t)B * N * USTR);
+    st.l_half = (long)B * N * LSTR;
+    st.dl_half = (long)B * N * USTR;
+    AL(st.L, (size_t)2 * st.l_half);
+    AL(st.dl, (size_t)2 * st.dl_half);
+    AL(st.lsel, B); AL(st.mu_spec, B); AL(st.delta_spec, B); AL(st.spec_st, B);
     AL(st.theta, B); AL(st.mu, B); AL(st.delta, B); AL(st.value, B); AL(st.d_cur, B); AL(st.eps_init, B); AL(st.ls_eps, B);
     AL(st.status, B); AL(st.iter, B); AL(st.ls_active, B); AL(st.ls_count, B); AL(st.slot_nom, B); AL(st.n_ls, B); AL(st.hist_n, B);
     AL(st.value_c, (size_t)B * E); AL(st.d_c, (size_t)B * E); AL(st.flag_c, (size_t)B * E);
@@ -206,8 +220,10 @@ static rat_rc alloc_state(rat_handle h) {
     // padded lanes of the slot pools must be exact zeros
     HIPCHK(hipMemsetAsync(st.xs, 0, slots * st.x_stride * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(st.us, 0, slots * st.u_stride * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(st.L, 0, (size_t)B * N * LSTR * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(st.dl, 0, (size_t)B * N * USTR * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st.L, 0, (size_t)2 * st.l_half * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st.dl, 0, (size_t)2 * st.dl_half * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(st.lsel, 0, (size_t)B * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(st.spec_st, 0, (size_t)B * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(st.flag_c, 0, (size_t)B * E * sizeof(int), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return RAT_OK;
@@ -302,9 +318,10 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
 }
 
 // ---- profiling helpers -----------------------------------------------------------------------------
-static void prof_begin(rat_handle h, int kind, int64_t ntraj) {
+static void prof_begin(rat_handle h, int kind, int64_t ntraj, hipStream_t s = nullptr) {
     h->prof_cur = h->prof && ((h->prof_mask >> kind) & 1u);
     if (!h->prof_cur) return;
+    if (!s) s = h->stream;
     if (h->ev_used == h->evs.size()) {
         EvRec e;
         (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
@@ -312,16 +329,17 @@ static void prof_begin(rat_handle h, int kind, int64_t ntraj) {
     }
     EvRec &e = h->evs[h->ev_used];
     e.kind = kind; e.ntraj = ntraj;
-    (void)hipEventRecord(e.a, h->stream);
+    (void)hipEventRecord(e.a, s);
 }
-static void prof_end(rat_handle h) {
+static void prof_end(rat_handle h, hipStream_t s = nullptr) {
     if (!h->prof_cur) return;
-    (void)hipEventRecord(h->evs[h->ev_used].b, h->stream);
+    (void)hipEventRecord(h->evs[h->ev_used].b, s ? s : h->stream);
     h->ev_used++;
 }
 static void prof_flush(rat_handle h) {
     if (!h->ev_used) return;
     (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream2);
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, h->evs[i].a, h->evs[i].b);
@@ -351,7 +369,7 @@ extern "C" rat_rc rat_profile_get(rat_handle h, int64_t *launches, int64_t *traj
 }
 #ifdef RAT_DIAG
 extern "C" rat_rc rat_diag_read(rat_handle h, double *out64) {
-    HIPCHK(hipMemcpy(out64, h->d_dump, 64 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out64, h->d_dump, 128 * 8, hipMemcpyDeviceToHost));
     return RAT_OK;
 }
 #endif
@@ -376,20 +394,32 @@ static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
 }
 
 // One ROUND advances every sample by one stage of its own solve!/step!/line_search! sequence (ileqg.jl:494-659):
-//   gain sweep   for samples that are running and not inside a line search (step!: re-linearisation = the accepted
-//                candidate's tiles, App. B.1; solve_approximate_dp!; then line_search! starts: epilogue of the kernel)
-//   rollout, linearise, policy-evaluation sweep of E candidates for every sample inside a line search
-//   select       replays the sequential accept rule, convergence / iter_max tests, counts the samples still running
-// Samples never wait for each other: one that needs another line-search round simply skips the next gain sweep.
+//   [plain gain sweep for samples that are running, not inside a line search and without a committed speculative sweep]
+//   rollout + linearise (fused) of the E line-search candidates of every sample inside a line search
+//   policy-evaluation sweep of the candidates   ||   on a second stream: SPECULATIVE gain sweep of the next step! on
+//                                                    candidate 0's tiles (what step! would linearise if it is accepted)
+//   select: replays the sequential accept rule, convergence / iter_max tests; on accepting candidate 0 it commits the
+//           speculative gains (next step! begins: iter += 1, line search at eps_init) -- otherwise they are discarded.
+// The speculative sweep reads exactly the inputs the reference's next solve_approximate_dp! would (tiles of the accepted
+// trajectory, mu, Delta), so results are unchanged; the serial depth of a 2-iteration solve drops from 5 sweeps to 3 and
+// each SIMD holds two waves whose VALU (elimination) and MFMA phases overlap.
+// Samples never wait for each other: one that needs another line-search round simply gets no gain sweep this round.
 static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     const int slot = round % CTR_RING;
     const int64_t nc = (int64_t)st.B * st.E;
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
-    LinArgs la; la.st = st; la.pb = h->pb; la.mode = 1;
-    prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
-    (void)la;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    if (!h->speculate || st.E > 1) {     // E > 1: a candidate k > 0 may be accepted, whose gain sweep was not speculated
+        prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
+    }
     prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);        // fused rollout + linearise
+    if (h->speculate) {
+        HIPCHK(hipEventRecord(h->ev_a, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_a, 0));
+        prof_begin(h, RAT_K_SWEEP_GAIN, st.B, h->stream2); launch_sweep(sweep_args(h, st, 4), st.B, true, false, h->stream2); prof_end(h, h->stream2);
+        HIPCHK(hipEventRecord(h->ev_b, h->stream2));
+    }
     prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(sweep_args(h, st, 1), (int)nc, false, false, h->stream); prof_end(h);
+    if (h->speculate) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
     prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
     HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
@@ -404,12 +434,21 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
     StateDev st = h->st;
     st.B = B;
     launch_init_state(st, h->opd, theta_dev, h->stream);
-    // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
-    LinArgs la; la.st = st; la.pb = h->pb; la.mode = 0;
-    (void)la;
+    // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation; the first gain
+    // sweep (step! number 1 re-linearises the same trajectory, App. B.1) runs speculatively beside it.
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
     prof_begin(h, RAT_K_ROLLOUT, B); launch_rollin(ra, h->stream); prof_end(h);         // fused rollout + linearise
+    if (h->speculate) {
+        HIPCHK(hipEventRecord(h->ev_a, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_a, 0));
+        prof_begin(h, RAT_K_SWEEP_GAIN, B, h->stream2); launch_sweep(sweep_args(h, st, 5), B, true, false, h->stream2); prof_end(h, h->stream2);
+        HIPCHK(hipEventRecord(h->ev_b, h->stream2));
+    }
     prof_begin(h, RAT_K_SWEEP_INIT, B); launch_sweep(sweep_args(h, st, 2), B, false, false, h->stream); prof_end(h);
+    if (h->speculate) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
+        launch_commit_init(st, h->stream);
+    }
     // while true: step!; convergence / iter_max test   (ileqg.jl:640-654).  The host runs one round ahead of the counter
     // it polls, so the GPU never idles on a host round trip; the one surplus round at the end finds no live sample.
     const int64_t max_rounds = ((int64_t)h->opd.iter_max + 1) * (4000 / st.E + 2);
@@ -536,6 +575,8 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     HIPCHK(hipMemcpy(&st_h, h->st.status, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&it_h, h->st.iter, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&nom, h->st.slot_nom, 4, hipMemcpyDeviceToHost));
+    int lsel = 0;
+    HIPCHK(hipMemcpy(&lsel, h->st.lsel, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&hn, h->st.hist_n, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&val, h->st.value, 8, hipMemcpyDeviceToHost));
     if (status) *status = st_h;
@@ -548,7 +589,7 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     }
     std::vector<double> xp, up, Lp((size_t)h->N * LSTR);
     if ((rc = fetch_slot(h, nom, &xp, &up, nullptr))) return rc;
-    HIPCHK(hipMemcpy(Lp.data(), h->st.L, Lp.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(Lp.data(), h->st.L + (size_t)lsel * h->st.l_half, Lp.size() * 8, hipMemcpyDeviceToHost));
     if (x) unpad_x(h, xp, x);
     if (l) unpad_u(h, up, l);
     if (L) unpad_L(h, Lp, L);
@@ -562,7 +603,7 @@ extern "C" rat_rc rat_rollout_open(rat_handle h, const double *x0, const double 
     if (rc) return rc;
     StateDev st;
     if ((rc = op_prepare(h, 0.0, 0.0, h->opts.delta_0, &st))) return rc;
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
     launch_rollout(ra, h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> xp;
@@ -594,7 +635,7 @@ extern "C" rat_rc rat_rollout_feedback(rat_handle h, const double *xbar, const d
     HIPCHK(hipMemset(st.dl, 0, (size_t)h->N * USTR * 8));
     const int one = 1;
     HIPCHK(hipMemcpy(st.ls_active, &one, 4, hipMemcpyHostToDevice));
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
     launch_rollout(ra, h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> xp, up;

@@ -11,6 +11,7 @@ struct SweepArgs {
     int mode;              // 0 gain sweep on nominal slots; 1 policy evaluation of line-search candidates;
                            // 2 policy evaluation of nominal slots with L = 0, mu = 0 (initialize!);
                            // 3 operator form of policy evaluation (sample 0, L/dl given, mu = mu_op)
+                           // 4 speculative gain sweep on line-search candidate 0; 5 speculative gain sweep on nominal slots
     const double *dl_in;   // mode 3: dl_array or null
     double mu_op;          // mode 3
     double *op_out;        // modes 0/3 operator forms: [0] = s_1, [1] = status ; else null
@@ -24,6 +25,7 @@ struct RolloutArgs {
     int mode;              // 0 open loop from (x0, u0) into the nominal slots; 1 closed loop candidates
     const double *x0;      // [12]
     const double *u0;      // [N*4]
+    double *dump;          // diagnostic builds only
 };
 
 struct LinArgs {
@@ -38,4 +40,5 @@ void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout +
 void launch_linearize(const LinArgs &a, hipStream_t s);
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
+void launch_commit_init(const StateDev &st, hipStream_t s);
 void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, hipStream_t s);

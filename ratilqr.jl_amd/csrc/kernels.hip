@@ -110,7 +110,7 @@ __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base
 // =====================================================================================================
 struct TileRegs {
     d4 z, c, lc;
-    double qr, q;
+    double qr, q, la;
 };
 
 // All loads are unconditional and branch-free (clamped lane offsets + selects): the number of loads in flight is then a
@@ -119,7 +119,7 @@ struct TileRegs {
 // which exposes a full HBM latency per time step.)
 template <bool GAIN, bool DUMP>
 __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict__ tp, const int (&offC)[4], int l, int j,
-                                          const double *__restrict__ Lp, const double *__restrict__ dlp, bool haveL) {
+                                          const double *__restrict__ Lp, const double *__restrict__ dlp, double mL, int g) {
     tr.z[0] = tp[TS_Z + l];
     tr.z[1] = tp[TS_Z + 64 + l];
     tr.z[2] = tp[TS_Z + 128 + l];
@@ -131,18 +131,18 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
     tr.qr = tp[TS_QR + j];
     tr.q = tp[TS_q];
     if (!GAIN) {
-        const int jc = (j < 12) ? j : 11;
-        const bool use = haveL && (j < 12);
-        const double l0 = Lp[jc], l1 = Lp[12 + jc], l2 = Lp[24 + jc], l3 = Lp[36 + jc];
-        tr.lc[0] = use ? l0 : 0.0;
-        tr.lc[1] = use ? l1 : 0.0;
-        tr.lc[2] = use ? l2 : 0.0;
-        tr.lc[3] = use ? l3 : 0.0;
+        const int jc = (j < 12) ? j : 11;      // mL = 1 on lanes that hold a gain column (gains given and j < 12), else 0
+        tr.lc[0] = Lp[jc] * mL;
+        tr.lc[1] = Lp[12 + jc] * mL;
+        tr.lc[2] = Lp[24 + jc] * mL;
+        tr.lc[3] = Lp[36 + jc] * mL;
+        tr.la = Lp[g * 12 + jc] * mL;          // this lane's own entry L[g][j] of the natural 4 x 16 layout
         if (DUMP && dlp && j == 12) {           // operator form only (rat_dp_policy_eval with a dl_array)
             tr.lc[0] = dlp[0];
             tr.lc[1] = dlp[1];
             tr.lc[2] = dlp[2];
             tr.lc[3] = dlp[3];
+            tr.la = dlp[g];
         }
     }
 }
@@ -162,6 +162,14 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
         cidx = tid;
         if (st.flag_c[cidx] == 2) return;
         slot = cand_slot(b, k, st.slot_nom[b], st.E);
+    } else if (a.mode == 4) {          // speculative gain sweep of the NEXT iteration on line-search candidate 0
+        b = tid;
+        if (!st.ls_active[b]) return;
+        if (st.flag_c[b * st.E] == 2) return;
+        slot = cand_slot(b, 0, st.slot_nom[b], st.E);
+    } else if (a.mode == 5) {          // speculative first gain sweep on the nominal tiles, concurrent with initialize!'s sweep
+        b = tid;
+        slot = b * (st.E + 1) + st.slot_nom[b];
     } else {
         b = tid;
         if (st.status[b] != ST_RUNNING) return;
@@ -173,14 +181,45 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     double delta = st.delta[b];
     const int N = st.N;
     const double *__restrict__ tile0 = st.tiles + (long)slot * st.tile_stride;
-    const bool haveL = (a.mode == 1 || a.mode == 3);
-    const double *__restrict__ Lb = st.L + (long)b * N * LSTR;
-    double *__restrict__ Lout = st.L + (long)b * N * LSTR;
-    double *__restrict__ dlout = st.dl + (long)b * N * USTR;
+    const int sel = st.lsel[b];
+    const int osel = (a.mode >= 4) ? (sel ^ 1) : sel;      // speculative sweeps fill the other half; committed by select
+    const double *__restrict__ Lb = st.L + (long)sel * st.l_half + (long)b * N * LSTR;
+    double *__restrict__ Lout = st.L + (long)osel * st.l_half + (long)b * N * LSTR;
+    double *__restrict__ dlout = st.dl + (long)osel * st.dl_half + (long)b * N * USTR;
 
     __shared__ double rowbuf[2][2][16];
-    __shared__ double hbuf[4][16];
-    __shared__ double fbuf[16];
+    __shared__ double ex[88];          // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0
+#define HBUF(r_, c_) ex[(r_) * 16 + (c_)]
+#define FBUF(c_) ex[64 + (c_)]
+    if (l < 8) ex[80 + l] = 0.0;
+
+    // The loop is bound by VALU issue of ONE wave (every instruction costs >= 4 cycles), so lane-position selects are
+    // replaced by per-lane 0/1 multipliers and per-lane LDS offsets computed once here (loop invariant, kept in VGPRs).
+    const double mL = ((a.mode == 1 || a.mode == 3) && j < 12) ? 1.0 : 0.0;
+    double m12 = (j < 12) ? 1.0 : 0.0;                       // lanes holding a state column
+    double nth12 = -st.theta[b] * m12;
+    double mA = (g == 0 && j < 12) ? 1.0 : 0.0, mB = (g == 0 && j == 12) ? 1.0 : 0.0, mH = (j == 12 + g) ? 1.0 : 0.0;
+    // elimination round kb (pivot block {2kb, 2kb+1}): cm = 0 on the pivot columns, crm = 0 on pivot columns and (in the
+    // register that holds the pivot rows) on the pivot rows, wa = -1 in a row's own pivot slot (rows are exchanged as
+    // m*cm + wa, which puts -I into the pivot block)
+    double cm[6], crm[6], wa[6];
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb) {
+        const int k = 2 * kb, kg = k & 3;
+        const bool colk = (j == k) || (j == k + 1), rowk = (g == kg) || (g == kg + 1);
+        cm[kb] = colk ? 0.0 : 1.0;
+        crm[kb] = (colk || rowk) ? 0.0 : 1.0;
+        wa[kb] = (j == k + (g - kg)) ? -1.0 : 0.0;
+    }
+    int hoff[4], foff[3], goff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        hoff[k] = (g <= k) ? (g * 16 + 12 + k) : (k * 16 + 12 + g);      // Symmetric(H): upper triangle (:371)
+        goff[k] = (j < 12) ? (k * 16 + j) : (j == 12 ? 64 + 12 + k : 80); // column j of [G | g | 0]
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) foff[r] = (j == 12) ? (64 + 4 * r + g) : 80;
+    const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
 
     int offC[4];
 #pragma unroll
@@ -233,7 +272,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
         }
         TileRegs nx;
         load_tile<GAIN, DUMP>(nx, tile0 + (long)(N - 1) * TSTRIDE, offC, l, j, Lb + (long)(N - 1) * LSTR,
-                        a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, haveL);
+                        a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, mL, g);
         bool h_not_pd = false;
         for (int t = N - 1; t >= 0; --t) {
             // opaque per-step copies of the lane indices: keeps the (lane == const) masks as one v_cmp at their use
@@ -247,7 +286,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                                 // wait with a counted vmcnt(N) instead of vmcnt(0) at the join of a branch.
                 const int tn = (t > 0) ? t - 1 : 0;
                 load_tile<GAIN, DUMP>(nx, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR,
-                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, haveL);
+                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g);
             }
             if (WTV) {          // time-varying W(k): separate instantiation, so that the common case keeps a static load count
 #pragma unroll
@@ -262,7 +301,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                 // M = Symmetric(inv(W) - theta S)   (ileqg.jl:365)
                 d4 m;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) m[r] = (j < 12) ? (winv[r] - theta * v[r]) : 0.0;
+                for (int r = 0; r < 3; ++r) m[r] = fma(nth12, v[r], winv[r]);     // inv(W) table is zero in columns >= 12
                 m[3] = 0.0;
                 DIAG_STAMP(0, m[0]);
                 // symmetric sweep operator with 2x2 block pivots K = {k, k+1}, k = 0, 2, .., 10:  m <- -M^-1.
@@ -278,11 +317,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                     const double p11 = readlane_f64(m[kr], kg * 16 + k);
                     const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
                     const double p22 = readlane_f64(m[kr], (kg + 1) * 16 + k + 1);
-                    if (g == kg || g == kg + 1) {
-                        const bool own = (j == k + (g - kg));                // my row's own pivot slot -> -1, the other -> 0
-                        const bool oth = (j == k + 1 - (g - kg));
-                        rowbuf[kb & 1][g - kg][j] = own ? -1.0 : (oth ? 0.0 : m[kr]);
-                    }
+                    if (g == kg || g == kg + 1)                              // own pivot slot -> -1, the other -> 0
+                        rowbuf[kb & 1][g - kg][j] = fma(m[kr], cm[kb], wa[kb]);
                     const double det = fma(p11, p22, -(p12 * p12));
                     const double idet = fast_rcp1(det);                      // overlaps the LDS row exchange
                     const double b11 = p22 * idet, b12 = -(p12 * idet), b22 = p11 * idet;
@@ -294,20 +330,16 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                     pd = pd && (p11 > 0.0) && (det > 0.0);
                     pivdet = (l == k) ? det : pivdet;
                     const double u1 = fma(b12, v2, b11 * v1), u2 = fma(b22, v2, b12 * v1);
-                    const bool colk = (j == k) || (j == k + 1), rowk = (g == kg) || (g == kg + 1);
-                    const double b0 = (colk || (kr == 0 && rowk)) ? 0.0 : m[0];
-                    const double b1 = (colk || (kr == 1 && rowk)) ? 0.0 : m[1];
-                    const double b2 = (colk || (kr == 2 && rowk)) ? 0.0 : m[2];
-                    m[0] = fma(-a20, u2, fma(-a10, u1, b0));
-                    m[1] = fma(-a21, u2, fma(-a11, u1, b1));
-                    m[2] = fma(-a22, u2, fma(-a12, u1, b2));
+                    m[0] = fma(-a20, u2, fma(-a10, u1, m[0] * (kr == 0 ? crm[kb] : cm[kb])));
+                    m[1] = fma(-a21, u2, fma(-a11, u1, m[1] * (kr == 1 ? crm[kb] : cm[kb])));
+                    m[2] = fma(-a22, u2, fma(-a12, u1, m[2] * (kr == 2 ? crm[kb] : cm[kb])));
                 }
                 DIAG_STAMP(1, m[0]);
                 if (!pd) { fail = 1; break; }
                 // theta M^-1 (the sweep left -M^-1); padded columns cleared
                 d4 minv;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) minv[r] = (j < 12) ? -theta * m[r] : 0.0;
+                for (int r = 0; r < 3; ++r) minv[r] = nth12 * m[r];
                 minv[3] = 0.0;
                 // logdet(W M) = sum over blocks of log(det P_k / (e_k e_k+1))   (ileqg.jl:387), reduced once per sweep
                 // (kept as a normalised running product: one log() per sweep instead of one per step)
@@ -323,7 +355,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                 DIAG_STAMP(2, vt[0]);
             } else {
                 // theta == 0: D = I ; 0.5 tr(W S)   (ileqg.jl:385)
-                if (j < 12) racc += wp[0] * v[0] + wp[1] * v[1] + wp[2] * v[2];
+                racc += m12 * (wp[0] * v[0] + wp[1] * v[1] + wp[2] * v[2]);
                 vt = v;
             }
             // T = V~[:, 0:12] [A|B] : rows 0..11 = (D S)[A|B], row 12 = (D s_vec)'[A|B]
@@ -331,23 +363,21 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             // F = [A|B]' T + [[Q,P'],[P,R]]  (:369-370 and the Q + A'DSA term of :390)
             d4 f = mm3(cur.z, tm, cur.c);
             // H block: rows 12..15 of F live in register 3;  + mu I  (:370)
-            const double gh = f[3] + ((j == 12 + g) ? mu : 0.0);
+            const double gh = fma(mu, mH, f[3]);
             const double fv = tm[3] + cur.qr;      // lanes g == 0: [q_vec + A' D s_vec | r + B' D s_vec]  (:368, :389)
             DIAG_STAMP(3, gh);
-            hbuf[g][j] = gh;
-            if (g == 0) fbuf[j] = fv;
+            HBUF(g, j) = gh;
+            if (g == 0) FBUF(j) = fv;
             WAVE_SYNC();
-            // H = Symmetric(H): upper triangle   (:371)
-            const double h00 = hbuf[0][12], h01 = hbuf[0][13], h02 = hbuf[0][14], h03 = hbuf[0][15];
-            const double h11 = hbuf[1][13], h12 = hbuf[1][14], h13 = hbuf[1][15];
-            const double h22 = hbuf[2][14], h23 = hbuf[2][15], h33 = hbuf[3][15];
-            // column j of [G | g | 0]
-            double g0, g1, g2, g3;
-            if (j < 12) { g0 = hbuf[0][j]; g1 = hbuf[1][j]; g2 = hbuf[2][j]; g3 = hbuf[3][j]; }
-            else if (j == 12) { g0 = fbuf[12]; g1 = fbuf[13]; g2 = fbuf[14]; g3 = fbuf[15]; }
-            else { g0 = g1 = g2 = g3 = 0.0; }
-            double x0, x1, x2, x3;
+            // row g of H = Symmetric(H) (upper triangle, :371) and this lane's entry of [G | g | 0]
+            const double hg0 = ex[hoff[0]], hg1 = ex[hoff[1]], hg2 = ex[hoff[2]], hg3 = ex[hoff[3]];
+            const double ga = fma(gh, m12, ex[gaoff]);
+            double x0, x1, x2, x3, la;
             if (GAIN) {
+                const double h00 = HBUF(0, 12), h01 = HBUF(0, 13), h02 = HBUF(0, 14), h03 = HBUF(0, 15);
+                const double h11 = HBUF(1, 13), h12 = HBUF(1, 14), h13 = HBUF(1, 15);
+                const double h22 = HBUF(2, 14), h23 = HBUF(2, 15), h33 = HBUF(3, 15);
+                const double g0 = ex[goff[0]], g1 = ex[goff[1]], g2 = ex[goff[2]], g3 = ex[goff[3]];   // column j of [G | g | 0]
                 // LDL' of H; all pivots > 0 <=> isposdef(H)   (:372)
                 const double d0 = h00, i0 = fast_rcp(d0);
                 const double l10 = h01 * i0, l20 = h02 * i0, l30 = h03 * i0;
@@ -366,15 +396,11 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                 x2 = y2 * i2 - l32 * x3;
                 x1 = y1 * i1 - l21 * x2 - l31 * x3;
                 x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+                la = (g == 0) ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));             // [L | dl] natural rows
             } else {
                 x0 = cur.lc[0]; x1 = cur.lc[1]; x2 = cur.lc[2]; x3 = cur.lc[3];
+                la = cur.la;
             }
-            const double la = (g == 0) ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));     // [L | dl] natural rows
-            const double ga = (g == 0) ? g0 : (g == 1 ? g1 : (g == 2 ? g2 : g3));     // [G | g]  natural rows
-            const double hg0 = (g == 0) ? h00 : (g == 1 ? h01 : (g == 2 ? h02 : h03));
-            const double hg1 = (g == 0) ? h01 : (g == 1 ? h11 : (g == 2 ? h12 : h13));
-            const double hg2 = (g == 0) ? h02 : (g == 1 ? h12 : (g == 2 ? h22 : h23));
-            const double hg3 = (g == 0) ? h03 : (g == 1 ? h13 : (g == 2 ? h23 : h33));
             const double ua = hg0 * x0 + hg1 * x1 + hg2 * x2 + hg3 * x3 + ga;         // H [L|dl] + [G|g]
             DIAG_STAMP(4, ua);
             if (GAIN) {
@@ -384,8 +410,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             // Fx = [[Q + A'DSA, f_x], [f_x', 2q + 2s + theta s'M^-1 s]]
             d4 fx;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) fx[r] = (j < 12) ? f[r] : (j == 12 ? fbuf[4 * r + g] : 0.0);
-            fx[3] = (g == 0) ? (j < 12 ? fv : (j == 12 ? 2.0 * cur.q + vt[3] : 0.0)) : 0.0;
+            for (int r = 0; r < 3; ++r) fx[r] = fma(f[r], m12, ex[foff[r]]);
+            fx[3] = fma(fv, mA, (2.0 * cur.q + vt[3]) * mB);
             // V = Fx + La' Ua + Ga' La    (:383, :389, :390)
             d4 vn = MFMA(la, ua, fx);
             vn = MFMA(ga, la, vn);
@@ -401,11 +427,11 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                     if (j == 12) dp[DUMP_SV + i] = v[r];
                 }
                 if (l == 12) dp[DUMP_s] = 0.5 * v[3] + coef * tot;
-                if (l < 4) dp[DUMP_g + l] = fbuf[12 + l];
-                if (j < 12) dp[DUMP_G + g * 12 + j] = hbuf[g][j];
-                else dp[DUMP_H + g * 4 + (j - 12)] = (g <= j - 12) ? hbuf[g][j] : hbuf[j - 12][12 + g];
+                if (l < 4) dp[DUMP_g + l] = FBUF(12 + l);
+                if (j < 12) dp[DUMP_G + g * 12 + j] = HBUF(g, j);
+                else dp[DUMP_H + g * 4 + (j - 12)] = (g <= j - 12) ? HBUF(g, j) : HBUF(j - 12, 12 + g);
             }
-            WAVE_SYNC();          // hbuf / fbuf are rewritten next step
+            WAVE_SYNC();          // the exchange area is rewritten next step
         }
         if (GAIN && h_not_pd) {
             // increase_mu_and_delta!  (ileqg.jl:471-474), then restart the whole sweep (:373-378)
@@ -433,6 +459,10 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
         } else if (a.mode == 3) {
             a.op_out[0] = s0;
             a.op_out[1] = (double)(fail ? 2 : 0);
+        } else if (a.mode >= 4) {
+            st.mu_spec[b] = mu;
+            st.delta_spec[b] = delta;
+            st.spec_st[b] = fail ? (fail == 1 ? 2 : 5) : 1;
         } else {
             st.mu[b] = mu;
             st.delta[b] = delta;
@@ -501,8 +531,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const double *__restrict__ lnom = (a.mode == 0) ? a.u0 : st.us + (long)slot_n * st.u_stride;
     double *__restrict__ xo = st.xs + (long)slot_o * st.x_stride;
     double *__restrict__ uo = st.us + (long)slot_o * st.u_stride;
-    const double *__restrict__ Lb = st.L + (long)b * N * LSTR;
-    const double *__restrict__ dlb = st.dl + (long)b * N * USTR;
+    const int lsel = st.lsel[b];
+    const double *__restrict__ Lb = st.L + (long)lsel * st.l_half + (long)b * N * LSTR;
+    const double *__restrict__ dlb = st.dl + (long)lsel * st.dl_half + (long)b * N * USTR;
 
     double eps = 0.0;
     if (live && a.mode == 1) {
@@ -622,6 +653,7 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // round trip through HBM between the two reference functions (ileqg.jl:62-87 then :258-322).  Same arithmetic as
 // rollout_kernel + linearize_kernel (which remain for the operator entry points).
 // =====================================================================================================
+template <int MODEL, int MODE>
 __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     const int l = threadIdx.x, j = l & 15, g = l >> 4;
     const StateDev &st = a.st;
@@ -629,7 +661,7 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     const int N = st.N;
     const int c = blockIdx.x;
     int b, k = 0;
-    if (a.mode == 0) { b = c; if (st.status[b] != ST_RUNNING) return; }
+    if (MODE == 0) { b = c; if (st.status[b] != ST_RUNNING) return; }
     else { b = c / st.E; k = c - b * st.E; if (!st.ls_active[b]) return; }
     __shared__ double shdx[12];
     __shared__ double shxu[16];
@@ -637,18 +669,19 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
 
     const int nom = st.slot_nom[b];
     const int slot_n = b * (st.E + 1) + nom;
-    const int slot_o = (a.mode == 0) ? slot_n : cand_slot(b, k, nom, st.E);
+    const int slot_o = (MODE == 0) ? slot_n : cand_slot(b, k, nom, st.E);
     const double *__restrict__ xbar = st.xs + (long)slot_n * st.x_stride;
-    const double *__restrict__ lnom = (a.mode == 0) ? a.u0 : st.us + (long)slot_n * st.u_stride;
+    const double *__restrict__ lnom = (MODE == 0) ? a.u0 : st.us + (long)slot_n * st.u_stride;
     double *__restrict__ xo = st.xs + (long)slot_o * st.x_stride;
     double *__restrict__ uo = st.us + (long)slot_o * st.u_stride;
     double *__restrict__ tile0 = st.tiles + (long)slot_o * st.tile_stride;
-    const double *__restrict__ Lb = st.L + (long)b * N * LSTR;
-    const double *__restrict__ dlb = st.dl + (long)b * N * USTR;
-    const bool lq = (pb.model == 1);
+    const int lsel = st.lsel[b];
+    const double *__restrict__ Lb = st.L + (long)lsel * st.l_half + (long)b * N * LSTR;
+    const double *__restrict__ dlb = st.dl + (long)lsel * st.dl_half + (long)b * N * USTR;
+    constexpr bool lq = (MODEL == 1);
 
     double eps = 0.0;
-    if (a.mode == 1) {
+    if (MODE == 1) {
         eps = st.ls_eps[b];
         for (int q = 0; q < k; ++q) eps *= a.op.lambda;        // eps_k = eps * lambda^k by repeated multiplication (:530,:557)
     }
@@ -673,7 +706,7 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
         }
     }
     double x = 0.0;
-    if (j < 12) x = (a.mode == 0) ? a.x0[j] : xbar[j];
+    if (j < 12) x = (MODE == 0) ? a.x0[j] : xbar[j];
     if (l < 12) xo[l] = x;
     double dmax = -INFINITY;
     bool dnan = false;
@@ -682,11 +715,13 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     double n_L[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) n_L[q] = 0.0;
-    if (a.mode == 1) {
+    if (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < 12; ++q) n_L[q] = Lb[ju * 12 + q];
     }
+    DIAG_DECL
     for (int t = 0; t < N; ++t) {
+        DIAG_START();
         const double c_xb = n_xb, c_l = n_l, c_dl = n_dl;
         double c_L[12];
 #pragma unroll
@@ -696,13 +731,13 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
             n_xb = xbar[(long)tn * XSTR + jx];
             n_l = lnom[(long)tn * USTR + ju];
             n_dl = dlb[(long)tn * USTR + ju];
-            if (a.mode == 1) {
+            if (MODE == 1) {
 #pragma unroll
                 for (int q = 0; q < 12; ++q) n_L[q] = Lb[(long)tn * LSTR + ju * 12 + q];
             }
         }
         double u = c_l;
-        if (a.mode == 1) {
+        if (MODE == 1) {
             if (l < 12) shdx[l] = x - c_xb;
             WAVE_SYNC();
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -717,6 +752,7 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
             const double du = c_l - u;
             if (l < 4) shq[l] = du * du;
         }
+        DIAG_STAMP(0, u);
         if (l < 12) shxu[l] = x;
         if (l < 4) shxu[12 + l] = u;
         WAVE_SYNC();
@@ -740,11 +776,12 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
         } else if (j < pb.n) {
             xn = powchk(x, pb.pl_a, dom) + powchk(xu[12 + (j & 3)], pb.pl_b, dom);
         }
-        if (a.mode == 1 && l == 0) {
+        if (MODE == 1 && l == 0) {
             const double dn = sqrt(shq[0] + shq[1] + shq[2] + shq[3]);
             if (dn != dn) dnan = true;                          // maximum() propagates NaN
             else if (dn > dmax) dmax = dn;
         }
+        DIAG_STAMP(1, xn);
         if (l < 12) xo[(long)(t + 1) * XSTR + l] = xn;
         if (l < 4) uo[(long)t * USTR + l] = u;
         // ---- tile of step t: approximate_model at (x_t, u_t)   (ileqg.jl:294-313) ---------------------
@@ -774,11 +811,15 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
             tp[TS_Q + l] = cq0; tp[TS_Q + 64 + l] = cq1;
             if (l < 16) tp[TS_Q + 128 + l] = cq2;
             tp[TS_PR + l] = cpr;
-            double acc = 0.0;                                       // [c_x | c_u] = C [x;u] + [qv;rv]
+            double acc, ac1 = 0.0, ac2 = 0.0, ac3 = 0.0, ac4 = 0.0;  // [c_x | c_u] = C [x;u] + [qv;rv]  (4 chains for ILP)
 #pragma unroll
-            for (int q = 0; q < 12; ++q) acc += crow[q] * xu[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc += crow[12 + q] * xu[12 + q];
+            for (int q = 0; q < 4; ++q) {
+                ac1 = fma(crow[q], xu[q], ac1);
+                ac2 = fma(crow[4 + q], xu[4 + q], ac2);
+                ac3 = fma(crow[8 + q], xu[8 + q], ac3);
+                ac4 = fma(crow[12 + q], xu[12 + q], ac4);
+            }
+            acc = ((ac1 + ac2) + ac3) + ac4;
             if (l < 16) tp[TS_QR + l] = acc + clin;
             const double part = row_sum16(xu[j] * (0.5 * acc + clin));    // every 16-lane row holds the same sum
             if (l == 0) tp[TS_q] = part + cq00;                     // c
@@ -819,7 +860,12 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
         }
         x = xn;
         WAVE_SYNC();
+        DIAG_STAMP(2, x);
     }
+#ifdef RAT_DIAG
+    if (l == 0 && blockIdx.x < 8 && a.dump)
+        for (int q = 0; q < 3; ++q) a.dump[64 + blockIdx.x * 8 + q] = (double)dg_acc[q];
+#endif
     // ---- terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316) ------------------------------------------
     {
         if (l < 12) shxu[l] = x;
@@ -842,7 +888,7 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     }
     const bool anydom = __ballot(dom != 0) != 0ull;
     if (l == 0) {
-        if (a.mode == 1) {
+        if (MODE == 1) {
             st.d_c[c] = dnan ? NAN : dmax;
             st.flag_c[c] = anydom ? 2 : 0;
         } else if (anydom) {
@@ -855,7 +901,16 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
 void launch_rollin(const RolloutArgs &a, hipStream_t s) {
     const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
     if (ncand <= 0) return;
-    hipLaunchKernelGGL(rollin_kernel, dim3(ncand), dim3(64), 0, s, a);
+    const dim3 grid(ncand), block(64);
+    // one compact instantiation per (model family, mode): the LQ hot loop must not carry the inlined pow() expansions
+    // of the power-law family through the instruction cache
+    if (a.pb.model == 1) {
+        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<1, 0>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rollin_kernel<1, 1>), grid, block, 0, s, a);
+    } else {
+        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<2, 0>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rollin_kernel<2, 1>), grid, block, 0, s, a);
+    }
 }
 
 // =====================================================================================================
@@ -1009,6 +1064,40 @@ __global__ void init_state_kernel(StateDev st, OptsDev op, const double *theta_i
     st.slot_nom[b] = 0;
     st.n_ls[b] = 0;
     st.hist_n[b] = 0;
+    st.lsel[b] = 0;
+    st.spec_st[b] = 0;
+}
+
+// Start of the next step! (ileqg.jl:598-613) for a sample whose gain sweep has already been run speculatively:
+// iter += 1, adopt its gains / mu / Delta (or its failure), and enter line_search! at eps_init (:502).
+__device__ __forceinline__ bool commit_spec(const StateDev &st, int b) {
+    const int sp = st.spec_st[b];
+    st.spec_st[b] = 0;
+    st.iter[b] += 1;                                       // :599
+    st.mu[b] = st.mu_spec[b];
+    st.delta[b] = st.delta_spec[b];
+    if (sp != 1) {                                         // @assert isposdef(M) (:366) / mu-restart divergence
+        st.status[b] = (sp == 2) ? 2 : 5;
+        st.value[b] = INFINITY;
+        st.ls_active[b] = 0;
+        return false;
+    }
+    st.lsel[b] ^= 1;                                       // ileqg.L_array <- L of the gain sweep (:380)
+    st.ls_eps[b] = st.eps_init[b];
+    st.ls_count[b] = 0;
+    st.ls_active[b] = 1;
+    return true;
+}
+
+// after initialize!: samples that survived the open-loop sweep start step! number 1 with the speculative gains
+__global__ void commit_init_kernel(StateDev st) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    if (st.status[b] != ST_RUNNING) { st.spec_st[b] = 0; return; }
+    if (st.spec_st[b] != 0) commit_spec(st, b);
+}
+void launch_commit_init(const StateDev &st, hipStream_t s) {
+    hipLaunchKernelGGL(commit_init_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st);
 }
 
 // Replays the sequential rule of line_search! (ileqg.jl:504-581) over the E speculatively evaluated
@@ -1049,11 +1138,13 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
         if (eps < op.eps_min) { chosen = k; break; }           // :558 forced accept of the candidate just evaluated
     }
     st.n_ls[b] += (chosen >= 0 || failed) ? (count - st.ls_count[b]) : st.E;
+    const int spec = st.spec_st[b];
     if (failed) {
-        st.status[b] = 4; st.value[b] = INFINITY; st.ls_active[b] = 0;
+        st.status[b] = 4; st.value[b] = INFINITY; st.ls_active[b] = 0; st.spec_st[b] = 0;
         return;
     }
     if (chosen < 0) {
+        st.spec_st[b] = 0;                                     // candidate 0 was not accepted: its gain sweep is void
         if (count > 4000) { st.status[b] = 7; st.value[b] = INFINITY; st.ls_active[b] = 0; return; }
         st.ls_eps[b] = eps;
         st.ls_count[b] = count;
@@ -1075,9 +1166,14 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
             st.eps_init[b] = eps;
         }
     }
-    if (op.d > st.d_cur[b] && st.mu[b] <= op.mu_min) st.status[b] = 0;              // converged  (:642)
-    else if (st.iter[b] == op.iter_max) st.status[b] = 3;                           // iter_max   (:648)
-    else atomicAdd(&ctr[1], 1);
+    if (op.d > st.d_cur[b] && st.mu[b] <= op.mu_min) { st.status[b] = 0; st.spec_st[b] = 0; }              // converged  (:642)
+    else if (st.iter[b] == op.iter_max) { st.status[b] = 3; st.spec_st[b] = 0; }                           // iter_max   (:648)
+    else if (chosen == 0 && spec != 0) {
+        if (commit_spec(st, b)) atomicAdd(&ctr[1], 1);         // next step! already has its gain sweep: straight to line search
+    } else {
+        st.spec_st[b] = 0;
+        atomicAdd(&ctr[1], 1);                                 // next round runs the plain gain sweep for this sample
+    }
 }
 
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s) {

@@ -70,7 +70,11 @@ struct StateDev {
     int B, E, N;
     long tile_stride, x_stride, u_stride;      // doubles per slot
     double *tiles, *xs, *us;                   // slot pools: B*(E+1) slots
-    double *L, *dl;                            // [B][N*48], [B][N*4]
+    double *L, *dl;                            // [2][Bmax][N*48], [2][Bmax][N*4]: double-buffered gains (lsel[b] = live half)
+    long l_half, dl_half;                      // doubles per half
+    int *lsel;                                 // [B] which half holds the committed L_array / dl of sample b
+    double *mu_spec, *delta_spec;              // [B] mu, Delta left by the speculative gain sweep
+    int *spec_st;                              // [B] 0 none, 1 speculative gain sweep valid, 2 it hit M not PD, 5 mu diverged
     double *theta, *mu, *delta, *value, *d_cur, *eps_init, *ls_eps;
     int *status, *iter, *ls_active, *ls_count, *slot_nom, *n_ls, *hist_n;
     double *value_c, *d_c;                     // [B*E]

@@ -260,3 +260,25 @@ def test_dp_failed_line_search_candidates(seed, theta):
         if ref is None:
             ref = v[0]
         assert v[0] == ref
+
+
+def test_speculative_gain_sweep_is_result_identical(monkeypatch):
+    """Opt-in mode (RATILQR_SPECULATE=1): the next step!'s gain sweep runs on candidate 0 concurrently with its
+    evaluation sweep and is committed by the select kernel.  Must not change a single bit of any result."""
+    prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
+    theta = np.array([0.0, 1.0, 4.0, 5.0, 5.9, 6.3, 6.6, 9.0])
+    sprob, sx0, su = stress_problem(2, kappa=0.03)
+    for E in (1, 4):
+        ref = rat.Context(prob, max_batch=theta.size, spec_eps=E).solve_batch(x0, u, theta)
+        ref_s = rat.Context(sprob, rat.ileqg.make_opts(iter_max=8), max_batch=3, spec_eps=E).solve_batch(sx0, su, np.array([0.0, 1.0, 4.0]))
+        monkeypatch.setenv("RATILQR_SPECULATE", "1")
+        got = rat.Context(prob, max_batch=theta.size, spec_eps=E).solve_batch(x0, u, theta)
+        got_s = rat.Context(sprob, rat.ileqg.make_opts(iter_max=8), max_batch=3, spec_eps=E).solve_batch(sx0, su, np.array([0.0, 1.0, 4.0]))
+        sctx = rat.Context(prob, spec_eps=E)
+        r1 = sctx.solve(x0, u, 5.0)
+        monkeypatch.delenv("RATILQR_SPECULATE")
+        r0 = rat.Context(prob, spec_eps=E).solve(x0, u, 5.0)
+        for a, b in zip(ref + ref_s, got + got_s):
+            assert np.array_equal(a, b)
+        assert np.array_equal(r0["L"], r1["L"]) and np.array_equal(r0["x"], r1["x"]) and r0["value"] == r1["value"]
+        assert np.array_equal(r0["eps_history"], r1["eps_history"])

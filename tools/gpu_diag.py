@@ -11,7 +11,9 @@ for E in (1, 8):
     ctx = rat.Context(prob, max_batch=1024, spec_eps=E)
     for th in (0.0, 1.0):
         ctx.solve_batch(x0, u, np.full(1024, th))
-        out = np.zeros(64)
+        out = np.zeros(128)
         rat.native.lib().rat_diag_read(ctx.h, out.ctypes.data_as(C.POINTER(C.c_double)))
-        d = out.reshape(8, 8)[:, :6].mean(0) / 50.0       # last launch = line-search eval sweep, per time step
+        d = out[:64].reshape(8, 8)[:, :6].mean(0) / 50.0
+        dr = out[64:].reshape(8, 8)[:, :3].mean(0) / 50.0       # last launch = line-search eval sweep, per time step
         print(f"E={E} theta={th}: cycles/step " + ", ".join(f"{n}={c:.0f}" for n, c in zip(names, d)) + f" | total {d.sum():.0f}")
+        print(f"      rollin cycles/step: dx+u={dr[0]:.0f}, xu+x'={dr[1]:.0f}, tile+rest={dr[2]:.0f} | total {dr.sum():.0f}")
