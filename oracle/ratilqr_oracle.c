@@ -660,19 +660,34 @@ int orc_compute_value_batch(const orc_problem *p, const orc_opts *o, const doubl
                             const double *theta, int64_t B, double *value, int32_t *status,
                             int32_t *iters, int32_t *ls_evals, int nthreads) {
     int bad = 0;
-#ifdef _OPENMP
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    /* One solver object per worker thread, re-initialised by initialize! for every sample: numerically identical to the
+     * reference's fresh ILEQGSolver per sample (:148; initialize! resets every field a solve reads), but without 256
+     * threads contending in malloc -- so that the reported CPU baseline is not an allocator benchmark. */
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
 #endif
-    for (int64_t i = 0; i < B; ++i) {
-        orc_solver *s = orc_solver_new(p, o);                                   /* fresh solver per sample :148 */
-        if (!s) { bad = 1; continue; }
-        int rc = orc_solve(s, p, x0, u, theta[i]);
-        value[i] = (rc == ORC_OK || rc == ORC_ITER_MAX) ? s->value_current : INFINITY;   /* catch -> Inf :163 */
-        if (status) status[i] = rc;
-        if (iters) iters[i] = (int32_t)s->iter_current;
-        if (ls_evals) ls_evals[i] = (int32_t)s->n_ls_evals;
-        orc_solver_free(s);
+    {
+        orc_solver *s = orc_solver_new(p, o);
+        if (!s) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            bad = 1;
+        } else {
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+            for (int64_t i = 0; i < B; ++i) {
+                s->mu = o->mu_min; s->delta = o->delta_0;                           /* constructor state (:206) */
+                int rc = orc_solve(s, p, x0, u, theta[i]);
+                value[i] = (rc == ORC_OK || rc == ORC_ITER_MAX) ? s->value_current : INFINITY;   /* catch -> Inf :163 */
+                if (status) status[i] = rc;
+                if (iters) iters[i] = (int32_t)s->iter_current;
+                if (ls_evals) ls_evals[i] = (int32_t)s->n_ls_evals;
+            }
+            orc_solver_free(s);
+        }
     }
     (void)nthreads;
     return bad ? -1 : 0;

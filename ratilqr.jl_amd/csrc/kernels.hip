@@ -13,9 +13,9 @@
 //   - the B operand of K-slice s of  (.) * X, and
 //   - the A operand of K-slice s of  X' * (.)
 // so every product of one backward step chains through registers with no data movement:
-//     Y  = M^-1 V             3 MFMA      (M = W^-1 - theta S, inverted by a 12-step symmetric sweep)
-//     V~ = V + V (theta Y)    3 MFMA      (V~ = [[D S, D s_vec],[., 2s + theta s' M^-1 s]])
-//     T  = V~ [A|B]           3 MFMA      (row 12 of T is s~'[A|B])
+//     X  = V [A|B]            3 MFMA      (independent of the inverse: runs on the matrix pipe under the elimination)
+//     Y  = theta M^-1 X       3 MFMA      (M = W^-1 - theta S, inverted by a symmetric sweep with 2x2 block pivots)
+//     T  = X + V Y            3 MFMA      (= (D S)[A|B]; row 12 of T is (D s_vec)'[A|B])
 //     F  = [A|B]' T + C       3 MFMA      (C = [[Q,P'],[P,R]] enters as the accumulator input)
 //     V  = Fx + La' Ua + Ga' La   2 MFMA  (La = [L|dl], Ga = [G|g], Ua = H La + Ga: 4 x 16 "natural" rows)
 // The 4x4 system H X = -[G|g] is solved redundantly by every lane for its own column (LDL').
@@ -188,9 +188,10 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     double *__restrict__ dlout = st.dl + (long)osel * st.dl_half + (long)b * N * USTR;
 
     __shared__ double rowbuf[2][2][16];
-    __shared__ double ex[88];          // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0
+    __shared__ double ex[104];         // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0, [84..99] = s_vec
 #define HBUF(r_, c_) ex[(r_) * 16 + (c_)]
 #define FBUF(c_) ex[64 + (c_)]
+#define SVB(c_) ex[84 + (c_)]
     if (l < 8) ex[80 + l] = 0.0;
 
     // The loop is bound by VALU issue of ONE wave (every instruction costs >= 4 cycles), so lane-position selects are
@@ -231,16 +232,16 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
 
     // noise tables (time-invariant case is hoisted out of the time loop)
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
-    double epinv = 1.0;
+    double ep0 = 1.0, ep1 = 1.0, ep2 = 1.0, ep3 = 1.0, ep4 = 1.0, ep5 = 1.0;   // 1/(e_k e_k+1) per pivot block (wave-uniform)
     if (!WTV) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             winv[r] = pb.Winv[64 * r + l];
             wp[r] = pb.Wp[64 * r + l];
         }
-        epinv = pb.epiv[j];                 // host stores the reciprocal pivots 1/e_k
+        ep0 = pb.epiv[0]; ep1 = pb.epiv[2]; ep2 = pb.epiv[4]; ep3 = pb.epiv[6]; ep4 = pb.epiv[8]; ep5 = pb.epiv[10];
     }
-    const double coef = (theta != 0.0) ? -1.0 / (2.0 * theta) : 0.5;
+    const double coef = (theta != 0.0) ? -1.0 / (2.0 * theta) : 0.0;      // of logdet(W M); traces / quadratic forms carry 1/2
 
     DIAG_DECL
     int restarts = 0;
@@ -274,30 +275,28 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
         load_tile<GAIN, DUMP>(nx, tile0 + (long)(N - 1) * TSTRIDE, offC, l, j, Lb + (long)(N - 1) * LSTR,
                         a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, mL, g);
         bool h_not_pd = false;
-        for (int t = N - 1; t >= 0; --t) {
+        // one backward step (ileqg.jl:361-391 / :435-460) on the tile registers `cur`; returns 0, 1 (M not PD), 2 (H not PD)
+        auto step = [&](const int t, const TileRegs &cur) -> int {
             // opaque per-step copies of the lane indices: keeps the (lane == const) masks as one v_cmp at their use
-            // instead of ~40 loop-invariant SGPR pairs (which spill: the kernel is SGPR-bound, not VGPR-bound)
+            // instead of loop-invariant SGPR pairs (which spill: the kernel is SGPR-bound, not VGPR-bound)
             int l = l_, g = g_, j = j_;
             asm volatile("" : "+v"(l), "+v"(g), "+v"(j));
             DIAG_START();
-            const TileRegs cur = nx;
-            {                   // software prefetch of step t-1 (a full step of latency hiding).  Unconditional (index
-                                // clamped at 0) so that the loads stay in straight-line code and the compiler can
-                                // wait with a counted vmcnt(N) instead of vmcnt(0) at the join of a branch.
-                const int tn = (t > 0) ? t - 1 : 0;
-                load_tile<GAIN, DUMP>(nx, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR,
-                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g);
-            }
             if (WTV) {          // time-varying W(k): separate instantiation, so that the common case keeps a static load count
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     winv[r] = pb.Winv[(long)t * 192 + 64 * r + l];
                     wp[r] = pb.Wp[(long)t * 192 + 64 * r + l];
                 }
-                epinv = pb.epiv[(long)t * 16 + j];
+                const double *ept = pb.epiv + (long)t * 16;
+                ep0 = ept[0]; ep1 = ept[2]; ep2 = ept[4]; ep3 = ept[6]; ep4 = ept[8]; ep5 = ept[10];
             }
-            d4 vt;
+            // X = V[:, 0:12] [A|B] (rows 0..11 = S [A|B], row 12 = s_vec'[A|B]).  Issued first: it does not depend on the
+            // inverse, so the matrix pipe works through it while the VALU runs the elimination below.
+            const d4 xz = mm3(v, cur.z, (d4){0, 0, 0, 0});
+            d4 tm;
             if (theta != 0.0) {
+                if (g == 0) SVB(j) = v[3];                                  // s_vec (row 12 of V) to every lane, off the critical path
                 // M = Symmetric(inv(W) - theta S)   (ileqg.jl:365)
                 d4 m;
 #pragma unroll
@@ -309,8 +308,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                 // Rows k, k+1 are exchanged through LDS with -I in their pivot slots, so that every lane runs the one formula
                 //   m'_ij = base_ij - vi1 U1_j - vi2 U2_j,   U_j = Bk [v1_j; v2_j],   base = 0 on pivot rows/columns, m elsewhere.
                 // Leading minors p11 > 0, det P > 0 for every block  <=>  isposdef(M)  (:366); det P = d_k d_{k+1}.
-                bool pd = true;
-                double pivdet = 1.0;
+                double pdmin = 1.0, nsum = 0.0;                              // min over leading minors; NaN/Inf tripwire (fmin drops NaNs)
 #pragma unroll
                 for (int kb = 0; kb < 6; ++kb) {
                     const int k = 2 * kb, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
@@ -327,39 +325,38 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                     const double a10 = rowbuf[kb & 1][0][g], a20 = rowbuf[kb & 1][1][g];
                     const double a11 = rowbuf[kb & 1][0][4 + g], a21 = rowbuf[kb & 1][1][4 + g];
                     const double a12 = rowbuf[kb & 1][0][8 + g], a22 = rowbuf[kb & 1][1][8 + g];
-                    pd = pd && (p11 > 0.0) && (det > 0.0);
-                    pivdet = (l == k) ? det : pivdet;
+                    pdmin = fmin(pdmin, fmin(p11, det));
+                    nsum += det;
+                    // logdet(W M) = sum_k log(det P_k / (e_k e_k+1))  (:387): every lane carries the same normalised
+                    // running product (det is wave-uniform), so no lane select and no reduction is needed for it
+                    rprod *= det * ((kb == 0) ? ep0 : (kb == 1) ? ep1 : (kb == 2) ? ep2 : (kb == 3) ? ep3 : (kb == 4) ? ep4 : ep5);
                     const double u1 = fma(b12, v2, b11 * v1), u2 = fma(b22, v2, b12 * v1);
                     m[0] = fma(-a20, u2, fma(-a10, u1, m[0] * (kr == 0 ? crm[kb] : cm[kb])));
                     m[1] = fma(-a21, u2, fma(-a11, u1, m[1] * (kr == 1 ? crm[kb] : cm[kb])));
                     m[2] = fma(-a22, u2, fma(-a12, u1, m[2] * (kr == 2 ? crm[kb] : cm[kb])));
                 }
                 DIAG_STAMP(1, m[0]);
-                if (!pd) { fail = 1; break; }
+                if (!(pdmin > 0.0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
                 // theta M^-1 (the sweep left -M^-1); padded columns cleared
                 d4 minv;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) minv[r] = nth12 * m[r];
                 minv[3] = 0.0;
-                // logdet(W M) = sum over blocks of log(det P_k / (e_k e_k+1))   (ileqg.jl:387), reduced once per sweep
-                // (kept as a normalised running product: one log() per sweep instead of one per step)
-                if ((l & 1) == 0 && l < 12) {
-                    rprod *= pivdet * epinv;
-                    rexp += __builtin_amdgcn_frexp_exp(rprod);
-                    rprod = __builtin_amdgcn_frexp_mant(rprod);
-                }
-                // Y = theta M^-1 [S | s_vec]
-                const d4 y = mm3(minv, v, (d4){0, 0, 0, 0});
-                // V~ = V + V[:, 0:12] (theta Y)  ->  D S, D s_vec, 2 s + theta s_vec' M^-1 s_vec   (:367, :387)
-                vt = mm3(v, y, v);
-                DIAG_STAMP(2, vt[0]);
+                // (the product is renormalised once per step: one log() per sweep instead of twelve per step)
+                rexp += __builtin_amdgcn_frexp_exp(rprod);
+                rprod = __builtin_amdgcn_frexp_mant(rprod);
+                // theta s_vec' M^-1 s_vec (:387): the constant term never feeds back into S, s_vec or the gains, so it is
+                // accumulated per lane (sum_ij (theta M^-1)_ij s_i s_j) and reduced once per sweep with the other scalars
+                racc += SVB(j) * (minv[0] * SVB(g) + minv[1] * SVB(4 + g) + minv[2] * SVB(8 + g));
+                // T = (D S)[A|B] = X + V (theta M^-1 X): rows 0..11 = (D S)[A|B], row 12 = (D s_vec)'[A|B]   (:367)
+                const d4 y2 = mm3(minv, xz, (d4){0, 0, 0, 0});
+                tm = mm3(v, y2, xz);
+                DIAG_STAMP(2, tm[0]);
             } else {
                 // theta == 0: D = I ; 0.5 tr(W S)   (ileqg.jl:385)
                 racc += m12 * (wp[0] * v[0] + wp[1] * v[1] + wp[2] * v[2]);
-                vt = v;
+                tm = xz;
             }
-            // T = V~[:, 0:12] [A|B] : rows 0..11 = (D S)[A|B], row 12 = (D s_vec)'[A|B]
-            const d4 tm = mm3(vt, cur.z, (d4){0, 0, 0, 0});
             // F = [A|B]' T + [[Q,P'],[P,R]]  (:369-370 and the Q + A'DSA term of :390)
             d4 f = mm3(cur.z, tm, cur.c);
             // H block: rows 12..15 of F live in register 3;  + mu I  (:370)
@@ -386,7 +383,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                 const double d2 = h22 - l20 * h02 - l21 * (l21 * d1), i2 = fast_rcp(d2);
                 const double l32 = (h23 - l30 * h02 - l31 * (l21 * d1)) * i2;
                 const double d3 = h33 - l30 * h03 - l31 * (l31 * d1) - l32 * (l32 * d2), i3 = fast_rcp(d3);
-                if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) { h_not_pd = true; break; }
+                if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) { h_not_pd = true; return 2; }
                 // X = -H \ [G | g]   (:379-382)
                 const double y0 = -g0;
                 const double y1 = -g1 - l10 * y0;
@@ -411,7 +408,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             d4 fx;
 #pragma unroll
             for (int r = 0; r < 3; ++r) fx[r] = fma(f[r], m12, ex[foff[r]]);
-            fx[3] = fma(fv, mA, (2.0 * cur.q + vt[3]) * mB);
+            fx[3] = fma(fv, mA, (2.0 * cur.q + v[3]) * mB);
             // V = Fx + La' Ua + Ga' La    (:383, :389, :390)
             d4 vn = MFMA(la, ua, fx);
             vn = MFMA(ga, la, vn);
@@ -419,19 +416,40 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             DIAG_STAMP(5, v[0]);
             if (DUMP) {
                 double *dp = a.dump + (long)t * DUMP_STRIDE;
-                const double tot = wave_sum(racc + ((theta != 0.0 && (l & 1) == 0 && l < 12) ? (log(rprod) + (double)rexp * 0.6931471805599453094) : 0.0));
+                const double tot = 0.5 * wave_sum(racc) + ((theta != 0.0) ? coef * (log(rprod) + (double)rexp * 0.6931471805599453094) : 0.0);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int i = 4 * r + g;
                     if (j < 12) dp[DUMP_S + i * 12 + j] = v[r];
                     if (j == 12) dp[DUMP_SV + i] = v[r];
                 }
-                if (l == 12) dp[DUMP_s] = 0.5 * v[3] + coef * tot;
+                if (l == 12) dp[DUMP_s] = 0.5 * v[3] + tot;
                 if (l < 4) dp[DUMP_g + l] = FBUF(12 + l);
                 if (j < 12) dp[DUMP_G + g * 12 + j] = HBUF(g, j);
                 else dp[DUMP_H + g * 4 + (j - 12)] = (g <= j - 12) ? HBUF(g, j) : HBUF(j - 12, 12 + g);
             }
             WAVE_SYNC();          // the exchange area is rewritten next step
+            return 0;
+        };
+        // Time loop, unrolled by two over ping-pong tile registers: the software prefetch of step t-1 (a full step of
+        // latency hiding) lands directly in the registers the next step reads, with no copies.  The prefetch is
+        // unconditional (index clamped at 0) so that the loads stay in straight-line code and the compiler can wait
+        // with a counted vmcnt(N) instead of vmcnt(0) at the join of a branch.
+        TileRegs rb;
+        for (int t = N - 1; t >= 0; t -= 2) {
+            {
+                const int tn = (t > 0) ? t - 1 : 0;
+                load_tile<GAIN, DUMP>(rb, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR,
+                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g);
+            }
+            if (step(t, nx)) break;
+            if (t == 0) break;
+            {
+                const int tn = (t > 1) ? t - 2 : 0;
+                load_tile<GAIN, DUMP>(nx, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR,
+                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g);
+            }
+            if (step(t - 1, rb)) break;
         }
         if (GAIN && h_not_pd) {
             // increase_mu_and_delta!  (ileqg.jl:471-474), then restart the whole sweep (:373-378)
@@ -447,9 +465,9 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     if (l_ == 0 && blockIdx.x < 8 && a.dump)
         for (int q = 0; q < 6; ++q) a.dump[blockIdx.x * 8 + q] = (double)dg_acc[q];
 #endif
-    const double tot = wave_sum(racc + ((theta != 0.0 && (l & 1) == 0 && l < 12) ? (log(rprod) + (double)rexp * 0.6931471805599453094) : 0.0));
+    const double tot = 0.5 * wave_sum(racc) + ((theta != 0.0) ? coef * (log(rprod) + (double)rexp * 0.6931471805599453094) : 0.0);
     if (l == 12) {
-        const double s0 = 0.5 * v[3] + coef * tot;
+        const double s0 = 0.5 * v[3] + tot;
         if (a.mode == 1) {
             st.value_c[cidx] = s0;
             st.flag_c[cidx] = fail ? 1 : 0;
