@@ -1,0 +1,37 @@
+"""Device path of the theta-sharding layer on one GPU (world size 1; N > 1 ranks are covered by the gloo test on CPU and
+run by the driver's multi-GPU bench): theta and values stay in HBM, CE result equals the single-call C-ABI solve."""
+import numpy as np
+import pytest
+import torch
+
+import ratilqr.jl_amd as rat
+from ratilqr.jl_amd import cross_entropy as ce
+from ratilqr.jl_amd import distributed as rd
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_evaluator_and_sharded_ce_equal_rat_ce_solve():
+    prob, x0, u = rat.synthetic_lq_problem()
+    z = np.random.default_rng(11).standard_normal(20000)
+    B = 96
+    ref_solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=B, num_elite=12)
+    ref = ce.solve_(ref_solver, prob, x0, u, z, kl_bound=0.1)
+
+    solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=B, num_elite=12)
+    ctx = rat.Context(prob, solver.ileqg_opts, max_batch=B)
+    ctx.set_initial(x0, u)
+    ev = rd.gpu_evaluator(ctx)
+    th = torch.linspace(0.1, 30.0, 40, dtype=torch.float64, device="cuda")
+    val = ev(th)
+    vh, st, _, _ = ctx.solve_batch(x0, u, th.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), vh) and np.isinf(vh[-1]) and st[-1] == 1
+
+    def final(theta):
+        r = ctx.solve(x0, u, theta)
+        return r["status"] in (0, 3), r["x"], r["l"], r["L"], r["value"]
+
+    got = rd.solve_sharded(solver, 0.1, z, ev, final, device="cuda")
+    assert got[0] == ref[0] and got[4] == ref[4] and got[5] == ref[5] and got[6] == ref[6]
+    assert np.array_equal(got[3], ref[3])
+    assert solver.c.mu_init == ref_solver.c.mu_init and solver.c.n_solves == ref_solver.c.n_solves
