@@ -319,7 +319,6 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                         rowbuf[kb & 1][g - kg][j] = fma(m[kr], cm[kb], wa[kb]);
                     const double det = fma(p11, p22, -(p12 * p12));
                     const double idet = fast_rcp1(det);                      // overlaps the LDS row exchange
-                    const double b11 = p22 * idet, b12 = -(p12 * idet), b22 = p11 * idet;
                     WAVE_SYNC();
                     const double v1 = rowbuf[kb & 1][0][j], v2 = rowbuf[kb & 1][1][j];
                     const double a10 = rowbuf[kb & 1][0][g], a20 = rowbuf[kb & 1][1][g];
@@ -330,7 +329,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                     // logdet(W M) = sum_k log(det P_k / (e_k e_k+1))  (:387): every lane carries the same normalised
                     // running product (det is wave-uniform), so no lane select and no reduction is needed for it
                     rprod *= det * ((kb == 0) ? ep0 : (kb == 1) ? ep1 : (kb == 2) ? ep2 : (kb == 3) ? ep3 : (kb == 4) ? ep4 : ep5);
-                    const double u1 = fma(b12, v2, b11 * v1), u2 = fma(b22, v2, b12 * v1);
+                    // U = Bk [v1; v2] with Bk = adj(P) / det: the adjugate products do not wait for the reciprocal
+                    const double u1 = fma(p22, v1, -(p12 * v2)) * idet, u2 = fma(p11, v2, -(p12 * v1)) * idet;
                     m[0] = fma(-a20, u2, fma(-a10, u1, m[0] * (kr == 0 ? crm[kb] : cm[kb])));
                     m[1] = fma(-a21, u2, fma(-a11, u1, m[1] * (kr == 1 ? crm[kb] : cm[kb])));
                     m[2] = fma(-a22, u2, fma(-a12, u1, m[2] * (kr == 2 ? crm[kb] : cm[kb])));
