@@ -208,6 +208,36 @@ rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0, const doub
                     double *theta_opt, double *x, double *l, double *L, double *value,
                     double *theta_min, double *theta_max);
 
+/* ---- RAT iLQR++: Nelder-Mead over theta ---------------------------------- */
+
+/* Replaces NelderMeadBilevelOptimizationSolver (nelder_mead_bilevel_optimization.jl:72-128).  Caller-owned plain data.
+ * c_high / c_low are Union{Nothing,Float64} in the reference and are NOT reset by initialize! (:164-168): they persist
+ * across solve! calls, as do theta_high_init / theta_low_init when they were shrunk (:290-303).  Reproduced as is. */
+typedef struct rat_nm_solver {
+    double  alpha, beta, gamma, eps, lambda;
+    int64_t iter_max;
+    double  theta_high_init, theta_low_init;
+    int64_t iter_current;
+    double  theta_high, theta_low;
+    int32_t has_c_high, has_c_low;
+    double  c_high, c_low;
+    int64_t n_solves;           /* iLEQG solves the SEQUENTIAL algorithm would have made (bookkeeping) */
+    int64_t n_batches;          /* batched device calls actually made */
+} rat_nm_solver;
+
+void   rat_nm_default(rat_nm_solver *s);                                     /* ctor defaults :102-128 */
+void   rat_nm_initialize(rat_nm_solver *s);                                  /* initialize!   :164-168 */
+/* compute_cost_worker(nm_solver, problem, x, u_array, theta, kl_bound)        :134-158 */
+rat_rc rat_nm_compute_cost(rat_handle h, const double *x0, const double *u0, double theta, double kl_bound, double *cost);
+/* step! :174-252.  All vertices the sequential logic can ask for in one iteration (reflection, expansion, the two
+ * possible contraction points and the two possible shrink points) are solved as ONE batch of <= 6 iLEQG solves; the
+ * reflect/expand/contract/shrink decisions are then replayed on the host, so the outcome is the sequential one. */
+rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound);
+/* solve!(nm_solver, problem, x_0, u_array; kl_bound)                           :276-352 ; *status = final iLEQG status
+ * (a failure there is an uncaught exception in the reference). */
+rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound,
+                    double *theta_opt, double *x, double *l, double *L, double *value, int32_t *status);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 #define RAT_K_ROLLOUT   0
 #define RAT_K_LINEARIZE 1

@@ -328,3 +328,46 @@ class CrossEntropyBilevelOptimizationSolver:
                                 _p(np.ascontiguousarray(u, float)), C.c_double(kl_bound), C.byref(th), _p(x), _p(l),
                                 _p(Lb), C.byref(val), C.byref(tmin), C.byref(tmax))
         return rc, th.value, x, l, _from_cm3(Lb, N, m, n), val.value, tmin.value, tmax.value
+
+
+# ---- NelderMeadBilevelOptimizationSolver (RAT iLQR++) ---------------------------------------------
+class _Nm(C.Structure):
+    _fields_ = [("ileqg", _Opts), ("alpha", C.c_double), ("beta", C.c_double), ("gamma", C.c_double), ("eps", C.c_double),
+                ("lam", C.c_double), ("iter_max", C.c_int64), ("theta_high_init", C.c_double), ("theta_low_init", C.c_double),
+                ("iter_current", C.c_int64), ("theta_high", C.c_double), ("theta_low", C.c_double),
+                ("has_c_high", C.c_int32), ("has_c_low", C.c_int32), ("c_high", C.c_double), ("c_low", C.c_double),
+                ("n_solves", C.c_int64)]
+
+
+class NelderMeadBilevelOptimizationSolver:
+    def __init__(self, alpha=1.0, beta=2.0, gamma=0.5, eps=1e-2, lam=0.5, iter_max=100, theta_high_init=3.0,
+                 theta_low_init=1e-8, **ileqg_opts):
+        self.c = _Nm()
+        lib().orc_nm_default(C.byref(self.c))
+        self.c.ileqg = make_opts(**ileqg_opts)
+        self.c.alpha, self.c.beta, self.c.gamma, self.c.eps, self.c.lam = alpha, beta, gamma, eps, lam
+        self.c.iter_max = iter_max
+        self.c.theta_high_init = self.c.theta_high = theta_high_init
+        self.c.theta_low_init = self.c.theta_low = theta_low_init
+
+    def initialize(self):
+        lib().orc_nm_initialize(C.byref(self.c))
+
+    def compute_cost(self, P: Problem, x0, u, theta, kl_bound):
+        f = lib().orc_nm_compute_cost
+        f.restype = C.c_double
+        return f(C.byref(self.c), C.byref(P.c), _p(np.ascontiguousarray(x0, float)), _p(np.ascontiguousarray(u, float)),
+                 C.c_double(theta), C.c_double(kl_bound))
+
+    def step(self, P: Problem, x0, u, kl_bound):
+        lib().orc_nm_step(C.byref(self.c), C.byref(P.c), _p(np.ascontiguousarray(x0, float)),
+                          _p(np.ascontiguousarray(u, float)), C.c_double(kl_bound))
+
+    def solve(self, P: Problem, x0, u, kl_bound):
+        n, m, N = P.n, P.m, P.N
+        x, l, Lb = np.zeros((N + 1, n)), np.zeros((N, m)), np.zeros(m * n * N)
+        th, val = C.c_double(), C.c_double()
+        rc = lib().orc_nm_solve(C.byref(self.c), C.byref(P.c), _p(np.ascontiguousarray(x0, float)),
+                                _p(np.ascontiguousarray(u, float)), C.c_double(kl_bound), C.byref(th), _p(x), _p(l), _p(Lb),
+                                C.byref(val))
+        return rc, th.value, x, l, _from_cm3(Lb, N, m, n), val.value

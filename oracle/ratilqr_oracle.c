@@ -822,3 +822,104 @@ int orc_ce_solve(orc_ce *c, const orc_problem *p, const double *x0, const double
         theta_opt = fmax(0.0, theta_opt - c->sigma);                            /* :412 */
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * NelderMeadBilevelOptimizationSolver (RAT iLQR++)  -- nelder_mead_bilevel_optimization.jl
+ * ---------------------------------------------------------------------------------------- */
+void orc_nm_default(orc_nm *s) {                                                /* :102-128 */
+    memset(s, 0, sizeof(*s));
+    orc_default_opts(&s->ileqg);
+    s->alpha = 1.0; s->beta = 2.0; s->gamma = 0.5; s->eps = 1e-2; s->lambda = 0.5; s->iter_max = 100;
+    s->theta_high_init = 3.0; s->theta_low_init = 1e-8;
+    s->theta_high = s->theta_high_init; s->theta_low = s->theta_low_init;
+    s->has_c_high = 0; s->has_c_low = 0;
+}
+void orc_nm_initialize(orc_nm *s) {                                             /* :164-168 (c_high/c_low untouched) */
+    s->iter_current = 0; s->theta_low = s->theta_low_init; s->theta_high = s->theta_high_init;
+}
+double orc_nm_compute_cost(orc_nm *s, const orc_problem *p, const double *x0, const double *u, double theta, double kl_bound) {  /* :134-158 */
+    orc_solver *sv = orc_solver_new(p, &s->ileqg);
+    double cost = INFINITY;
+    if (sv) {
+        int rc = orc_solve(sv, p, x0, u, theta);
+        if (rc == ORC_OK || rc == ORC_ITER_MAX) cost = sv->value_current + kl_bound / theta;
+        orc_solver_free(sv);
+    }
+    s->n_solves++;
+    return cost;
+}
+void orc_nm_step(orc_nm *s, const orc_problem *p, const double *x0, const double *u, double kl_bound) {   /* :174-252 */
+    s->iter_current++;
+    if (s->c_high < s->c_low) {                                                 /* :184-187 */
+        double t = s->theta_low; s->theta_low = s->theta_high; s->theta_high = t;
+        t = s->c_low; s->c_low = s->c_high; s->c_high = t;
+    }
+    const double th_m = s->theta_low;
+    double th_r = th_m + s->alpha * (th_m - s->theta_high);                     /* reflection :195 */
+    th_r = fmax(s->theta_low_init, th_r);
+    const double c_r = orc_nm_compute_cost(s, p, x0, u, th_r, kl_bound);
+    if (c_r < s->c_low) {
+        double th_e = th_m + s->beta * (th_r - th_m);                           /* expansion :204 */
+        th_e = fmax(s->theta_low_init, th_e);
+        const double c_e = orc_nm_compute_cost(s, p, x0, u, th_e, kl_bound);
+        if (c_e < c_r) { s->theta_high = th_e; s->c_high = c_e; }
+        else { s->theta_high = th_r; s->c_high = c_r; }
+    } else {
+        if (c_r < s->c_high) { s->theta_high = th_r; s->c_high = c_r; }        /* :227-230 */
+        double th_c = th_m + s->gamma * (s->theta_high - th_m);                 /* contraction :232 */
+        th_c = fmax(s->theta_low_init, th_c);
+        const double c_c = orc_nm_compute_cost(s, p, x0, u, th_c, kl_bound);
+        if (c_c > s->c_high) {                                                  /* shrink :238-240 */
+            s->theta_high = (s->theta_high + s->theta_low) / 2;
+            s->c_high = orc_nm_compute_cost(s, p, x0, u, s->theta_high, kl_bound);
+        } else { s->theta_high = th_c; s->c_high = c_c; }
+    }
+}
+int orc_nm_solve(orc_nm *s, const orc_problem *p, const double *x0, const double *u, double kl_bound,
+                 double *theta_opt, double *x, double *l, double *L, double *value) {      /* :276-352 */
+    if (!(kl_bound >= 0)) return -3;
+    orc_nm_initialize(s);
+    double th_opt;
+    if (kl_bound > 0) {
+        if (!s->has_c_high) {                                                   /* :283-293 */
+            for (int guard = 0;; ++guard) {
+                if (guard > 2000) return -4;
+                s->c_high = orc_nm_compute_cost(s, p, x0, u, s->theta_high, kl_bound);
+                s->has_c_high = 1;
+                if (!isinf(s->c_high)) break;
+                s->theta_high *= s->lambda; s->theta_high_init *= s->lambda;
+            }
+        }
+        if (!s->has_c_low) {                                                    /* :294-304 */
+            for (int guard = 0;; ++guard) {
+                if (guard > 2000) return -4;
+                s->c_low = orc_nm_compute_cost(s, p, x0, u, s->theta_low, kl_bound);
+                s->has_c_low = 1;
+                if (!isinf(s->c_low)) break;
+                s->theta_low *= s->lambda; s->theta_low_init *= s->lambda;
+            }
+        }
+        for (;;) {                                                              /* :306-324 */
+            orc_nm_step(s, p, x0, u, kl_bound);
+            const double c_mean = (s->c_low + s->c_high) / 2;
+            const double stdev = sqrt(0.5 * ((s->c_high - c_mean) * (s->c_high - c_mean) + (s->c_low - c_mean) * (s->c_low - c_mean)));
+            if (stdev < s->eps) break;
+            if (s->iter_current == s->iter_max) break;
+        }
+        th_opt = s->theta_low;                                                  /* :325 */
+    } else {
+        th_opt = 0.0;
+    }
+    orc_solver *sv = orc_solver_new(p, &s->ileqg);
+    int rc = orc_solve(sv, p, x0, u, th_opt);                                   /* :346 (not in a try) */
+    if (rc == ORC_OK || rc == ORC_ITER_MAX) {
+        const int n = p->n, m = p->m, N = p->N;
+        if (x) memcpy(x, sv->x, sizeof(double) * n * (N + 1));
+        if (l) memcpy(l, sv->l, sizeof(double) * m * N);
+        if (L) memcpy(L, sv->L, sizeof(double) * m * n * N);
+        *theta_opt = th_opt;
+        *value = (kl_bound > 0) ? sv->value_current + kl_bound / th_opt : sv->value_current;     /* :347-351 */
+    }
+    orc_solver_free(sv);
+    return rc;
+}

@@ -168,6 +168,26 @@ int orc_ce_solve(orc_ce *c, const orc_problem *p, const double *x0, const double
                  double *theta_opt, double *x, double *l, double *L, double *value,
                  double *theta_min, double *theta_max);
 
+/* ---- RAT iLQR++: NelderMeadBilevelOptimizationSolver (nelder_mead_bilevel_optimization.jl:72-352) ---- */
+typedef struct orc_nm {
+    orc_opts ileqg;
+    double alpha, beta, gamma, eps, lambda;
+    int64_t iter_max;
+    double theta_high_init, theta_low_init;
+    int64_t iter_current;
+    double theta_high, theta_low;
+    int32_t has_c_high, has_c_low;      /* Union{Nothing, Float64}: NOT reset by initialize! (stale across solve! calls) */
+    double c_high, c_low;
+    int64_t n_solves;
+} orc_nm;
+void orc_nm_default(orc_nm *s);                                                         /* :102-128 */
+void orc_nm_initialize(orc_nm *s);                                                      /* :164-168 */
+double orc_nm_compute_cost(orc_nm *s, const orc_problem *p, const double *x0, const double *u, double theta, double kl_bound);  /* :134-158 */
+void orc_nm_step(orc_nm *s, const orc_problem *p, const double *x0, const double *u, double kl_bound);   /* :174-252 */
+/* solve! :276-352 ; returns the final iLEQG status (a failure there is an uncaught exception in the reference) */
+int orc_nm_solve(orc_nm *s, const orc_problem *p, const double *x0, const double *u, double kl_bound,
+                 double *theta_opt, double *x, double *l, double *L, double *value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,3 +37,5 @@ from .cross_entropy import (  # noqa: F401,E402
     compute_cost_serial,
     get_positive_samples,
 )
+from . import nelder_mead  # noqa: F401,E402
+from .nelder_mead import NelderMeadBilevelOptimizationSolver, compute_cost_worker  # noqa: F401,E402

@@ -51,13 +51,22 @@ class CeSolver(C.Structure):
                 ("n_solves", C.c_int64), ("n_redraws", C.c_int64)]
 
 
+class NmSolver(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("beta", C.c_double), ("gamma", C.c_double), ("eps", C.c_double), ("lam", C.c_double),
+                ("iter_max", C.c_int64), ("theta_high_init", C.c_double), ("theta_low_init", C.c_double),
+                ("iter_current", C.c_int64), ("theta_high", C.c_double), ("theta_low", C.c_double),
+                ("has_c_high", C.c_int32), ("has_c_low", C.c_int32), ("c_high", C.c_double), ("c_low", C.c_double),
+                ("n_solves", C.c_int64), ("n_batches", C.c_int64)]
+
+
 EXPORTS = [
     "rat_version", "rat_last_error", "rat_default_ileqg_opts", "rat_create", "rat_destroy", "rat_set_ileqg_opts",
     "rat_problem_set", "rat_ileqg_solve_batch", "rat_set_initial", "rat_ileqg_solve_batch_dev", "rat_ileqg_solve",
     "rat_rollout_open", "rat_rollout_feedback", "rat_integrate_cost", "rat_approximate_model", "rat_dp_gain_sweep",
     "rat_dp_policy_eval", "rat_ce_default", "rat_ce_initialize", "rat_ce_set_stream", "rat_ce_seed",
     "rat_ce_stream_pos", "rat_ce_get_positive_samples", "rat_ce_compute_cost", "rat_ce_begin_step", "rat_ce_draw",
-    "rat_ce_update", "rat_ce_draw_stream", "rat_ce_step", "rat_ce_solve", "rat_profile_enable", "rat_profile_reset", "rat_profile_get",
+    "rat_ce_update", "rat_ce_draw_stream", "rat_ce_step", "rat_ce_solve", "rat_nm_default", "rat_nm_initialize",
+    "rat_nm_compute_cost", "rat_nm_step", "rat_nm_solve", "rat_profile_enable", "rat_profile_reset", "rat_profile_get",
     "rat_stream", "rat_layout_info",
 ]
 

@@ -1003,3 +1003,115 @@ extern "C" rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0,
         th_opt = std::max(0.0, th_opt - c->sigma);                                   // :412
     }
 }
+
+// ---- RAT iLQR++ (Nelder-Mead over theta) ----------------------------------------------------------------------
+extern "C" void rat_nm_default(rat_nm_solver *s) {                             // nelder_mead_bilevel_optimization.jl:102-128
+    memset(s, 0, sizeof(*s));
+    s->alpha = 1.0; s->beta = 2.0; s->gamma = 0.5; s->eps = 1e-2; s->lambda = 0.5; s->iter_max = 100;
+    s->theta_high_init = 3.0; s->theta_low_init = 1e-8;
+    s->theta_high = s->theta_high_init; s->theta_low = s->theta_low_init;
+}
+extern "C" void rat_nm_initialize(rat_nm_solver *s) {                          // :164-168 (c_high / c_low are left alone)
+    s->iter_current = 0; s->theta_low = s->theta_low_init; s->theta_high = s->theta_high_init;
+}
+extern "C" rat_rc rat_nm_compute_cost(rat_handle h, const double *x0, const double *u0, double theta, double kl_bound, double *cost) {   // :134-158
+    if (!h || !cost) return fail(RAT_ERR_ARG, "null");
+    double v = 0;
+    rat_rc rc = rat_ileqg_solve_batch(h, x0, u0, &theta, 1, &v, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    *cost = v + kl_bound / theta;                                              // Inf stays Inf
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound) {   // :174-252
+    if (!h || !s) return fail(RAT_ERR_ARG, "null");
+    s->iter_current += 1;
+    if (s->c_high < s->c_low) {                                                // :184-187
+        std::swap(s->theta_low, s->theta_high);
+        std::swap(s->c_low, s->c_high);
+    }
+    const double th_m = s->theta_low, lo = s->theta_low_init;
+    // every vertex the sequential code can reach this iteration, computed with its own expressions
+    const double th_r = std::max(lo, th_m + s->alpha * (th_m - s->theta_high));          // reflection      :195-196
+    const double th_e = std::max(lo, th_m + s->beta * (th_r - th_m));                    // expansion       :204-205
+    const double th_c_old = std::max(lo, th_m + s->gamma * (s->theta_high - th_m));      // contraction with theta_high kept  :232-233
+    const double th_c_ref = std::max(lo, th_m + s->gamma * (th_r - th_m));               // contraction after theta_high <- theta_r
+    const double th_s_old = (s->theta_high + s->theta_low) / 2;                          // shrink          :239
+    const double th_s_ref = (th_r + s->theta_low) / 2;
+    double th[6] = {th_r, th_e, th_c_old, th_c_ref, th_s_old, th_s_ref}, c[6];
+    if (h->Bmax >= 6) {
+        rat_rc rc = rat_ileqg_solve_batch(h, x0, u0, th, 6, c, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        for (int i = 0; i < 6; ++i) c[i] = c[i] + kl_bound / th[i];
+        s->n_batches += 1;
+    } else {                                                                    // handle too small to speculate: evaluate on demand
+        for (int i = 0; i < 6; ++i) c[i] = NAN;
+    }
+    auto cost_of = [&](int i, double *out) -> rat_rc {
+        if (c[i] == c[i]) { *out = c[i]; s->n_solves += 1; return RAT_OK; }
+        s->n_solves += 1; s->n_batches += 1;
+        return rat_nm_compute_cost(h, x0, u0, th[i], kl_bound, out);
+    };
+    rat_rc rc;
+    double c_r, c_e, c_c;
+    if ((rc = cost_of(0, &c_r))) return rc;
+    if (c_r < s->c_low) {                                                       // :202
+        if ((rc = cost_of(1, &c_e))) return rc;
+        if (c_e < c_r) { s->theta_high = th_e; s->c_high = c_e; }              // :209-220
+        else { s->theta_high = th_r; s->c_high = c_r; }
+    } else {
+        bool took_r = false;
+        if (c_r < s->c_high) { s->theta_high = th_r; s->c_high = c_r; took_r = true; }   // :227-230
+        if ((rc = cost_of(took_r ? 3 : 2, &c_c))) return rc;                    // :232-234
+        if (c_c > s->c_high) {                                                  // :238-240
+            s->theta_high = took_r ? th_s_ref : th_s_old;
+            if ((rc = cost_of(took_r ? 5 : 4, &s->c_high))) return rc;
+        } else { s->theta_high = took_r ? th_c_ref : th_c_old; s->c_high = c_c; }   // :245-250
+    }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound,
+                               double *theta_opt, double *x, double *l, double *L, double *value, int32_t *status) {   // :276-352
+    if (!h || !s || !theta_opt || !value) return fail(RAT_ERR_ARG, "null");
+    if (!(kl_bound >= 0)) return fail(RAT_ERR_ARG, "KL Divergence Bound must be non-negative (:279)");
+    rat_nm_initialize(s);
+    double th_opt;
+    rat_rc rc;
+    if (kl_bound > 0) {
+        if (!s->has_c_high) {                                                   // :283-293
+            for (int guard = 0;; ++guard) {
+                if (guard > 2000) return fail(RAT_ERR_DIVERGED, "theta_high halving loop cut");
+                if ((rc = rat_nm_compute_cost(h, x0, u0, s->theta_high, kl_bound, &s->c_high))) return rc;
+                s->has_c_high = 1; s->n_solves++; s->n_batches++;
+                if (!std::isinf(s->c_high)) break;
+                s->theta_high *= s->lambda; s->theta_high_init *= s->lambda;
+            }
+        }
+        if (!s->has_c_low) {                                                    // :294-304
+            for (int guard = 0;; ++guard) {
+                if (guard > 2000) return fail(RAT_ERR_DIVERGED, "theta_low halving loop cut");
+                if ((rc = rat_nm_compute_cost(h, x0, u0, s->theta_low, kl_bound, &s->c_low))) return rc;
+                s->has_c_low = 1; s->n_solves++; s->n_batches++;
+                if (!std::isinf(s->c_low)) break;
+                s->theta_low *= s->lambda; s->theta_low_init *= s->lambda;
+            }
+        }
+        for (;;) {                                                              // :306-324
+            if ((rc = rat_nm_step(h, s, x0, u0, kl_bound))) return rc;
+            const double c_mean = (s->c_low + s->c_high) / 2;
+            const double stdev = std::sqrt(0.5 * ((s->c_high - c_mean) * (s->c_high - c_mean) + (s->c_low - c_mean) * (s->c_low - c_mean)));
+            if (stdev < s->eps) break;
+            if (s->iter_current == s->iter_max) break;
+        }
+        th_opt = s->theta_low;                                                  // :325
+    } else {
+        th_opt = 0.0;                                                           // :332
+    }
+    int32_t st = 0; double val = 0;
+    if ((rc = rat_ileqg_solve(h, x0, u0, th_opt, x, l, L, &val, &st, nullptr, nullptr, 0, nullptr))) return rc;   // :346 (not in a try)
+    if (status) *status = st;
+    *theta_opt = th_opt;
+    *value = (kl_bound > 0) ? val + kl_bound / th_opt : val;                    // :347-351
+    return RAT_OK;
+}
