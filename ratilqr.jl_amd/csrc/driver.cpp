@@ -54,6 +54,7 @@ struct rat_handle_s {
     int *h_counters = nullptr;       // pinned, [CTR_RING][2]
     hipEvent_t round_ev[CTR_RING] = {};
     bool have_initial = false;
+    int pred_rounds = 1;             // rounds the previous batch needed: that many are enqueued before the host first polls
     // profiling
     bool prof = false, prof_cur = false;
     unsigned prof_mask = 0xFFFFFFFFu;   // bit k: record kernel kind k
@@ -449,22 +450,32 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
         launch_commit_init(st, h->stream);
     }
-    // while true: step!; convergence / iter_max test   (ileqg.jl:640-654).  The host runs one round ahead of the counter
-    // it polls, so the GPU never idles on a host round trip; the one surplus round at the end finds no live sample.
+    // while true: step!; convergence / iter_max test   (ileqg.jl:640-654).  No host round trip per round: the host enqueues as
+    // many rounds as the previous batch needed, then polls the per-round counter; it only falls back to round-by-round
+    // polling for the extra rounds of a batch that runs longer (a surplus round finds no live sample and exits at once).
     const int64_t max_rounds = ((int64_t)h->opd.iter_max + 1) * (4000 / st.E + 2);
     rat_rc rc;
-    if ((rc = enqueue_round(h, st, 0))) return rc;
-    for (int64_t r = 0;; ++r) {
-        if (r + 1 > max_rounds) return fail(RAT_ERR_DIVERGED, "round guard tripped");
-        const size_t ev0 = h->ev_used;
-        if ((rc = enqueue_round(h, st, (int)((r + 1) % (2 * CTR_RING))))) return rc;
-        const int slot = (int)(r % (2 * CTR_RING)) % CTR_RING;
-        HIPCHK(hipEventSynchronize(h->round_ev[slot]));
-        if (h->h_counters[2 * slot + 1] == 0) {
-            for (size_t i = ev0; i < h->ev_used; ++i) h->evs[i].kind = -1;    // the round just enqueued has no live sample
-            break;
-        }
+    const int P = std::max(1, std::min(h->pred_rounds, CTR_RING - 2));
+    std::vector<size_t> ev_start;                      // first profiling event of every enqueued round
+    for (int r = 0; r < P; ++r) {
+        ev_start.push_back(h->ev_used);
+        if ((rc = enqueue_round(h, st, r))) return rc;
     }
+    int64_t r = P - 1, needed = -1;
+    for (;;) {
+        const int slot = (int)(r % CTR_RING);
+        HIPCHK(hipEventSynchronize(h->round_ev[slot]));
+        if (h->h_counters[2 * slot + 1] == 0) break;
+        if (++r > max_rounds) return fail(RAT_ERR_DIVERGED, "round guard tripped");
+        ev_start.push_back(h->ev_used);
+        if ((rc = enqueue_round(h, st, (int)(r % (2 * CTR_RING))))) return rc;
+    }
+    // how many rounds were really needed (first round whose counter reads zero): prediction for the next batch
+    for (int64_t q = std::max<int64_t>(0, r - (CTR_RING - 3)); q <= r; ++q)
+        if (h->h_counters[2 * (q % CTR_RING) + 1] == 0) { needed = q + 1; break; }
+    h->pred_rounds = (int)std::max<int64_t>(1, needed < 0 ? r + 1 : needed);
+    if (needed >= 0 && (size_t)needed < ev_start.size())
+        for (size_t i = ev_start[(size_t)needed]; i < h->ev_used; ++i) h->evs[i].kind = -1;   // launches of surplus rounds: not counted
     return RAT_OK;
 }
 
