@@ -238,6 +238,56 @@ rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, const doubl
 rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound,
                     double *theta_opt, double *x, double *l, double *L, double *value, int32_t *status);
 
+/* ---- PETS: cross-entropy over control sequences with stochastic rollouts ---------- */
+
+/* Replaces FiniteHorizonGenerativeOptimalControlProblem(f_stochastic, c, h, N) (optimal_control_problems.jl:126-131) by a
+ * device model family:  f_stochastic(x, u, rng, use_true_model) = A x + B u + kappa x.^3 + w
+ *   w : noise_kind 0 -> N(nmean, nchol nchol') ; 1 -> uniform on [nlo, nhi)^n (test/pets_test.jl:15)
+ *   use_true_model : with probability tw2 the noise is N(tmean2, tchol2 tchol2') instead (2-component mixture of the docs
+ *                    example, optimal_control_problems.jl:103-110); tw2 = 0 disables it
+ *   c(k, x, u) = the LQ quadratic form of `lq` (time-varying tables allowed) + l1u * sum(abs.(u)) ; h quadratic (lq.Qf ...). */
+typedef struct rat_gen_problem_desc {
+    rat_problem_desc lq;        /* model must be RAT_MODEL_LQ; lq.W is ignored (may be NULL) */
+    double l1u;
+    int32_t noise_kind;
+    const double *nmean;        /* n        */
+    const double *nchol;        /* n*n column-major, lower triangular */
+    double nlo, nhi;
+    double tw2;
+    const double *tmean2;       /* n        */
+    const double *tchol2;       /* n*n      */
+} rat_gen_problem_desc;
+
+/* Replaces CrossEntropyDirectOptimizationSolver (pets.jl:36-68).  Caller-owned; the mu and Sigma pointers are caller-owned buffers
+ * [N][m] and [N][m*m] (column-major blocks, time slowest). */
+typedef struct rat_pets_solver {
+    int64_t num_control_samples, num_trajectory_samples, num_elite, iter_max;
+    double  smoothing_factor;
+    int64_t N, m, iter_current;
+    double *mu_init, *Sigma_init, *mu, *Sigma;
+} rat_pets_solver;
+
+rat_rc rat_pets_problem_set(rat_handle h, const rat_gen_problem_desc *desc);
+void   rat_pets_initialize(rat_pets_solver *s);                               /* initialize!  pets.jl:70-74 */
+/* compute_cost_serial(direct_solver, problem, x, control_sequence_array, rng, use_true_model)  pets.jl:128-157
+ *   controls[S][N][m] (time-major, m fastest), cost[S] = mean over K stochastic rollouts of sum c + h.
+ * Randomness, serial semantics: trajectory j = ii*K + kk consumes zn[(j*N + t)*n .. +n) at step t (N(0,1) draws for Gaussian
+ * noise, U[0,1) draws for uniform noise) and zu[j*N + t] (mixture choice; may be NULL when tw2 = 0).  zn = NULL selects the
+ * device generator (Philox4x32-10 keyed by `seed`, counter = (trajectory, step, lane)): statistical parity only. */
+rat_rc rat_pets_compute_cost(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K,
+                             int32_t use_true_model, const double *zn, const double *zu, uint64_t seed, double *cost);
+/* draw the control sequences of one step! (pets.jl:206-216): controls[ii][t] = mu_t + chol(Sigma_t) * zc[(ii*N + t)*m ..] */
+rat_rc rat_pets_sample_controls(const rat_pets_solver *s, const double *zc, double *controls);
+/* get_elite_samples + compute_new_distribution (pets.jl:159-191); elite_idx[num_elite] may be NULL */
+rat_rc rat_pets_update(rat_pets_solver *s, const double *controls, const double *cost, int64_t *elite_idx);
+/* step! (pets.jl:193-245): sample, evaluate, elites, smoothed update.  zc: S*N*m normals; zn/zu/seed as above. */
+rat_rc rat_pets_step(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc,
+                     const double *zn, const double *zu, uint64_t seed, double *controls_out, double *cost_out);
+/* solve! (pets.jl:270-281): iter_max steps from (mu_init, Sigma_init); streams hold iter_max consecutive step blocks
+ * (zc may not be NULL; zn NULL -> device generator with seed + iteration). */
+rat_rc rat_pets_solve(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc,
+                      const double *zn, const double *zu, uint64_t seed);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 #define RAT_K_ROLLOUT   0
 #define RAT_K_LINEARIZE 1

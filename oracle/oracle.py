@@ -371,3 +371,75 @@ class NelderMeadBilevelOptimizationSolver:
                                 _p(np.ascontiguousarray(u, float)), C.c_double(kl_bound), C.byref(th), _p(x), _p(l), _p(Lb),
                                 C.byref(val))
         return rc, th.value, x, l, _from_cm3(Lb, N, m, n), val.value
+
+
+# ---- PETS (pets.jl) on the generative family -------------------------------------------------------------
+class _GenProblem(C.Structure):
+    _fields_ = [("lq", _Problem), ("l1u", C.c_double), ("noise_kind", C.c_int32), ("nmean", _dp), ("nchol", _dp),
+                ("nlo", C.c_double), ("nhi", C.c_double), ("tw2", C.c_double), ("tmean2", _dp), ("tchol2", _dp)]
+
+
+class _Pets(C.Structure):
+    _fields_ = [("num_control_samples", C.c_int64), ("num_trajectory_samples", C.c_int64), ("num_elite", C.c_int64),
+                ("iter_max", C.c_int64), ("smoothing_factor", C.c_double), ("N", C.c_int64), ("m", C.c_int64),
+                ("iter_current", C.c_int64), ("mu_init", _dp), ("Sigma_init", _dp), ("mu", _dp), ("Sigma", _dp)]
+
+
+class GenProblem:
+    def __init__(self, prob):
+        self.lq = Problem(prob.lq)
+        self.n, self.m, self.N = prob.n, prob.m, prob.N
+        t = prob.gen_tables()
+        self._keep = {k: np.ascontiguousarray(t[k], dtype=np.float64) for k in ("nmean", "nchol", "tmean2", "tchol2")}
+        g = _GenProblem()
+        g.lq = self.lq.c
+        g.l1u, g.noise_kind, g.nlo, g.nhi, g.tw2 = t["l1u"], t["noise_kind"], t["nlo"], t["nhi"], t["tw2"]
+        for k, v in self._keep.items():
+            setattr(g, k, _p(v))
+        self.c = g
+
+
+def pets_compute_cost(G: GenProblem, x0, controls, K, use_true_model, zn, zu=None):
+    controls = np.ascontiguousarray(controls, float)
+    S = controls.shape[0]
+    cost = np.zeros(S)
+    zn = np.ascontiguousarray(zn, float)
+    zu = None if zu is None else np.ascontiguousarray(zu, float)
+    lib().orc_pets_compute_cost(C.byref(G.c), _p(np.ascontiguousarray(x0, float)), _p(controls), C.c_int64(S), C.c_int64(K),
+                                C.c_int(int(use_true_model)), _p(zn), _p(zu) if zu is not None else None, _p(cost))
+    return cost
+
+
+class PetsSolver:
+    def __init__(self, mu_init, Sigma_init, num_control_samples=10, num_trajectory_samples=10, num_elite=3, iter_max=5,
+                 smoothing_factor=0.1):
+        mu_init, Sigma_init = np.asarray(mu_init, float), np.asarray(Sigma_init, float)
+        self.N, self.m = mu_init.shape
+        self._mi, self._si = np.ascontiguousarray(mu_init).ravel().copy(), _cm3(Sigma_init).copy()
+        self._mu, self._sg = self._mi.copy(), self._si.copy()
+        c = _Pets()
+        c.num_control_samples, c.num_trajectory_samples, c.num_elite, c.iter_max = num_control_samples, num_trajectory_samples, num_elite, iter_max
+        c.smoothing_factor, c.N, c.m, c.iter_current = smoothing_factor, self.N, self.m, 0
+        c.mu_init, c.Sigma_init, c.mu, c.Sigma = _p(self._mi), _p(self._si), _p(self._mu), _p(self._sg)
+        self.c = c
+
+    mu_array = property(lambda s: s._mu.reshape(s.N, s.m).copy())
+    Sigma_array = property(lambda s: s._sg.reshape(s.N, s.m, s.m).transpose(0, 2, 1).copy())
+
+    def initialize(self):
+        lib().orc_pets_initialize(C.byref(self.c))
+
+    def update(self, controls, cost):
+        idx = np.zeros(self.c.num_elite, np.int64)
+        lib().orc_pets_update(C.byref(self.c), _p(np.ascontiguousarray(controls, float)), _p(np.ascontiguousarray(cost, float)),
+                              idx.ctypes.data_as(C.POINTER(C.c_int64)))
+        return idx
+
+    def step(self, G: GenProblem, x0, use_true_model, zc, zn, zu=None):
+        S = self.c.num_control_samples
+        ctrl, cost = np.zeros((S, self.N, self.m)), np.zeros(S)
+        zc, zn = np.ascontiguousarray(zc, float), np.ascontiguousarray(zn, float)
+        zu = None if zu is None else np.ascontiguousarray(zu, float)
+        rc = lib().orc_pets_step(C.byref(self.c), C.byref(G.c), _p(np.ascontiguousarray(x0, float)), C.c_int(int(use_true_model)),
+                                 _p(zc), _p(zn), _p(zu) if zu is not None else None, _p(ctrl), _p(cost))
+        return rc, ctrl, cost

@@ -923,3 +923,117 @@ int orc_nm_solve(orc_nm *s, const orc_problem *p, const double *x0, const double
     orc_solver_free(sv);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * PETS (pets.jl) on the generative LQ family, serial semantics with injected streams
+ * ---------------------------------------------------------------------------------------- */
+static double gen_cost(const orc_gen_problem *p, int k, const double *x, const double *u) {
+    double c = 0.0;
+    model_c(&p->lq, k, x, u, &c);
+    if (p->l1u != 0.0) { double a = 0; for (int i = 0; i < p->lq.m; ++i) a += fabs(u[i]); c += p->l1u * a; }
+    return c;
+}
+static void gen_step(const orc_gen_problem *p, const double *x, const double *u, int use_true, const double *zn, double zu, double *xn) {
+    const int n = p->lq.n;
+    model_f(&p->lq, x, u, xn);
+    if (use_true && zu < p->tw2) {                                   /* second mixture component */
+        for (int i = 0; i < n; ++i) { double a = p->tmean2[i]; for (int j = 0; j <= i; ++j) a += p->tchol2[IDX(i, j, n)] * zn[j]; xn[i] += a; }
+    } else if (p->noise_kind == 0) {
+        for (int i = 0; i < n; ++i) { double a = p->nmean[i]; for (int j = 0; j <= i; ++j) a += p->nchol[IDX(i, j, n)] * zn[j]; xn[i] += a; }
+    } else {
+        for (int i = 0; i < n; ++i) xn[i] += p->nlo + (p->nhi - p->nlo) * zn[i];
+    }
+}
+/* compute_cost_serial  -- pets.jl:128-157 */
+int orc_pets_compute_cost(const orc_gen_problem *p, const double *x0, const double *controls, int64_t S, int64_t K,
+                          int use_true_model, const double *zn, const double *zu, double *cost) {
+    const int n = p->lq.n, m = p->lq.m, N = p->lq.N;
+    double x[MAXD], xn[MAXD];
+    for (int64_t ii = 0; ii < S; ++ii) {
+        double sum = 0.0;
+        for (int64_t kk = 0; kk < K; ++kk) {
+            const int64_t j = ii * K + kk;
+            memcpy(x, x0, sizeof(double) * n);
+            double c = 0.0;
+            for (int t = 0; t < N; ++t) {
+                const double *u = controls + ((size_t)ii * N + t) * m;
+                c += gen_cost(p, t, x, u);                                               /* :143 */
+                gen_step(p, x, u, use_true_model, zn + ((size_t)j * N + t) * n, zu ? zu[(size_t)j * N + t] : 1.0, xn);   /* :144 */
+                memcpy(x, xn, sizeof(double) * n);
+            }
+            double h; model_h(&p->lq, x, &h);
+            c += h;                                                                      /* :147 */
+            sum += c;
+        }
+        cost[ii] = sum / (double)K;                                                      /* mean :150 */
+    }
+    return 0;
+}
+void orc_pets_initialize(orc_pets *s) {                                                  /* :70-74 */
+    s->iter_current = 0;
+    memcpy(s->mu, s->mu_init, sizeof(double) * s->N * s->m);
+    memcpy(s->Sigma, s->Sigma_init, sizeof(double) * s->N * s->m * s->m);
+}
+void orc_pets_update(orc_pets *s, const double *controls, const double *cost, int64_t *elite_idx) {   /* :159-191 */
+    const int64_t S = s->num_control_samples, E = s->num_elite, N = s->N, m = s->m;
+    pair_t *pr = (pair_t *)malloc(sizeof(pair_t) * S);
+    for (int64_t i = 0; i < S; ++i) { pr[i].theta = 0; pr[i].cost = cost[i]; pr[i].idx = i; }
+    stable_sort_pairs(pr, S);                                                            /* sort(by = cost) :167 */
+    for (int64_t e = 0; e < E; ++e) if (elite_idx) elite_idx[e] = pr[e].idx;
+    const double sf = s->smoothing_factor;
+    for (int64_t t = 0; t < N; ++t) {
+        for (int64_t a = 0; a < m; ++a) {
+            double mean = 0;
+            for (int64_t e = 0; e < E; ++e) mean += controls[((size_t)pr[e].idx * N + t) * m + a];
+            mean /= (double)E;                                                           /* mean :183 */
+            double var = 0;
+            for (int64_t e = 0; e < E; ++e) { double d = controls[((size_t)pr[e].idx * N + t) * m + a] - mean; var += d * d; }
+            var /= (double)(E - 1);                                                      /* var (unbiased) :184 */
+            s->mu[t * m + a] = (1.0 - sf) * mean + sf * s->mu[t * m + a];                 /* :186 */
+            for (int64_t b = 0; b < m; ++b) {                                            /* Diagonal(var) :184, :187 */
+                double *Sg = &s->Sigma[(size_t)t * m * m + a + m * b];
+                *Sg = (1.0 - sf) * (a == b ? var : 0.0) + sf * *Sg;
+            }
+        }
+    }
+    free(pr);
+}
+/* lower Cholesky of a small SPD matrix (MvNormal sampling: mu + L z) */
+static int chol_lower(int n, const double *A, double *Lo) {
+    memset(Lo, 0, sizeof(double) * n * n);
+    for (int j = 0; j < n; ++j) {
+        double d = A[IDX(j, j, n)];
+        for (int k = 0; k < j; ++k) d -= Lo[IDX(j, k, n)] * Lo[IDX(j, k, n)];
+        if (!(d > 0.0)) return 0;
+        Lo[IDX(j, j, n)] = sqrt(d);
+        for (int i = j + 1; i < n; ++i) {
+            double v = A[IDX(i, j, n)];
+            for (int k = 0; k < j; ++k) v -= Lo[IDX(i, k, n)] * Lo[IDX(j, k, n)];
+            Lo[IDX(i, j, n)] = v / Lo[IDX(j, j, n)];
+        }
+    }
+    return 1;
+}
+int orc_pets_step(orc_pets *s, const orc_gen_problem *p, const double *x0, int use_true_model,
+                  const double *zc, const double *zn, const double *zu, double *controls_out, double *cost_out) {   /* :193-245 */
+    const int64_t S = s->num_control_samples, N = s->N, m = s->m;
+    s->iter_current++;
+    double *controls = (double *)malloc(sizeof(double) * S * N * m), *cost = (double *)malloc(sizeof(double) * S);
+    double Lc[MAXD * MAXD];
+    for (int64_t ii = 0; ii < S; ++ii)                                                   /* :206-216 */
+        for (int64_t t = 0; t < N; ++t) {
+            if (!chol_lower((int)m, s->Sigma + (size_t)t * m * m, Lc)) { free(controls); free(cost); return -1; }
+            const double *z = zc + ((size_t)ii * N + t) * m;
+            for (int64_t a = 0; a < m; ++a) {
+                double v = s->mu[t * m + a];
+                for (int64_t b = 0; b <= a; ++b) v += Lc[IDX(a, b, m)] * z[b];
+                controls[((size_t)ii * N + t) * m + a] = v;                               /* rand(rng, MvNormal(mu, Sigma)) */
+            }
+        }
+    orc_pets_compute_cost(p, x0, controls, S, s->num_trajectory_samples, use_true_model, zn, zu, cost);
+    orc_pets_update(s, controls, cost, NULL);
+    if (controls_out) memcpy(controls_out, controls, sizeof(double) * S * N * m);
+    if (cost_out) memcpy(cost_out, cost, sizeof(double) * S);
+    free(controls); free(cost);
+    return 0;
+}

@@ -188,6 +188,39 @@ void orc_nm_step(orc_nm *s, const orc_problem *p, const double *x0, const double
 int orc_nm_solve(orc_nm *s, const orc_problem *p, const double *x0, const double *u, double kl_bound,
                  double *theta_opt, double *x, double *l, double *L, double *value);
 
+/* ---- PETS: CrossEntropyDirectOptimizationSolver (pets.jl) on the generative model family ------------------------
+ * Replaces FiniteHorizonGenerativeOptimalControlProblem(f_stochastic, c, h, N) (optimal_control_problems.jl:126-131):
+ *   f_stochastic(x, u, rng, use_true_model) = A x + B u + kappa x.^3 + w
+ *   w: noise_kind 0 = N(nmean, nchol nchol')   1 = uniform on [nlo, nhi)^n   (test/pets_test.jl:15: rand(rng, n))
+ *   use_true_model: 2-component Gaussian mixture (docs example optimal_control_problems.jl:103-110): component 2 with
+ *                   probability tw2 has mean tmean2 and Cholesky factor tchol2, otherwise the model noise above.
+ *   c(k, x, u) = LQ quadratic form (tables of orc_problem, incl. time variation) + l1u * sum(abs.(u)) ;  h = quadratic.
+ * Randomness is injected (serial semantics of compute_cost_serial, pets.jl:128-157): for trajectory j = ii*K + kk and
+ * step t the model consumes zn[(j*N + t)*n .. +n) (N(0,1) or U[0,1) draws) and, for the mixture, zu[j*N + t]. */
+typedef struct orc_gen_problem {
+    orc_problem lq;            /* A, B, kappa, cost tables, Qf ... (W unused) */
+    double l1u;
+    int32_t noise_kind;
+    const double *nmean, *nchol;   /* n, n*n col-major lower */
+    double nlo, nhi;
+    double tw2;
+    const double *tmean2, *tchol2;
+} orc_gen_problem;
+int orc_pets_compute_cost(const orc_gen_problem *p, const double *x0, const double *controls /* [S][N][m] */,
+                          int64_t S, int64_t K, int use_true_model, const double *zn, const double *zu, double *cost);
+typedef struct orc_pets {
+    int64_t num_control_samples, num_trajectory_samples, num_elite, iter_max;
+    double smoothing_factor;
+    int64_t N, m, iter_current;
+    double *mu_init, *Sigma_init, *mu, *Sigma;     /* [N][m], [N][m*m] col-major; caller-owned */
+} orc_pets;
+void orc_pets_initialize(orc_pets *s);                                                  /* pets.jl:70-74 */
+/* get_elite_samples + compute_new_distribution (pets.jl:159-191): elite_idx[num_elite] out (may be NULL) */
+void orc_pets_update(orc_pets *s, const double *controls, const double *cost, int64_t *elite_idx);
+/* step! (:193-245), serial semantics; zc = N(0,1) stream for the control samples (S*N*m per step), zn/zu as above */
+int orc_pets_step(orc_pets *s, const orc_gen_problem *p, const double *x0, int use_true_model,
+                  const double *zc, const double *zn, const double *zu, double *controls_out, double *cost_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,3 +39,6 @@ from .cross_entropy import (  # noqa: F401,E402
 )
 from . import nelder_mead  # noqa: F401,E402
 from .nelder_mead import NelderMeadBilevelOptimizationSolver, compute_cost_worker  # noqa: F401,E402
+from .problems import FiniteHorizonGenerativeOptimalControlProblem, LQGenerativeProblem  # noqa: F401,E402
+from . import pets  # noqa: F401,E402
+from .pets import CrossEntropyDirectOptimizationSolver  # noqa: F401,E402

@@ -51,6 +51,17 @@ class CeSolver(C.Structure):
                 ("n_solves", C.c_int64), ("n_redraws", C.c_int64)]
 
 
+class GenProblemDesc(C.Structure):
+    _fields_ = [("lq", ProblemDesc), ("l1u", C.c_double), ("noise_kind", C.c_int32), ("nmean", _dp), ("nchol", _dp),
+                ("nlo", C.c_double), ("nhi", C.c_double), ("tw2", C.c_double), ("tmean2", _dp), ("tchol2", _dp)]
+
+
+class PetsSolver(C.Structure):
+    _fields_ = [("num_control_samples", C.c_int64), ("num_trajectory_samples", C.c_int64), ("num_elite", C.c_int64),
+                ("iter_max", C.c_int64), ("smoothing_factor", C.c_double), ("N", C.c_int64), ("m", C.c_int64),
+                ("iter_current", C.c_int64), ("mu_init", _dp), ("Sigma_init", _dp), ("mu", _dp), ("Sigma", _dp)]
+
+
 class NmSolver(C.Structure):
     _fields_ = [("alpha", C.c_double), ("beta", C.c_double), ("gamma", C.c_double), ("eps", C.c_double), ("lam", C.c_double),
                 ("iter_max", C.c_int64), ("theta_high_init", C.c_double), ("theta_low_init", C.c_double),
@@ -66,7 +77,8 @@ EXPORTS = [
     "rat_dp_policy_eval", "rat_ce_default", "rat_ce_initialize", "rat_ce_set_stream", "rat_ce_seed",
     "rat_ce_stream_pos", "rat_ce_get_positive_samples", "rat_ce_compute_cost", "rat_ce_begin_step", "rat_ce_draw",
     "rat_ce_update", "rat_ce_draw_stream", "rat_ce_step", "rat_ce_solve", "rat_nm_default", "rat_nm_initialize",
-    "rat_nm_compute_cost", "rat_nm_step", "rat_nm_solve", "rat_profile_enable", "rat_profile_reset", "rat_profile_get",
+    "rat_nm_compute_cost", "rat_nm_step", "rat_nm_solve", "rat_pets_problem_set", "rat_pets_initialize",
+    "rat_pets_compute_cost", "rat_pets_sample_controls", "rat_pets_update", "rat_pets_step", "rat_pets_solve", "rat_profile_enable", "rat_profile_reset", "rat_profile_get",
     "rat_stream", "rat_layout_info",
 ]
 

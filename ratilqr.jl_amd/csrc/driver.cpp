@@ -62,6 +62,13 @@ struct rat_handle_s {
     size_t ev_used = 0;
     int64_t p_launch[RAT_K_COUNT] = {0}, p_traj[RAT_K_COUNT] = {0};
     double p_ms[RAT_K_COUNT] = {0};
+    // PETS
+    bool have_gen = false;
+    GenDev gen;
+    int gn = 0, gm = 0, gN = 0;
+    std::vector<void *> gen_allocs;
+    double *d_px0 = nullptr, *d_pctrl = nullptr, *d_pzn = nullptr, *d_pzu = nullptr, *d_ptraj = nullptr, *d_pcost = nullptr;
+    size_t cap_ctrl = 0, cap_zn = 0, cap_zu = 0, cap_traj = 0, cap_cost = 0;
     // CE randomness
     const double *z = nullptr;
     int64_t nz = 0, zpos = 0;
@@ -127,6 +134,8 @@ extern "C" void rat_destroy(rat_handle h) {
     (void)hipStreamSynchronize(h->stream);
     free_list(h->pb_allocs);
     free_list(h->st_allocs);
+    free_list(h->gen_allocs);
+    for (double *q : {h->d_px0, h->d_pctrl, h->d_pzn, h->d_pzu, h->d_ptraj, h->d_pcost}) if (q) (void)hipFree(q);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
@@ -1124,5 +1133,210 @@ extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0,
     if (status) *status = st;
     *theta_opt = th_opt;
     *value = (kl_bound > 0) ? val + kl_bound / th_opt : val;                    // :347-351
+    return RAT_OK;
+}
+
+// ---- PETS (pets.jl) on the generative family ---------------------------------------------------------------------
+static bool host_chol_lower(int n, const double *A, double *Lo) {          // column-major in/out
+    std::fill(Lo, Lo + n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double d = A[j + n * j];
+        for (int k = 0; k < j; ++k) d -= Lo[j + n * k] * Lo[j + n * k];
+        if (!(d > 0.0)) return false;
+        Lo[j + n * j] = std::sqrt(d);
+        for (int i = j + 1; i < n; ++i) {
+            double v = A[i + n * j];
+            for (int k = 0; k < j; ++k) v -= Lo[i + n * k] * Lo[j + n * k];
+            Lo[i + n * j] = v / Lo[j + n * j];
+        }
+    }
+    return true;
+}
+
+extern "C" rat_rc rat_pets_problem_set(rat_handle h, const rat_gen_problem_desc *d) {
+    if (!h || !d) return fail(RAT_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(h->device));
+    const rat_problem_desc &q = d->lq;
+    const int n = q.n, m = q.m, N = q.N;
+    if (q.model != RAT_MODEL_LQ) return fail(RAT_ERR_UNSUPPORTED, "generative family is built on RAT_MODEL_LQ");
+    if (n < 1 || m < 1 || N < 1) return fail(RAT_ERR_ARG, "n, m, N must be positive");
+    if (n > RAT_NP || m > RAT_MP) return fail(RAT_ERR_UNSUPPORTED, "kernels are compiled for n <= 12, m <= 4");
+    if (!q.A || !q.B || !q.Q || !q.R || !q.P || !q.qv || !q.rv || !q.q0 || !q.Qf || !q.qvf) return fail(RAT_ERR_ARG, "a table pointer is null");
+    if (d->noise_kind == 0 && (!d->nmean || !d->nchol)) return fail(RAT_ERR_ARG, "Gaussian noise needs nmean / nchol");
+    if (d->tw2 > 0 && (!d->tmean2 || !d->tchol2)) return fail(RAT_ERR_ARG, "mixture noise needs tmean2 / tchol2");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_list(h->gen_allocs);
+    GenDev g;
+    memset(&g, 0, sizeof(g));
+    g.n = n; g.m = m; g.N = N; g.cost_tv = q.cost_tv ? 1 : 0; g.noise_kind = d->noise_kind;
+    g.q0f = q.q0f; g.kappa = q.kappa; g.l1u = d->l1u; g.nlo = d->nlo; g.nhi = d->nhi; g.tw2 = d->tw2;
+    const int Nc = g.cost_tv ? N : 1;
+    std::vector<double> Zt(192, 0.0), Ctab((size_t)Nc * 256, 0.0), lin((size_t)Nc * 16, 0.0), q0(Nc, 0.0), Qf(144, 0.0), qvf(16, 0.0);
+    for (int i = 0; i < n; ++i) {
+        for (int jj = 0; jj < n; ++jj) Zt[i * 16 + jj] = q.A[i + n * jj];
+        for (int a = 0; a < m; ++a) Zt[i * 16 + 12 + a] = q.B[i + n * a];
+    }
+    for (int k = 0; k < Nc; ++k) {
+        double *C = &Ctab[(size_t)k * 256];
+        const double *Q = q.Q + (size_t)k * n * n, *R = q.R + (size_t)k * m * m, *P = q.P + (size_t)k * m * n;
+        // c(k, x, u) is evaluated as written: 1/2 x'Qx + 1/2 u'Ru + u'Px; the symmetric part is what a quadratic form sees
+        for (int i = 0; i < n; ++i) for (int jj = 0; jj < n; ++jj) C[i * 16 + jj] = 0.5 * (Q[i + n * jj] + Q[jj + n * i]);
+        for (int a = 0; a < m; ++a) for (int b = 0; b < m; ++b) C[(12 + a) * 16 + 12 + b] = 0.5 * (R[a + m * b] + R[b + m * a]);
+        for (int a = 0; a < m; ++a) for (int jj = 0; jj < n; ++jj) { C[(12 + a) * 16 + jj] = P[a + m * jj]; C[jj * 16 + 12 + a] = P[a + m * jj]; }
+        for (int i = 0; i < n; ++i) lin[(size_t)k * 16 + i] = q.qv[(size_t)k * n + i];
+        for (int a = 0; a < m; ++a) lin[(size_t)k * 16 + 12 + a] = q.rv[(size_t)k * m + a];
+        q0[k] = q.q0[k];
+    }
+    for (int i = 0; i < n; ++i) {
+        for (int jj = 0; jj < n; ++jj) Qf[i * 12 + jj] = 0.5 * (q.Qf[i + n * jj] + q.Qf[jj + n * i]);
+        qvf[i] = q.qvf[i];
+    }
+    auto pack_vec = [&](const double *v) { std::vector<double> o(16, 0.0); if (v) for (int i = 0; i < n; ++i) o[i] = v[i]; return o; };
+    auto pack_low = [&](const double *Lm) { std::vector<double> o(192, 0.0); if (Lm) for (int i = 0; i < n; ++i) for (int jj = 0; jj <= i; ++jj) o[i * 16 + jj] = Lm[i + n * jj]; return o; };
+    rat_rc rc;
+#define UPG(field, vec) if ((rc = dev_upload(h, h->gen_allocs, &g.field, vec))) return rc
+    UPG(Zt, Zt); UPG(Ctab, Ctab); UPG(lin, lin); UPG(q0, q0); UPG(Qf, Qf); UPG(qvf, qvf);
+    { auto v = pack_vec(d->nmean); UPG(nmean, v); }
+    { auto v = pack_low(d->nchol); UPG(nchol, v); }
+    if (d->tw2 > 0) { auto v = pack_vec(d->tmean2); UPG(tmean2, v); auto w = pack_low(d->tchol2); UPG(tchol2, w); }
+#undef UPG
+    h->gen = g; h->gn = n; h->gm = m; h->gN = N; h->have_gen = true;
+    return RAT_OK;
+}
+
+extern "C" void rat_pets_initialize(rat_pets_solver *s) {                     // pets.jl:70-74
+    s->iter_current = 0;
+    memcpy(s->mu, s->mu_init, sizeof(double) * s->N * s->m);
+    memcpy(s->Sigma, s->Sigma_init, sizeof(double) * s->N * s->m * s->m);
+}
+
+static rat_rc grow(double **p, size_t *cap, size_t need) {
+    if (need <= *cap) return RAT_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    HIPCHK(hipMalloc((void **)p, need * sizeof(double)));
+    *cap = need;
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_pets_compute_cost(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K,
+                                        int32_t use_true_model, const double *zn, const double *zu, uint64_t seed, double *cost) {   // pets.jl:128-157
+    if (!h || !x0 || !controls || !cost) return fail(RAT_ERR_ARG, "null");
+    if (!h->have_gen) return fail(RAT_ERR_NO_PROBLEM, "rat_pets_problem_set was not called");
+    if (S < 1 || K < 1) return fail(RAT_ERR_ARG, "S, K must be positive");
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->gn, m = h->gm, N = h->gN;
+    const size_t ntraj = (size_t)S * K;
+    rat_rc rc;
+    if (!h->d_px0) HIPCHK(hipMalloc((void **)&h->d_px0, XSTR * sizeof(double)));
+    if ((rc = grow(&h->d_pctrl, &h->cap_ctrl, (size_t)S * N * USTR))) return rc;
+    if ((rc = grow(&h->d_ptraj, &h->cap_traj, ntraj))) return rc;
+    if ((rc = grow(&h->d_pcost, &h->cap_cost, (size_t)S))) return rc;
+    std::vector<double> xp(XSTR, 0.0), cp((size_t)S * N * USTR, 0.0);
+    for (int i = 0; i < n; ++i) xp[i] = x0[i];
+    for (int64_t ii = 0; ii < S; ++ii) for (int t = 0; t < N; ++t) for (int a = 0; a < m; ++a)
+        cp[((size_t)ii * N + t) * USTR + a] = controls[((size_t)ii * N + t) * m + a];
+    HIPCHK(hipMemcpyAsync(h->d_px0, xp.data(), xp.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pctrl, cp.data(), cp.size() * 8, hipMemcpyHostToDevice, h->stream));
+    PetsArgs a;
+    a.g = h->gen; a.x0 = h->d_px0; a.controls = h->d_pctrl; a.S = S; a.K = K; a.use_true = use_true_model ? 1 : 0;
+    a.zn = nullptr; a.zu = nullptr; a.seed = seed; a.traj_cost = h->d_ptraj; a.cost = h->d_pcost;
+    if (zn) {
+        if ((rc = grow(&h->d_pzn, &h->cap_zn, ntraj * N * n))) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_pzn, zn, ntraj * N * n * 8, hipMemcpyHostToDevice, h->stream));
+        a.zn = h->d_pzn;
+        if (zu) {
+            if ((rc = grow(&h->d_pzu, &h->cap_zu, ntraj * N))) return rc;
+            HIPCHK(hipMemcpyAsync(h->d_pzu, zu, ntraj * N * 8, hipMemcpyHostToDevice, h->stream));
+            a.zu = h->d_pzu;
+        }
+    }
+    launch_pets(a, h->stream);
+    HIPCHK(hipMemcpyAsync(cost, h->d_pcost, (size_t)S * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_pets_sample_controls(const rat_pets_solver *s, const double *zc, double *controls) {   // pets.jl:206-216
+    if (!s || !zc || !controls) return fail(RAT_ERR_ARG, "null");
+    const int64_t S = s->num_control_samples, N = s->N, m = s->m;
+    std::vector<double> Lc((size_t)N * m * m);
+    for (int64_t t = 0; t < N; ++t)
+        if (!host_chol_lower((int)m, s->Sigma + (size_t)t * m * m, &Lc[(size_t)t * m * m]))
+            return fail(RAT_ERR_ARG, "Sigma_t is not positive definite (MvNormal would throw)");
+    for (int64_t ii = 0; ii < S; ++ii)
+        for (int64_t t = 0; t < N; ++t) {
+            const double *z = zc + ((size_t)ii * N + t) * m, *Lt = &Lc[(size_t)t * m * m];
+            for (int64_t a = 0; a < m; ++a) {
+                double v = s->mu[t * m + a];
+                for (int64_t b = 0; b <= a; ++b) v += Lt[a + m * b] * z[b];
+                controls[((size_t)ii * N + t) * m + a] = v;                    // rand(rng, MvNormal(mu_t, Sigma_t))
+            }
+        }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_pets_update(rat_pets_solver *s, const double *controls, const double *cost, int64_t *elite_idx) {   // pets.jl:159-191
+    if (!s || !controls || !cost) return fail(RAT_ERR_ARG, "null");
+    const int64_t S = s->num_control_samples, E = s->num_elite, N = s->N, m = s->m;
+    if (E < 2 || E > S) return fail(RAT_ERR_ARG, "num_elite must be in [2, num_control_samples]");
+    std::vector<int64_t> idx(S);
+    for (int64_t i = 0; i < S; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {      // sort(by = cost) :167, isless: NaN last
+        const double x = cost[a], y = cost[b];
+        if (x != x) return false;
+        if (y != y) return true;
+        return x < y;
+    });
+    for (int64_t e = 0; e < E; ++e) if (elite_idx) elite_idx[e] = idx[e];
+    const double sf = s->smoothing_factor;
+    for (int64_t t = 0; t < N; ++t)
+        for (int64_t a = 0; a < m; ++a) {
+            double mean = 0;
+            for (int64_t e = 0; e < E; ++e) mean += controls[((size_t)idx[e] * N + t) * m + a];
+            mean /= (double)E;                                                 // :183
+            double var = 0;
+            for (int64_t e = 0; e < E; ++e) { const double d = controls[((size_t)idx[e] * N + t) * m + a] - mean; var += d * d; }
+            var /= (double)(E - 1);                                            // var = unbiased :184
+            s->mu[t * m + a] = (1.0 - sf) * mean + sf * s->mu[t * m + a];       // :186
+            for (int64_t b = 0; b < m; ++b) {                                  // Diagonal(var) :184, smoothing :187
+                double *Sg = &s->Sigma[(size_t)t * m * m + a + m * b];
+                *Sg = (1.0 - sf) * (a == b ? var : 0.0) + sf * *Sg;
+            }
+        }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_pets_step(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc,
+                                const double *zn, const double *zu, uint64_t seed, double *controls_out, double *cost_out) {   // pets.jl:193-245
+    if (!h || !s || !zc) return fail(RAT_ERR_ARG, "null");
+    if (!h->have_gen) return fail(RAT_ERR_NO_PROBLEM, "rat_pets_problem_set was not called");
+    if (s->N != h->gN || s->m != h->gm) return fail(RAT_ERR_ARG, "solver N / m do not match the problem");
+    const int64_t S = s->num_control_samples;
+    s->iter_current += 1;
+    std::vector<double> controls((size_t)S * s->N * s->m), cost(S);
+    rat_rc rc = rat_pets_sample_controls(s, zc, controls.data());
+    if (rc) return rc;
+    if ((rc = rat_pets_compute_cost(h, x0, controls.data(), S, s->num_trajectory_samples, use_true_model, zn, zu, seed, cost.data()))) return rc;
+    if ((rc = rat_pets_update(s, controls.data(), cost.data(), nullptr))) return rc;
+    if (controls_out) memcpy(controls_out, controls.data(), controls.size() * 8);
+    if (cost_out) memcpy(cost_out, cost.data(), cost.size() * 8);
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_pets_solve(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc,
+                                 const double *zn, const double *zu, uint64_t seed) {   // pets.jl:270-281
+    if (!h || !s || !zc) return fail(RAT_ERR_ARG, "null");
+    if (!h->have_gen) return fail(RAT_ERR_NO_PROBLEM, "rat_pets_problem_set was not called");
+    rat_pets_initialize(s);
+    const size_t nzc = (size_t)s->num_control_samples * s->N * s->m;
+    const size_t ntraj = (size_t)s->num_control_samples * s->num_trajectory_samples;
+    const size_t nzn = ntraj * s->N * h->gn, nzu = ntraj * s->N;
+    while (s->iter_current < s->iter_max) {
+        const int64_t it = s->iter_current;
+        rat_rc rc = rat_pets_step(h, s, x0, use_true_model, zc + it * nzc, zn ? zn + it * nzn : nullptr, (zn && zu) ? zu + it * nzu : nullptr,
+                                  seed + (uint64_t)it, nullptr, nullptr);
+        if (rc) return rc;
+    }
     return RAT_OK;
 }

@@ -34,6 +34,25 @@ struct LinArgs {
     int mode;              // 0 nominal slots, 1 candidate slots
 };
 
+struct GenDev {                 // device tables of the generative family (PETS)
+    int n, m, N, cost_tv, noise_kind;
+    const double *Zt, *Ctab, *lin, *q0, *Qf, *qvf;
+    double q0f, kappa, l1u, nlo, nhi, tw2;
+    const double *nmean, *nchol, *tmean2, *tchol2;   // [16], [12][16] row-major lower
+};
+struct PetsArgs {
+    GenDev g;
+    const double *x0;           // [12]
+    const double *controls;     // [S][N][4] padded
+    long S, K;
+    int use_true;
+    const double *zn, *zu;      // injected draws or null (device Philox)
+    unsigned long long seed;
+    double *traj_cost;          // [S*K]
+    double *cost;               // [S]
+};
+void launch_pets(const PetsArgs &a, hipStream_t s);
+
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s);
 void launch_rollout(const RolloutArgs &a, hipStream_t s);
 void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout + linearise (solver hot loop)

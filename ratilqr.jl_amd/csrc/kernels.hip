@@ -1215,3 +1215,115 @@ __global__ void gather_kernel(StateDev st, double *value, int *status, int *iter
 void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, hipStream_t s) {
     hipLaunchKernelGGL(gather_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, value, status, iters, ls_evals);
 }
+
+// =====================================================================================================
+// PETS (pets.jl:76-157): stochastic forward rollouts with running cost, 4 trajectories per wavefront (16-lane rows).
+// Noise comes from an injected stream (parity with the oracle, serial semantics) or from Philox4x32-10 on the device.
+// =====================================================================================================
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u01(unsigned hi, unsigned lo) {       // 53-bit uniform in [0, 1)
+    return (double)((((unsigned long long)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
+    const int row = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const GenDev &g = a.g;
+    const long ntraj = a.S * a.K;
+    const long tj = (long)blockIdx.x * 4 + row;
+    const bool live = tj < ntraj;
+    const long ii = live ? tj / a.K : 0;
+    __shared__ double shxu[4][16];
+    __shared__ double shz[4][16];
+    const int N = g.N, n = g.n;
+    const int jx = (j < 12) ? j : 11;
+    double zr[16], crow[16], nrow[12], trow[12];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zr[q] = g.Zt[jx * 16 + q];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) { nrow[q] = g.nchol[jx * 16 + q]; trow[q] = g.tchol2 ? g.tchol2[jx * 16 + q] : 0.0; }
+    const double nmean = g.nmean[jx], tmean = g.tmean2 ? g.tmean2[jx] : 0.0;
+    double x = (j < 12) ? a.x0[j] : 0.0;
+    double cacc = 0.0;
+    const double *__restrict__ uc = a.controls + ii * N * USTR;
+    for (int t = 0; t < N; ++t) {
+        const int kc = g.cost_tv ? t : 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) crow[q] = g.Ctab[(long)kc * 256 + j * 16 + q];
+        const double u = uc[(long)t * USTR + (j & 3)];
+        // draws of this (trajectory, step): zn (per state lane) and the mixture selector
+        double z = 0.0, zsel = 1.0;
+        if (a.zn) {
+            if (j < n && live) z = a.zn[((tj * N + t) * (long)n) + j];
+            if (a.zu && live) zsel = a.zu[tj * N + t];
+        } else {
+            unsigned r[4];
+            philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)t, (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+            const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+            z = (g.noise_kind == 1 && !(a.use_true && g.tw2 > 0.0)) ? u1 : sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925286766559 * u2);
+            unsigned rs[4];
+            philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)t, 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);
+            zsel = u01(rs[0], rs[1]);
+        }
+        if (j < 12) shxu[row][j] = x;
+        if (j < 4) shxu[row][12 + j] = u;
+        shz[row][j] = (j < n) ? z : 0.0;
+        WAVE_SYNC();
+        // stage cost c(t, x, u) = 1/2 xu' C xu + lin' xu + q0 + l1u sum|u|      (pets.jl:143)
+        double acc = 0.0, dyn = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { acc = fma(crow[q], shxu[row][q], acc); dyn = fma(zr[q], shxu[row][q], dyn); }
+        const double lin = g.lin[(long)kc * 16 + j];
+        const double xuj = (j < 12) ? x : u;
+        double part = xuj * (0.5 * acc + lin) + ((j >= 12 && j - 12 < g.m) ? g.l1u * fabs(u) : 0.0);
+        part = row_sum16(part);
+        cacc += part + g.q0[kc];
+        // stochastic transition x <- f_stochastic(x, u, rng, use_true_model)     (pets.jl:144)
+        if (g.kappa != 0.0) dyn += g.kappa * (x * x * x);
+        double w;
+        const bool second = a.use_true && (zsel < g.tw2);
+        if (second || g.noise_kind == 0) {
+            double nz = 0.0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) nz = fma(second ? trow[q] : nrow[q], shz[row][q], nz);
+            w = (second ? tmean : nmean) + nz;
+        } else {
+            w = g.nlo + (g.nhi - g.nlo) * z;
+        }
+        x = (j < n) ? dyn + w : 0.0;
+        WAVE_SYNC();
+    }
+    // terminal cost h(x_N)     (pets.jl:147)
+    if (j < 12) shxu[row][j] = x;
+    WAVE_SYNC();
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc = fma(g.Qf[jx * 12 + q], shxu[row][q], acc);
+    double part = (j < 12) ? x * (0.5 * acc + g.qvf[jx]) : 0.0;
+    part = row_sum16(part);
+    if (live && j == 0) a.traj_cost[tj] = cacc + part + g.q0f;
+}
+
+// mean over the K rollouts of each control sample, summed in trajectory order (deterministic)   (pets.jl:150)
+__global__ void pets_mean_kernel(PetsArgs a) {
+    const long ii = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ii >= a.S) return;
+    double s = 0.0;
+    for (long kk = 0; kk < a.K; ++kk) s += a.traj_cost[ii * a.K + kk];
+    a.cost[ii] = s / (double)a.K;
+}
+
+void launch_pets(const PetsArgs &a, hipStream_t s) {
+    const long ntraj = a.S * a.K;
+    if (ntraj <= 0) return;
+    hipLaunchKernelGGL(pets_rollout_kernel, dim3((unsigned)((ntraj + 3) / 4)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(pets_mean_kernel, dim3((unsigned)((a.S + 255) / 256)), dim3(256), 0, s, a);
+}

@@ -188,3 +188,62 @@ def synthetic_lq_problem(n=12, m=4, N=50, rho=0.9, w=1e-3, r_weight=0.1, seed=0,
     prob = LQRiskSensitiveProblem(A, B, Q=np.eye(n), R=r_weight * np.eye(m), N=N, W=w * np.eye(n), Qf=np.eye(n),
                                   kappa=kappa)
     return prob, x0, np.zeros((N, m))
+
+
+class FiniteHorizonGenerativeOptimalControlProblem(OptimalControlProblem):
+    """Field-compatible base of the generative model family (optimal_control_problems.jl:126-131):
+    ``f_stochastic(x, u, rng, use_true_model=False)``, ``c(k, x, u)``, ``h(x)``, ``N``."""
+
+
+class LQGenerativeProblem(FiniteHorizonGenerativeOptimalControlProblem):
+    r"""f_stochastic(x, u, rng, use_true_model) = A x + B u + kappa x.^3 + w  (device family of the PETS path).
+
+    noise = ("gaussian", mean, cov) or ("uniform", lo, hi)  (the latter is ``x + u + rand(rng, n)`` of test/pets_test.jl:15);
+    true_noise = (w2, mean2, cov2): with ``use_true_model`` the noise is N(mean2, cov2) with probability w2, else the model
+    noise (2-component mixture of the docs example).  c(k,x,u) = LQ quadratic form + l1u*sum(abs.(u)); h quadratic."""
+
+    def __init__(self, A, B, N, noise, Q=None, R=None, P=None, qv=None, rv=None, q0=None, Qf=None, qvf=None, q0f=0.0,
+                 kappa=0.0, l1u=0.0, true_noise=None):
+        A = np.asarray(A, float)
+        n, m = A.shape[0], np.asarray(B).shape[1]
+        self.lq = LQRiskSensitiveProblem(A, B, Q=np.zeros((n, n)) if Q is None else Q, R=np.zeros((m, m)) if R is None else R,
+                                         N=N, W=np.eye(n), P=P, qv=qv, rv=rv, q0=q0, Qf=Qf, qvf=qvf, q0f=q0f, kappa=kappa)
+        self.n, self.m, self.N = n, m, int(N)
+        self.l1u = float(l1u)
+        self.noise = noise
+        self.true_noise = true_noise
+        if noise[0] == "gaussian":
+            self.noise_kind, self.nmean = 0, np.asarray(noise[1], float)
+            self.nchol = np.linalg.cholesky(np.asarray(noise[2], float))
+            self.nlo = self.nhi = 0.0
+        elif noise[0] == "uniform":
+            self.noise_kind, self.nmean, self.nchol = 1, np.zeros(n), np.zeros((n, n))
+            self.nlo, self.nhi = float(noise[1]), float(noise[2])
+        else:
+            raise ValueError(noise[0])
+        if true_noise is not None:
+            self.tw2, self.tmean2 = float(true_noise[0]), np.asarray(true_noise[1], float)
+            self.tchol2 = np.linalg.cholesky(np.asarray(true_noise[2], float))
+        else:
+            self.tw2, self.tmean2, self.tchol2 = 0.0, np.zeros(n), np.zeros((n, n))
+
+    def f_stochastic(self, x, u, rng, use_true_model=False):
+        x = np.asarray(x, float)
+        xn = self.lq.f(x, u)
+        if use_true_model and self.tw2 > 0 and rng.random() < self.tw2:
+            return xn + self.tmean2 + self.tchol2 @ rng.standard_normal(self.n)
+        if self.noise_kind == 0:
+            return xn + self.nmean + self.nchol @ rng.standard_normal(self.n)
+        return xn + self.nlo + (self.nhi - self.nlo) * rng.random(self.n)
+
+    def c(self, k, x, u):
+        return self.lq.c(k, x, u) + self.l1u * float(np.sum(np.abs(u)))
+
+    def h(self, x):
+        return self.lq.h(x)
+
+    def gen_tables(self) -> dict:
+        t = dict(self.lq.c_tables())
+        t.update(l1u=self.l1u, noise_kind=self.noise_kind, nmean=_colmajor(self.nmean), nchol=_colmajor(self.nchol),
+                 nlo=self.nlo, nhi=self.nhi, tw2=self.tw2, tmean2=_colmajor(self.tmean2), tchol2=_colmajor(self.tchol2))
+        return t
