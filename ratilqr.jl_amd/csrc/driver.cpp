@@ -37,6 +37,7 @@ struct rat_handle_s {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // speculative gain sweeps run here, concurrently with the evaluation sweep
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    bool dual = false;               // RATILQR_DUAL=1: fused evaluation + next-gain-sweep wavefronts (E = 1 only)
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
     rat_ileqg_opts opts;
     OptsDev opd;
@@ -115,6 +116,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     HIPCHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
     if (const char *e = getenv("RATILQR_SPECULATE")) h->speculate = (e[0] == '1');
+    if (const char *e = getenv("RATILQR_DUAL")) h->dual = (e[0] == '1') && spec_eps == 1;
     HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
     for (int i = 0; i < CTR_RING; ++i) HIPCHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
     memset(&h->st, 0, sizeof(h->st));
@@ -418,6 +420,16 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     const int slot = round % CTR_RING;
     const int64_t nc = (int64_t)st.B * st.E;
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    if (h->dual) {
+        // fused path (E = 1): the plain gain sweep only serves samples whose fused gain recursion was abandoned (H not PD)
+        prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
+        prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);
+        prof_begin(h, RAT_K_SWEEP_DUAL, st.B); launch_sweep_dual(sweep_args(h, st, 7), st.B, h->stream); prof_end(h);
+        prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
+        HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
+        return RAT_OK;
+    }
     if (!h->speculate || st.E > 1) {     // E > 1: a candidate k > 0 may be accepted, whose gain sweep was not speculated
         prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
     }
@@ -448,6 +460,10 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
     // sweep (step! number 1 re-linearises the same trajectory, App. B.1) runs speculatively beside it.
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
     prof_begin(h, RAT_K_ROLLOUT, B); launch_rollin(ra, h->stream); prof_end(h);         // fused rollout + linearise
+    if (h->dual) {
+        prof_begin(h, RAT_K_SWEEP_DUAL, B); launch_sweep_dual(sweep_args(h, st, 6), B, h->stream); prof_end(h);
+        launch_commit_init(st, h->stream);
+    } else {
     if (h->speculate) {
         HIPCHK(hipEventRecord(h->ev_a, h->stream));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_a, 0));
@@ -458,6 +474,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
     if (h->speculate) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
         launch_commit_init(st, h->stream);
+    }
     }
     // while true: step!; convergence / iter_max test   (ileqg.jl:640-654).  No host round trip per round: the host enqueues as
     // many rounds as the previous batch needed, then polls the per-round counter; it only falls back to round-by-round

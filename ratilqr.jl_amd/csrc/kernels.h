@@ -59,5 +59,6 @@ void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout +
 void launch_linearize(const LinArgs &a, hipStream_t s);
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
+void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s);   // modes 6 (initialize! + first gain sweep), 7 (candidate 0 + next gain sweep)
 void launch_commit_init(const StateDev &st, hipStream_t s);
 void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, hipStream_t s);

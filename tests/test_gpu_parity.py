@@ -282,3 +282,27 @@ def test_speculative_gain_sweep_is_result_identical(monkeypatch):
             assert np.array_equal(a, b)
         assert np.array_equal(r0["L"], r1["L"]) and np.array_equal(r0["x"], r1["x"]) and r0["value"] == r1["value"]
         assert np.array_equal(r0["eps_history"], r1["eps_history"])
+
+
+def test_dual_sweep_wavefronts_are_result_identical(monkeypatch):
+    """Opt-in mode (RATILQR_DUAL=1, E = 1): one wavefront runs candidate 0's policy evaluation and the next step!'s gain sweep
+    over a single pass of the tiles.  Same expressions as the separate kernels: every output must be bit-identical."""
+    prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
+    theta = np.array([0.0, 1.0, 4.0, 5.0, 5.9, 6.3, 6.6, 9.0, 30.0])
+    sprob, sx0, su = stress_problem(2, kappa=0.03)
+    lprob, lx0, lu = rat.synthetic_lq_problem()
+    th_l = np.concatenate([[0.0], np.linspace(0.01, 14.0, 30), [50.0]])
+    ref = rat.Context(prob, max_batch=theta.size).solve_batch(x0, u, theta)
+    ref_s = rat.Context(sprob, rat.ileqg.make_opts(iter_max=8), max_batch=3).solve_batch(sx0, su, np.array([0.0, 1.0, 4.0]))
+    ref_l = rat.Context(lprob, max_batch=32).solve_batch(lx0, lu, th_l)
+    r0 = rat.Context(prob).solve(x0, u, 5.0)
+    monkeypatch.setenv("RATILQR_DUAL", "1")
+    got = rat.Context(prob, max_batch=theta.size).solve_batch(x0, u, theta)
+    got_s = rat.Context(sprob, rat.ileqg.make_opts(iter_max=8), max_batch=3).solve_batch(sx0, su, np.array([0.0, 1.0, 4.0]))
+    got_l = rat.Context(lprob, max_batch=32).solve_batch(lx0, lu, th_l)
+    r1 = rat.Context(prob).solve(x0, u, 5.0)
+    monkeypatch.delenv("RATILQR_DUAL")
+    for a, b in zip(ref + ref_s + ref_l, got + got_s + got_l):
+        assert np.array_equal(a, b)
+    assert np.array_equal(r0["L"], r1["L"]) and np.array_equal(r0["x"], r1["x"]) and r0["value"] == r1["value"]
+    assert np.array_equal(r0["eps_history"], r1["eps_history"])
