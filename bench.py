@@ -25,6 +25,13 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
+def algo_bytes_per_candidate(prob, n=12, m=4, N=50):
+    """one policy-evaluation sweep reads the tile bundle (N (2n^2 + 2nm + m^2 + n + m + 1) +
+    n^2 + n + 1 doubles at the kernels' padded n=12, m=4) and the gains (N m n doubles) and writes one value."""
+    per_step = 2 * n * n + 2 * n * m + m * m + n + m + 1
+    return 8 * (N * per_step + n * n + n + 1) + 8 * N * m * n + 8
+
+
 def draw_theta(B, seed):
     """Positive samples of N(1, 2) -- the CE solver's first-iteration distribution (mu_init=1, sigma_init=2)."""
     rng = np.random.default_rng(seed)
@@ -135,8 +142,7 @@ def main():
         torch.cuda.synchronize()
         e8 = time.perf_counter() - t8
         p8 = ctx8.profile_get()["sweep_eval"]
-        lay8 = ctx8.layout_info()
-        bpt = lay8["tile_bytes"] + lay8["L_bytes"] + 8
+        bpt = algo_bytes_per_candidate(prob)
         ach8 = bpt * (p8["trajectories"] / max(p8["launches"], 1)) / (p8["ms"] / max(p8["launches"], 1) * 1e-3) / 1e9
         second = {"spec_eps": 8, "value": B * K8 / e8, "unit": "solves/s", "ms_per_step": e8 / K8 * 1e3, "steps": K8,
                   "values_identical_to_primary": bool(torch.equal(v8, value)),
@@ -149,7 +155,8 @@ def main():
         lay = ctx.layout_info()
         # algorithmic bytes of the dominant kernel (policy-evaluation sweep of line-search candidates):
         # tile bundle + gains read, one value written -- SURVEY.md section 8(d): 187.3 KB per candidate.
-        bytes_per_traj = lay["tile_bytes"] + lay["L_bytes"] + 8
+        # (information content, not the padded HBM record: the physical register-image record is 11.7 % larger)
+        bytes_per_traj = algo_bytes_per_candidate(prob)
         pe = prof["sweep_eval"]
         avg_ms = pe["ms"] / max(pe["launches"], 1)
         traj_per_launch = pe["trajectories"] / max(pe["launches"], 1)
@@ -186,7 +193,8 @@ def main():
                 "bound": "hbm", "kernel": "sweep_kernel<eval> (policy-evaluation Riccati sweep of line-search candidates)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "bytes_per_trajectory": bytes_per_traj, "trajectories_per_launch": traj_per_launch,
+                "bytes_per_trajectory": bytes_per_traj, "hbm_record_bytes_per_trajectory": lay["tile_bytes"] + lay["L_bytes"] + 8,
+                "trajectories_per_launch": traj_per_launch,
                 "avg_launch_ms": avg_ms, "launches": pe["launches"],
             },
             "kernel_ms_per_step": {k: v["ms"] / n_all for k, v in prof_all.items()},

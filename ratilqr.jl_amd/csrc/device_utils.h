@@ -71,8 +71,9 @@ __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base
 // Diagnostic build only (make diag): s_memtime stamps per segment of the time step; shares of one wave's cycles are
 // written to the dump buffer.  Never compiled into the product library.
 #ifdef RAT_DIAG
-#define DIAG_DECL unsigned long long dg_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long dg_prev = 0;
-#define DIAG_START() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dg_prev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DIAG_DECL unsigned long long dg_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long dg_prev = 0, dg_gap = 0;
+#define DIAG_START() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        { unsigned long long now_ = __builtin_readcyclecounter(); if (dg_prev) dg_gap += now_ - dg_prev; dg_prev = now_; } __builtin_amdgcn_sched_barrier(0); } while (0)
 #define DIAG_STAMP(i, val) do { asm volatile("" :: "v"(val)); __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         { unsigned long long now_ = __builtin_readcyclecounter(); dg_acc[i] += now_ - dg_prev; dg_prev = now_; } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else

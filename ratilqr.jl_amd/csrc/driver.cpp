@@ -726,15 +726,15 @@ extern "C" rat_rc rat_approximate_model(rat_handle h, const double *u, const dou
         for (int i = 0; i < n; ++i) {
             if (qv) qv[(size_t)t * n + i] = ts[TS_QR + i];
             for (int jj = 0; jj < n; ++jj) {
-                if (Q) Q[(size_t)t * n * n + i + n * jj] = ts[TS_Q + i * 12 + jj];
-                if (A) A[(size_t)t * n * n + i + n * jj] = ts[TS_Z + i * 16 + jj];
+                if (Q) Q[(size_t)t * n * n + i + n * jj] = ts[TS_CPOS(i, jj)];
+                if (A) A[(size_t)t * n * n + i + n * jj] = ts[TS_ZPOS(i, jj)];
             }
-            for (int g = 0; g < m; ++g) if (B) B[(size_t)t * n * m + i + n * g] = ts[TS_Z + i * 16 + 12 + g];
+            for (int g = 0; g < m; ++g) if (B) B[(size_t)t * n * m + i + n * g] = ts[TS_ZPOS(i, 12 + g)];
         }
         for (int g = 0; g < m; ++g) {
             if (r) r[(size_t)t * m + g] = ts[TS_QR + 12 + g];
-            for (int jj = 0; jj < n; ++jj) if (P) P[(size_t)t * m * n + g + m * jj] = ts[TS_PR + g * 16 + jj];
-            for (int g2 = 0; g2 < m; ++g2) if (R) R[(size_t)t * m * m + g + m * g2] = ts[TS_PR + g * 16 + 12 + g2];
+            for (int jj = 0; jj < n; ++jj) if (P) P[(size_t)t * m * n + g + m * jj] = ts[TS_CPOS(12 + g, jj)];
+            for (int g2 = 0; g2 < m; ++g2) if (R) R[(size_t)t * m * m + g + m * g2] = ts[TS_CPOS(12 + g, 12 + g2)];
         }
         if (W) memcpy(W + (size_t)t * n * n, h->hW.data() + (h->W_tv ? (size_t)t * n * n : 0), sizeof(double) * n * n);   // :312
     }
@@ -758,17 +758,17 @@ static void pack_tiles(const rat_handle h, const double *q, const double *qv, co
         for (int i = 0; i < n; ++i) {
             ts[TS_QR + i] = qv[(size_t)t * n + i];
             for (int jj = 0; jj < n; ++jj) {
-                ts[TS_Q + i * 12 + jj] = Q[(size_t)t * n * n + i + n * jj];
-                ts[TS_Z + i * 16 + jj] = A[(size_t)t * n * n + i + n * jj];
+                ts[TS_CPOS(i, jj)] = Q[(size_t)t * n * n + i + n * jj];
+                ts[TS_ZPOS(i, jj)] = A[(size_t)t * n * n + i + n * jj];
             }
-            for (int g = 0; g < m; ++g) ts[TS_Z + i * 16 + 12 + g] = B[(size_t)t * n * m + i + n * g];
+            for (int g = 0; g < m; ++g) ts[TS_ZPOS(i, 12 + g)] = B[(size_t)t * n * m + i + n * g];
         }
         for (int g = 0; g < m; ++g) {
             ts[TS_QR + 12 + g] = r[(size_t)t * m + g];
-            for (int jj = 0; jj < n; ++jj) ts[TS_PR + g * 16 + jj] = P[(size_t)t * m * n + g + m * jj];
-            for (int g2 = 0; g2 < m; ++g2) ts[TS_PR + g * 16 + 12 + g2] = R[(size_t)t * m * m + g + m * g2];
+            for (int jj = 0; jj < n; ++jj) ts[TS_CPOS(12 + g, jj)] = P[(size_t)t * m * n + g + m * jj];
+            for (int g2 = 0; g2 < m; ++g2) ts[TS_CPOS(12 + g, 12 + g2)] = R[(size_t)t * m * m + g + m * g2];
         }
-        for (int g = m; g < RAT_MP; ++g) ts[TS_PR + g * 16 + 12 + g] = 1.0;
+        for (int g = m; g < RAT_MP; ++g) ts[TS_CPOS(12 + g, 12 + g)] = 1.0;
     }
     double *tt = &tp[(size_t)N * TSTRIDE];
     tt[TT_q] = q[N];

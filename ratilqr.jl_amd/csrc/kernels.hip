@@ -33,45 +33,34 @@
 // sweep_kernel
 // =====================================================================================================
 struct TileRegs {
-    d4 z, c, lc;
-    double qr, q, la;
+    d4 z, c;
+    double x, la;          // x: lanes 0..15 = qr, lane 16 = q;  la: this lane's entry L[g][j] of the natural 4 x 16 gain layout
 };
 
-// All loads are unconditional and branch-free (clamped lane offsets + selects): the number of loads in flight is then a
+// All loads are unconditional and branch-free (clamped lane offsets): the number of loads in flight is then a
 // compile-time constant, so the prefetch of step t-1 can stay outstanding across the whole of step t behind a counted
 // s_waitcnt vmcnt(N).  (A lane-conditional load makes the count path-dependent and degrades the wait to ~vmcnt(0),
-// which exposes a full HBM latency per time step.)
-template <bool GAIN, bool DUMP>
-__device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict__ tp, const int (&offC)[4], int l, int j,
-                                          const double *__restrict__ Lp, const double *__restrict__ dlp, double mL, int g) {
-    tr.z[0] = tp[TS_Z + l];
-    tr.z[1] = tp[TS_Z + 64 + l];
-    tr.z[2] = tp[TS_Z + 128 + l];
-    tr.z[3] = 0.0;
-    tr.c[0] = tp[offC[0]];
-    tr.c[1] = tp[offC[1]];
-    tr.c[2] = tp[offC[2]];
-    tr.c[3] = tp[offC[3]];
-    tr.qr = tp[TS_QR + j];
-    tr.q = tp[TS_q];
-    if (!GAIN) {
-        const int jc = (j < 12) ? j : 11;      // mL = 1 on lanes that hold a gain column (gains given and j < 12), else 0
-        tr.lc[0] = Lp[jc] * mL;
-        tr.lc[1] = Lp[12 + jc] * mL;
-        tr.lc[2] = Lp[24 + jc] * mL;
-        tr.lc[3] = Lp[36 + jc] * mL;
-        tr.la = Lp[g * 12 + jc] * mL;          // this lane's own entry L[g][j] of the natural 4 x 16 layout
-        if (DUMP && dlp && j == 12) {           // operator form only (rat_dp_policy_eval with a dl_array)
-            tr.lc[0] = dlp[0];
-            tr.lc[1] = dlp[1];
-            tr.lc[2] = dlp[2];
-            tr.lc[3] = dlp[3];
-            tr.la = dlp[g];
-        }
+// which exposes a full HBM latency per time step.)  The record is a register image (layout.h): three 16-B/lane loads
+// fetch R0..R5, two 8-B/lane loads R6 and the [qr | q] row; policy evaluation adds one for its gain row.
+template <bool HASL, bool DUMP>
+__device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict__ tp, int l, int lx, int lq,
+                                          const double *__restrict__ Lp, const double *__restrict__ dlp, double mL, int g, int j) {
+    const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
+    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = t2[128 + l];
+    tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
+    tr.c[0] = w1.y; tr.c[1] = w2.x; tr.c[2] = w2.y;
+    tr.c[3] = tp[TS_R6 + l];
+    tr.x = tp[TS_QR + lx];
+    tr.la = 0.0;
+    if (HASL) {
+        tr.la = Lp[lq] * mL;                   // mL = 1 on lanes that hold a gain column (j < 12), else 0
+        if (DUMP && dlp && j == 12) tr.la = dlp[g];      // operator form only (rat_dp_policy_eval with a dl_array)
     }
 }
 
-template <bool GAIN, bool DUMP, bool WTV>
+// HASL (policy evaluation only): a gain history is given.  false for initialize!'s sweep (ileqg.jl:221-224), whose gains
+// are all zero: no gain loads and V = Fx without the two rank-4 updates.
+template <bool GAIN, bool DUMP, bool WTV, bool HASL>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     const int l_ = threadIdx.x, g_ = l_ >> 4, j_ = l_ & 15;
     const int l = l_, g = g_, j = j_;
@@ -112,6 +101,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     double *__restrict__ dlout = st.dl + (long)osel * st.dl_half + (long)b * N * USTR;
 
     __shared__ double rowbuf[2][2][16];
+    __shared__ double lbuf[64];        // policy evaluation: the step's gain row block [L | dl], natural 4 x 16 layout
     __shared__ double ex[104];         // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0, [84..99] = s_vec
 #define HBUF(r_, c_) ex[(r_) * 16 + (c_)]
 #define FBUF(c_) ex[64 + (c_)]
@@ -146,13 +136,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     for (int r = 0; r < 3; ++r) foff[r] = (j == 12) ? (64 + 4 * r + g) : 80;
     const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
 
-    int offC[4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int i = 4 * r + g;
-        offC[r] = (j < 12) ? (TS_Q + i * 12 + j) : (TS_PR + (j - 12) * 16 + i);
-    }
-    offC[3] = TS_PR + g * 16 + j;
+    const int lx = (l < 17) ? l : 17;                        // [qr | q | pad] row: lanes past q read the (zero) pad slot
+    const int lq = g * 12 + ((j < 12) ? j : 11);             // own entry of L_t (4 x 12 row-major), clamped
 
     // noise tables (time-invariant case is hoisted out of the time loop)
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
@@ -196,8 +181,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             if (l == 12) dp[DUMP_s] = 0.5 * v[3];
         }
         TileRegs nx;
-        load_tile<GAIN, DUMP>(nx, tile0 + (long)(N - 1) * TSTRIDE, offC, l, j, Lb + (long)(N - 1) * LSTR,
-                        a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, mL, g);
+        load_tile<HASL, DUMP>(nx, tile0 + (long)(N - 1) * TSTRIDE, l, lx, lq, Lb + (long)(N - 1) * LSTR,
+                        a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, mL, g, j);
         bool h_not_pd = false;
         // one backward step (ileqg.jl:361-391 / :435-460) on the tile registers `cur`; returns 0, 1 (M not PD), 2 (H not PD)
         auto step = [&](const int t, const TileRegs &cur) -> int {
@@ -218,6 +203,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             // X = V[:, 0:12] [A|B] (rows 0..11 = S [A|B], row 12 = s_vec'[A|B]).  Issued first: it does not depend on the
             // inverse, so the matrix pipe works through it while the VALU runs the elimination below.
             const d4 xz = mm3(v, cur.z, (d4){0, 0, 0, 0});
+            if (HASL) lbuf[l] = cur.la;                                     // rows of [L | dl] to every lane (read after the next fence)
+            const double qc = readlane_f64(cur.x, 16);                      // c (ileqg.jl:296)
             d4 tm;
             if (theta != 0.0) {
                 if (g == 0) SVB(j) = v[3];                                  // s_vec (row 12 of V) to every lane, off the critical path
@@ -285,7 +272,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             d4 f = mm3(cur.z, tm, cur.c);
             // H block: rows 12..15 of F live in register 3;  + mu I  (:370)
             const double gh = fma(mu, mH, f[3]);
-            const double fv = tm[3] + cur.qr;      // lanes g == 0: [q_vec + A' D s_vec | r + B' D s_vec]  (:368, :389)
+            const double fv = tm[3] + cur.x;      // lanes g == 0: [q_vec + A' D s_vec | r + B' D s_vec]  (:368, :389)
             DIAG_STAMP(3, gh);
             HBUF(g, j) = gh;
             if (g == 0) FBUF(j) = fv;
@@ -318,9 +305,11 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
                 x1 = y1 * i1 - l21 * x2 - l31 * x3;
                 x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
                 la = (g == 0) ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));             // [L | dl] natural rows
-            } else {
-                x0 = cur.lc[0]; x1 = cur.lc[1]; x2 = cur.lc[2]; x3 = cur.lc[3];
+            } else if (HASL) {
+                x0 = lbuf[j]; x1 = lbuf[16 + j]; x2 = lbuf[32 + j]; x3 = lbuf[48 + j];   // column j of [L | dl]
                 la = cur.la;
+            } else {
+                x0 = x1 = x2 = x3 = la = 0.0;
             }
             const double ua = hg0 * x0 + hg1 * x1 + hg2 * x2 + hg3 * x3 + ga;         // H [L|dl] + [G|g]
             DIAG_STAMP(4, ua);
@@ -332,11 +321,15 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             d4 fx;
 #pragma unroll
             for (int r = 0; r < 3; ++r) fx[r] = fma(f[r], m12, ex[foff[r]]);
-            fx[3] = fma(fv, mA, (2.0 * cur.q + v[3]) * mB);
+            fx[3] = fma(fv, mA, (2.0 * qc + v[3]) * mB);
             // V = Fx + La' Ua + Ga' La    (:383, :389, :390)
-            d4 vn = MFMA(la, ua, fx);
-            vn = MFMA(ga, la, vn);
-            v = vn;
+            if (GAIN || HASL) {
+                d4 vn = MFMA(la, ua, fx);
+                vn = MFMA(ga, la, vn);
+                v = vn;
+            } else {
+                v = fx;
+            }
             DIAG_STAMP(5, v[0]);
             if (DUMP) {
                 double *dp = a.dump + (long)t * DUMP_STRIDE;
@@ -363,15 +356,15 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
         for (int t = N - 1; t >= 0; t -= 2) {
             {
                 const int tn = (t > 0) ? t - 1 : 0;
-                load_tile<GAIN, DUMP>(rb, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR,
-                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g);
+                load_tile<HASL, DUMP>(rb, tile0 + (long)tn * TSTRIDE, l, lx, lq, Lb + (long)tn * LSTR,
+                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g, j);
             }
             if (step(t, nx)) break;
             if (t == 0) break;
             {
                 const int tn = (t > 1) ? t - 2 : 0;
-                load_tile<GAIN, DUMP>(nx, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR,
-                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g);
+                load_tile<HASL, DUMP>(nx, tile0 + (long)tn * TSTRIDE, l, lx, lq, Lb + (long)tn * LSTR,
+                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g, j);
             }
             if (step(t - 1, rb)) break;
         }
@@ -420,21 +413,23 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     }
 }
 
-template <bool GAIN, bool DUMP>
+template <bool GAIN, bool DUMP, bool HASL>
 static void launch_sweep_w(const SweepArgs &a, dim3 grid, hipStream_t s) {
-    if (a.pb.W_tv) hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, true>), grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, false>), grid, dim3(64), 0, s, a);
+    if (a.pb.W_tv) hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, true, HASL>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, false, HASL>), grid, dim3(64), 0, s, a);
 }
 
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s) {
     if (ntraj <= 0) return;
     dim3 grid(ntraj);
     if (gain) {
-        if (dump) launch_sweep_w<true, true>(a, grid, s);
-        else launch_sweep_w<true, false>(a, grid, s);
+        if (dump) launch_sweep_w<true, true, false>(a, grid, s);
+        else launch_sweep_w<true, false, false>(a, grid, s);
+    } else if (a.mode == 2) {                      // initialize!: zero gains
+        launch_sweep_w<false, false, false>(a, grid, s);
     } else {
-        if (dump) launch_sweep_w<false, true>(a, grid, s);
-        else launch_sweep_w<false, false>(a, grid, s);
+        if (dump) launch_sweep_w<false, true, true>(a, grid, s);
+        else launch_sweep_w<false, false, true>(a, grid, s);
     }
 }
 
@@ -595,9 +590,15 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // round trip through HBM between the two reference functions (ileqg.jl:62-87 then :258-322).  Same arithmetic as
 // rollout_kernel + linearize_kernel (which remain for the operator entry points).
 // =====================================================================================================
-template <int MODEL, int MODE>
+// CTV: time-varying cost tables (LQ family).  A template parameter, not a branch: a conditional per-step table load would put
+// a path-dependent number of loads between the prefetch and the tile stores and collapse every counted vmcnt wait.
+template <int MODEL, int MODE, bool CTV>
 __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     const int l = threadIdx.x, j = l & 15, g = l >> 4;
+#ifdef RAT_DIAG
+    const unsigned long long dg_entry = __builtin_readcyclecounter();
+    unsigned long long dg_loop0 = 0;
+#endif
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
     const int N = st.N;
@@ -628,21 +629,23 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
         for (int q = 0; q < k; ++q) eps *= a.op.lambda;        // eps_k = eps * lambda^k by repeated multiplication (:530,:557)
     }
     // per-lane constants of the LQ family (dynamics are time-invariant; cost tables only when !cost_tv)
+    // (the tile is a register image, layout.h: lane l owns element 64 r + l of Z and of C = [[Q, 0], [P, R]])
     double zr[16], crow[16];
     double zt0 = 0, zt1 = 0, zt2 = 0, cq0 = 0, cq1 = 0, cq2 = 0, cpr = 0, clin = 0, cq00 = 0;
-    const int e2 = (l + 128 < 144) ? l + 128 : 0;              // Q element handled by the third (partial) store
+    const double mq = (j < 12) ? 1.0 : 0.0;                     // rows 0..11 of C: columns 12..15 are dead slots, written as 0
+    const int lx = (l < 17) ? l : 17;                           // [qr | q | pad] row: lanes past q all write 0.0 to the pad slot
     const int jx = (j < 12) ? j : 11, ju = j & 3;
     if (lq) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) zr[q] = pb.Zt[jx * 16 + q];
         zt0 = pb.Zt[l]; zt1 = pb.Zt[64 + l]; zt2 = pb.Zt[128 + l];
-        if (!pb.cost_tv) {
+        if (!CTV) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) crow[q] = pb.Ctab[j * 16 + q];
-            cq0 = pb.Ctab[(l / 12) * 16 + l % 12];
-            cq1 = pb.Ctab[((l + 64) / 12) * 16 + (l + 64) % 12];
-            cq2 = pb.Ctab[(e2 / 12) * 16 + e2 % 12];
-            cpr = pb.Ctab[(12 + g) * 16 + j];
+            cq0 = pb.Ctab[l] * mq;
+            cq1 = pb.Ctab[64 + l] * mq;
+            cq2 = pb.Ctab[128 + l] * mq;
+            cpr = pb.Ctab[192 + l];
             clin = pb.lin[j];
             cq00 = pb.q0[0];
         }
@@ -661,7 +664,22 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
 #pragma unroll
         for (int q = 0; q < 12; ++q) n_L[q] = Lb[ju * 12 + q];
     }
+    // gfx9 counts loads and stores in ONE in-order vmcnt.  The prefetch of step t+1 is issued at the top of step t and
+    // the stores of step t after it, so the wait for the prefetch at the top of step t+1 may leave all of step t's stores
+    // in flight -- vmcnt(loads + stores per step) -- and the tile stream drains behind the next step's arithmetic.  That
+    // count has to hold on every path into the loop: (1) all stores of a step are unconditional (idle lanes write 0.0
+    // to the record's pad slot), and (2) the first prefetch above is followed by as many (pad) stores as a step issues.
+    // A lane-conditional store, or a loop entry without them, makes the compiler fall back to vmcnt(loads), which
+    // drains the whole tile at the top of every step (measured: 2800 instead of 1800 cycles per step).
+    {
+        constexpr int kStoresPerStep = 7;
+#pragma unroll
+        for (int q = 0; q < kStoresPerStep; ++q) tile0[(long)((q < N) ? q : N - 1) * TSTRIDE + TS_PAD] = 0.0;
+    }
     DIAG_DECL
+#ifdef RAT_DIAG
+    dg_loop0 = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < N; ++t) {
         DIAG_START();
         const double c_xb = n_xb, c_l = n_l, c_dl = n_dl;
@@ -724,20 +742,20 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
             else if (dn > dmax) dmax = dn;
         }
         DIAG_STAMP(1, xn);
-        if (l < 12) xo[(long)(t + 1) * XSTR + l] = xn;
-        if (l < 4) uo[(long)t * USTR + l] = u;
         // ---- tile of step t: approximate_model at (x_t, u_t)   (ileqg.jl:294-313) ---------------------
         double *__restrict__ tp = tile0 + (long)t * TSTRIDE;
+        *((l < 12) ? xo + (long)(t + 1) * XSTR + l : tp + TS_PAD) = (l < 12) ? xn : 0.0;
+        *((l < 4) ? uo + (long)t * USTR + l : tp + TS_PAD) = (l < 4) ? u : 0.0;
         if (lq) {
-            const int kc = pb.cost_tv ? t : 0;
-            if (pb.cost_tv) {
+            const int kc = CTV ? t : 0;
+            if (CTV) {
                 const double *__restrict__ C = pb.Ctab + (long)kc * 256;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) crow[q] = C[j * 16 + q];
-                cq0 = C[(l / 12) * 16 + l % 12];
-                cq1 = C[((l + 64) / 12) * 16 + (l + 64) % 12];
-                cq2 = C[(e2 / 12) * 16 + e2 % 12];
-                cpr = C[(12 + g) * 16 + j];
+                cq0 = C[l] * mq;
+                cq1 = C[64 + l] * mq;
+                cq2 = C[128 + l] * mq;
+                cpr = C[192 + l];
                 clin = pb.lin[(long)kc * 16 + j];
                 cq00 = pb.q0[kc];
             }
@@ -749,10 +767,11 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
                 if (j == i1) z1 += 3.0 * pb.kappa * (xu[i1 & 15] * xu[i1 & 15]);
                 if (j == i2) z2 += 3.0 * pb.kappa * (xu[i2 & 15] * xu[i2 & 15]);
             }
-            tp[TS_Z + l] = z0; tp[TS_Z + 64 + l] = z1; tp[TS_Z + 128 + l] = z2;
-            tp[TS_Q + l] = cq0; tp[TS_Q + 64 + l] = cq1;
-            if (l < 16) tp[TS_Q + 128 + l] = cq2;
-            tp[TS_PR + l] = cpr;
+            double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
+            t2[l] = make_double2(z0, z1);
+            t2[64 + l] = make_double2(z2, cq0);
+            t2[128 + l] = make_double2(cq1, cq2);
+            tp[TS_R6 + l] = cpr;
             double acc, ac1 = 0.0, ac2 = 0.0, ac3 = 0.0, ac4 = 0.0;  // [c_x | c_u] = C [x;u] + [qv;rv]  (4 chains for ILP)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -762,30 +781,26 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
                 ac4 = fma(crow[12 + q], xu[12 + q], ac4);
             }
             acc = ((ac1 + ac2) + ac3) + ac4;
-            if (l < 16) tp[TS_QR + l] = acc + clin;
             const double part = row_sum16(xu[j] * (0.5 * acc + clin));    // every 16-lane row holds the same sum
-            if (l == 0) tp[TS_q] = part + cq00;                     // c
+            tp[TS_QR + lx] = (l < 16) ? acc + clin : (l == 16 ? part + cq00 : 0.0);   // [c_x | c_u], c, pad
         } else {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const int e = 64 * r + l, i = e >> 4, cc = e & 15;
-                double val = 0.0;
+                const int i = 4 * r + g;
+                double val = 0.0, cv = 0.0;
                 if (i < pb.n) {
-                    if (cc == i) val = pb.pl_a * powchk(xu[i & 15], pb.pl_a - 1.0, dom);
-                    else if (cc == 12 + i) val = pb.pl_b * powchk(xu[12 + (i & 3)], pb.pl_b - 1.0, dom);
+                    if (j == i) {
+                        val = pb.pl_a * powchk(xu[i & 15], pb.pl_a - 1.0, dom);
+                        cv = pb.pl_cx * pb.pl_p * (pb.pl_p - 1.0) * powchk(xu[i & 15], pb.pl_p - 2.0, dom);
+                    } else if (j == 12 + i) val = pb.pl_b * powchk(xu[12 + (i & 3)], pb.pl_b - 1.0, dom);
                 }
-                tp[TS_Z + e] = val;
-            }
-            for (int e = l; e < 144; e += 64) {
-                const int i = e / 12, jj = e - i * 12;
-                double val = 0.0;
-                if (i == jj && i < pb.n) val = pb.pl_cx * pb.pl_p * (pb.pl_p - 1.0) * powchk(xu[i & 15], pb.pl_p - 2.0, dom);
-                tp[TS_Q + e] = val;
+                tp[TS_REG(r, l)] = val;
+                tp[TS_REG(3 + r, l)] = cv;
             }
             {
                 double val = 0.0;
                 if (j == 12 + g) val = (g < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(xu[12 + g], pb.pl_pu - 2.0, dom) : 1.0;
-                tp[TS_PR + l] = val;
+                tp[TS_R6 + l] = val;
             }
             double part = 0.0, val = 0.0;
             if (l < pb.n) {
@@ -795,18 +810,21 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
                 val = pb.pl_cu * pb.pl_pu * powchk(xu[l & 15], pb.pl_pu - 1.0, dom);
                 part = pb.pl_cu * powchk(xu[l & 15], pb.pl_pu, dom);
             }
-            if (l < 16) tp[TS_QR + l] = val;
             if (l >= 16) part = 0.0;
-            part = row_sum16(part);
-            if (l == 0) tp[TS_q] = part;
+            part = wave_sum(part);
+            tp[TS_QR + lx] = (l < 16) ? val : (l == 16 ? part : 0.0);
         }
         x = xn;
         WAVE_SYNC();
         DIAG_STAMP(2, x);
     }
 #ifdef RAT_DIAG
-    if (l == 0 && blockIdx.x < 8 && a.dump)
+    if (l == 0 && blockIdx.x < 8 && a.dump) {
         for (int q = 0; q < 3; ++q) a.dump[64 + blockIdx.x * 8 + q] = (double)dg_acc[q];
+        a.dump[64 + blockIdx.x * 8 + 3] = (double)(dg_loop0 - dg_entry);                       // prologue
+        a.dump[64 + blockIdx.x * 8 + 5] = (double)dg_gap;                                      // between end-of-step stamp and next start
+        a.dump[64 + blockIdx.x * 8 + 4] = (double)(__builtin_readcyclecounter() - dg_entry);  // entry .. end of time loop
+    }
 #endif
     // ---- terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316) ------------------------------------------
     {
@@ -846,12 +864,15 @@ void launch_rollin(const RolloutArgs &a, hipStream_t s) {
     const dim3 grid(ncand), block(64);
     // one compact instantiation per (model family, mode): the LQ hot loop must not carry the inlined pow() expansions
     // of the power-law family through the instruction cache
-    if (a.pb.model == 1) {
-        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<1, 0>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((rollin_kernel<1, 1>), grid, block, 0, s, a);
+    if (a.pb.model == 1 && a.pb.cost_tv) {
+        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<1, 0, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rollin_kernel<1, 1, true>), grid, block, 0, s, a);
+    } else if (a.pb.model == 1) {
+        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<1, 0, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rollin_kernel<1, 1, false>), grid, block, 0, s, a);
     } else {
-        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<2, 0>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((rollin_kernel<2, 1>), grid, block, 0, s, a);
+        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<2, 0, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rollin_kernel<2, 1, false>), grid, block, 0, s, a);
     }
 }
 
@@ -906,19 +927,16 @@ __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
     const int kc = pb.cost_tv ? t : 0;
     if (pb.model == 1) {
         // f_x = A + diag(3 kappa x^2), f_u = B    (:303, :308)
+        const double *__restrict__ C = pb.Ctab + (long)kc * 256;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int e = 64 * r + l, i = e >> 4;
             double val = pb.Zt[e];
             if (pb.kappa != 0.0 && (e & 15) == i) val += 3.0 * pb.kappa * (xp[i] * xp[i]);
-            tp[TS_Z + e] = val;
+            tp[TS_REG(r, l)] = val;
+            tp[TS_REG(3 + r, l)] = (j < 12) ? C[e] : 0.0;            // c_xx   (:298); columns 12..15 are dead slots
         }
-        const double *__restrict__ C = pb.Ctab + (long)kc * 256;
-        for (int e = l; e < 144; e += 64) {                          // c_xx   (:298)
-            const int i = e / 12, jj = e - i * 12;
-            tp[TS_Q + e] = C[i * 16 + jj];
-        }
-        tp[TS_PR + l] = C[(12 + (l >> 4)) * 16 + j];                 // [c_ux | c_uu]   (:300-301)
+        tp[TS_R6 + l] = C[192 + l];                                  // [c_ux | c_uu]   (:300-301)
         double part = 0.0;
         if (l < 16) {                                                // [c_x | c_u] = C [x;u] + [qv;rv]   (:297, :299)
             double acc = 0.0;
@@ -932,30 +950,27 @@ __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
             part = xu * (0.5 * acc + lin);
         }
         const double tot = wave_sum(part);
-        if (l == 0) tp[TS_q] = tot + pb.q0[kc];                      // c   (:296)
+        if (l == 0) { tp[TS_q] = tot + pb.q0[kc]; tp[TS_PAD] = 0.0; }   // c   (:296)
     } else {
         // power-law family: every derivative is diagonal
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int e = 64 * r + l, i = e >> 4, cc = e & 15;
-            double val = 0.0;
+            double val = 0.0, cv = 0.0;
             if (i < pb.n) {
-                if (cc == i) val = pb.pl_a * powchk(xp[i], pb.pl_a - 1.0, dom);
-                else if (cc == 12 + i) val = pb.pl_b * powchk(up[i], pb.pl_b - 1.0, dom);
+                if (cc == i) {
+                    val = pb.pl_a * powchk(xp[i], pb.pl_a - 1.0, dom);
+                    cv = pb.pl_cx * pb.pl_p * (pb.pl_p - 1.0) * powchk(xp[i], pb.pl_p - 2.0, dom);
+                } else if (cc == 12 + i) val = pb.pl_b * powchk(up[i], pb.pl_b - 1.0, dom);
             }
-            tp[TS_Z + e] = val;
-        }
-        for (int e = l; e < 144; e += 64) {
-            const int i = e / 12, jj = e - i * 12;
-            double val = 0.0;
-            if (i == jj && i < pb.n) val = pb.pl_cx * pb.pl_p * (pb.pl_p - 1.0) * powchk(xp[i], pb.pl_p - 2.0, dom);
-            tp[TS_Q + e] = val;
+            tp[TS_REG(r, l)] = val;
+            tp[TS_REG(3 + r, l)] = cv;
         }
         {
             const int gg = l >> 4;
             double val = 0.0;
             if (j == 12 + gg) val = (gg < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(up[gg], pb.pl_pu - 2.0, dom) : 1.0;
-            tp[TS_PR + l] = val;
+            tp[TS_R6 + l] = val;
         }
         double part = 0.0;
         if (l < 16) {
@@ -970,7 +985,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
             tp[TS_QR + l] = val;
         }
         const double tot = wave_sum(part);
-        if (l == 0) tp[TS_q] = tot;
+        if (l == 0) { tp[TS_q] = tot; tp[TS_PAD] = 0.0; }
     }
     if (__ballot(dom != 0) != 0ull && l == 0) {
         if (a.mode == 0) { st.status[b] = 4; st.value[b] = INFINITY; }

@@ -5,17 +5,22 @@
 // the Q-function Hessian [[Q,P'],[P,R]] is one 16x16 accumulator.  Smaller problems are embedded with
 // zero padding (identity on the padded diagonals of W^-1 and R, which leaves every result unchanged).
 //
-// Tile bundle of one trajectory (what approximate_model, ileqg.jl:258-322, produces), doubles:
-//   step t = 0..N-1, stride TSTRIDE = 417 = n^2 + nm + n^2 + m^2 + mn + n + m + 1 at n=12, m=4:
-//     [TS_Z  .. +192)  Z  = [A | B]   12 x 16 row-major        (f_x | f_u)
-//     [TS_Q  .. +144)  Q  = c_xx      12 x 12 row-major (symmetric)
-//     [TS_PR .. + 64)  PR = [P | R]    4 x 16 row-major        (c_ux | c_uu)
-//     [TS_QR .. + 16)  qr = [q_vec | r]                        (c_x | c_u)
-//     [TS_q]           q  = c
-//   terminal block at N*TSTRIDE: Qf 12x12 row-major (144), q_vec (12), q (1)  -> TTERM = 157
-//   total = N*417 + 157 doubles = 21,007 doubles = 168,056 B at N = 50.
-// Row-major 16-wide blocks make every MFMA operand / accumulator register one coalesced 512-B load:
-// lane l of a wave reads element 64*r + l of the block into register r.
+// Tile bundle of one trajectory (what approximate_model, ileqg.jl:258-322, produces).  One step record is a REGISTER IMAGE
+// of what the backward sweep keeps per lane, so that the sweep fetches it with three 16-B/lane loads and two 8-B/lane
+// loads (a VMEM instruction costs a single-wave-per-SIMD kernel ~40 issue cycles whatever its width: fewer, wider):
+//   logical registers (64 doubles each, element 64 r + l = row 4 r + (l >> 4), column l & 15 of a 16-wide row-major block)
+//     R0..R2  Z = [A | B]              12 x 16   (f_x | f_u)
+//     R3..R6  C = [[Q, *], [P, R]]     16 x 16   (c_xx | unused ; c_ux | c_uu); the 48 slots of rows 0..11, columns 12..15
+//                                                are never consumed by the sweep (written as zeros)
+//   physical record, step t = 0..N-1, stride TSTRIDE = 466 doubles:
+//     [  0 .. 384)  three 128-double chunks; chunk c holds registers 2c and 2c+1 interleaved per lane:
+//                   position 128 c + 2 l + h  <->  register 2 c + h, lane l      (one global_load_dwordx4 per chunk)
+//     [384 .. 448)  register R6 (rows 12..15 of C = [P | R]), position 384 + l
+//     [448 .. 464)  qr = [q_vec | r]  (c_x | c_u)
+//     [464]         q  = c            [465] pad (keeps every record 16-B aligned)
+//   terminal block at N*TSTRIDE: Qf 12x12 row-major (144), q_vec (12), q (1), pad (1)  -> TTERM = 158
+// The information content is SURVEY.md section 8's n^2 + nm + n^2 + m^2 + mn + n + m + 1 = 417 doubles per step
+// (+157 terminal = 168,056 B at N = 50); the physical record carries 49 dead doubles per step on top (+11.7 %).
 #pragma once
 
 #define RAT_NP 12
@@ -23,16 +28,23 @@
 #define RAT_PD 16
 #define RAT_AUG 12          /* index of the homogeneous coordinate in the augmented value matrix */
 
-#define TS_Z   0
-#define TS_Q   192
-#define TS_PR  336
-#define TS_QR  400
-#define TS_q   416
-#define TSTRIDE 417
+#define TS_R6  384
+#define TS_QR  448
+#define TS_q   464
+#define TS_PAD 465
+#define TSTRIDE 466
+#define TS_INFO 417         /* doubles of information per step */
 #define TT_Q   0
 #define TT_QV  144
 #define TT_q   156
-#define TTERM  157
+#define TTERM  158
+#define TT_INFO 157
+
+/* physical position of lane l of logical register R (0..6) */
+#define TS_REG(R, l) ((R) < 6 ? 128 * ((R) >> 1) + 2 * (l) + ((R) & 1) : TS_R6 + (l))
+/* [A|B] row i (0..11), column c (0..15);  C row i (0..15), column c (0..15) */
+#define TS_ZPOS(i, c) TS_REG(((i) * 16 + (c)) >> 6, ((i) * 16 + (c)) & 63)
+#define TS_CPOS(i, c) TS_REG(3 + (((i) * 16 + (c)) >> 6), ((i) * 16 + (c)) & 63)
 
 #define XSTR 12             /* doubles per time step of a state history   */
 #define USTR 4              /* doubles per time step of a control history */

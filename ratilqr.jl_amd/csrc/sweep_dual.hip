@@ -21,21 +21,17 @@
 
 struct DTile {
     d4 z, c, lc;
-    double qr, q, la;
+    double x, la;          // x: lanes 0..15 = qr, lane 16 = q (register-image record, layout.h)
 };
 
-__device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, const int (&offC)[4], int l, int j,
+__device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, int lx, int l, int j,
                                       const double *__restrict__ Lp, double mL, int g) {
-    tr.z[0] = tp[TS_Z + l];
-    tr.z[1] = tp[TS_Z + 64 + l];
-    tr.z[2] = tp[TS_Z + 128 + l];
-    tr.z[3] = 0.0;
-    tr.c[0] = tp[offC[0]];
-    tr.c[1] = tp[offC[1]];
-    tr.c[2] = tp[offC[2]];
-    tr.c[3] = tp[offC[3]];
-    tr.qr = tp[TS_QR + j];
-    tr.q = tp[TS_q];
+    const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
+    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = t2[128 + l];
+    tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
+    tr.c[0] = w1.y; tr.c[1] = w2.x; tr.c[2] = w2.y;
+    tr.c[3] = tp[TS_R6 + l];
+    tr.x = tp[TS_QR + lx];
     const int jc = (j < 12) ? j : 11;
     tr.lc[0] = Lp[jc] * mL;
     tr.lc[1] = Lp[12 + jc] * mL;
@@ -131,13 +127,7 @@ __global__ __launch_bounds__(64) void sweep_dual_kernel(SweepArgs a) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) foff[r] = (j == 12) ? (64 + 4 * r + g) : 80;
     const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
-    int offC[4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int i = 4 * r + g;
-        offC[r] = (j < 12) ? (TS_Q + i * 12 + j) : (TS_PR + (j - 12) * 16 + i);
-    }
-    offC[3] = TS_PR + g * 16 + j;
+    const int lx = (l < 17) ? l : 17;
 
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
     double ep[6] = {1, 1, 1, 1, 1, 1};
@@ -212,7 +202,7 @@ __global__ __launch_bounds__(64) void sweep_dual_kernel(SweepArgs a) {
         d4 fA = mm3(cur.z, tmA, cur.c);
         d4 fB = mm3(cur.z, tmB, cur.c);
         const double ghA = fma(muA, mH, fA[3]), ghB = fma(muB, mH, fB[3]);
-        const double fvA = tmA[3] + cur.qr, fvB = tmB[3] + cur.qr;
+        const double fvA = tmA[3] + cur.x, fvB = tmB[3] + cur.x;
         exA[g * 16 + j] = ghA; exB[g * 16 + j] = ghB;
         if (g == 0) { exA[64 + j] = fvA; exB[64 + j] = fvB; }
         WAVE_SYNC();
@@ -250,8 +240,9 @@ __global__ __launch_bounds__(64) void sweep_dual_kernel(SweepArgs a) {
         d4 fxA, fxB;
 #pragma unroll
         for (int r = 0; r < 3; ++r) { fxA[r] = fma(fA[r], m12, exA[foff[r]]); fxB[r] = fma(fB[r], m12, exB[foff[r]]); }
-        fxA[3] = fma(fvA, mA_, (2.0 * cur.q + vA[3]) * mB_);
-        fxB[3] = fma(fvB, mA_, (2.0 * cur.q + vB[3]) * mB_);
+        const double qc = readlane_f64(cur.x, 16);
+        fxA[3] = fma(fvA, mA_, (2.0 * qc + vA[3]) * mB_);
+        fxB[3] = fma(fvB, mA_, (2.0 * qc + vB[3]) * mB_);
         d4 vnA = MFMA(cur.la, uaA, fxA);
         d4 vnB = MFMA(laB, uaB, fxB);
         vnA = MFMA(gaA, cur.la, vnA);
@@ -262,17 +253,17 @@ __global__ __launch_bounds__(64) void sweep_dual_kernel(SweepArgs a) {
     };
 
     DTile ra, rb2;
-    dload(ra, tile0 + (long)(N - 1) * TSTRIDE, offC, l, j, Lb + (long)(N - 1) * LSTR, mL, g);
+    dload(ra, tile0 + (long)(N - 1) * TSTRIDE, lx, l, j, Lb + (long)(N - 1) * LSTR, mL, g);
     for (int t = N - 1; t >= 0; t -= 2) {
         {
             const int tn = (t > 0) ? t - 1 : 0;
-            dload(rb2, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR, mL, g);
+            dload(rb2, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
         }
         if (step(t, ra)) break;
         if (t == 0) break;
         {
             const int tn = (t > 1) ? t - 2 : 0;
-            dload(ra, tile0 + (long)tn * TSTRIDE, offC, l, j, Lb + (long)tn * LSTR, mL, g);
+            dload(ra, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
         }
         if (step(t - 1, rb2)) break;
     }

@@ -15,5 +15,7 @@ for E in (1, 8):
         rat.native.lib().rat_diag_read(ctx.h, out.ctypes.data_as(C.POINTER(C.c_double)))
         d = out[:64].reshape(8, 8)[:, :6].mean(0) / 50.0
         dr = out[64:].reshape(8, 8)[:, :3].mean(0) / 50.0       # last launch = line-search eval sweep, per time step
+        pro, whole = out[64:].reshape(8, 8)[:, 3].mean(), out[64:].reshape(8, 8)[:, 4].mean()
         print(f"E={E} theta={th}: cycles/step " + ", ".join(f"{n}={c:.0f}" for n, c in zip(names, d)) + f" | total {d.sum():.0f}")
-        print(f"      rollin cycles/step: dx+u={dr[0]:.0f}, xu+x'={dr[1]:.0f}, tile+rest={dr[2]:.0f} | total {dr.sum():.0f}")
+        print(f"      rollin cycles/step: dx+u={dr[0]:.0f}, xu+x'={dr[1]:.0f}, tile+rest={dr[2]:.0f} | total {dr.sum():.0f}"
+              f" | wave: prologue {pro:.0f} cycles, entry..loop end {whole:.0f} cycles, gaps {out[64:].reshape(8, 8)[:, 5].mean():.0f}")
