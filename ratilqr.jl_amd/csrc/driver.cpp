@@ -39,6 +39,7 @@ struct rat_handle_s {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     bool dual = false;               // RATILQR_DUAL=1: fused evaluation + next-gain-sweep wavefronts (E = 1 only)
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
+    bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
     rat_ileqg_opts opts;
     OptsDev opd;
     int Bmax = 0, E = 1;
@@ -117,6 +118,8 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     HIPCHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
     if (const char *e = getenv("RATILQR_SPECULATE")) h->speculate = (e[0] == '1');
     if (const char *e = getenv("RATILQR_DUAL")) h->dual = (e[0] == '1') && spec_eps == 1;
+    if (const char *e = getenv("RATILQR_FUSED")) h->fused = (e[0] != '0');
+    if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
     HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
     for (int i = 0; i < CTR_RING; ++i) HIPCHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
     memset(&h->st, 0, sizeof(h->st));
@@ -459,6 +462,14 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
     // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation; the first gain
     // sweep (step! number 1 re-linearises the same trajectory, App. B.1) runs speculatively beside it.
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    if (h->fused) {                  // the whole state machine below, per sample, inside one launch
+        FusedArgs fa;
+        fa.sw = sweep_args(h, st, 0);
+        fa.ro = ra;
+        fa.max_rounds = (int)std::min<int64_t>(((int64_t)h->opd.iter_max + 1) * 4002, 2000000000);
+        prof_begin(h, RAT_K_SOLVE_FUSED, B); launch_solve_fused(fa, h->stream); prof_end(h);
+        return RAT_OK;
+    }
     prof_begin(h, RAT_K_ROLLOUT, B); launch_rollin(ra, h->stream); prof_end(h);         // fused rollout + linearise
     if (h->dual) {
         prof_begin(h, RAT_K_SWEEP_DUAL, B); launch_sweep_dual(sweep_args(h, st, 6), B, h->stream); prof_end(h);
@@ -606,6 +617,7 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     if (eps_hist && cap > 0) { HIPCHK(hipMalloc((void **)&d_hist, (size_t)cap * 16)); }
     h->st.hist = d_hist; h->st.hist_cap = cap;
     rc = run_batch(h, h->d_theta, 1);
+    if (!rc) HIPCHK(hipStreamSynchronize(h->stream));       // the fused solve returns with its launch still in flight
     h->st.hist = nullptr; h->st.hist_cap = 0;
     if (rc) { if (d_hist) (void)hipFree(d_hist); return rc; }
     int st_h = 0, it_h = 0, nom = 0, hn = 0; double val = 0;

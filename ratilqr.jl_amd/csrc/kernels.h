@@ -28,6 +28,12 @@ struct RolloutArgs {
     double *dump;          // diagnostic builds only
 };
 
+struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per sample (E = 1)
+    SweepArgs sw;          // st / pb / op of the batch (mode is set per phase on the device)
+    RolloutArgs ro;
+    int max_rounds;        // guard on phases per sample
+};
+
 struct LinArgs {
     StateDev st;
     ProblemDev pb;
@@ -57,6 +63,7 @@ void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream
 void launch_rollout(const RolloutArgs &a, hipStream_t s);
 void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout + linearise (solver hot loop)
 void launch_linearize(const LinArgs &a, hipStream_t s);
+void launch_solve_fused(const FusedArgs &a, hipStream_t s);   // complete solve! per sample in one launch (E = 1)
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s);   // modes 6 (initialize! + first gain sweep), 7 (candidate 0 + next gain sweep)

@@ -60,13 +60,14 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
 
 // HASL (policy evaluation only): a gain history is given.  false for initialize!'s sweep (ileqg.jl:221-224), whose gains
 // are all zero: no gain loads and V = Fx without the two rank-4 updates.
+// sweep_body is the whole sweep of ONE wavefront (trajectory `tid` of the launch); sweep_kernel wraps it one block per
+// trajectory, solve_fused_kernel calls it as one phase of a sample's complete solve.
 template <bool GAIN, bool DUMP, bool WTV, bool HASL>
-__global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
+__device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     const int l_ = threadIdx.x, g_ = l_ >> 4, j_ = l_ & 15;
     const int l = l_, g = g_, j = j_;
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
-    const int tid = blockIdx.x;
     int b, slot, cidx = -1;
     if (a.mode == 1) {
         b = tid / st.E;
@@ -411,6 +412,14 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
             if (a.op_out) { a.op_out[0] = s0; a.op_out[1] = (double)(fail ? (fail == 1 ? 2 : 5) : 0); }
         }
     }
+#undef HBUF
+#undef FBUF
+#undef SVB
+}
+
+template <bool GAIN, bool DUMP, bool WTV, bool HASL>
+__global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
+    sweep_body<GAIN, DUMP, WTV, HASL>(a, blockIdx.x);
 }
 
 template <bool GAIN, bool DUMP, bool HASL>
@@ -593,7 +602,7 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // CTV: time-varying cost tables (LQ family).  A template parameter, not a branch: a conditional per-step table load would put
 // a path-dependent number of loads between the prefetch and the tile stores and collapse every counted vmcnt wait.
 template <int MODEL, int MODE, bool CTV>
-__global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
+__device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const int l = threadIdx.x, j = l & 15, g = l >> 4;
 #ifdef RAT_DIAG
     const unsigned long long dg_entry = __builtin_readcyclecounter();
@@ -602,7 +611,6 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
     const int N = st.N;
-    const int c = blockIdx.x;
     int b, k = 0;
     if (MODE == 0) { b = c; if (st.status[b] != ST_RUNNING) return; }
     else { b = c / st.E; k = c - b * st.E; if (!st.ls_active[b]) return; }
@@ -858,6 +866,11 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     }
 }
 
+template <int MODEL, int MODE, bool CTV>
+__global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
+    rollin_body<MODEL, MODE, CTV>(a, blockIdx.x);
+}
+
 void launch_rollin(const RolloutArgs &a, hipStream_t s) {
     const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
     if (ncand <= 0) return;
@@ -1060,16 +1073,9 @@ void launch_commit_init(const StateDev &st, hipStream_t s) {
 // Replays the sequential rule of line_search! (ileqg.jl:504-581) over the E speculatively evaluated
 // candidates of each sample, then the convergence test of solve! (:642-653).
 // Counters of round `slot`: [2*slot] samples still inside their line search, [2*slot+1] samples still running.
-__global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) {                          // clear the ring entry two rounds ahead (stream order makes this race-free)
-        const int z = (slot + 2) % CTR_RING;
-        st.counters[2 * z] = 0;
-        st.counters[2 * z + 1] = 0;
-    }
-    if (b >= st.B) return;
+// ctr: the round's counter pair, or null (fused solve: nobody polls)
+__device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev &op, const int b, int *ctr) {
     if (!st.ls_active[b]) return;
-    int *ctr = st.counters + 2 * slot;
     double eps = st.ls_eps[b];
     const double cur = st.value[b];
     int count = st.ls_count[b];
@@ -1105,8 +1111,7 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
         if (count > 4000) { st.status[b] = 7; st.value[b] = INFINITY; st.ls_active[b] = 0; return; }
         st.ls_eps[b] = eps;
         st.ls_count[b] = count;
-        atomicAdd(&ctr[0], 1);
-        atomicAdd(&ctr[1], 1);
+        if (ctr) { atomicAdd(&ctr[0], 1); atomicAdd(&ctr[1], 1); }
         return;
     }
     // accept (:539-555 / :559-575)
@@ -1126,11 +1131,85 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
     if (op.d > st.d_cur[b] && st.mu[b] <= op.mu_min) { st.status[b] = 0; st.spec_st[b] = 0; }              // converged  (:642)
     else if (st.iter[b] == op.iter_max) { st.status[b] = 3; st.spec_st[b] = 0; }                           // iter_max   (:648)
     else if (chosen == 0 && spec != 0) {
-        if (commit_spec(st, b)) atomicAdd(&ctr[1], 1);         // next step! already has its gain sweep: straight to line search
+        if (commit_spec(st, b) && ctr) atomicAdd(&ctr[1], 1);  // next step! already has its gain sweep: straight to line search
     } else {
         st.spec_st[b] = 0;
-        atomicAdd(&ctr[1], 1);                                 // next round runs the plain gain sweep for this sample
+        if (ctr) atomicAdd(&ctr[1], 1);                        // next round runs the plain gain sweep for this sample
     }
+}
+
+__global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) {                          // clear the ring entry two rounds ahead (stream order makes this race-free)
+        const int z = (slot + 2) % CTR_RING;
+        st.counters[2 * z] = 0;
+        st.counters[2 * z + 1] = 0;
+    }
+    if (b >= st.B) return;
+    ls_select_body(st, op, b, st.counters + 2 * slot);
+}
+
+// =====================================================================================================
+// solve_fused_kernel: the COMPLETE solve! of one theta-sample in one persistent wavefront (E = 1).
+//   initialize! (open-loop rollout + linearise, open-loop policy evaluation)               ileqg.jl:214-236
+//   while running: step! = gain sweep (mu restarts inside), then line_search!: closed-loop rollout + linearise,
+//                  policy evaluation, accept rule; convergence / iter_max tests           ileqg.jl:598-613, 494-592, 640-654
+// The phases are the SAME device functions the per-phase kernels wrap (identical arithmetic, identical results); what
+// the fusion removes is everything between them: ten launches per 2-iteration solve, each with its dispatch latency, a
+// prologue of dependent state loads (~8k cycles measured), a tail in which the slowest wave holds the grid, and the host
+// round polling.  Samples run unsynchronised, so their tile-store bursts no longer hit HBM in lockstep.  Per-sample
+// control state stays in the StateDev arrays (each phase boundary is a handful of L2 round trips); a wave's own stores
+// are visible to its later loads through the CU's write-through L1 after a workgroup-scope fence (vmcnt(0)).
+// =====================================================================================================
+#define PHASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
+__device__ __forceinline__ int uniform_load(const int *p) { return __builtin_amdgcn_readfirstlane(__atomic_load_n(p, __ATOMIC_RELAXED)); }
+
+template <int MODEL, bool CTV, bool WTV>
+__global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
+    const int b = blockIdx.x;
+    const StateDev &st = fa.sw.st;
+    {
+        RolloutArgs ra = fa.ro; ra.mode = 0;
+        rollin_body<MODEL, 0, CTV>(ra, b);
+        PHASE_FENCE();
+        SweepArgs sa = fa.sw; sa.mode = 2;
+        sweep_body<false, false, WTV, false>(sa, b);
+        PHASE_FENCE();
+    }
+    for (int guard = 0; guard < fa.max_rounds; ++guard) {
+        if (uniform_load(&st.status[b]) != ST_RUNNING) break;
+        if (!uniform_load(&st.ls_active[b])) {               // step!: solve_approximate_dp!  (ileqg.jl:598-613)
+            SweepArgs sa = fa.sw; sa.mode = 0;
+            sweep_body<true, false, WTV, false>(sa, b);
+            PHASE_FENCE();
+            continue;
+        }
+        {                                                    // one candidate of line_search!  (ileqg.jl:504-581)
+            RolloutArgs ra = fa.ro; ra.mode = 1;
+            rollin_body<MODEL, 1, CTV>(ra, b);
+            PHASE_FENCE();
+            SweepArgs sa = fa.sw; sa.mode = 1;
+            sweep_body<false, false, WTV, true>(sa, b);
+            PHASE_FENCE();
+            if (threadIdx.x == 0) ls_select_body(st, fa.sw.op, b, nullptr);
+            PHASE_FENCE();
+        }
+    }
+}
+
+void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
+    const int B = fa.sw.st.B;
+    if (B <= 0) return;
+    const dim3 grid(B), block(64);
+    const bool wtv = fa.sw.pb.W_tv != 0;
+#define FUSED_LAUNCH(M, C, W) hipLaunchKernelGGL((solve_fused_kernel<M, C, W>), grid, block, 0, s, fa)
+    if (fa.sw.pb.model == 1) {
+        if (fa.sw.pb.cost_tv) { if (wtv) FUSED_LAUNCH(1, true, true); else FUSED_LAUNCH(1, true, false); }
+        else { if (wtv) FUSED_LAUNCH(1, false, true); else FUSED_LAUNCH(1, false, false); }
+    } else {
+        if (wtv) FUSED_LAUNCH(2, false, true); else FUSED_LAUNCH(2, false, false);
+    }
+#undef FUSED_LAUNCH
 }
 
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s) {
