@@ -25,11 +25,32 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
-def algo_bytes_per_candidate(prob, n=12, m=4, N=50):
-    """one policy-evaluation sweep reads the tile bundle (N (2n^2 + 2nm + m^2 + n + m + 1) +
-    n^2 + n + 1 doubles at the kernels' padded n=12, m=4) and the gains (N m n doubles) and writes one value."""
-    per_step = 2 * n * n + 2 * n * m + m * m + n + m + 1
-    return 8 * (N * per_step + n * n + n + 1) + 8 * N * m * n + 8
+def algo_bytes(n=12, m=4, N=50):
+    """SURVEY.md section 8(d) "algorithmic bytes per unit" (unfused three-kernel formulation), in bytes.
+    tile bundle = N (2n^2 + 2nm + m^2 + n + m + 1) + n^2 + n + 1 doubles; x = (N+1) n; l, dl = N m; L = N m n."""
+    tile = N * (2 * n * n + 2 * n * m + m * m + n + m + 1) + n * n + n + 1
+    x, l, L = (N + 1) * n, N * m, N * m * n
+    d = {
+        "rollout_candidate": 8 * ((x + l + l + L) + (x + l)),      # reads xbar, l, dl, L; writes x, u
+        "rollout_init": 8 * (l + x),                                # open loop: reads u, writes x
+        "linearise": 8 * ((x + l) + tile),
+        "sweep_eval": 8 * (tile + L + 1),
+        "sweep_gain": 8 * (tile + L + l + 1),
+    }
+    d["candidate"] = d["rollout_candidate"] + d["linearise"] + d["sweep_eval"]           # 395.6 KB
+    d["init"] = d["rollout_init"] + d["linearise"] + d["sweep_eval"]                     # 368.3 KB
+    return d
+
+
+def algo_bytes_per_candidate(prob=None):
+    return algo_bytes()["sweep_eval"]
+
+
+def algo_bytes_of_solves(iters, ls_evals):
+    """Bytes of complete solves: initialize! + one gain sweep per step! + one candidate per line-search evaluation
+    (1.54 MB for the 2-iteration, 2-evaluation LQ solve of SURVEY.md section 8d)."""
+    a = algo_bytes()
+    return float(len(iters)) * a["init"] + float(np.sum(iters)) * a["sweep_gain"] + float(np.sum(ls_evals)) * a["candidate"]
 
 
 def draw_theta(B, seed):
@@ -100,7 +121,9 @@ def main():
     torch.cuda.synchronize()
     prof_all = ctx.profile_get()
     n_all = max(2, min(K, 5))
-    ctx.profile(True, kinds=["sweep_eval"])
+    fused = prof_all["solve_fused"]["launches"] > 0
+    main_kind = "solve_fused" if fused else "sweep_eval"
+    ctx.profile(True, kinds=[main_kind])
     ctx.profile_reset()
     if world > 1:
         dist.barrier()
@@ -151,22 +174,57 @@ def main():
                                "avg_launch_ms": p8["ms"] / max(p8["launches"], 1)}}
         del ctx8
 
+    # per-phase breakdown of the same batch on the round-based path (one launch per phase; what the fused kernel replaces)
+    unfused = None
+    if fused and world == 1:
+        os.environ["RATILQR_FUSED"] = "0"
+        ctxu = rat.Context(prob, max_batch=B, spec_eps=E, device=local_rank)
+        del os.environ["RATILQR_FUSED"]
+        ctxu.set_initial(x0, u0)
+        vu = torch.empty(B, dtype=torch.float64, device=dev)
+        for _ in range(2):
+            ctxu.solve_batch_dev(theta.data_ptr(), B, vu.data_ptr())
+        ctxu.profile(True)
+        ctxu.profile_reset()
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for _ in range(5):
+            ctxu.solve_batch_dev(theta.data_ptr(), B, vu.data_ptr())
+        torch.cuda.synchronize()
+        eu = (time.perf_counter() - tu) / 5
+        pu = ctxu.profile_get()
+        pe = pu["sweep_eval"]
+        ach_e = algo_bytes()["sweep_eval"] * (pe["trajectories"] / max(pe["launches"], 1)) / (pe["ms"] / max(pe["launches"], 1) * 1e-3) / 1e9
+        unfused = {"ms_per_step_with_events": eu * 1e3, "values_identical_to_fused": bool(torch.equal(vu, value)),
+                   "kernel_ms_per_step": {k: v["ms"] / 5 for k, v in pu.items() if v["launches"]},
+                   "sweep_eval_roofline": {"achieved": ach_e, "unit": "GB/s", "frac": ach_e / HBM_PEAK_GBS,
+                                           "avg_launch_ms": pe["ms"] / max(pe["launches"], 1)}}
+        del ctxu
+
     if rank == 0:
         lay = ctx.layout_info()
-        # algorithmic bytes of the dominant kernel (policy-evaluation sweep of line-search candidates):
-        # tile bundle + gains read, one value written -- SURVEY.md section 8(d): 187.3 KB per candidate.
-        # (information content, not the padded HBM record: the physical register-image record is 11.7 % larger)
-        bytes_per_traj = algo_bytes_per_candidate(prob)
-        pe = prof["sweep_eval"]
+        # Algorithmic bytes (information content, not the padded HBM records).
+        #  fused path: the dominant kernel is the whole solve -- initialize! + iters gain sweeps + ls_evals candidates
+        #              per sample (1.54 MB for this workload's 2-iteration solves), summed over the launch's samples;
+        #  round-based path: the policy-evaluation sweep, 187.3 KB per candidate.
+        pe = prof[main_kind]
         avg_ms = pe["ms"] / max(pe["launches"], 1)
         traj_per_launch = pe["trajectories"] / max(pe["launches"], 1)
-        achieved = bytes_per_traj * traj_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        if fused:
+            bytes_per_launch = algo_bytes_of_solves(it_h, ls_h)
+            bytes_per_traj = bytes_per_launch / B
+            kernel_name = "solve_fused_kernel (one persistent wavefront per theta-sample: whole solve!)"
+        else:
+            bytes_per_traj = algo_bytes_per_candidate(prob)
+            bytes_per_launch = bytes_per_traj * traj_per_launch
+            kernel_name = "sweep_kernel<eval> (policy-evaluation Riccati sweep of line-search candidates)"
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(f"sweep_eval_E{E}_B{B}", None)
+                traffic = tj.get(f"{main_kind}_E{E}_B{B}", None)
             except Exception:
                 traffic = None
         out = {
@@ -190,7 +248,7 @@ def main():
                 "feasible_fraction": feasible, "mean_iters": float(it_h.mean()), "mean_ls_evals": float(ls_h.mean()),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "sweep_kernel<eval> (policy-evaluation Riccati sweep of line-search candidates)",
+                "bound": "hbm", "kernel": kernel_name,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "bytes_per_trajectory": bytes_per_traj, "hbm_record_bytes_per_trajectory": lay["tile_bytes"] + lay["L_bytes"] + 8,
@@ -199,6 +257,8 @@ def main():
             },
             "kernel_ms_per_step": {k: v["ms"] / n_all for k, v in prof_all.items()},
         }
+        if unfused is not None:
+            out["round_based_path"] = unfused
         if second is not None:
             out["secondary_spec_eps8"] = second
         if world == 1 and not args.no_cpu:

@@ -382,7 +382,11 @@ extern "C" rat_rc rat_profile_get(rat_handle h, int64_t *launches, int64_t *traj
     for (int k = 0; k < RAT_K_COUNT; ++k) { if (launches) launches[k] = h->p_launch[k]; if (traj) traj[k] = h->p_traj[k]; if (ms) ms[k] = h->p_ms[k]; }
     return RAT_OK;
 }
-#ifdef RAT_DIAG
+#if defined(RAT_DIAG) || defined(RAT_DIAG_PHASES)
+extern "C" rat_rc rat_diag_read_n(rat_handle h, double *out, int64_t off, int64_t n) {
+    HIPCHK(hipMemcpy(out, h->d_dump + off, n * 8, hipMemcpyDeviceToHost));
+    return RAT_OK;
+}
 extern "C" rat_rc rat_diag_read(rat_handle h, double *out64) {
     HIPCHK(hipMemcpy(out64, h->d_dump, 128 * 8, hipMemcpyDeviceToHost));
     return RAT_OK;
@@ -402,7 +406,7 @@ extern "C" rat_rc rat_layout_info(rat_handle h, int64_t *tile_bytes, int64_t *L_
 static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     SweepArgs a;
     a.st = st; a.pb = h->pb; a.op = h->opd; a.mode = mode; a.dl_in = nullptr; a.mu_op = 0.0; a.op_out = nullptr; a.dump = nullptr;
-#ifdef RAT_DIAG
+#if defined(RAT_DIAG) || defined(RAT_DIAG_PHASES)
     a.dump = h->d_dump;
 #endif
     return a;

@@ -29,6 +29,10 @@
 
 #include "device_utils.h"
 
+#ifndef ROLLIN_PREFETCH
+#define ROLLIN_PREFETCH 5          /* rotating operand sets of rollin_body: prefetch distance ROLLIN_PREFETCH - 1 steps */
+#endif
+
 // =====================================================================================================
 // sweep_kernel
 // =====================================================================================================
@@ -593,11 +597,20 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 }
 
 // =====================================================================================================
-// rollin_kernel: fused simulate_dynamics + approximate_model for the solver's hot loop.  ONE wavefront per
-// trajectory: lanes 0..15 run the (sequential, latency-bound) rollout step, then all 64 lanes stream the 417-double
-// tile of that step to HBM, so the tile writes ride in the rollout's idle issue slots and x_t, u_t never make a
-// round trip through HBM between the two reference functions (ileqg.jl:62-87 then :258-322).  Same arithmetic as
-// rollout_kernel + linearize_kernel (which remain for the operator entry points).
+// rollin: fused simulate_dynamics + approximate_model for the solver's hot loop (ileqg.jl:62-87 then :258-322).
+// ONE wavefront per trajectory.  The recursion x_{t+1} = [A|B][x_t; u_t], u_t = l_t + eps dl_t + L_t (x_t - xbar_t) is a
+// chain of tiny matrix-vector products whose operands would have to be broadcast through LDS every step; instead the
+// vectors live in "B-form" -- register s of lane (g, j) holds component 4 s + g, the B-operand (and, read the other way,
+// the A-operand) slice s of v_mfma_f64_16x16x4_f64 with the vector replicated across the 16 columns -- and every product
+// is issued to the matrix pipe with a constant (or prefetched) operand on the other side:
+//   L_t dx_t           A = L_t column slices,  B = dx in B-form          -> row g of D = (L dx)_g   = B-form slice 3 of [x; u]
+//   [A|B][x; u]        A = [A|B] column slices, B = [x; u] in B-form     -> register r of D = x_{t+1} in B-form: the recursion
+//                                                                           closes without a single cross-lane move
+//   transposition      A = [x; u] in B-form,   B = unit selectors        -> every lane j holds [x; u]_j ("by-j": stores, c_x)
+//   C [x; u]           A = [x; u] in B-form,   B = C row slices          -> every lane j holds (C [x;u])_j = [c_x | c_u]_j - lin_j
+// The critical path per step is 3 + 1 dependent MFMAs (the first three [A|B] slices do not wait for u); the 466-double
+// tile record of the step is streamed out behind it.  x_t, u_t never make a round trip through HBM between the two
+// reference functions.  rollout_kernel + linearize_kernel (operator entry points) compute the same quantities.
 // =====================================================================================================
 // CTV: time-varying cost tables (LQ family).  A template parameter, not a branch: a conditional per-step table load would put
 // a path-dependent number of loads between the prefetch and the tile stores and collapse every counted vmcnt wait.
@@ -614,9 +627,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     int b, k = 0;
     if (MODE == 0) { b = c; if (st.status[b] != ST_RUNNING) return; }
     else { b = c / st.E; k = c - b * st.E; if (!st.ls_active[b]) return; }
-    __shared__ double shdx[12];
     __shared__ double shxu[16];
-    __shared__ double shq[4];
 
     const int nom = st.slot_nom[b];
     const int slot_n = b * (st.E + 1) + nom;
@@ -630,202 +641,211 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const double *__restrict__ Lb = st.L + (long)lsel * st.l_half + (long)b * N * LSTR;
     const double *__restrict__ dlb = st.dl + (long)lsel * st.dl_half + (long)b * N * USTR;
     constexpr bool lq = (MODEL == 1);
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
 
     double eps = 0.0;
     if (MODE == 1) {
         eps = st.ls_eps[b];
         for (int q = 0; q < k; ++q) eps *= a.op.lambda;        // eps_k = eps * lambda^k by repeated multiplication (:530,:557)
     }
-    // per-lane constants of the LQ family (dynamics are time-invariant; cost tables only when !cost_tv)
-    // (the tile is a register image, layout.h: lane l owns element 64 r + l of Z and of C = [[Q, 0], [P, R]])
-    double zr[16], crow[16];
+    // per-lane constants (dynamics are time-invariant; cost tables only when !CTV).  The tile is a register image
+    // (layout.h): lane l owns element 64 r + l of Z and of C = [[Q, 0], [P, R]].
+    double zA[4] = {0, 0, 0, 0};        // A-operand slice s of [A|B]: lane (g, j) holds [A|B][j][4 s + g], rows j >= 12 zero
+    double cf[4] = {0, 0, 0, 0};        // B-operand slice s of the full symmetric C: lane (g, j) holds C[4 s + g][j]
+    double es[4];                       // B-operand slice s of the transposition: 1 where j == 4 s + g
     double zt0 = 0, zt1 = 0, zt2 = 0, cq0 = 0, cq1 = 0, cq2 = 0, cpr = 0, clin = 0, cq00 = 0;
     const double mq = (j < 12) ? 1.0 : 0.0;                     // rows 0..11 of C: columns 12..15 are dead slots, written as 0
     const int lx = (l < 17) ? l : 17;                           // [qr | q | pad] row: lanes past q all write 0.0 to the pad slot
-    const int jx = (j < 12) ? j : 11, ju = j & 3;
+    const int jx = (j < 12) ? j : 11, j3 = j & 3;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) es[s] = (j == 4 * s + g) ? 1.0 : 0.0;
+    const double dgz[3] = {es[0], es[1], es[2]};                // 1 on the lane that holds the diagonal element of row 4 r + g of f_x
     if (lq) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) zr[q] = pb.Zt[jx * 16 + q];
+        for (int s = 0; s < 4; ++s) zA[s] = pb.Zt[jx * 16 + 4 * s + g] * mq;
         zt0 = pb.Zt[l]; zt1 = pb.Zt[64 + l]; zt2 = pb.Zt[128 + l];
         if (!CTV) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) crow[q] = pb.Ctab[j * 16 + q];
-            cq0 = pb.Ctab[l] * mq;
-            cq1 = pb.Ctab[64 + l] * mq;
-            cq2 = pb.Ctab[128 + l] * mq;
-            cpr = pb.Ctab[192 + l];
+            for (int s = 0; s < 4; ++s) cf[s] = pb.Ctab[64 * s + l];
+            cq0 = cf[0] * mq; cq1 = cf[1] * mq; cq2 = cf[2] * mq; cpr = cf[3];
             clin = pb.lin[j];
             cq00 = pb.q0[0];
         }
     }
-    double x = 0.0;
-    if (j < 12) x = (MODE == 0) ? a.x0[j] : xbar[j];
-    if (l < 12) xo[l] = x;
+    // one store per step writes x_t (lanes 0..11), u_t (lanes 12..15) and, from the idle lanes, 0.0 to the record's pad slot:
+    // per-lane base and stride instead of a per-step address select (which compiles to a divergent branch)
+    double *const pxu = (l < 12) ? xo + l : (l < 16 ? uo + (l - 12) : tile0 + TS_PAD);
+    const long sxu = (l < 12) ? XSTR : (l < 16 ? USTR : TSTRIDE);
+    const double mxu = (l < 16) ? 1.0 : 0.0;
+    double xb[3];                                               // x_t in B-form
+#pragma unroll
+    for (int s = 0; s < 3; ++s) xb[s] = (MODE == 0) ? a.x0[4 * s + g] : xbar[4 * s + g];
     double dmax = -INFINITY;
     bool dnan = false;
     int dom = 0;
-    double n_xb = xbar[jx], n_l = lnom[ju], n_dl = dlb[ju];
-    double n_L[12];
+    // Software prefetch of the step operands, RD-1 steps ahead, in RD rotating register sets (the time loop is unrolled by RD).
+    // gfx9 counts loads and stores in ONE in-order vmcnt, so waiting for a prefetched operand also waits for every store
+    // issued before that prefetch.  With the prefetch of step t+RD-1 issued at the top of step t, the wait at the top of
+    // step t+RD-1 leaves the tile stores of the last RD-1 steps in flight (vmcnt = stores + (RD-2)(loads + stores) + loads),
+    // which is what keeps the HBM write pipe full: a distance of one drains the tile stream behind a single step of
+    // arithmetic and the wave then idles a write latency (~1 us) per step.  The count has to hold on every path into the
+    // loop: (1) all stores of a step are unconditional (idle lanes write 0.0 to the record's pad slot), (2) each prefetch of
+    // the prologue is followed by as many (pad) stores as a step issues, (3) the loads are unconditional (clamped step index).
+    // A register set is refilled at the top of the step AFTER the one that consumed it: its old value is dead by then, so
+    // the loop-carried sets need no copies (a copy of a just-loaded register would wait for the load and drain the queue).
+    constexpr int RD = ROLLIN_PREFETCH;
+    constexpr int kStoresPerStep = 6;
+    struct StepIn { double l, dl, xb[3], La[3]; };
+    StepIn buf[RD];
+    auto issue = [&](StepIn &in, const int tq) {
+        const int tn = (tq < N) ? tq : N - 1;
+        in.l = lnom[(long)tn * USTR + g];
+        in.dl = 0.0;
 #pragma unroll
-    for (int q = 0; q < 12; ++q) n_L[q] = 0.0;
-    if (MODE == 1) {
+        for (int s = 0; s < 3; ++s) in.xb[s] = in.La[s] = 0.0;
+        if (MODE == 1) {
+            in.dl = dlb[(long)tn * USTR + g];
 #pragma unroll
-        for (int q = 0; q < 12; ++q) n_L[q] = Lb[ju * 12 + q];
+            for (int s = 0; s < 3; ++s) {
+                in.xb[s] = xbar[(long)tn * XSTR + 4 * s + g];
+                in.La[s] = Lb[(long)tn * LSTR + j3 * 12 + 4 * s + g];   // A-operand slice s of L_t: rows >= 4 of the product are never read
+            }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < RD - 1; ++d) {
+        issue(buf[d], d);
+#pragma unroll
+        for (int q = 0; q < kStoresPerStep; ++q) {              // (distinct pad slots: identical stores would be merged away)
+            const int tq = d * kStoresPerStep + q;
+            tile0[(long)((tq < N) ? tq : N - 1) * TSTRIDE + TS_PAD] = 0.0;
+        }
     }
-    // gfx9 counts loads and stores in ONE in-order vmcnt.  The prefetch of step t+1 is issued at the top of step t and
-    // the stores of step t after it, so the wait for the prefetch at the top of step t+1 may leave all of step t's stores
-    // in flight -- vmcnt(loads + stores per step) -- and the tile stream drains behind the next step's arithmetic.  That
-    // count has to hold on every path into the loop: (1) all stores of a step are unconditional (idle lanes write 0.0
-    // to the record's pad slot), and (2) the first prefetch above is followed by as many (pad) stores as a step issues.
-    // A lane-conditional store, or a loop entry without them, makes the compiler fall back to vmcnt(loads), which
-    // drains the whole tile at the top of every step (measured: 2800 instead of 1800 cycles per step).
-    {
-        constexpr int kStoresPerStep = 7;
+    buf[RD - 1].l = buf[RD - 1].dl = 0.0;       // (defined on entry; refilled at the top of step 0)
 #pragma unroll
-        for (int q = 0; q < kStoresPerStep; ++q) tile0[(long)((q < N) ? q : N - 1) * TSTRIDE + TS_PAD] = 0.0;
-    }
+    for (int s = 0; s < 3; ++s) buf[RD - 1].xb[s] = buf[RD - 1].La[s] = 0.0;
     DIAG_DECL
 #ifdef RAT_DIAG
     dg_loop0 = __builtin_readcyclecounter();
 #endif
-    for (int t = 0; t < N; ++t) {
+    auto step = [&](const int t, const StepIn &cur) {
         DIAG_START();
-        const double c_xb = n_xb, c_l = n_l, c_dl = n_dl;
-        double c_L[12];
+        const double c_l = cur.l, c_dl = cur.dl;
+        const double c_xb[3] = {cur.xb[0], cur.xb[1], cur.xb[2]}, c_La[3] = {cur.La[0], cur.La[1], cur.La[2]};
+        double *__restrict__ tp = tile0 + (long)t * TSTRIDE;
+        if (CTV) {
+            const double *__restrict__ C = pb.Ctab + (long)t * 256;
 #pragma unroll
-        for (int q = 0; q < 12; ++q) c_L[q] = n_L[q];
-        {
-            const int tn = (t + 1 < N) ? t + 1 : t;             // unconditional prefetch of step t+1 (static load count)
-            n_xb = xbar[(long)tn * XSTR + jx];
-            n_l = lnom[(long)tn * USTR + ju];
-            n_dl = dlb[(long)tn * USTR + ju];
-            if (MODE == 1) {
-#pragma unroll
-                for (int q = 0; q < 12; ++q) n_L[q] = Lb[(long)tn * LSTR + ju * 12 + q];
-            }
+            for (int s = 0; s < 4; ++s) cf[s] = C[64 * s + l];
+            cq0 = cf[0] * mq; cq1 = cf[1] * mq; cq2 = cf[2] * mq; cpr = cf[3];
+            clin = pb.lin[(long)t * 16 + j];
+            cq00 = pb.q0[t];
         }
-        double u = c_l;
+        // ---- x_{t+1} = f(x_t, u_t): the x-part of [A|B][x; u] does not wait for the feedback control -----------------
+        d4 xa = zero4;
+        if (lq) {
+            xa = MFMA(zA[0], xb[0], xa);
+            xa = MFMA(zA[1], xb[1], xa);
+            xa = MFMA(zA[2], xb[2], xa);
+        }
+        double u = c_l;                                             // u_g on the lanes of row g (B-form slice 3)
         if (MODE == 1) {
-            if (l < 12) shdx[l] = x - c_xb;
-            WAVE_SYNC();
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                          // L_t (x_t - xbar_t)   (:82)
-                a0 = fma(c_L[q], shdx[q], a0);
-                a1 = fma(c_L[4 + q], shdx[4 + q], a1);
-                a2 = fma(c_L[8 + q], shdx[8 + q], a2);
-            }
-            const double lnew = c_l + eps * c_dl;                     // l + eps dl           (:509)
-            u = lnew + ((a0 + a1) + a2);
-            const double du = c_l - u;
-            if (l < 4) shq[l] = du * du;
+            d4 fb = MFMA(c_La[0], xb[0] - c_xb[0], zero4);          // L_t (x_t - xbar_t)   (:82)
+            fb = MFMA(c_La[1], xb[1] - c_xb[1], fb);
+            fb = MFMA(c_La[2], xb[2] - c_xb[2], fb);
+            const double lnew = c_l + eps * c_dl;                   // l + eps dl           (:509)
+            u = lnew + fb[0];
+            // d = maximum(norm(l_t - u_t))  (:517-519): sqrt is monotone, so the maximum is taken over the squared norms and
+            // rooted once after the loop (same bits); maximum() propagates NaN
+            const double du = c_l - u, dsq = du * du;
+            const double dn2 = ((readlane_f64(dsq, 0) + readlane_f64(dsq, 16)) + readlane_f64(dsq, 32)) + readlane_f64(dsq, 48);
+            dnan |= (dn2 != dn2);
+            dmax = (dn2 > dmax) ? dn2 : dmax;
         }
         DIAG_STAMP(0, u);
-        if (l < 12) shxu[l] = x;
-        if (l < 4) shxu[12 + l] = u;
-        WAVE_SYNC();
-        double xu[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) xu[q] = shxu[q];
-        // ---- x_{t+1} = f(x_t, u_t) ------------------------------------------------------------------
-        double xn = 0.0;
+        double xn[3] = {0.0, 0.0, 0.0};
         if (lq) {
-            double acc = 0.0, acc2 = 0.0, acc3 = 0.0, accb = 0.0;
+            xa = MFMA(zA[3], u, xa);
+            // + kappa x^3, branch-free (kappa = 0 adds 0): the whole step stays ONE basic block, so the scheduler can run the
+            // off-path chains (transposition, C [x;u], tile stores) of one step under the recursion of the next
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc = fma(zr[q], xu[q], acc);
-                acc2 = fma(zr[4 + q], xu[4 + q], acc2);
-                acc3 = fma(zr[8 + q], xu[8 + q], acc3);
-                accb = fma(zr[12 + q], xu[12 + q], accb);
-            }
-            acc = ((acc + acc2) + acc3) + accb;
-            if (pb.kappa != 0.0) acc += pb.kappa * (x * x * x);
-            xn = (j < 12) ? acc : 0.0;
-        } else if (j < pb.n) {
-            xn = powchk(x, pb.pl_a, dom) + powchk(xu[12 + (j & 3)], pb.pl_b, dom);
+            for (int r = 0; r < 3; ++r) xn[r] = xa[r] + pb.kappa * (xb[r] * xb[r] * xb[r]);
+        } else if (g < pb.n) {
+            xn[0] = powchk(xb[0], pb.pl_a, dom) + powchk(u, pb.pl_b, dom);
         }
-        if (MODE == 1 && l == 0) {
-            const double dn = sqrt(shq[0] + shq[1] + shq[2] + shq[3]);
-            if (dn != dn) dnan = true;                          // maximum() propagates NaN
-            else if (dn > dmax) dmax = dn;
-        }
-        DIAG_STAMP(1, xn);
+        DIAG_STAMP(1, xn[0]);
+        // ---- [x_t; u_t] by lane j (exact: products with 1.0 and sums with 0.0) ---------------------------------------------
+        d4 tj = MFMA(xb[0], es[0], zero4);
+        tj = MFMA(xb[1], es[1], tj);
+        tj = MFMA(xb[2], es[2], tj);
+        tj = MFMA(u, es[3], tj);
+        const double xuj = tj[0];
+        pxu[(long)t * sxu] = xuj * mxu;                             // x_t | u_t | (idle lanes: 0.0 to the pad slot), one store
         // ---- tile of step t: approximate_model at (x_t, u_t)   (ileqg.jl:294-313) ---------------------
-        double *__restrict__ tp = tile0 + (long)t * TSTRIDE;
-        *((l < 12) ? xo + (long)(t + 1) * XSTR + l : tp + TS_PAD) = (l < 12) ? xn : 0.0;
-        *((l < 4) ? uo + (long)t * USTR + l : tp + TS_PAD) = (l < 4) ? u : 0.0;
         if (lq) {
-            const int kc = CTV ? t : 0;
-            if (CTV) {
-                const double *__restrict__ C = pb.Ctab + (long)kc * 256;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) crow[q] = C[j * 16 + q];
-                cq0 = C[l] * mq;
-                cq1 = C[64 + l] * mq;
-                cq2 = C[128 + l] * mq;
-                cpr = C[192 + l];
-                clin = pb.lin[(long)kc * 16 + j];
-                cq00 = pb.q0[kc];
-            }
-            // f_x = A + diag(3 kappa x^2) | f_u = B
-            double z0 = zt0, z1 = zt1, z2 = zt2;
-            if (pb.kappa != 0.0) {
-                const int i0 = l >> 4, i1 = (64 + l) >> 4, i2 = (128 + l) >> 4;
-                if (j == i0) z0 += 3.0 * pb.kappa * (xu[i0 & 15] * xu[i0 & 15]);
-                if (j == i1) z1 += 3.0 * pb.kappa * (xu[i1 & 15] * xu[i1 & 15]);
-                if (j == i2) z2 += 3.0 * pb.kappa * (xu[i2 & 15] * xu[i2 & 15]);
-            }
+            // f_x = A + diag(3 kappa x^2) | f_u = B: the diagonal element of row 4 r + g sits on lane (g, 4 r + g), which holds x_{4r+g}
+            const double z0 = zt0 + dgz[0] * (3.0 * pb.kappa * (xb[0] * xb[0]));
+            const double z1 = zt1 + dgz[1] * (3.0 * pb.kappa * (xb[1] * xb[1]));
+            const double z2 = zt2 + dgz[2] * (3.0 * pb.kappa * (xb[2] * xb[2]));
             double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
             t2[l] = make_double2(z0, z1);
             t2[64 + l] = make_double2(z2, cq0);
             t2[128 + l] = make_double2(cq1, cq2);
             tp[TS_R6 + l] = cpr;
-            double acc, ac1 = 0.0, ac2 = 0.0, ac3 = 0.0, ac4 = 0.0;  // [c_x | c_u] = C [x;u] + [qv;rv]  (4 chains for ILP)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ac1 = fma(crow[q], xu[q], ac1);
-                ac2 = fma(crow[4 + q], xu[4 + q], ac2);
-                ac3 = fma(crow[8 + q], xu[8 + q], ac3);
-                ac4 = fma(crow[12 + q], xu[12 + q], ac4);
-            }
-            acc = ((ac1 + ac2) + ac3) + ac4;
-            const double part = row_sum16(xu[j] * (0.5 * acc + clin));    // every 16-lane row holds the same sum
+            d4 cx = MFMA(xb[0], cf[0], zero4);                      // [c_x | c_u] = C [x;u] + [qv;rv]
+            cx = MFMA(xb[1], cf[1], cx);
+            cx = MFMA(xb[2], cf[2], cx);
+            cx = MFMA(u, cf[3], cx);
+            const double acc = cx[0];
+            const double part = row_sum16(xuj * (0.5 * acc + clin));    // every 16-lane row holds the same sum
             tp[TS_QR + lx] = (l < 16) ? acc + clin : (l == 16 ? part + cq00 : 0.0);   // [c_x | c_u], c, pad
         } else {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int i = 4 * r + g;
-                double val = 0.0, cv = 0.0;
-                if (i < pb.n) {
-                    if (j == i) {
-                        val = pb.pl_a * powchk(xu[i & 15], pb.pl_a - 1.0, dom);
-                        cv = pb.pl_cx * pb.pl_p * (pb.pl_p - 1.0) * powchk(xu[i & 15], pb.pl_p - 2.0, dom);
-                    } else if (j == 12 + i) val = pb.pl_b * powchk(xu[12 + (i & 3)], pb.pl_b - 1.0, dom);
-                }
-                tp[TS_REG(r, l)] = val;
-                tp[TS_REG(3 + r, l)] = cv;
+            // power-law family (n == m <= 4): every derivative is diagonal, and row g's entries sit on the lanes of row g
+            double val = 0.0, cv = 0.0;
+            if (g < pb.n) {
+                if (j == g) {
+                    val = pb.pl_a * powchk(xb[0], pb.pl_a - 1.0, dom);
+                    cv = pb.pl_cx * pb.pl_p * (pb.pl_p - 1.0) * powchk(xb[0], pb.pl_p - 2.0, dom);
+                } else if (j == 12 + g) val = pb.pl_b * powchk(u, pb.pl_b - 1.0, dom);
             }
+            double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
+            t2[l] = make_double2(val, 0.0);
+            t2[64 + l] = make_double2(0.0, cv);
+            t2[128 + l] = make_double2(0.0, 0.0);
             {
-                double val = 0.0;
-                if (j == 12 + g) val = (g < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(xu[12 + g], pb.pl_pu - 2.0, dom) : 1.0;
-                tp[TS_R6 + l] = val;
+                double rv = 0.0;
+                if (j == 12 + g) rv = (g < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(u, pb.pl_pu - 2.0, dom) : 1.0;
+                tp[TS_R6 + l] = rv;
             }
-            double part = 0.0, val = 0.0;
+            double part = 0.0, qv = 0.0;
             if (l < pb.n) {
-                val = pb.pl_cx * pb.pl_p * powchk(xu[l & 15], pb.pl_p - 1.0, dom);
-                part = pb.pl_cx * powchk(xu[l & 15], pb.pl_p, dom);
+                qv = pb.pl_cx * pb.pl_p * powchk(xuj, pb.pl_p - 1.0, dom);
+                part = pb.pl_cx * powchk(xuj, pb.pl_p, dom);
             } else if (l >= 12 && l - 12 < pb.m) {
-                val = pb.pl_cu * pb.pl_pu * powchk(xu[l & 15], pb.pl_pu - 1.0, dom);
-                part = pb.pl_cu * powchk(xu[l & 15], pb.pl_pu, dom);
+                qv = pb.pl_cu * pb.pl_pu * powchk(xuj, pb.pl_pu - 1.0, dom);
+                part = pb.pl_cu * powchk(xuj, pb.pl_pu, dom);
             }
             if (l >= 16) part = 0.0;
             part = wave_sum(part);
-            tp[TS_QR + lx] = (l < 16) ? val : (l == 16 ? part : 0.0);
+            tp[TS_QR + lx] = (l < 16) ? qv : (l == 16 ? part : 0.0);
         }
-        x = xn;
-        WAVE_SYNC();
-        DIAG_STAMP(2, x);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xb[r] = xn[r];
+        DIAG_STAMP(2, xb[0]);
+    };
+    // single-exit main loop over whole groups of RD steps (a second exit would put a path from the middle of the group
+    // back to the loop header into the control-flow graph and cap the header's vmcnt at that path's count), then the tail
+    int t0 = 0;
+    for (; t0 + RD <= N; t0 += RD) {
+#pragma unroll
+        for (int d = 0; d < RD; ++d) {
+            issue(buf[(d + RD - 1) % RD], t0 + d + RD - 1);
+            step(t0 + d, buf[d]);
+        }
     }
+#pragma unroll
+    for (int d = 0; d < RD - 1; ++d)                            // N mod RD steps: their operands are already in buf[0..]
+        if (t0 + d < N) step(t0 + d, buf[d]);
 #ifdef RAT_DIAG
     if (l == 0 && blockIdx.x < 8 && a.dump) {
         for (int q = 0; q < 3; ++q) a.dump[64 + blockIdx.x * 8 + q] = (double)dg_acc[q];
@@ -834,9 +854,13 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
         a.dump[64 + blockIdx.x * 8 + 4] = (double)(__builtin_readcyclecounter() - dg_entry);  // entry .. end of time loop
     }
 #endif
-    // ---- terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316) ------------------------------------------
+    // ---- x_N and the terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316) -------------------------------
     {
-        if (l < 12) shxu[l] = x;
+        d4 tj = MFMA(xb[0], es[0], zero4);
+        tj = MFMA(xb[1], es[1], tj);
+        tj = MFMA(xb[2], es[2], tj);
+        const double x = tj[0];                                     // x_N by lane j (lanes j >= 12: 0)
+        if (l < 12) { xo[(long)N * XSTR + l] = x; shxu[l] = x; }
         WAVE_SYNC();
         double *__restrict__ tp = tile0 + (long)N * TSTRIDE;
         if (lq) {
@@ -853,11 +877,12 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
             if (l < 12) tp[TT_QV + l] = 0.0;
             if (l == 0) tp[TT_q] = pb.pl_h;
         }
+        WAVE_SYNC();                                                // shxu may be rewritten by the next phase of a fused solve
     }
     const bool anydom = __ballot(dom != 0) != 0ull;
     if (l == 0) {
         if (MODE == 1) {
-            st.d_c[c] = dnan ? NAN : dmax;
+            st.d_c[c] = dnan ? NAN : sqrt(dmax);
             st.flag_c[c] = anydom ? 2 : 0;
         } else if (anydom) {
             st.status[b] = 4;               // RAT_ST_DOMAIN
@@ -1164,35 +1189,56 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
 #define PHASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
 __device__ __forceinline__ int uniform_load(const int *p) { return __builtin_amdgcn_readfirstlane(__atomic_load_n(p, __ATOMIC_RELAXED)); }
 
+#ifdef RAT_DIAG_PHASES
+#define PHASE_MARK() do { if (threadIdx.x == 0 && blockIdx.x < 8 && fa.sw.dump && dg_pi < 40) \
+        fa.sw.dump[256 + blockIdx.x * 40 + dg_pi] = (double)(__builtin_readcyclecounter() - dg_t0); ++dg_pi; } while (0)
+#else
+#define PHASE_MARK() do {} while (0)
+#endif
+
 template <int MODEL, bool CTV, bool WTV>
 __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
     const int b = blockIdx.x;
     const StateDev &st = fa.sw.st;
+#ifdef RAT_DIAG_PHASES
+    const unsigned long long dg_t0 = __builtin_readcyclecounter();
+    int dg_pi = 0;
+#endif
     {
         RolloutArgs ra = fa.ro; ra.mode = 0;
         rollin_body<MODEL, 0, CTV>(ra, b);
+        PHASE_MARK();
         PHASE_FENCE();
+        PHASE_MARK();
         SweepArgs sa = fa.sw; sa.mode = 2;
         sweep_body<false, false, WTV, false>(sa, b);
+        PHASE_MARK();
         PHASE_FENCE();
+        PHASE_MARK();
     }
     for (int guard = 0; guard < fa.max_rounds; ++guard) {
         if (uniform_load(&st.status[b]) != ST_RUNNING) break;
         if (!uniform_load(&st.ls_active[b])) {               // step!: solve_approximate_dp!  (ileqg.jl:598-613)
             SweepArgs sa = fa.sw; sa.mode = 0;
             sweep_body<true, false, WTV, false>(sa, b);
+            PHASE_MARK();
             PHASE_FENCE();
+            PHASE_MARK();
             continue;
         }
         {                                                    // one candidate of line_search!  (ileqg.jl:504-581)
             RolloutArgs ra = fa.ro; ra.mode = 1;
             rollin_body<MODEL, 1, CTV>(ra, b);
+            PHASE_MARK();
             PHASE_FENCE();
+            PHASE_MARK();
             SweepArgs sa = fa.sw; sa.mode = 1;
             sweep_body<false, false, WTV, true>(sa, b);
+            PHASE_MARK();
             PHASE_FENCE();
             if (threadIdx.x == 0) ls_select_body(st, fa.sw.op, b, nullptr);
             PHASE_FENCE();
+            PHASE_MARK();
         }
     }
 }

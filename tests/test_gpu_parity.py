@@ -306,3 +306,37 @@ def test_dual_sweep_wavefronts_are_result_identical(monkeypatch):
         assert np.array_equal(a, b)
     assert np.array_equal(r0["L"], r1["L"]) and np.array_equal(r0["x"], r1["x"]) and r0["value"] == r1["value"]
     assert np.array_equal(r0["eps_history"], r1["eps_history"])
+
+
+def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
+    """Default for E = 1: one persistent wavefront per theta-sample runs the whole solve! in one launch.  It calls the same
+    device functions as the per-phase kernels of the round-based path (RATILQR_FUSED=0): every output must be bit-identical --
+    values, statuses (infeasible theta, mu divergence), iteration and line-search counts, trajectories, gains, eps history,
+    on the LQ family (with cubic drift, time-varying cost and noise tables via the stress problems) and the power-law family."""
+    prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
+    theta = np.array([0.0, 1.0, 4.0, 5.0, 5.9, 6.3, 6.6, 9.0, 30.0])
+    lprob, lx0, lu = rat.synthetic_lq_problem()
+    th_l = np.concatenate([[0.0], np.linspace(0.01, 14.0, 30), [50.0]])
+    stress = [stress_problem(i, kappa=0.03) for i in range(4)]
+    th_s = np.array([0.0, 0.3, 1.0, 4.0])
+    pl = rat.PowerLawRiskSensitiveProblem(2, 10, 0.01 * np.eye(2), a=1.3, b=1.5, p=2.5, hconst=1.0)
+    pl_u = 0.1 * np.ones((10, 2))
+
+    def run_all():
+        out = []
+        out += rat.Context(prob, max_batch=theta.size).solve_batch(x0, u, theta)
+        out += rat.Context(lprob, max_batch=32).solve_batch(lx0, lu, th_l)
+        for sp, sx, su in stress:
+            out += rat.Context(sp, rat.ileqg.make_opts(iter_max=8), max_batch=4).solve_batch(sx, su, th_s)
+        out += rat.Context(pl, max_batch=3).solve_batch(np.zeros(2), pl_u, np.array([0.0, 0.5, 2.0]))
+        r = rat.Context(prob).solve(x0, u, 5.0)
+        out += [r["L"], r["x"], r["l"], np.array([r["value"]]), np.asarray(r["eps_history"], dtype=float)]
+        return out
+
+    fused = run_all()
+    monkeypatch.setenv("RATILQR_FUSED", "0")
+    rounds = run_all()
+    monkeypatch.delenv("RATILQR_FUSED")
+    assert len(fused) == len(rounds)
+    for a, b in zip(fused, rounds):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)

@@ -2,6 +2,7 @@
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["RATILQR_SO"] = os.path.join(ROOT, "ratilqr.jl_amd", "csrc", "libratilqr_hip_diag.so")
+os.environ["RATILQR_FUSED"] = "0"      # per-phase kernels (the stamps sit in their bodies)
 sys.path.insert(0, ROOT)
 import numpy as np
 import ratilqr.jl_amd as rat
