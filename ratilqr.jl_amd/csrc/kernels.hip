@@ -606,10 +606,13 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 //   L_t dx_t           A = L_t column slices,  B = dx in B-form          -> row g of D = (L dx)_g   = B-form slice 3 of [x; u]
 //   [A|B][x; u]        A = [A|B] column slices, B = [x; u] in B-form     -> register r of D = x_{t+1} in B-form: the recursion
 //                                                                           closes without a single cross-lane move
-//   transposition      A = [x; u] in B-form,   B = unit selectors        -> every lane j holds [x; u]_j ("by-j": stores, c_x)
-//   C [x; u]           A = [x; u] in B-form,   B = C row slices          -> every lane j holds (C [x;u])_j = [c_x | c_u]_j - lin_j
-// The critical path per step is 3 + 1 dependent MFMAs (the first three [A|B] slices do not wait for u); the 466-double
-// tile record of the step is streamed out behind it.  x_t, u_t never make a round trip through HBM between the two
+//   C [x; u]           A = C column slices (C symmetric: the register image of C), B = [x; u] in B-form
+//                                                                        -> register r of D = (C [x;u])_{4r+g} = [c_x | c_u] - lin in B-form
+// The critical path per step is 3 + 1 dependent MFMAs (the first three [A|B] slices do not wait for u).  Off the critical
+// path a B-form vector is "packed" -- lane (g, s), s < 4, selects its register s, so 16 lanes hold the 16 components -- and
+// [x_t; u_t], [c_x | c_u] and c leave through per-lane store addresses.  No LDS and no fence inside the time loop: the
+// whole group of RD steps is one basic block of pure data flow, which lets the scheduler run one step's cost gradient and
+// tile stores under the recursion of the next (an in-order wavefront has no other source of overlap).  x_t, u_t never make a round trip through HBM between the two
 // reference functions.  rollout_kernel + linearize_kernel (operator entry points) compute the same quantities.
 // =====================================================================================================
 // CTV: time-varying cost tables (LQ family).  A template parameter, not a branch: a conditional per-step table load would put
@@ -627,7 +630,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     int b, k = 0;
     if (MODE == 0) { b = c; if (st.status[b] != ST_RUNNING) return; }
     else { b = c / st.E; k = c - b * st.E; if (!st.ls_active[b]) return; }
-    __shared__ double shxu[16];
+    __shared__ double shxu[16];                                  // terminal tile only
 
     const int nom = st.slot_nom[b];
     const int slot_n = b * (st.E + 1) + nom;
@@ -651,12 +654,12 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     // per-lane constants (dynamics are time-invariant; cost tables only when !CTV).  The tile is a register image
     // (layout.h): lane l owns element 64 r + l of Z and of C = [[Q, 0], [P, R]].
     double zA[4] = {0, 0, 0, 0};        // A-operand slice s of [A|B]: lane (g, j) holds [A|B][j][4 s + g], rows j >= 12 zero
-    double cf[4] = {0, 0, 0, 0};        // B-operand slice s of the full symmetric C: lane (g, j) holds C[4 s + g][j]
-    double es[4];                       // B-operand slice s of the transposition: 1 where j == 4 s + g
+    double cf[4] = {0, 0, 0, 0};        // register r of the C image: lane (g, j) holds C[4 r + g][j] = C[j][4 r + g] (A-operand slice r)
+    double es[4];                       // B-operand slice s of the by-j transposition (x_N only): 1 where j == 4 s + g
     double zt0 = 0, zt1 = 0, zt2 = 0, cq0 = 0, cq1 = 0, cq2 = 0, cpr = 0, clin = 0, cq00 = 0;
     const double mq = (j < 12) ? 1.0 : 0.0;                     // rows 0..11 of C: columns 12..15 are dead slots, written as 0
-    const int lx = (l < 17) ? l : 17;                           // [qr | q | pad] row: lanes past q all write 0.0 to the pad slot
     const int jx = (j < 12) ? j : 11, j3 = j & 3;
+    const int pkc = 4 * j3 + g;                                 // component this lane carries in packed form (lanes j < 4)
 #pragma unroll
     for (int s = 0; s < 4; ++s) es[s] = (j == 4 * s + g) ? 1.0 : 0.0;
     const double dgz[3] = {es[0], es[1], es[2]};                // 1 on the lane that holds the diagonal element of row 4 r + g of f_x
@@ -668,15 +671,17 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) cf[s] = pb.Ctab[64 * s + l];
             cq0 = cf[0] * mq; cq1 = cf[1] * mq; cq2 = cf[2] * mq; cpr = cf[3];
-            clin = pb.lin[j];
+            clin = pb.lin[pkc];
             cq00 = pb.q0[0];
         }
     }
     // one store per step writes x_t (lanes 0..11), u_t (lanes 12..15) and, from the idle lanes, 0.0 to the record's pad slot:
     // per-lane base and stride instead of a per-step address select (which compiles to a divergent branch)
-    double *const pxu = (l < 12) ? xo + l : (l < 16 ? uo + (l - 12) : tile0 + TS_PAD);
-    const long sxu = (l < 12) ? XSTR : (l < 16 ? USTR : TSTRIDE);
-    const double mxu = (l < 16) ? 1.0 : 0.0;
+    // [x_t; u_t] packed: lane (g, s), s < 4, holds component 4 s + g (B-form register s of that lane)
+    double *const pxu = (j < 3) ? xo + 4 * j + g : (j == 3 ? uo + g : tile0 + TS_PAD);
+    const long sxu = (j < 3) ? XSTR : (j == 3 ? USTR : TSTRIDE);
+    // [c_x | c_u] packed the same way; lane 4 carries c, the other idle lanes 0.0 for the pad slot
+    const int qoff = (j < 4) ? TS_QR + 4 * j + g : (l == 4 ? TS_q : TS_PAD);
     double xb[3];                                               // x_t in B-form
 #pragma unroll
     for (int s = 0; s < 3; ++s) xb[s] = (MODE == 0) ? a.x0[4 * s + g] : xbar[4 * s + g];
@@ -738,7 +743,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) cf[s] = C[64 * s + l];
             cq0 = cf[0] * mq; cq1 = cf[1] * mq; cq2 = cf[2] * mq; cpr = cf[3];
-            clin = pb.lin[(long)t * 16 + j];
+            clin = pb.lin[(long)t * 16 + pkc];
             cq00 = pb.q0[t];
         }
         // ---- x_{t+1} = f(x_t, u_t): the x-part of [A|B][x; u] does not wait for the feedback control -----------------
@@ -774,13 +779,9 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
             xn[0] = powchk(xb[0], pb.pl_a, dom) + powchk(u, pb.pl_b, dom);
         }
         DIAG_STAMP(1, xn[0]);
-        // ---- [x_t; u_t] by lane j (exact: products with 1.0 and sums with 0.0) ---------------------------------------------
-        d4 tj = MFMA(xb[0], es[0], zero4);
-        tj = MFMA(xb[1], es[1], tj);
-        tj = MFMA(xb[2], es[2], tj);
-        tj = MFMA(u, es[3], tj);
-        const double xuj = tj[0];
-        pxu[(long)t * sxu] = xuj * mxu;                             // x_t | u_t | (idle lanes: 0.0 to the pad slot), one store
+        // ---- [x_t; u_t] packed on 16 lanes -> one store (idle lanes: 0.0 to the pad slot) ---------------------------------
+        const double pk = (j == 0) ? xb[0] : (j == 1 ? xb[1] : (j == 2 ? xb[2] : (j == 3 ? u : 0.0)));
+        pxu[(long)t * sxu] = pk;
         // ---- tile of step t: approximate_model at (x_t, u_t)   (ileqg.jl:294-313) ---------------------
         if (lq) {
             // f_x = A + diag(3 kappa x^2) | f_u = B: the diagonal element of row 4 r + g sits on lane (g, 4 r + g), which holds x_{4r+g}
@@ -792,13 +793,15 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
             t2[64 + l] = make_double2(z2, cq0);
             t2[128 + l] = make_double2(cq1, cq2);
             tp[TS_R6 + l] = cpr;
-            d4 cx = MFMA(xb[0], cf[0], zero4);                      // [c_x | c_u] = C [x;u] + [qv;rv]
-            cx = MFMA(xb[1], cf[1], cx);
-            cx = MFMA(xb[2], cf[2], cx);
-            cx = MFMA(u, cf[3], cx);
-            const double acc = cx[0];
-            const double part = row_sum16(xuj * (0.5 * acc + clin));    // every 16-lane row holds the same sum
-            tp[TS_QR + lx] = (l < 16) ? acc + clin : (l == 16 ? part + cq00 : 0.0);   // [c_x | c_u], c, pad
+            d4 cx = MFMA(cf[0], xb[0], zero4);                      // C [x;u] in B-form
+            cx = MFMA(cf[1], xb[1], cx);
+            cx = MFMA(cf[2], xb[2], cx);
+            cx = MFMA(cf[3], u, cx);
+            const double acc = (j == 0) ? cx[0] : (j == 1 ? cx[1] : (j == 2 ? cx[2] : cx[3]));      // packed (lanes j < 4)
+            // c = [x;u]' (1/2 C [x;u] + lin) + q0  (:296): 16 packed terms, summed per row and then over the four rows
+            const double w = row_sum16((j < 4) ? pk * (0.5 * acc + clin) : 0.0);
+            const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
+            tp[qoff] = (j < 4) ? acc + clin : (l == 4 ? part + cq00 : 0.0);   // [c_x | c_u] = C [x;u] + [qv;rv]  (:297,:299), c, pad
         } else {
             // power-law family (n == m <= 4): every derivative is diagonal, and row g's entries sit on the lanes of row g
             double val = 0.0, cv = 0.0;
@@ -817,17 +820,16 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
                 if (j == 12 + g) rv = (g < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(u, pb.pl_pu - 2.0, dom) : 1.0;
                 tp[TS_R6 + l] = rv;
             }
-            double part = 0.0, qv = 0.0;
-            if (l < pb.n) {
-                qv = pb.pl_cx * pb.pl_p * powchk(xuj, pb.pl_p - 1.0, dom);
-                part = pb.pl_cx * powchk(xuj, pb.pl_p, dom);
-            } else if (l >= 12 && l - 12 < pb.m) {
-                qv = pb.pl_cu * pb.pl_pu * powchk(xuj, pb.pl_pu - 1.0, dom);
-                part = pb.pl_cu * powchk(xuj, pb.pl_pu, dom);
+            double part = 0.0, qv = 0.0;                            // packed: x_g on lane (g, 0), u_g on lane (g, 3)
+            if (j == 0 && g < pb.n) {
+                qv = pb.pl_cx * pb.pl_p * powchk(pk, pb.pl_p - 1.0, dom);
+                part = pb.pl_cx * powchk(pk, pb.pl_p, dom);
+            } else if (j == 3 && g < pb.m) {
+                qv = pb.pl_cu * pb.pl_pu * powchk(pk, pb.pl_pu - 1.0, dom);
+                part = pb.pl_cu * powchk(pk, pb.pl_pu, dom);
             }
-            if (l >= 16) part = 0.0;
             part = wave_sum(part);
-            tp[TS_QR + lx] = (l < 16) ? qv : (l == 16 ? part : 0.0);
+            tp[qoff] = (j < 4) ? qv : (l == 4 ? part : 0.0);
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) xb[r] = xn[r];
