@@ -40,6 +40,7 @@ struct rat_handle_s {
     bool dual = false;               // RATILQR_DUAL=1: fused evaluation + next-gain-sweep wavefronts (E = 1 only)
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
     bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
+    bool fused_dual = true;          // ... with policy evaluation + following gain sweep paired in one pass (RATILQR_FUSED_DUAL=0: separate)
     rat_ileqg_opts opts;
     OptsDev opd;
     int Bmax = 0, E = 1;
@@ -120,6 +121,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_DUAL")) h->dual = (e[0] == '1') && spec_eps == 1;
     if (const char *e = getenv("RATILQR_FUSED")) h->fused = (e[0] != '0');
     if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
+    if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
     HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
     for (int i = 0; i < CTR_RING; ++i) HIPCHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
     memset(&h->st, 0, sizeof(h->st));
@@ -471,6 +473,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
         fa.sw = sweep_args(h, st, 0);
         fa.ro = ra;
         fa.max_rounds = (int)std::min<int64_t>(((int64_t)h->opd.iter_max + 1) * 4002, 2000000000);
+        fa.dual = h->fused_dual ? 1 : 0;
         prof_begin(h, RAT_K_SOLVE_FUSED, B); launch_solve_fused(fa, h->stream); prof_end(h);
         return RAT_OK;
     }

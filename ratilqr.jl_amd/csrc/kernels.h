@@ -32,6 +32,7 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     SweepArgs sw;          // st / pb / op of the batch (mode is set per phase on the device)
     RolloutArgs ro;
     int max_rounds;        // guard on phases per sample
+    int dual;              // pair each policy evaluation with the gain sweep that would follow it (sweep_dual_body)
 };
 
 struct LinArgs {

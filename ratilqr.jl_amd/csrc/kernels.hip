@@ -28,6 +28,7 @@
 #include "kernels.h"
 
 #include "device_utils.h"
+#include "sweep_dual.h"
 
 #ifndef ROLLIN_PREFETCH
 #define ROLLIN_PREFETCH 5          /* rotating operand sets of rollin_body: prefetch distance ROLLIN_PREFETCH - 1 steps */
@@ -68,7 +69,10 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
 // trajectory, solve_fused_kernel calls it as one phase of a sample's complete solve.
 template <bool GAIN, bool DUMP, bool WTV, bool HASL>
 __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
-    const int l_ = threadIdx.x, g_ = l_ >> 4, j_ = l_ & 15;
+    int lane_ = threadIdx.x;
+    asm volatile("" : "+v"(lane_));      // opaque per phase: keeps the per-lane constants of one phase from being shared with
+                                         // (and kept live across) the other phases inlined into solve_fused_kernel
+    const int l_ = lane_, g_ = l_ >> 4, j_ = l_ & 15;
     const int l = l_, g = g_, j = j_;
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
@@ -619,7 +623,9 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // a path-dependent number of loads between the prefetch and the tile stores and collapse every counted vmcnt wait.
 template <int MODEL, int MODE, bool CTV>
 __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
-    const int l = threadIdx.x, j = l & 15, g = l >> 4;
+    int lane_ = threadIdx.x;
+    asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
+    const int l = lane_, j = l & 15, g = l >> 4;
 #ifdef RAT_DIAG
     const unsigned long long dg_entry = __builtin_readcyclecounter();
     unsigned long long dg_loop0 = 0;
@@ -1087,11 +1093,14 @@ __device__ __forceinline__ bool commit_spec(const StateDev &st, int b) {
 }
 
 // after initialize!: samples that survived the open-loop sweep start step! number 1 with the speculative gains
+__device__ __forceinline__ void commit_init_body(const StateDev &st, const int b) {
+    if (st.status[b] != ST_RUNNING) { st.spec_st[b] = 0; return; }
+    if (st.spec_st[b] != 0) commit_spec(st, b);
+}
 __global__ void commit_init_kernel(StateDev st) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= st.B) return;
-    if (st.status[b] != ST_RUNNING) { st.spec_st[b] = 0; return; }
-    if (st.spec_st[b] != 0) commit_spec(st, b);
+    commit_init_body(st, b);
 }
 void launch_commit_init(const StateDev &st, hipStream_t s) {
     hipLaunchKernelGGL(commit_init_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st);
@@ -1190,6 +1199,7 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
 // =====================================================================================================
 #define PHASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
 __device__ __forceinline__ int uniform_load(const int *p) { return __builtin_amdgcn_readfirstlane(__atomic_load_n(p, __ATOMIC_RELAXED)); }
+__device__ __forceinline__ double uniform_load_f64(const double *p) { return readlane_f64(*(const volatile double *)p, 0); }
 
 #ifdef RAT_DIAG_PHASES
 #define PHASE_MARK() do { if (threadIdx.x == 0 && blockIdx.x < 8 && fa.sw.dump && dg_pi < 40) \
@@ -1198,7 +1208,13 @@ __device__ __forceinline__ int uniform_load(const int *p) { return __builtin_amd
 #define PHASE_MARK() do {} while (0)
 #endif
 
-template <int MODEL, bool CTV, bool WTV>
+// DUALF: where the next step!'s gain sweep reads the very tiles a policy evaluation is about to read -- initialize!'s sweep and the
+// first step!, a line-search candidate and the step! that follows its acceptance -- ONE pass runs both recursions in the wave
+// (sweep_dual_body: two independent dependency chains interleaved in one basic block, tiles read once; every expression is the one
+// of the separate sweeps, so results are bit-identical).  The gains of the second recursion are committed by the accept rule
+// (commit_spec) or dropped.  A candidate whose acceptance would END the solve (d < d_tol with mu at its floor, or iter_max) gets the
+// plain policy evaluation: nothing would consume the gains.
+template <int MODEL, bool CTV, bool WTV, bool DUALF>
 __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
     const int b = blockIdx.x;
     const StateDev &st = fa.sw.st;
@@ -1212,11 +1228,21 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
         PHASE_MARK();
         PHASE_FENCE();
         PHASE_MARK();
-        SweepArgs sa = fa.sw; sa.mode = 2;
-        sweep_body<false, false, WTV, false>(sa, b);
-        PHASE_MARK();
-        PHASE_FENCE();
-        PHASE_MARK();
+        if (DUALF) {
+            SweepArgs sa = fa.sw; sa.mode = 6;
+            sweep_dual_body<WTV>(sa, b);
+            PHASE_MARK();
+            PHASE_FENCE();
+            if (threadIdx.x == 0) commit_init_body(st, b);
+            PHASE_FENCE();
+            PHASE_MARK();
+        } else {
+            SweepArgs sa = fa.sw; sa.mode = 2;
+            sweep_body<false, false, WTV, false>(sa, b);
+            PHASE_MARK();
+            PHASE_FENCE();
+            PHASE_MARK();
+        }
     }
     for (int guard = 0; guard < fa.max_rounds; ++guard) {
         if (uniform_load(&st.status[b]) != ST_RUNNING) break;
@@ -1234,8 +1260,19 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
-            SweepArgs sa = fa.sw; sa.mode = 1;
-            sweep_body<false, false, WTV, true>(sa, b);
+            bool pair = DUALF;
+            if (DUALF) {                                     // would accepting this candidate end solve!?  (ileqg.jl:642-653)
+                const double dc = uniform_load_f64(&st.d_c[b]), mu = uniform_load_f64(&st.mu[b]);
+                const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || uniform_load(&st.iter[b]) == fa.sw.op.iter_max;
+                pair = !ends;
+            }
+            if (pair) {
+                SweepArgs sa = fa.sw; sa.mode = 7;
+                sweep_dual_body<WTV>(sa, b);
+            } else {
+                SweepArgs sa = fa.sw; sa.mode = 1;
+                sweep_body<false, false, WTV, true>(sa, b);
+            }
             PHASE_MARK();
             PHASE_FENCE();
             if (threadIdx.x == 0) ls_select_body(st, fa.sw.op, b, nullptr);
@@ -1250,7 +1287,8 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
     if (B <= 0) return;
     const dim3 grid(B), block(64);
     const bool wtv = fa.sw.pb.W_tv != 0;
-#define FUSED_LAUNCH(M, C, W) hipLaunchKernelGGL((solve_fused_kernel<M, C, W>), grid, block, 0, s, fa)
+#define FUSED_LAUNCH(M, C, W) do { if (fa.dual) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true>), grid, block, 0, s, fa); \
+                                   else hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.model == 1) {
         if (fa.sw.pb.cost_tv) { if (wtv) FUSED_LAUNCH(1, true, true); else FUSED_LAUNCH(1, true, false); }
         else { if (wtv) FUSED_LAUNCH(1, false, true); else FUSED_LAUNCH(1, false, false); }

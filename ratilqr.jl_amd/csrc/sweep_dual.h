@@ -1,0 +1,288 @@
+// sweep_dual.h -- TWO independent Riccati recursions per wavefront over ONE pass through a trajectory's tiles.
+//
+//   recursion A : policy evaluation            solve_approximate_dp   (ileqg.jl:412-465)
+//                   mode 6: initialize!'s open-loop sweep (L = 0, mu = 0)          (ileqg.jl:234)
+//                   mode 7: line-search candidate 0 under the current gains         (ileqg.jl:522-528)
+//   recursion B : the gain sweep the NEXT step! will run on these very tiles        solve_approximate_dp!  (ileqg.jl:341-406)
+//                   (step! re-linearises the accepted trajectory, App. B.1: if candidate 0 is accepted -- or, in mode 6, if
+//                   initialize! succeeds -- B's gains, mu, Delta are exactly what the reference computes next; otherwise they are
+//                   discarded by ls_select_kernel / commit_init_kernel).  Its output goes to the idle half of the gain buffers.
+//
+// Why: at E = 1 a sweep kernel runs one wave per SIMD and that wave is idle ~45 % of its cycles waiting on its own serial
+// pivot chain (profiles/r01_pmc_sq_E1.md).  Two waves per SIMD overlapped poorly; two recursions inside ONE wave give the
+// compiler two independent dependency chains to interleave in a single basic block, and the tiles are read once for both.
+// Every arithmetic expression is the one of sweep_kernel, so results are bit-identical to the unfused order (tested).
+//
+// B has no mu-restart loop here: if H is not PD (or M is not PD) B is abandoned (spec_st = 0 / 2) and A continues; the plain
+// gain sweep then runs for that sample in the next round, restarts included.
+#pragma once
+#include "device_utils.h"
+#include "kernels.h"
+#include "layout.h"
+
+struct DTile {
+    d4 z, c, lc;
+    double x, la;          // x: lanes 0..15 = qr, lane 16 = q (register-image record, layout.h)
+};
+
+__device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, int lx, int l, int j,
+                                      const double *__restrict__ Lp, double mL, int g) {
+    const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
+    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = t2[128 + l];
+    tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
+    tr.c[0] = w1.y; tr.c[1] = w2.x; tr.c[2] = w2.y;
+    tr.c[3] = tp[TS_R6 + l];
+    tr.x = tp[TS_QR + lx];
+    const int jc = (j < 12) ? j : 11;
+    tr.lc[0] = Lp[jc] * mL;
+    tr.lc[1] = Lp[12 + jc] * mL;
+    tr.lc[2] = Lp[24 + jc] * mL;
+    tr.lc[3] = Lp[36 + jc] * mL;
+    tr.la = Lp[g * 12 + jc] * mL;
+}
+
+// one 2x2-block round of the symmetric sweep (see sweep_kernel) for BOTH recursions under a single fence: the two row
+// exchanges are issued back to back, so the two pivot chains (readlane -> adjugate -> rcp -> update) interleave.
+// Straight-line: the row exchange is an unconditional store to a per-lane offset (non-owner lanes hit a private dummy slot).
+template <int KB>
+__device__ __forceinline__ void elim_round2(d4 &mA, d4 &mB, double *__restrict__ rbA, double *__restrict__ rbB, int woff,
+                                            double cmk, double crmk, double wak, int j, int g, double ep,
+                                            double &pdA, double &nsA, double &rprodA, double &pdB, double &nsB, double &rprodB) {
+    constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;
+    const double pA11 = readlane_f64(mA[kr], kg * 16 + k), pB11 = readlane_f64(mB[kr], kg * 16 + k);
+    const double pA12 = readlane_f64(mA[kr], kg * 16 + k + 1), pB12 = readlane_f64(mB[kr], kg * 16 + k + 1);
+    const double pA22 = readlane_f64(mA[kr], (kg + 1) * 16 + k + 1), pB22 = readlane_f64(mB[kr], (kg + 1) * 16 + k + 1);
+    rbA[woff] = fma(mA[kr], cmk, wak);
+    rbB[woff] = fma(mB[kr], cmk, wak);
+    const double detA = fma(pA11, pA22, -(pA12 * pA12)), detB = fma(pB11, pB22, -(pB12 * pB12));
+    const double idA = fast_rcp1(detA), idB = fast_rcp1(detB);
+    WAVE_SYNC();
+    const double *__restrict__ a0 = rbA + (KB & 1) * 32, *__restrict__ a1 = a0 + 16;
+    const double *__restrict__ b0 = rbB + (KB & 1) * 32, *__restrict__ b1 = b0 + 16;
+    const double vA1 = a0[j], vA2 = a1[j], vB1 = b0[j], vB2 = b1[j];
+    const double aA10 = a0[g], aA20 = a1[g], aA11 = a0[4 + g], aA21 = a1[4 + g], aA12 = a0[8 + g], aA22 = a1[8 + g];
+    const double aB10 = b0[g], aB20 = b1[g], aB11 = b0[4 + g], aB21 = b1[4 + g], aB12 = b0[8 + g], aB22 = b1[8 + g];
+    pdA = fmin(pdA, fmin(pA11, detA)); pdB = fmin(pdB, fmin(pB11, detB));
+    nsA += detA; nsB += detB;
+    rprodA *= detA * ep; rprodB *= detB * ep;
+    const double uA1 = fma(pA22, vA1, -(pA12 * vA2)) * idA, uA2 = fma(pA11, vA2, -(pA12 * vA1)) * idA;
+    const double uB1 = fma(pB22, vB1, -(pB12 * vB2)) * idB, uB2 = fma(pB11, vB2, -(pB12 * vB1)) * idB;
+    const double k0 = (kr == 0 ? crmk : cmk), k1 = (kr == 1 ? crmk : cmk), k2 = (kr == 2 ? crmk : cmk);
+    mA[0] = fma(-aA20, uA2, fma(-aA10, uA1, mA[0] * k0)); mB[0] = fma(-aB20, uB2, fma(-aB10, uB1, mB[0] * k0));
+    mA[1] = fma(-aA21, uA2, fma(-aA11, uA1, mA[1] * k1)); mB[1] = fma(-aB21, uB2, fma(-aB11, uB1, mB[1] * k1));
+    mA[2] = fma(-aA22, uA2, fma(-aA12, uA1, mA[2] * k2)); mB[2] = fma(-aB22, uB2, fma(-aB12, uB1, mB[2] * k2));
+}
+
+template <bool WTV>
+__device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b) {
+    int lane_ = threadIdx.x;
+    asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
+    const int l_ = lane_, g_ = l_ >> 4, j_ = l_ & 15;
+    const int l = l_, g = g_, j = j_;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    int slot, cidx = -1;
+    if (a.mode == 7) {
+        if (!st.ls_active[b]) return;
+        cidx = b * st.E;
+        if (st.flag_c[cidx] == 2) return;
+        slot = cand_slot(b, 0, st.slot_nom[b], st.E);
+    } else {
+        if (st.status[b] != ST_RUNNING) return;
+        slot = b * (st.E + 1) + st.slot_nom[b];
+    }
+    const double theta = st.theta[b];
+    const double muA = (a.mode == 6) ? 0.0 : st.mu[b];
+    const double muB = st.mu[b];                              // initialize! leaves mu = 0 (set by init_state_kernel)
+    const int N = st.N;
+    const double *__restrict__ tile0 = st.tiles + (long)slot * st.tile_stride;
+    const int sel = st.lsel[b];
+    const double *__restrict__ Lb = st.L + (long)sel * st.l_half + (long)b * N * LSTR;
+    double *__restrict__ Lout = st.L + (long)(sel ^ 1) * st.l_half + (long)b * N * LSTR;
+    double *__restrict__ dlout = st.dl + (long)(sel ^ 1) * st.dl_half + (long)b * N * USTR;
+
+    __shared__ double rbA[2 * 2 * 16 + 64], rbB[2 * 2 * 16 + 64];       // row exchange (+ 64 private dummy slots)
+    __shared__ double exA[104], exB[104];                              // [G|H] 4x16, f 16, [80] = 0, [84..99] = s_vec
+    if (l < 8) { exA[80 + l] = 0.0; exB[80 + l] = 0.0; }
+
+    const double mL = (a.mode == 7 && j < 12) ? 1.0 : 0.0;
+    const double m12 = (j < 12) ? 1.0 : 0.0;
+    const double nth12 = -theta * m12;
+    const double mA_ = (g == 0 && j < 12) ? 1.0 : 0.0, mB_ = (g == 0 && j == 12) ? 1.0 : 0.0, mH = (j == 12 + g) ? 1.0 : 0.0;
+    double cm[6], crm[6], wa[6];
+    int woff[6];
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb) {
+        const int k = 2 * kb, kg = k & 3;
+        const bool colk = (j == k) || (j == k + 1), rowk = (g == kg) || (g == kg + 1);
+        cm[kb] = colk ? 0.0 : 1.0;
+        crm[kb] = (colk || rowk) ? 0.0 : 1.0;
+        wa[kb] = (j == k + (g - kg)) ? -1.0 : 0.0;
+        woff[kb] = rowk ? ((kb & 1) * 32 + (g - kg) * 16 + j) : (64 + l);
+    }
+    int hoff[4], foff[3], goff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        hoff[k] = (g <= k) ? (g * 16 + 12 + k) : (k * 16 + 12 + g);
+        goff[k] = (j < 12) ? (k * 16 + j) : (j == 12 ? 64 + 12 + k : 80);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) foff[r] = (j == 12) ? (64 + 4 * r + g) : 80;
+    const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
+    const int lx = (l < 17) ? l : 17;
+
+    d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
+    double ep[6] = {1, 1, 1, 1, 1, 1};
+    if (!WTV) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { winv[r] = pb.Winv[64 * r + l]; wp[r] = pb.Wp[64 * r + l]; }
+#pragma unroll
+        for (int kb = 0; kb < 6; ++kb) ep[kb] = pb.epiv[2 * kb];
+    }
+    const double coef = (theta != 0.0) ? -1.0 / (2.0 * theta) : 0.0;
+
+    // terminal condition (ileqg.jl:352-354 / 429-431): both recursions start from the same V_N
+    d4 vA, vB;
+    {
+        const double *__restrict__ tt = tile0 + (long)N * TSTRIDE;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = 4 * r + g;
+            vA[r] = (j < 12) ? tt[TT_Q + i * 12 + j] : (j == 12 ? tt[TT_QV + i] : 0.0);
+        }
+        vA[3] = (g == 0) ? (j < 12 ? tt[TT_QV + j] : (j == 12 ? 2.0 * tt[TT_q] : 0.0)) : 0.0;
+        vB = vA;
+    }
+    double raccA = 0.0, raccB = 0.0, rprodA = 1.0, rprodB = 1.0;
+    int rexpA = 0, rexpB = 0;
+    int failA = 0, deadB = 0;        // deadB: 1 = H not PD (needs the restart loop of the plain kernel), 2 = M not PD
+
+    auto step = [&](const int t, const DTile &cur) -> int {
+        int l = l_, g = g_, j = j_;
+        asm volatile("" : "+v"(l), "+v"(g), "+v"(j));
+        if (WTV) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { winv[r] = pb.Winv[(long)t * 192 + 64 * r + l]; wp[r] = pb.Wp[(long)t * 192 + 64 * r + l]; }
+#pragma unroll
+            for (int kb = 0; kb < 6; ++kb) ep[kb] = pb.epiv[(long)t * 16 + 2 * kb];
+        }
+        const d4 xzA = mm3(vA, cur.z, (d4){0, 0, 0, 0});
+        const d4 xzB = mm3(vB, cur.z, (d4){0, 0, 0, 0});
+        d4 tmA, tmB;
+        if (theta != 0.0) {
+            if (g == 0) { exA[84 + j] = vA[3]; exB[84 + j] = vB[3]; }
+            d4 mA, mB;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { mA[r] = fma(nth12, vA[r], winv[r]); mB[r] = fma(nth12, vB[r], winv[r]); }
+            mA[3] = 0.0; mB[3] = 0.0;
+            double pdA = 1.0, nsA = 0.0, pdB = 1.0, nsB = 0.0;
+            elim_round2<0>(mA, mB, rbA, rbB, woff[0], cm[0], crm[0], wa[0], j, g, ep[0], pdA, nsA, rprodA, pdB, nsB, rprodB);
+            elim_round2<1>(mA, mB, rbA, rbB, woff[1], cm[1], crm[1], wa[1], j, g, ep[1], pdA, nsA, rprodA, pdB, nsB, rprodB);
+            elim_round2<2>(mA, mB, rbA, rbB, woff[2], cm[2], crm[2], wa[2], j, g, ep[2], pdA, nsA, rprodA, pdB, nsB, rprodB);
+            elim_round2<3>(mA, mB, rbA, rbB, woff[3], cm[3], crm[3], wa[3], j, g, ep[3], pdA, nsA, rprodA, pdB, nsB, rprodB);
+            elim_round2<4>(mA, mB, rbA, rbB, woff[4], cm[4], crm[4], wa[4], j, g, ep[4], pdA, nsA, rprodA, pdB, nsB, rprodB);
+            elim_round2<5>(mA, mB, rbA, rbB, woff[5], cm[5], crm[5], wa[5], j, g, ep[5], pdA, nsA, rprodA, pdB, nsB, rprodB);
+            if (!(pdA > 0.0) || !(nsA * 0.0 == 0.0)) { failA = 1; return 1; }       // @assert isposdef(M) (:440)
+            if (!deadB && (!(pdB > 0.0) || !(nsB * 0.0 == 0.0))) deadB = 2;         // @assert isposdef(M) (:366)
+            d4 minvA, minvB;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { minvA[r] = nth12 * mA[r]; minvB[r] = nth12 * mB[r]; }
+            minvA[3] = 0.0; minvB[3] = 0.0;
+            rexpA += __builtin_amdgcn_frexp_exp(rprodA); rprodA = __builtin_amdgcn_frexp_mant(rprodA);
+            rexpB += __builtin_amdgcn_frexp_exp(rprodB); rprodB = __builtin_amdgcn_frexp_mant(rprodB);
+            raccA += exA[84 + j] * (minvA[0] * exA[84 + g] + minvA[1] * exA[84 + 4 + g] + minvA[2] * exA[84 + 8 + g]);
+            raccB += exB[84 + j] * (minvB[0] * exB[84 + g] + minvB[1] * exB[84 + 4 + g] + minvB[2] * exB[84 + 8 + g]);
+            const d4 y2A = mm3(minvA, xzA, (d4){0, 0, 0, 0});
+            const d4 y2B = mm3(minvB, xzB, (d4){0, 0, 0, 0});
+            tmA = mm3(vA, y2A, xzA);
+            tmB = mm3(vB, y2B, xzB);
+        } else {
+            raccA += m12 * (wp[0] * vA[0] + wp[1] * vA[1] + wp[2] * vA[2]);
+            raccB += m12 * (wp[0] * vB[0] + wp[1] * vB[1] + wp[2] * vB[2]);
+            tmA = xzA; tmB = xzB;
+        }
+        d4 fA = mm3(cur.z, tmA, cur.c);
+        d4 fB = mm3(cur.z, tmB, cur.c);
+        const double ghA = fma(muA, mH, fA[3]), ghB = fma(muB, mH, fB[3]);
+        const double fvA = tmA[3] + cur.x, fvB = tmB[3] + cur.x;
+        exA[g * 16 + j] = ghA; exB[g * 16 + j] = ghB;
+        if (g == 0) { exA[64 + j] = fvA; exB[64 + j] = fvB; }
+        WAVE_SYNC();
+        // ---- A: given policy (:446-451) ----
+        const double hA0 = exA[hoff[0]], hA1 = exA[hoff[1]], hA2 = exA[hoff[2]], hA3 = exA[hoff[3]];
+        const double gaA = fma(ghA, m12, exA[gaoff]);
+        const double uaA = hA0 * cur.lc[0] + hA1 * cur.lc[1] + hA2 * cur.lc[2] + hA3 * cur.lc[3] + gaA;
+        // ---- B: optimal gains (:372-382) ----
+        const double hB0 = exB[hoff[0]], hB1 = exB[hoff[1]], hB2 = exB[hoff[2]], hB3 = exB[hoff[3]];
+        const double gaB = fma(ghB, m12, exB[gaoff]);
+        const double h00 = exB[12], h01 = exB[13], h02 = exB[14], h03 = exB[15];
+        const double h11 = exB[16 + 13], h12 = exB[16 + 14], h13 = exB[16 + 15];
+        const double h22 = exB[32 + 14], h23 = exB[32 + 15], h33 = exB[48 + 15];
+        const double g0 = exB[goff[0]], g1 = exB[goff[1]], g2 = exB[goff[2]], g3 = exB[goff[3]];
+        const double d0 = h00, i0 = fast_rcp(d0);
+        const double l10 = h01 * i0, l20 = h02 * i0, l30 = h03 * i0;
+        const double d1 = h11 - l10 * h01, i1 = fast_rcp(d1);
+        const double l21 = (h12 - l20 * h01) * i1, l31 = (h13 - l30 * h01) * i1;
+        const double d2 = h22 - l20 * h02 - l21 * (l21 * d1), i2 = fast_rcp(d2);
+        const double l32 = (h23 - l30 * h02 - l31 * (l21 * d1)) * i2;
+        const double d3 = h33 - l30 * h03 - l31 * (l31 * d1) - l32 * (l32 * d2), i3 = fast_rcp(d3);
+        if (!deadB && !(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) deadB = 1;    // !isposdef(H) (:372): left to the plain kernel
+        const double y0 = -g0;
+        const double y1 = -g1 - l10 * y0;
+        const double y2 = -g2 - l20 * y0 - l21 * y1;
+        const double y3 = -g3 - l30 * y0 - l31 * y1 - l32 * y2;
+        const double x3 = y3 * i3;
+        const double x2 = y2 * i2 - l32 * x3;
+        const double x1 = y1 * i1 - l21 * x2 - l31 * x3;
+        const double x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+        const double laB = (g == 0) ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
+        const double uaB = hB0 * x0 + hB1 * x1 + hB2 * x2 + hB3 * x3 + gaB;
+        if (j < 12) Lout[(long)t * LSTR + g * 12 + j] = laB;
+        else if (j == 12) dlout[(long)t * USTR + g] = laB;
+        d4 fxA, fxB;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { fxA[r] = fma(fA[r], m12, exA[foff[r]]); fxB[r] = fma(fB[r], m12, exB[foff[r]]); }
+        const double qc = readlane_f64(cur.x, 16);
+        fxA[3] = fma(fvA, mA_, (2.0 * qc + vA[3]) * mB_);
+        fxB[3] = fma(fvB, mA_, (2.0 * qc + vB[3]) * mB_);
+        d4 vnA = MFMA(cur.la, uaA, fxA);
+        d4 vnB = MFMA(laB, uaB, fxB);
+        vnA = MFMA(gaA, cur.la, vnA);
+        vnB = MFMA(gaB, laB, vnB);
+        vA = vnA; vB = vnB;
+        WAVE_SYNC();
+        return 0;
+    };
+
+    DTile ra, rb2;
+    dload(ra, tile0 + (long)(N - 1) * TSTRIDE, lx, l, j, Lb + (long)(N - 1) * LSTR, mL, g);
+    for (int t = N - 1; t >= 0; t -= 2) {
+        {
+            const int tn = (t > 0) ? t - 1 : 0;
+            dload(rb2, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
+        }
+        if (step(t, ra)) break;
+        if (t == 0) break;
+        {
+            const int tn = (t > 1) ? t - 2 : 0;
+            dload(ra, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
+        }
+        if (step(t - 1, rb2)) break;
+    }
+    const double totA = 0.5 * wave_sum(raccA) + ((theta != 0.0) ? coef * (log(rprodA) + (double)rexpA * 0.6931471805599453094) : 0.0);
+    (void)raccB; (void)rprodB; (void)rexpB;          // B's value s_1 is not used by step! (only L, dl, mu, Delta are)
+    if (l == 12) {
+        const double s0 = 0.5 * vA[3] + totA;
+        if (a.mode == 7) {
+            st.value_c[cidx] = s0;
+            st.flag_c[cidx] = failA ? 1 : 0;
+        } else {
+            st.value[b] = failA ? INFINITY : s0;
+            if (failA) st.status[b] = 1;                      // RAT_ST_M_NOT_PD_INIT
+        }
+        st.mu_spec[b] = muB;                                   // no restart happened: mu, Delta unchanged by the gain sweep
+        st.delta_spec[b] = st.delta[b];
+        st.spec_st[b] = (failA || deadB == 1) ? 0 : (deadB == 2 ? 2 : 1);
+    }
+}
+

@@ -309,8 +309,9 @@ def test_dual_sweep_wavefronts_are_result_identical(monkeypatch):
 
 
 def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
-    """Default for E = 1: one persistent wavefront per theta-sample runs the whole solve! in one launch.  It calls the same
-    device functions as the per-phase kernels of the round-based path (RATILQR_FUSED=0): every output must be bit-identical --
+    """Default for E = 1: one persistent wavefront per theta-sample runs the whole solve! in one launch, pairing each policy
+    evaluation with the gain sweep that would follow it (RATILQR_FUSED_DUAL=0: separate passes).  It calls the same device
+    functions as the per-phase kernels of the round-based path (RATILQR_FUSED=0): every output must be bit-identical --
     values, statuses (infeasible theta, mu divergence), iteration and line-search counts, trajectories, gains, eps history,
     on the LQ family (with cubic drift, time-varying cost and noise tables via the stress problems) and the power-law family."""
     prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
@@ -333,10 +334,14 @@ def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
         out += [r["L"], r["x"], r["l"], np.array([r["value"]]), np.asarray(r["eps_history"], dtype=float)]
         return out
 
-    fused = run_all()
+    fused = run_all()                                # default: fused, policy evaluation paired with the following gain sweep
+    monkeypatch.setenv("RATILQR_FUSED_DUAL", "0")
+    fused_plain = run_all()                          # fused, one recursion per pass
+    monkeypatch.delenv("RATILQR_FUSED_DUAL")
     monkeypatch.setenv("RATILQR_FUSED", "0")
-    rounds = run_all()
+    rounds = run_all()                               # one launch per phase
     monkeypatch.delenv("RATILQR_FUSED")
-    assert len(fused) == len(rounds)
-    for a, b in zip(fused, rounds):
+    assert len(fused) == len(rounds) == len(fused_plain)
+    for a, b, c in zip(fused, rounds, fused_plain):
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+        assert np.array_equal(np.asarray(a), np.asarray(c), equal_nan=True)

@@ -8,9 +8,15 @@ import numpy as np
 import ratilqr.jl_amd as rat
 prob, x0, u = rat.synthetic_lq_problem()
 ctx = rat.Context(prob, max_batch=1024, spec_eps=1)
-names = ["rollin0", "fence", "sweep init", "fence",
-         "gain 1", "fence", "rollin 1", "fence", "eval 1", "fence+select",
-         "gain 2", "fence", "rollin 2", "fence", "eval 2", "fence+select"]
+import sys as _sys
+DUAL = os.environ.get("RATILQR_FUSED_DUAL", "1") != "0"
+if DUAL:        # default: policy evaluation + following gain sweep paired in one pass
+    names = ["rollin0", "fence", "init eval + gain 1", "fence+commit",
+             "rollin 1", "fence", "eval 1 + gain 2", "fence+select", "rollin 2", "fence", "eval 2", "fence+select"]
+else:
+    names = ["rollin0", "fence", "sweep init", "fence",
+             "gain 1", "fence", "rollin 1", "fence", "eval 1", "fence+select",
+             "gain 2", "fence", "rollin 2", "fence", "eval 2", "fence+select"]
 for th in (0.0, 1.0):
     for _ in range(2):
         ctx.solve_batch(x0, u, np.full(1024, th))
