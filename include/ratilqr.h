@@ -138,6 +138,15 @@ rat_rc rat_rollout_feedback(rat_handle h, const double *xbar, const double *l, c
                             double *x_new, double *u_new, int32_t *domain_fail);
 /* integrate_cost(problem, x_array, u_array)                    ileqg.jl:115-124 */
 rat_rc rat_integrate_cost(rat_handle h, const double *x, const double *u, double *cost);
+/* simulate_dynamics(problem, x_0, u_array, rng)  ileqg.jl:44-55  (L == NULL: open loop, only the first column of x_nom is read) and
+ * simulate_dynamics(problem, x_array, l_array, L_array, rng)  ileqg.jl:94-109  (affine policy u_k = l_k + L_k (x_k - x_nom_k)):
+ * K independent Monte-Carlo rollouts x_{k+1} = f(x_k, u_k) + w_k, w_k ~ N(0, W(k)), drawn as chol_lower(W(k)) z_k (what
+ * rand(rng, MvNormal(0, W)) computes).  z: [n x N x K] injected standard-normal draws (column-major, rollout slowest) or NULL for the
+ * device generator (Philox4x32-10 keyed by seed; the reference's MersenneTwister stream is not reproducible).
+ * Outputs (any may be NULL): x_out [n x (N+1) x K], u_out [m x N x K], cost_out [K] = integrate_cost of each rollout
+ * (ileqg.jl:115-124; NaN where a rollout hit a DomainError), *domain_fail = 1 if any rollout did. */
+rat_rc rat_rollout_noisy(rat_handle h, const double *x_nom, const double *l, const double *L, int64_t K,
+                         const double *z, uint64_t seed, double *x_out, double *u_out, double *cost_out, int32_t *domain_fail);
 /* approximate_model(problem, u_array, x_array)                 ileqg.jl:258-322
  * -> q[N+1], qv[n*(N+1)], Q[n*n*(N+1)], r[m*N], R[m*m*N], P[m*n*N], A[n*n*N], B[n*m*N], W[n*n*N] */
 rat_rc rat_approximate_model(rat_handle h, const double *u, const double *x,

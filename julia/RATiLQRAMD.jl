@@ -106,6 +106,29 @@ function solve!(s::ILEQGSolver, problem::LQRiskSensitiveProblem, x_0::Vector{Flo
     return [x[:, t] for t in 1:N+1], [l[:, t] for t in 1:N], [L[:, :, t] for t in 1:N], value[], copy(s.ϵ_history)
 end
 
+"""
+simulate_dynamics(problem, x_0, u_array, rng) -- ileqg.jl:44-55 -- and simulate_dynamics(problem, x_array, l_array, L_array, rng)
+-- ileqg.jl:94-109, K Monte-Carlo rollouts per call.  `z` (n×N×K standard-normal draws, e.g. `randn(rng, n, N, K)`) keeps the
+caller's rng in charge of the noise; `z = nothing` uses the device generator keyed by `seed`.  Returns the K state arrays,
+(the K control arrays,) and the realised cost of every rollout (integrate_cost, ileqg.jl:115-124).
+"""
+function simulate_dynamics_noisy(s::ILEQGSolver, problem::LQRiskSensitiveProblem, x_nom, l_array::Vector{Vector{Float64}},
+                                 L_array::Union{Nothing,Vector{Matrix{Float64}}}=nothing; K::Integer=1, z=nothing, seed::UInt64=UInt64(0))
+    n, m = size(problem.B); N = problem.N
+    z === nothing || (K = size(z, 3))
+    xn = x_nom isa Vector{Float64} ? x_nom : reduce(hcat, x_nom)
+    l = reduce(hcat, l_array)
+    L = L_array === nothing ? C_NULL : cat(L_array...; dims=3)
+    x = Array{Float64}(undef, n, N + 1, K); u = Array{Float64}(undef, m, N, K); cost = Vector{Float64}(undef, K); dom = Ref(Int32(0))
+    check(ccall((:rat_rollout_noisy, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, UInt64, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}, Ref{Int32}),
+                s.h.ptr, xn, l, L, K, z === nothing ? C_NULL : z, seed, x, u, cost, dom))
+    dom[] != 0 && throw(DomainError(NaN, "simulate_dynamics"))
+    xs = [[x[:, t, k] for t in 1:N+1] for k in 1:K]
+    return L_array === nothing ? (xs, cost) : (xs, [[u[:, t, k] for t in 1:N] for k in 1:K], cost)
+end
+
 "CrossEntropyBilevelOptimizationSolver(; kwargs...) -- cross_entropy_bilevel_optimization.jl:70-127"
 mutable struct AMDCrossEntropyBilevelOptimizationSolver
     opts::IleqgOpts
@@ -155,5 +178,6 @@ function solve!(s::AMDCrossEntropyBilevelOptimizationSolver, problem::LQRiskSens
     return θ[], [x[:, t] for t in 1:N+1], [l[:, t] for t in 1:N], [L[:, :, t] for t in 1:N], val[], θmin[], θmax[]
 end
 
-export OptimalControlProblem, LQRiskSensitiveProblem, ILEQGSolver, AMDCrossEntropyBilevelOptimizationSolver, solve!, compute_cost
+export OptimalControlProblem, LQRiskSensitiveProblem, ILEQGSolver, AMDCrossEntropyBilevelOptimizationSolver, solve!, compute_cost,
+       simulate_dynamics_noisy
 end

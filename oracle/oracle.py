@@ -138,6 +138,18 @@ def simulate_feedback(P: Problem, xbar, l, L):
     return rc, xn, un
 
 
+def simulate_noisy(P: Problem, x_nom, l, L, z):
+    """K noisy rollouts (open loop if L is None); z has shape (K, N, n).  Returns rc, x (K, N+1, n), u (K, N, m), cost (K,)."""
+    z = np.ascontiguousarray(z, float)
+    K = z.shape[0]
+    x, u, cost = np.zeros((K, P.N + 1, P.n)), np.zeros((K, P.N, P.m)), np.zeros(K)
+    x_nom, l = np.ascontiguousarray(x_nom, float), np.ascontiguousarray(l, float)
+    Lc = _cm3(L) if L is not None else None
+    rc = lib().orc_simulate_noisy(C.byref(P.c), _p(x_nom), _p(l), _p(Lc) if Lc is not None else None, C.c_int64(K),
+                                  _p(z), _p(x), _p(u), _p(cost))
+    return rc, x, u, cost
+
+
 def integrate_cost(P: Problem, x, u):
     out = C.c_double()
     x, u = np.ascontiguousarray(x, float), np.ascontiguousarray(u, float)

@@ -255,6 +255,51 @@ int orc_simulate_feedback(const orc_problem *p, const double *xbar, const double
     }
     return 0;
 }
+static int chol_lower(int n, const double *A, double *Lo);
+/* simulate_dynamics with process noise -- ileqg.jl:44-55 (open loop, L == NULL) and :94-109 (affine feedback policy):
+ * K independent rollouts, x_{k+1} = f(x_k, u_k) + w_k, w_k ~ N(0, W(k)) drawn as chol_lower(W(k)) z_k from the injected
+ * standard-normal stream z [K][N][n] (Distributions.jl MvNormal sampling = unwhitening by the lower Cholesky factor; the
+ * reference's RNG stream itself is not reproducible: parity unpinned there).  x_nom is the nominal state array (only its first
+ * column is used in the open-loop form).  cost_out[k] = integrate_cost of rollout k (ileqg.jl:115-124).  Outputs may be NULL. */
+int orc_simulate_noisy(const orc_problem *p, const double *x_nom, const double *l, const double *L, int64_t K,
+                       const double *z, double *x_out, double *u_out, double *cost_out) {
+    const int n = p->n, m = p->m, N = p->N;
+    double *x = (double *)malloc(sizeof(double) * (size_t)n * (N + 1)), *u = (double *)malloc(sizeof(double) * (size_t)m * N);
+    double *Lc = (double *)malloc(sizeof(double) * (size_t)n * n * N), dx[MAXD];
+    int rc = 0;
+    for (int t = 0; t < N && !rc; ++t)
+        if (!chol_lower(n, tv(p->W, p->W_tv, t, (size_t)n * n), Lc + (size_t)t * n * n)) rc = ORC_ERR_DOMAIN;
+    for (int64_t k = 0; k < K && !rc; ++k) {
+        memcpy(x, x_nom, sizeof(double) * n);
+        for (int t = 0; t < N && !rc; ++t) {
+            const double *xt = x + (size_t)t * n;
+            double *ut = u + (size_t)t * m, *xn = x + (size_t)(t + 1) * n;
+            for (int i = 0; i < m; ++i) ut[i] = l[(size_t)t * m + i];
+            if (L) {
+                const double *Lt = L + (size_t)t * m * n;
+                for (int j = 0; j < n; ++j) dx[j] = xt[j] - x_nom[(size_t)t * n + j];
+                for (int i = 0; i < m; ++i) {
+                    double acc = 0.0;
+                    for (int j = 0; j < n; ++j) acc += Lt[IDX(i, j, m)] * dx[j];
+                    ut[i] = l[(size_t)t * m + i] + acc;
+                }
+            }
+            rc = model_f(p, xt, ut, xn);
+            const double *zt = z + ((size_t)k * N + t) * n, *Lw = Lc + (size_t)t * n * n;
+            for (int i = 0; i < n; ++i) {
+                double w = 0.0;
+                for (int j = 0; j <= i; ++j) w += Lw[IDX(i, j, n)] * zt[j];
+                xn[i] += w;
+            }
+        }
+        if (rc) break;
+        if (x_out) memcpy(x_out + (size_t)k * n * (N + 1), x, sizeof(double) * (size_t)n * (N + 1));
+        if (u_out) memcpy(u_out + (size_t)k * m * N, u, sizeof(double) * (size_t)m * N);
+        if (cost_out) rc = orc_integrate_cost(p, x, u, &cost_out[k]);
+    }
+    free(x); free(u); free(Lc);
+    return rc;
+}
 /* integrate_cost -- ileqg.jl:115-124 */
 int orc_integrate_cost(const orc_problem *p, const double *x, const double *u, double *cost) {
     double acc = 0.0, c;

@@ -82,6 +82,9 @@ int orc_simulate_feedback(const orc_problem *p, const double *xbar, const double
                           double *x_new, double *u_new);
 /* integrate_cost (ileqg.jl:115-124) */
 int orc_integrate_cost(const orc_problem *p, const double *x, const double *u, double *cost);
+/* Monte-Carlo rollouts under process noise (ileqg.jl:44-55, :94-109); z [K][N][n] injected N(0,1) draws; L == NULL: open loop */
+int orc_simulate_noisy(const orc_problem *p, const double *x_nom, const double *l, const double *L, int64_t K,
+                       const double *z, double *x_out, double *u_out, double *cost_out);
 
 /* ---- a6: approximate_model (ileqg.jl:258-322) ---------------------------------------
  * outputs (col-major, time slowest): q[N+1], qv[n*(N+1)], Q[n*n*(N+1)], r[m*N], R[m*m*N],

@@ -18,6 +18,7 @@ from .ileqg import (  # noqa: F401,E402
     ApproximationResult,
     DynamicProgrammingResult,
     simulate_dynamics,
+    simulate_dynamics_noisy,
     integrate_cost,
     approximate_model,
     solve_approximate_dp,

@@ -73,7 +73,7 @@ class NmSolver(C.Structure):
 EXPORTS = [
     "rat_version", "rat_last_error", "rat_default_ileqg_opts", "rat_create", "rat_destroy", "rat_set_ileqg_opts",
     "rat_problem_set", "rat_ileqg_solve_batch", "rat_set_initial", "rat_ileqg_solve_batch_dev", "rat_ileqg_solve",
-    "rat_rollout_open", "rat_rollout_feedback", "rat_integrate_cost", "rat_approximate_model", "rat_dp_gain_sweep",
+    "rat_rollout_open", "rat_rollout_feedback", "rat_rollout_noisy", "rat_integrate_cost", "rat_approximate_model", "rat_dp_gain_sweep",
     "rat_dp_policy_eval", "rat_ce_default", "rat_ce_initialize", "rat_ce_set_stream", "rat_ce_seed",
     "rat_ce_stream_pos", "rat_ce_get_positive_samples", "rat_ce_compute_cost", "rat_ce_begin_step", "rat_ce_draw",
     "rat_ce_update", "rat_ce_draw_stream", "rat_ce_step", "rat_ce_solve", "rat_nm_default", "rat_nm_initialize",

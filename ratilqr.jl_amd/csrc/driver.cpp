@@ -704,6 +704,82 @@ extern "C" rat_rc rat_rollout_feedback(rat_handle h, const double *xbar, const d
     return RAT_OK;
 }
 
+static bool host_chol_lower(int n, const double *A, double *Lo);
+
+// simulate_dynamics(problem, x_0 | x_array, u_array | (l_array, L_array), rng)  -- ileqg.jl:44-55, :94-109
+extern "C" rat_rc rat_rollout_noisy(rat_handle h, const double *x_nom, const double *l, const double *L, int64_t K,
+                                    const double *z, uint64_t seed, double *x_out, double *u_out, double *cost_out,
+                                    int32_t *domain_fail) {
+    if (!h || !x_nom || !l) return fail(RAT_ERR_ARG, "null");
+    if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
+    if (K < 1) return fail(RAT_ERR_ARG, "K must be positive");
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->n, m = h->m, N = h->N, Nw = h->W_tv ? N : 1;
+    // lower Cholesky factors of W(k) (MvNormal sampling unwhitens with them), padded to 12 x 16 row-major
+    std::vector<double> Lc((size_t)n * n), Wc((size_t)Nw * 192, 0.0);
+    for (int k = 0; k < Nw; ++k) {
+        if (!host_chol_lower(n, h->hW.data() + (size_t)k * n * n, Lc.data()))
+            return fail(RAT_ERR_ARG, "W(k) is not positive definite (MvNormal would throw)");
+        for (int i = 0; i < n; ++i) for (int jj = 0; jj <= i; ++jj) Wc[(size_t)k * 192 + i * 16 + jj] = Lc[i + n * jj];
+    }
+    std::vector<double> xp, up, Lp;
+    if (L) { pad_x(h, x_nom, xp); pad_L(h, L, Lp); }
+    else { xp.assign((size_t)(N + 1) * XSTR, 0.0); for (int i = 0; i < n; ++i) xp[i] = x_nom[i]; }
+    pad_u(h, l, up);
+    const int64_t chunk = std::min<int64_t>(K, 1 << 16);
+    double *d_wc = nullptr, *d_x = nullptr, *d_l = nullptr, *d_L = nullptr, *d_z = nullptr, *d_xo = nullptr, *d_uo = nullptr, *d_c = nullptr;
+    int *d_dom = nullptr;
+    auto freeall = [&]() { for (void *q : {(void *)d_wc, (void *)d_x, (void *)d_l, (void *)d_L, (void *)d_z, (void *)d_xo, (void *)d_uo, (void *)d_c, (void *)d_dom}) if (q) (void)hipFree(q); };
+#define NALLOC(ptr, count) do { if (hipMalloc((void **)&(ptr), (size_t)(count) * sizeof(*(ptr))) != hipSuccess) { freeall(); return fail(RAT_ERR_HIP, "hipMalloc failed"); } } while (0)
+    NALLOC(d_wc, Wc.size()); NALLOC(d_x, xp.size()); NALLOC(d_l, up.size());
+    if (L) NALLOC(d_L, Lp.size());
+    if (z) NALLOC(d_z, (size_t)chunk * N * n);
+    if (x_out) NALLOC(d_xo, (size_t)chunk * (N + 1) * XSTR);
+    if (u_out) NALLOC(d_uo, (size_t)chunk * N * USTR);
+    NALLOC(d_c, chunk); NALLOC(d_dom, chunk);
+#undef NALLOC
+    rat_rc rc = RAT_OK;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == RAT_OK) rc = fail(RAT_ERR_HIP, hipGetErrorString(e)); };
+    chk(hipMemcpy(d_wc, Wc.data(), Wc.size() * 8, hipMemcpyHostToDevice));
+    chk(hipMemcpy(d_x, xp.data(), xp.size() * 8, hipMemcpyHostToDevice));
+    chk(hipMemcpy(d_l, up.data(), up.size() * 8, hipMemcpyHostToDevice));
+    if (L) chk(hipMemcpy(d_L, Lp.data(), Lp.size() * 8, hipMemcpyHostToDevice));
+    std::vector<double> xo, uo, co((size_t)chunk);
+    std::vector<int> dm((size_t)chunk);
+    int any_dom = 0;
+    for (int64_t k0 = 0; k0 < K && rc == RAT_OK; k0 += chunk) {
+        const int64_t kc = std::min(chunk, K - k0);
+        if (z) chk(hipMemcpy(d_z, z + (size_t)k0 * N * n, (size_t)kc * N * n * 8, hipMemcpyHostToDevice));
+        NoisyArgs a;
+        a.pb = h->pb; a.Wchol = d_wc; a.xnom = d_x; a.l = d_l; a.L = d_L; a.K = (long)kc; a.z = d_z;
+        a.seed = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(k0 / chunk);       // distinct Philox keys per chunk
+        a.x_out = d_xo; a.u_out = d_uo; a.cost = d_c; a.dom = d_dom;
+        launch_noisy_rollout(a, h->stream);
+        chk(hipStreamSynchronize(h->stream));
+        chk(hipMemcpy(co.data(), d_c, (size_t)kc * 8, hipMemcpyDeviceToHost));
+        chk(hipMemcpy(dm.data(), d_dom, (size_t)kc * 4, hipMemcpyDeviceToHost));
+        for (int64_t q = 0; q < kc; ++q) {
+            any_dom |= dm[(size_t)q];
+            if (cost_out) cost_out[k0 + q] = dm[(size_t)q] ? NAN : co[(size_t)q];
+        }
+        if (x_out) {
+            xo.resize((size_t)kc * (N + 1) * XSTR);
+            chk(hipMemcpy(xo.data(), d_xo, xo.size() * 8, hipMemcpyDeviceToHost));
+            for (int64_t q = 0; q < kc; ++q) for (int t = 0; t <= N; ++t) for (int i = 0; i < n; ++i)
+                x_out[((size_t)(k0 + q) * (N + 1) + t) * n + i] = xo[((size_t)q * (N + 1) + t) * XSTR + i];
+        }
+        if (u_out) {
+            uo.resize((size_t)kc * N * USTR);
+            chk(hipMemcpy(uo.data(), d_uo, uo.size() * 8, hipMemcpyDeviceToHost));
+            for (int64_t q = 0; q < kc; ++q) for (int t = 0; t < N; ++t) for (int g = 0; g < m; ++g)
+                u_out[((size_t)(k0 + q) * N + t) * m + g] = uo[((size_t)q * N + t) * USTR + g];
+        }
+    }
+    freeall();
+    if (domain_fail) *domain_fail = any_dom;
+    return rc;
+}
+
 static rat_rc linearize_slot0(rat_handle h, const double *u, const double *x, std::vector<double> *tiles, int32_t *domain_fail) {
     StateDev st;
     rat_rc rc = op_prepare(h, 0.0, 0.0, h->opts.delta_0, &st);

@@ -60,6 +60,20 @@ struct PetsArgs {
 };
 void launch_pets(const PetsArgs &a, hipStream_t s);
 
+struct NoisyArgs {              // Monte-Carlo rollouts under process noise (simulate_dynamics with rng)
+    ProblemDev pb;
+    const double *Wchol;        // [Nw][12][16] lower Cholesky factors of W(k), row-major, zero padded
+    const double *xnom;         // [(N+1)][12] nominal states (open loop: only row 0 is used)
+    const double *l;            // [N][4]
+    const double *L;            // [N][4][12] or null (open loop)
+    long K;
+    const double *z;            // [K][N][n] injected N(0,1) draws or null (device Philox)
+    unsigned long long seed;
+    double *x_out, *u_out, *cost;   // [K][(N+1)][12], [K][N][4], [K]; any may be null
+    int *dom;                       // [K] DomainError flags or null
+};
+void launch_noisy_rollout(const NoisyArgs &a, hipStream_t s);
+
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s);
 void launch_rollout(const RolloutArgs &a, hipStream_t s);
 void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout + linearise (solver hot loop)

@@ -1416,6 +1416,102 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
     if (live && j == 0) a.traj_cost[tj] = cacc + part + g.q0f;
 }
 
+// =====================================================================================================
+// noisy_rollout_kernel: Monte-Carlo rollouts under process noise, x_{k+1} = f(x_k, u_k) + w_k, w_k ~ N(0, W(k)), open loop or under
+// the affine policy u_k = l_k + L_k (x_k - xbar_k)   (simulate_dynamics with rng, ileqg.jl:44-55 / :94-109), with the realised
+// cost of every rollout (integrate_cost, :115-124).  Four rollouts per wavefront (one per 16-lane row), lane j < 12 owns state j.
+// w_k = chol_lower(W(k)) z_k with z_k from an injected standard-normal stream (parity with the oracle) or Philox4x32-10.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void noisy_rollout_kernel(NoisyArgs a) {
+    const int row = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const ProblemDev &pb = a.pb;
+    const long k = (long)blockIdx.x * 4 + row;
+    const bool live = k < a.K;
+    const int N = pb.N, n = pb.n;
+    __shared__ double shdx[4][12], shxu[4][16], shz[4][16];
+    const int jx = (j < 12) ? j : 11, ju = j & 3;
+    const bool lq = (pb.model == 1);
+    double zr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zr[q] = lq ? pb.Zt[jx * 16 + q] : 0.0;
+    double x = (j < 12) ? a.xnom[j] : 0.0;
+    double cacc = 0.0;
+    int dom = 0;
+    for (int t = 0; t < N; ++t) {
+        const int kc = pb.cost_tv ? t : 0, kw = pb.W_tv ? t : 0;
+        if (live && j < 12 && a.x_out) a.x_out[(k * (N + 1) + t) * XSTR + j] = x;
+        double u = a.l[(long)t * USTR + ju];
+        if (a.L) {                                                   // L_t (x_t - xbar_t)   (:104)
+            if (j < 12) shdx[row][j] = x - a.xnom[(long)t * XSTR + j];
+            WAVE_SYNC();
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) acc = fma(a.L[(long)t * LSTR + ju * 12 + q], shdx[row][q], acc);
+            u += acc;
+        }
+        if (live && j < 4 && a.u_out) a.u_out[(k * N + t) * USTR + j] = u;
+        double z = 0.0;
+        if (a.z) { if (live && j < n) z = a.z[(k * N + t) * (long)n + j]; }
+        else {
+            unsigned r[4];
+            philox4x32_10((unsigned)k, (unsigned)(k >> 32), (unsigned)t, (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+            z = sqrt(-2.0 * log(1.0 - u01(r[0], r[1]))) * cos(6.283185307179586476925286766559 * u01(r[2], r[3]));
+        }
+        if (j < 12) shxu[row][j] = x;
+        if (j < 4) shxu[row][12 + j] = u;
+        shz[row][j] = (j < n) ? z : 0.0;
+        WAVE_SYNC();
+        double xn = 0.0, part = 0.0, q0 = 0.0;
+        if (lq) {
+            double acc = 0.0, dyn = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                acc = fma(pb.Ctab[(long)kc * 256 + j * 16 + q], shxu[row][q], acc);
+                dyn = fma(zr[q], shxu[row][q], dyn);
+            }
+            if (pb.kappa != 0.0) dyn += pb.kappa * (x * x * x);
+            xn = dyn;
+            const double xuj = (j < 12) ? x : u;
+            part = xuj * (0.5 * acc + pb.lin[(long)kc * 16 + j]);     // c = 1/2 xu' C xu + lin' xu + q0
+            q0 = pb.q0[kc];
+        } else {
+            if (j < n) {
+                xn = powchk(x, pb.pl_a, dom) + powchk(shxu[row][12 + ju], pb.pl_b, dom);
+                part = pb.pl_cx * powchk(x, pb.pl_p, dom) + pb.pl_cu * powchk(shxu[row][12 + ju], pb.pl_pu, dom);
+            }
+        }
+        cacc += row_sum16(part) + q0;
+        double w = 0.0;                                               // w_k = chol_lower(W(k)) z_k
+#pragma unroll
+        for (int q = 0; q < 12; ++q) w = fma(a.Wchol[(long)kw * 192 + jx * 16 + q], shz[row][q], w);
+        x = (j < n) ? xn + w : 0.0;
+        WAVE_SYNC();
+    }
+    if (live && j < 12 && a.x_out) a.x_out[(k * (N + 1) + N) * XSTR + j] = x;
+    // terminal cost h(x_N)
+    if (j < 12) shxu[row][j] = x;
+    WAVE_SYNC();
+    double hcost;
+    if (lq) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) acc = fma(pb.Qf[jx * 12 + q], shxu[row][q], acc);
+        hcost = row_sum16((j < 12) ? x * (0.5 * acc + pb.qvf[jx]) : 0.0) + pb.q0f;
+    } else {
+        hcost = pb.pl_h;
+    }
+    const unsigned long long bal = __ballot(dom != 0);
+    if (live && j == 0) {
+        if (a.cost) a.cost[k] = cacc + hcost;
+        if (a.dom) a.dom[k] = ((bal >> (row * 16)) & 0xFFFFull) != 0;
+    }
+}
+
+void launch_noisy_rollout(const NoisyArgs &a, hipStream_t s) {
+    if (a.K <= 0) return;
+    hipLaunchKernelGGL(noisy_rollout_kernel, dim3((unsigned)((a.K + 3) / 4)), dim3(64), 0, s, a);
+}
+
 // mean over the K rollouts of each control sample, summed in trajectory order (deterministic)   (pets.jl:150)
 __global__ void pets_mean_kernel(PetsArgs a) {
     const long ii = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -59,6 +59,22 @@ class Context:
             raise ArithmeticError("DomainError in simulate_dynamics")
         return xn, un
 
+    def rollout_noisy(self, x_nom, l, L=None, K=None, z=None, seed=0, want_x=True, want_u=True):
+        """K Monte-Carlo rollouts under process noise w ~ N(0, W(k)) (ileqg.jl:44-55 open loop with L=None and x_nom = x_0,
+        :94-109 under the affine policy).  z: injected N(0,1) draws of shape (K, N, n), or None for the device generator.
+        Returns x (K, N+1, n), u (K, N, m), cost (K,) -- x/u are None when not wanted."""
+        if z is not None:
+            z = nv.f64(z)
+            K = z.shape[0]
+        K = int(K)
+        x = np.zeros((K, self.N + 1, self.n)) if want_x else None
+        u = np.zeros((K, self.N, self.m)) if want_u else None
+        cost = np.zeros(K)
+        dom = C.c_int32()
+        nv.check(nv.lib().rat_rollout_noisy(self.h, nv.P(nv.f64(x_nom)), nv.P(nv.f64(l)), nv.P(nv.cm3(L)) if L is not None else None,
+                                            C.c_int64(K), nv.P(z), C.c_uint64(int(seed)), nv.P(x), nv.P(u), nv.P(cost), C.byref(dom)))
+        return x, u, cost, bool(dom.value)
+
     def integrate_cost(self, x, u):
         out = C.c_double()
         nv.check(nv.lib().rat_integrate_cost(self.h, nv.P(nv.f64(x)), nv.P(nv.f64(u)), C.byref(out)))
@@ -248,6 +264,17 @@ def simulate_dynamics(problem, a, b, c=None, f_returns_jacobian=False):
     if c is None:
         return ctx.rollout_open(a, b)
     return ctx.rollout_feedback(a, b, c)
+
+
+def simulate_dynamics_noisy(problem, a, b, c=None, K=1, z=None, seed=0):
+    """The rng methods of simulate_dynamics, K rollouts at once: simulate_dynamics(problem, x_0, u_array, rng) (ileqg.jl:44-55)
+    or simulate_dynamics(problem, x_array, l_array, L_array, rng) (ileqg.jl:94-109).  The rng is an injected standard-normal
+    array z of shape (K, N, n) or a seed of the device generator.  Returns (x, cost) or (x, u, cost), rollout index first."""
+    ctx = _ctx(problem)
+    x, u, cost, dom = ctx.rollout_noisy(a, b, c, K=K, z=z, seed=seed)
+    if dom:
+        raise ArithmeticError("DomainError in simulate_dynamics")
+    return (x, cost) if c is None else (x, u, cost)
 
 
 def integrate_cost(problem, x_array, u_array):          # ileqg.jl:115-124

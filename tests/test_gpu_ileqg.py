@@ -204,3 +204,58 @@ def test_infeasible_theta_raises_like_the_reference():
     with pytest.raises(AssertionError):
         rat.solve_(s, prob, x0, u, theta=50.0)
     assert s.status == rat.native.ST_M_NOT_PD_INIT
+
+
+# ---- simulate_dynamics with process noise (ileqg.jl:44-55, :94-109): SURVEY section 8f #4 ---------------------------------------
+def _noisy_problems():
+    rng = np.random.default_rng(3)
+    n, m, Nn = 12, 4, 20
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    G = rng.standard_normal((Nn, n, n))
+    Wtv = 1e-2 * (np.einsum("tij,tkj->tik", G, G) / n + np.eye(n))           # time-varying dense SPD covariances
+    lq = rat.LQRiskSensitiveProblem(0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), Q=np.eye(n), R=0.1 * np.eye(m),
+                                    P=0.05 * rng.standard_normal((m, n)), N=Nn, W=Wtv, Qf=np.eye(n), kappa=0.02,
+                                    qv=0.1 * rng.standard_normal(n), rv=0.1 * rng.standard_normal(m), q0=0.3)
+    small = rat.LQRiskSensitiveProblem(np.eye(2), np.eye(2), Q=np.eye(2), R=2 * np.eye(2), P=np.eye(2), N=N, W=np.array([[2.0, 0.6], [0.6, 1.0]]),
+                                       Qf=np.eye(2))
+    return (lq, rng.standard_normal(n), 0.1 * rng.standard_normal((Nn, m)), 0.2 * rng.standard_normal((Nn, m, n))), \
+           (small, np.array([0.5, -1.0]), np.ones((N, 2)), 0.3 * np.ones((N, 2, 2)))
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_noisy_rollouts_match_the_oracle_on_injected_noise(which):
+    prob, x0, l, L = _noisy_problems()[which]
+    P = orc.Problem(prob)
+    K = 37                                                          # ragged: not a multiple of the 4 rollouts per wavefront
+    z = np.random.default_rng(11).standard_normal((K, prob.N, prob.n))
+    # open loop: simulate_dynamics(problem, x_0, u_array, rng)
+    x, cost = rat.simulate_dynamics_noisy(prob, x0, l, z=z)
+    rc, xo, uo, co = orc.simulate_noisy(P, x0, l, None, z)
+    assert rc == 0 and rel(x, xo) < 1e-12 and rel(cost, co) < 1e-12
+    assert np.all(x[:, 0] == x0)
+    # zero noise reproduces the deterministic rollout and integrate_cost exactly
+    x_det = rat.simulate_dynamics(prob, x0, l)
+    xz, cz = rat.simulate_dynamics_noisy(prob, x0, l, z=np.zeros((3, prob.N, prob.n)))
+    assert rel(xz[0], x_det) < 1e-14 and abs(cz[0] - rat.integrate_cost(prob, x_det, l)) <= 1e-12 * abs(cz[0])
+    # affine policy around the nominal trajectory: simulate_dynamics(problem, x_array, l_array, L_array, rng)
+    x2, u2, c2 = rat.simulate_dynamics_noisy(prob, x_det, l, L, z=z)
+    rc, xo2, uo2, co2 = orc.simulate_noisy(P, x_det, l, L, z)
+    assert rc == 0 and rel(x2, xo2) < 1e-12 and rel(u2, uo2) < 1e-12 and rel(c2, co2) < 1e-12
+    for k in (0, K - 1):                                            # the realised cost is integrate_cost of the realised trajectory
+        assert abs(c2[k] - rat.integrate_cost(prob, x2[k], u2[k])) <= 1e-12 * abs(c2[k])
+        for t in range(prob.N):
+            assert np.allclose(u2[k, t], l[t] + L[t] @ (x2[k, t] - x_det[t]), rtol=1e-13, atol=1e-13)
+
+
+def test_noisy_rollouts_device_generator_has_the_right_moments():
+    prob, x0, l, L = _noisy_problems()[1]                           # f = x + u, W = [[2, .6], [.6, 1]]
+    K = 40000
+    x, cost = rat.simulate_dynamics_noisy(prob, x0, l, K=K, seed=7)
+    w = x[:, 1:] - (x[:, :-1] + l[None])                            # realised noise of every step: w_k = x_{k+1} - f(x_k, u_k)
+    w = w.reshape(-1, 2)
+    assert np.all(np.abs(w.mean(0)) < 0.01)
+    assert np.allclose(np.cov(w.T), prob.Wtab, atol=0.02)
+    x_b, cost_b = rat.simulate_dynamics_noisy(prob, x0, l, K=16, seed=7)
+    assert np.array_equal(x_b, x[:16])                              # counter-based: reproducible, independent of K
+    x_c, _ = rat.simulate_dynamics_noisy(prob, x0, l, K=16, seed=8)
+    assert not np.array_equal(x_c, x_b)

@@ -208,3 +208,30 @@ def test_infeasible_theta_is_reported_at_init():              # F6: open-loop sw
     assert np.all(np.isfinite(v[:3])) and np.all(st[:3] == 0) and np.all(it[:3] == 2) and np.all(ls[:3] == 2)
     assert np.isinf(v[3]) and st[3] == orc.ERR_M_NOT_PD_INIT
     assert v[0] < v[1] < v[2]
+
+
+def test_noisy_rollouts_of_the_oracle(base):                  # simulate_dynamics(..., rng)  ileqg.jl:44-55, :94-109
+    """The reference has no test of its rng rollouts; what can be pinned without Julia: with f = x + u and W = I the realised
+    noise is the injected draw itself, zero noise reproduces the deterministic methods, the feedback law is the stated one and
+    the cost of a rollout is integrate_cost of that rollout."""
+    prob, P, u, x = base
+    z = np.random.default_rng(5).standard_normal((9, N, 2))
+    rc, xn, un, cost = orc.simulate_noisy(P, np.zeros(2), u, None, z)
+    assert rc == 0 and np.all(un == u[None])
+    assert np.allclose(xn[:, 1:] - xn[:, :-1] - u[None], z, rtol=0, atol=1e-13)      # chol(I) = I: w_k = z_k
+    rc, x0n, _, c0 = orc.simulate_noisy(P, np.zeros(2), u, None, np.zeros((2, N, 2)))
+    assert rc == 0 and np.all(x0n[0] == x) and c0[0] == 46.0                          # == K1 / K2
+    Wd = np.array([[2.0, 0.6], [0.6, 1.0]])
+    prob2 = rat.LQRiskSensitiveProblem(np.eye(2), np.eye(2), Q=np.eye(2), R=2 * np.eye(2), P=np.eye(2), N=N, W=Wd, Qf=np.eye(2))
+    P2 = orc.Problem(prob2)
+    L = 0.3 * np.ones((N, 2, 2))
+    rc, xd = orc.simulate_open(P2, np.array([0.5, -1.0]), u)
+    rc, xf, uf, cf = orc.simulate_noisy(P2, xd, u, L, z)
+    assert rc == 0
+    Lc = np.linalg.cholesky(Wd)
+    for k in (0, 8):
+        for t in range(N):
+            assert np.allclose(uf[k, t], u[t] + L[t] @ (xf[k, t] - xd[t]), rtol=1e-14, atol=1e-14)
+            assert np.allclose(xf[k, t + 1], xf[k, t] + uf[k, t] + Lc @ z[k, t], rtol=1e-13, atol=1e-13)
+        rc, ck = orc.integrate_cost(P2, xf[k], uf[k])
+        assert ck == cf[k]
