@@ -70,6 +70,14 @@ __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base
 
 // Diagnostic build only (make diag): s_memtime stamps per segment of the time step; shares of one wave's cycles are
 // written to the dump buffer.  Never compiled into the product library.
+// Phase-timeline build only (make diagp): absolute cycle stamps at the entry / loop start / loop end / exit of the phase bodies
+#ifdef RAT_DIAG_PHASES
+#define BODY_MARK(dump_, slot_) do { if (threadIdx.x == 0 && blockIdx.x < 8 && (dump_)) \
+        (dump_)[640 + blockIdx.x * 32 + (slot_)] = (double)__builtin_readcyclecounter(); } while (0)
+#else
+#define BODY_MARK(dump_, slot_) do {} while (0)
+#endif
+
 #ifdef RAT_DIAG
 #define DIAG_DECL unsigned long long dg_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long dg_prev = 0, dg_gap = 0;
 #define DIAG_START() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \

@@ -33,6 +33,7 @@
 #ifndef ROLLIN_PREFETCH
 #define ROLLIN_PREFETCH 5          /* rotating operand sets of rollin_body: prefetch distance ROLLIN_PREFETCH - 1 steps */
 #endif
+#define ROLLIN_NST 52              /* longest horizon whose closed-loop operands are staged in LDS by the fused solve (28.5 KB) */
 
 // =====================================================================================================
 // sweep_kernel
@@ -76,6 +77,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     const int l = l_, g = g_, j = j_;
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
+    constexpr int dgs = (GAIN ? 0 : (HASL ? 4 : 8));
+    BODY_MARK(a.dump, dgs + 0);
     int b, slot, cidx = -1;
     if (a.mode == 1) {
         b = tid / st.E;
@@ -362,6 +365,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
         // unconditional (index clamped at 0) so that the loads stay in straight-line code and the compiler can wait
         // with a counted vmcnt(N) instead of vmcnt(0) at the join of a branch.
         TileRegs rb;
+        BODY_MARK(a.dump, dgs + 1);
         for (int t = N - 1; t >= 0; t -= 2) {
             {
                 const int tn = (t > 0) ? t - 1 : 0;
@@ -377,6 +381,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
             }
             if (step(t - 1, rb)) break;
         }
+        BODY_MARK(a.dump, dgs + 2);
         if (GAIN && h_not_pd) {
             // increase_mu_and_delta!  (ileqg.jl:471-474), then restart the whole sweep (:373-378)
             delta = fmax(a.op.delta_0, delta * a.op.delta_0);
@@ -420,6 +425,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
             if (a.op_out) { a.op_out[0] = s0; a.op_out[1] = (double)(fail ? (fail == 1 ? 2 : 5) : 0); }
         }
     }
+    BODY_MARK(a.dump, dgs + 3);
 #undef HBUF
 #undef FBUF
 #undef SVB
@@ -621,7 +627,9 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // =====================================================================================================
 // CTV: time-varying cost tables (LQ family).  A template parameter, not a branch: a conditional per-step table load would put
 // a path-dependent number of loads between the prefetch and the tile stores and collapse every counted vmcnt wait.
-template <int MODEL, int MODE, bool CTV>
+// STAGE (closed loop, N <= ROLLIN_NST): the operands of the whole trajectory -- L, xbar, l, dl: 27 KB -- are copied into LDS before the
+// time loop (57 loads in flight at once), so the loop issues no global loads at all and its tile stores never meet a vmcnt wait.
+template <int MODEL, int MODE, bool CTV, bool STAGE = false>
 __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     int lane_ = threadIdx.x;
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
@@ -633,6 +641,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
     const int N = st.N;
+    BODY_MARK(a.dump, 12 + 4 * MODE + 0);
     int b, k = 0;
     if (MODE == 0) { b = c; if (st.status[b] != ST_RUNNING) return; }
     else { b = c / st.E; k = c - b * st.E; if (!st.ls_active[b]) return; }
@@ -708,12 +717,42 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     constexpr int kStoresPerStep = 6;
     struct StepIn { double l, dl, xb[3], La[3]; };
     StepIn buf[RD];
+    constexpr bool staged = STAGE && MODE == 1;
+    constexpr int cL = (ROLLIN_NST * LSTR + 63) / 64, cX = ((ROLLIN_NST + 1) * XSTR + 63) / 64, cU = (ROLLIN_NST * USTR + 63) / 64;
+    __shared__ double stg[staged ? (cL + cX + 2 * cU) * 64 : 1];
+    double *const sL = stg, *const sX = stg + (staged ? cL * 64 : 0), *const sl = sX + (staged ? cX * 64 : 0), *const sdl = sl + (staged ? cU * 64 : 0);
+    if (staged) {
+        double tL[cL], tX[cX], tl[cU], tdl[cU];
+#pragma unroll
+        for (int q = 0; q < cL; ++q) { const int e = 64 * q + l; tL[q] = Lb[(e < N * LSTR) ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < cX; ++q) { const int e = 64 * q + l; tX[q] = xbar[(e < (N + 1) * XSTR) ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < cU; ++q) { const int e = 64 * q + l; tl[q] = lnom[(e < N * USTR) ? e : 0]; tdl[q] = dlb[(e < N * USTR) ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < cL; ++q) sL[64 * q + l] = tL[q];
+#pragma unroll
+        for (int q = 0; q < cX; ++q) sX[64 * q + l] = tX[q];
+#pragma unroll
+        for (int q = 0; q < cU; ++q) { sl[64 * q + l] = tl[q]; sdl[64 * q + l] = tdl[q]; }
+        WAVE_SYNC();
+    }
     auto issue = [&](StepIn &in, const int tq) {
         const int tn = (tq < N) ? tq : N - 1;
-        in.l = lnom[(long)tn * USTR + g];
         in.dl = 0.0;
 #pragma unroll
         for (int s = 0; s < 3; ++s) in.xb[s] = in.La[s] = 0.0;
+        if (staged) {
+            in.l = sl[tn * USTR + g];
+            in.dl = sdl[tn * USTR + g];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                in.xb[s] = sX[tn * XSTR + 4 * s + g];
+                in.La[s] = sL[tn * LSTR + j3 * 12 + 4 * s + g];
+            }
+            return;
+        }
+        in.l = lnom[(long)tn * USTR + g];
         if (MODE == 1) {
             in.dl = dlb[(long)tn * USTR + g];
 #pragma unroll
@@ -844,6 +883,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     // single-exit main loop over whole groups of RD steps (a second exit would put a path from the middle of the group
     // back to the loop header into the control-flow graph and cap the header's vmcnt at that path's count), then the tail
     int t0 = 0;
+    BODY_MARK(a.dump, 12 + 4 * MODE + 1);
     for (; t0 + RD <= N; t0 += RD) {
 #pragma unroll
         for (int d = 0; d < RD; ++d) {
@@ -862,6 +902,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
         a.dump[64 + blockIdx.x * 8 + 4] = (double)(__builtin_readcyclecounter() - dg_entry);  // entry .. end of time loop
     }
 #endif
+    BODY_MARK(a.dump, 12 + 4 * MODE + 2);
     // ---- x_N and the terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316) -------------------------------
     {
         d4 tj = MFMA(xb[0], es[0], zero4);
@@ -897,6 +938,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
             st.value[b] = INFINITY;
         }
     }
+    BODY_MARK(a.dump, 12 + 4 * MODE + 3);
 }
 
 template <int MODEL, int MODE, bool CTV>
@@ -1214,7 +1256,7 @@ __device__ __forceinline__ double uniform_load_f64(const double *p) { return rea
 // of the separate sweeps, so results are bit-identical).  The gains of the second recursion are committed by the accept rule
 // (commit_spec) or dropped.  A candidate whose acceptance would END the solve (d < d_tol with mu at its floor, or iter_max) gets the
 // plain policy evaluation: nothing would consume the gains.
-template <int MODEL, bool CTV, bool WTV, bool DUALF>
+template <int MODEL, bool CTV, bool WTV, bool DUALF, bool STG>
 __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
     const int b = blockIdx.x;
     const StateDev &st = fa.sw.st;
@@ -1256,7 +1298,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
         }
         {                                                    // one candidate of line_search!  (ileqg.jl:504-581)
             RolloutArgs ra = fa.ro; ra.mode = 1;
-            rollin_body<MODEL, 1, CTV>(ra, b);
+            rollin_body<MODEL, 1, CTV, STG>(ra, b);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1287,8 +1329,11 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
     if (B <= 0) return;
     const dim3 grid(B), block(64);
     const bool wtv = fa.sw.pb.W_tv != 0;
-#define FUSED_LAUNCH(M, C, W) do { if (fa.dual) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true>), grid, block, 0, s, fa); \
-                                   else hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false>), grid, block, 0, s, fa); } while (0)
+    const bool stg = fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST;
+#define FUSED_LAUNCH(M, C, W) do { \
+        if (fa.dual && stg && M == 1) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, M == 1>), grid, block, 0, s, fa); \
+        else if (fa.dual) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, false>), grid, block, 0, s, fa); \
+        else hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.model == 1) {
         if (fa.sw.pb.cost_tv) { if (wtv) FUSED_LAUNCH(1, true, true); else FUSED_LAUNCH(1, true, false); }
         else { if (wtv) FUSED_LAUNCH(1, false, true); else FUSED_LAUNCH(1, false, false); }

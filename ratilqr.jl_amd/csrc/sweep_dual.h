@@ -81,6 +81,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     const int l = l_, g = g_, j = j_;
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
+    const int dgs = 20 + 4 * (a.mode - 6);
+    BODY_MARK(a.dump, dgs + 0);
     int slot, cidx = -1;
     if (a.mode == 7) {
         if (!st.ls_active[b]) return;
@@ -256,6 +258,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
 
     DTile ra, rb2;
     dload(ra, tile0 + (long)(N - 1) * TSTRIDE, lx, l, j, Lb + (long)(N - 1) * LSTR, mL, g);
+    BODY_MARK(a.dump, dgs + 1);
     for (int t = N - 1; t >= 0; t -= 2) {
         {
             const int tn = (t > 0) ? t - 1 : 0;
@@ -269,6 +272,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         }
         if (step(t - 1, rb2)) break;
     }
+    BODY_MARK(a.dump, dgs + 2);
     const double totA = 0.5 * wave_sum(raccA) + ((theta != 0.0) ? coef * (log(rprodA) + (double)rexpA * 0.6931471805599453094) : 0.0);
     (void)raccB; (void)rprodB; (void)rexpB;          // B's value s_1 is not used by step! (only L, dl, mu, Delta are)
     if (l == 12) {
@@ -284,5 +288,6 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         st.delta_spec[b] = st.delta[b];
         st.spec_st[b] = (failA || deadB == 1) ? 0 : (deadB == 2 ? 2 : 1);
     }
+    BODY_MARK(a.dump, dgs + 3);
 }
 

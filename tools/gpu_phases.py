@@ -28,3 +28,14 @@ for th in (0.0, 1.0):
     d = np.diff(np.concatenate([np.zeros((8, 1)), t], axis=1), axis=1).mean(0)
     print(f"theta={th}: total {t[:, -1].mean():.0f} cycles = {t[:, -1].mean() / 2.34e3:.1f} us at 2.34 GHz")
     print("   " + ", ".join(f"{n}={c:.0f}" for n, c in zip(names, d)))
+    inner = np.zeros(256)
+    lib.rat_diag_read_n(ctx.h, inner.ctypes.data_as(C.POINTER(C.c_double)), 640, 256)
+    inner = inner.reshape(8, 32)
+    lab = ["sweep gain", "sweep eval", "sweep init", "rollin open", "rollin closed", "dual init+gain", "dual eval+gain"]
+    print("   last occurrence of each body: prologue / time loop / epilogue cycles")
+    for q, nm in enumerate(lab):
+        m = inner[:, 4 * q:4 * q + 4]
+        if np.all(m[:, 0] == 0):
+            continue
+        dd = np.diff(m, axis=1).mean(0)
+        print(f"     {nm:16s} {dd[0]:8.0f} / {dd[1]:8.0f} / {dd[2]:8.0f}")
