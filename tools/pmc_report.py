@@ -1,0 +1,58 @@
+"""Writes profiles/traffic.json and profiles/r01_pmc_hbm_traffic.md from the PMC passes of tools/profile_round.sh
+(gpurun_out/r01b/pmc_{fetch,write}_e{1,8}/runc_counter_collection.csv)."""
+import collections, csv, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out", "r01b")
+
+
+def load(path):
+    per = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return per
+
+
+tr = {}
+for E in (1, 8):
+    f = load(f"{O}/pmc_fetch_e{E}/runc_counter_collection.csv")
+    w = load(f"{O}/pmc_write_e{E}/runc_counter_collection.csv")
+    for k in f:
+        t = (2 * max(f[k]) + max(w.get(k, [0]))) * 1024
+        if "solve_fused" in k:
+            tr[f"solve_fused_E{E}_B1024"] = t
+        if "sweep_kernel<false, false, false, true>" in k:
+            tr[f"sweep_eval_E{E}_B1024"] = t
+json.dump(tr, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+out = '''# r01 HBM traffic per launch from rocprofv3 PMC counters (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes)
+
+Commands (tools/profile_round.sh, one counter per pass, no trace domains in the same run):
+`rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-second [--spec-eps 8]`,
+summarised by `python tools/pmc_summary.py FETCH=... WRITE=... kernel`; this file is written by tools/pmc_report.py.
+
+Units: KB per dispatch as reported. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests at 64 B, so
+read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.  Calibration on this access pattern: the gain sweep reads each byte of its
+1024 tile bundles exactly once -- physical record 466 doubles/step (layout.h): 1024 x 187,664 B = 192.2 MB -- and
+2 x FETCH_SIZE = 193.3 MB reproduces that, so the 2x correction holds here.
+
+The default E = 1 path is ONE launch per batch (`solve_fused_kernel`); the per-phase kernels in the E = 1 table come from
+bench.py's secondary `round_based_path` measurement (RATILQR_FUSED=0), the E = 8 table is the round-based path throughout.
+
+'''
+for E in (1, 8):
+    t = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f"FETCH={O}/pmc_fetch_e{E}/runc_counter_collection.csv",
+                        f"WRITE={O}/pmc_write_e{E}/runc_counter_collection.csv", "kernel<", "_kernel("], capture_output=True, text=True).stdout
+    out += f"## E = {E}, B = 1024\n\n" + "\n".join(l for l in t.split("\n") if "at::native" not in l) + "\n"
+fs = tr["solve_fused_E1_B1024"]
+out += f'''## Reading
+
+* `solve_fused_kernel` (1024 complete 2-iteration solves per launch): {fs/1e6:.1f} MB of HBM traffic per launch = {fs/1024/1e6:.3f} MB per solve,
+  against 1.537 MB of algorithmic bytes per solve (SURVEY.md section 8d, unfused three-kernel formulation: initialize! 368.3 KB +
+  2 gain sweeps x 188.9 KB + 2 candidates x 395.6 KB) = {(fs/1024/1537256-1)*100:+.1f} %.  Two effects against each other: the padded
+  register-image tile record (466 instead of 417 doubles per step, +11.7 % on every tile pass) and the paired recursions, which
+  read the tiles of `initialize!` and of the first candidate ONCE for the policy evaluation and the gain sweep that follows it
+  (the three-kernel formulation reads them twice).  No re-reads.
+* policy-evaluation sweep, round-based path: {tr["sweep_eval_E1_B1024"]/1e6:.1f} MB per launch at E = 1 (1024 candidates), {tr["sweep_eval_E8_B1024"]/1e6:.1f} MB at E = 8 (8192);
+  algorithmic 187,264 B per candidate = 191.8 MB / 1,534 MB (+11 %: the padded record).
+'''
+open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.md"), "w").write(out)
+print(tr)
