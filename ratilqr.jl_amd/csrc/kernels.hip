@@ -77,7 +77,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     const int l = l_, g = g_, j = j_;
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
-    constexpr int dgs = (GAIN ? 0 : (HASL ? 4 : 8));
+    [[maybe_unused]] constexpr int dgs = (GAIN ? 0 : (HASL ? 4 : 8));
     BODY_MARK(a.dump, dgs + 0);
     int b, slot, cidx = -1;
     if (a.mode == 1) {

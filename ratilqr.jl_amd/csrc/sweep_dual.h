@@ -81,7 +81,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     const int l = l_, g = g_, j = j_;
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
-    const int dgs = 20 + 4 * (a.mode - 6);
+    [[maybe_unused]] const int dgs = 20 + 4 * (a.mode - 6);
     BODY_MARK(a.dump, dgs + 0);
     int slot, cidx = -1;
     if (a.mode == 7) {
