@@ -215,9 +215,17 @@ def _ctx(problem) -> Context:
     """Default context of a problem for the stateless reference functions (simulate_dynamics, ...)."""
     c = _ctx_cache.get(problem)
     if c is None:
-        c = Context(problem)
+        c = make_context(problem)
         _ctx_cache[problem] = c
     return c
+
+
+def make_context(problem, opts=None, max_batch=1, spec_eps=1, device=0) -> Context:
+    """Context of a device model family, or the host-closure context of a generic problem (generic.py)."""
+    if getattr(problem, "model", 0) == 0:
+        from .generic import GenericContext
+        return GenericContext(problem, opts, max_batch=max_batch, spec_eps=spec_eps, device=device)
+    return Context(problem, opts, max_batch=max_batch, spec_eps=spec_eps, device=device)
 
 
 def make_opts(mu_min=1e-6, Delta_0=2.0, lam=0.5, d=1e-2, iter_max=100, eps_init=1.0, adaptive_eps_init=False,
@@ -253,7 +261,7 @@ class ILEQGSolver:
         self.eps_history = []
         self.eps_init_init = eps_init
         self.status = None
-        self.ctx = Context(problem, self.opts, max_batch=max_batch, spec_eps=spec_eps, device=device)
+        self.ctx = make_context(problem, self.opts, max_batch=max_batch, spec_eps=spec_eps, device=device)
 
 
 # ---- the reference's free functions ----------------------------------------------------------------
@@ -386,6 +394,8 @@ def solve_(ileqg: ILEQGSolver, problem, x_0, u_array, theta, verbose=False):
     """solve!(ileqg, problem, x_0, u_array; θ)  (ileqg.jl:635-659) on the fused device state machine.
 
     Returns (x_array, l_array, L_array, value, ϵ_history).  Raises where the reference throws."""
+    if getattr(problem, "model", 0) == 0:            # generic closures: host rollouts + linearisation, device sweeps
+        return solve_stepwise_(ileqg, problem, x_0, u_array, theta)
     r = ileqg.ctx.solve(x_0, u_array, theta)
     ileqg.status = r["status"]
     ileqg.iter_current = r["iters"]
