@@ -121,3 +121,42 @@ def solve_sharded(ce_solver, kl_bound, z: np.ndarray, evaluate_shard, final_solv
             return theta_opt, x, l, Lg, value, 0.0, 0.0
         theta_opt = max(0.0, theta_opt - c.sigma)                                     # :412
     raise nv.RatError("final-solve retry loop cut (reference would spin, SURVEY App. B.15)")
+
+
+# ---- PETS (pets.jl:100-126): control samples sharded over the ranks -----------------------------------------------------------
+def pets_compute_cost_sharded(control_sequence_array: np.ndarray, evaluate_shard, device="cpu", group=None) -> np.ndarray:
+    """compute_cost of the PETS solver (pets.jl:100-126) with the S control samples split in contiguous blocks over the ranks.
+
+    All K noisy trajectories of a control sample stay on one rank (their mean is the sample's cost, :150), so the only exchange
+    is one all-gather of S/G doubles per rank.  ``evaluate_shard(controls_block, lo)`` returns the block's costs as a tensor
+    on ``device`` (``lo`` = global index of the block's first sample: noise streams are addressed by global sample index, which
+    makes the result independent of the number of ranks).  Elite selection / refit run replicated on every rank."""
+    ctrl = np.ascontiguousarray(control_sequence_array, dtype=np.float64)
+    S = ctrl.shape[0]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(S, world, rank)
+    local = evaluate_shard(ctrl[lo:hi], lo)
+    return allgather_values(torch.as_tensor(local, dtype=torch.float64, device=device), S, group).cpu().numpy()
+
+
+def pets_gpu_evaluator(direct_solver, problem, x, use_true_model=False, streams=None, seed=0):
+    """evaluate_shard for pets_compute_cost_sharded on this rank's GPU.  ``streams=(zn, zu)`` are the full injected draw arrays
+    of compute_cost_serial (addressed by global sample index); without them the device generator is keyed by (seed, block)."""
+    ctx = direct_solver.context(problem)
+    K, N, n = int(direct_solver.c.num_trajectory_samples), problem.N, problem.n
+    xx = nv.f64(x)
+
+    def ev(block: np.ndarray, lo: int) -> torch.Tensor:
+        Sb = block.shape[0]
+        cost = np.zeros(Sb)
+        if Sb:
+            zn = zu = None
+            if streams is not None:
+                zn = nv.f64(np.asarray(streams[0])[lo * K * N * n: (lo + Sb) * K * N * n])
+                zu = None if streams[1] is None else nv.f64(np.asarray(streams[1])[lo * K * N: (lo + Sb) * K * N])
+            nv.check(nv.lib().rat_pets_compute_cost(ctx.h, nv.P(xx), nv.P(nv.f64(block)), C.c_int64(Sb), C.c_int64(K), int(use_true_model),
+                                                    nv.P(zn), nv.P(zu), C.c_uint64(int(seed) + 0x9E3779B9 * int(lo)), nv.P(cost)))
+        return torch.as_tensor(cost, dtype=torch.float64)
+
+    return ev

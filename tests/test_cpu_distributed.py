@@ -82,3 +82,41 @@ def test_two_rank_ce_matches_single_process_oracle(tmp_path):
     assert rc == 0
     ref = np.array([th, val, tmin, tmax, oc.c.mu, oc.c.sigma, oc.c.mu_init, oc.c.n_solves])
     assert np.array_equal(got[0], ref)       # same evaluator, same stream -> bitwise the same CE trajectory
+
+
+# ---- PETS: control samples sharded over the ranks (BASELINE config 5) ------------------------------------------------------------
+def _pets_setup():
+    prob = rat.LQGenerativeProblem(np.eye(2), np.eye(2), 6, ("uniform", 0.0, 1.0), l1u=1.0, q0f=1.0)
+    rng = np.random.default_rng(7)
+    S, K = 11, 5                                                    # ragged over 2 ranks: 6 + 5
+    ctrl = rng.random((S, prob.N, 2))
+    zn = rng.random(S * K * prob.N * 2)
+    return prob, ctrl, zn, S, K
+
+
+def _pets_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob, ctrl, zn, S, K = _pets_setup()
+    G = orc.GenProblem(prob)
+    seen = []
+
+    def evaluate(block, lo):                                        # the oracle stands in for the device rollouts
+        seen.append((lo, block.shape[0]))
+        z = zn[lo * K * prob.N * 2: (lo + block.shape[0]) * K * prob.N * 2]
+        return torch.as_tensor(orc.pets_compute_cost(G, np.zeros(2), block, K, False, z), dtype=torch.float64)
+
+    cost = rd.pets_compute_cost_sharded(ctrl, evaluate)
+    assert seen == [rd.shard_bounds(S, world, rank)[0:1] + (rd.shard_bounds(S, world, rank)[1] - rd.shard_bounds(S, world, rank)[0],)]
+    np.save(os.path.join(out_dir, f"p{rank}.npy"), cost)
+    dist.destroy_process_group()
+
+
+def test_two_rank_pets_cost_matches_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_pets_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [np.load(os.path.join(str(tmp_path), f"p{r}.npy")) for r in range(2)]
+    prob, ctrl, zn, S, K = _pets_setup()
+    ref = orc.pets_compute_cost(orc.GenProblem(prob), np.zeros(2), ctrl, K, False, zn)
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], ref)

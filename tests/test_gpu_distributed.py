@@ -35,3 +35,29 @@ def test_gpu_evaluator_and_sharded_ce_equal_rat_ce_solve():
     assert got[0] == ref[0] and got[4] == ref[4] and got[5] == ref[5] and got[6] == ref[6]
     assert np.array_equal(got[3], ref[3])
     assert solver.c.mu_init == ref_solver.c.mu_init and solver.c.n_solves == ref_solver.c.n_solves
+
+
+def test_pets_sharded_cost_equals_the_single_call():
+    """BASELINE config 5 (PETS rollouts, control samples sharded): the device evaluator of a shard addresses the injected noise by
+    global sample index, so the world-size-1 result is the single-call result bit for bit, and an arbitrary block evaluated alone
+    reproduces its slice (what a rank of a larger world computes; N > 1 ranks: gloo test on CPU)."""
+    from ratilqr.jl_amd import pets
+    rng = np.random.default_rng(5)
+    Nh, n, m, S, K = 30, 12, 4, 40, 25
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    prob = rat.LQGenerativeProblem(0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), Nh, ("gaussian", np.zeros(n), 0.05 * np.eye(n)),
+                                   Q=np.eye(n), R=0.1 * np.eye(m), Qf=np.eye(n))
+    ds = rat.CrossEntropyDirectOptimizationSolver(np.zeros((Nh, m)), np.stack([np.eye(m)] * Nh), num_control_samples=S, num_trajectory_samples=K)
+    ctrl, x0 = 0.3 * rng.standard_normal((S, Nh, m)), rng.standard_normal(n)
+    zn, zu = pets.draw_noise(prob, rng, S, K)
+    ref = pets.compute_cost_serial(ds, prob, x0, ctrl, None, streams=(zn, zu))
+    ev = rd.pets_gpu_evaluator(ds, prob, x0, streams=(zn, zu))
+    got = rd.pets_compute_cost_sharded(ctrl, ev)
+    assert np.array_equal(got, ref)
+    lo, hi = rd.shard_bounds(S, 3, 1)
+    assert np.array_equal(ev(ctrl[lo:hi], lo).numpy(), ref[lo:hi])
+    # device generator: finite, reproducible, and different blocks get different noise
+    ev2 = rd.pets_gpu_evaluator(ds, prob, x0, seed=3)
+    a, b = ev2(ctrl[:8], 0).numpy(), ev2(ctrl[:8], 0).numpy()
+    c = ev2(ctrl[:8], 8).numpy()
+    assert np.all(np.isfinite(a)) and np.array_equal(a, b) and not np.array_equal(a, c)
