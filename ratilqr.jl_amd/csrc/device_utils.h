@@ -62,6 +62,67 @@ __device__ __forceinline__ double row_sum16(double x) {
     return x;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One 2x2-block round of the symmetric sweep (in-place inversion of M = inv(W) - theta S, ileqg.jl:365-367) with the rank-2
+// update on the matrix pipe.  m holds M (12 x 12 in the 12 x 16 accumulator layout, register r = rows 4r..4r+3).
+//   P = M_KK (K = {k, k+1}, k = 2 KB), Bk = P^-1:   M'_KK = -Bk,  M'_Kj = Bk M_Kj,  M'_iK = M_iK Bk,  M'_ij = M_ij - M_iK Bk M_Kj
+// With the pivot rows t (other rows zeroed, -I written into the pivot block) every entry obeys the ONE formula
+//   M' = M o mask - t' (Bk t)            t: 2 x 16 pivot rows,  t' its transpose (M is symmetric: M_iK = (M_Ki)')
+// which is a K = 2 contraction: v_mfma_f64_16x16x4 with A = t read as the A operand (lane (g, j) of the register that holds the
+// pivot rows IS A[row j][k-slot g]: no data movement), B = -(Bk t) computed on the pivot-row lanes (each needs its partner row's
+// entry: one v_permlane16_swap exchanges rows 0<->1, 2<->3), C = M o mask.  No LDS, no fence, ~30 instructions per round.
+// Leading minors p11 > 0, det P > 0 for every block  <=>  isposdef(M)  (:366); det P = d_k d_{k+1} feeds logdet.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct ElimMasks {
+    double tm[6], wa[6];        // pivot rows of round kb: tm = 1 on (pivot row, non-pivot column), wa = -1 on the pivot block's diagonal
+    double cm[6], crm[6];       // cm = 0 on the pivot columns; crm = 0 on pivot columns and (register of the pivot rows) pivot rows
+    double e0[2], e1[2];        // row selectors for kg = 0 / 2: e0 = 1 on row kg, e1 = 1 on row kg + 1
+    bool odd;                   // lane sits in an odd 16-lane row
+};
+__device__ __forceinline__ void elim_masks(ElimMasks &em, int g, int j) {
+#pragma unroll
+    for (int kb = 0; kb < 6; ++kb) {
+        const int k = 2 * kb, kg = k & 3;
+        const bool colk = (j == k) || (j == k + 1), rowk = (g == kg) || (g == kg + 1);
+        em.tm[kb] = (rowk && !colk) ? 1.0 : 0.0;
+        em.wa[kb] = (rowk && j == k + (g - kg)) ? -1.0 : 0.0;
+        em.cm[kb] = colk ? 0.0 : 1.0;
+        em.crm[kb] = (colk || rowk) ? 0.0 : 1.0;
+    }
+    em.e0[0] = (g == 0) ? 1.0 : 0.0; em.e1[0] = (g == 1) ? 1.0 : 0.0;
+    em.e0[1] = (g == 2) ? 1.0 : 0.0; em.e1[1] = (g == 3) ? 1.0 : 0.0;
+    em.odd = (g & 1) != 0;
+}
+__device__ __forceinline__ double row_partner(double x, bool odd) {       // the same column of the adjacent row (0<->1, 2<->3)
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [0] = (r0, r0, r2, r2), [1] = (r1, r1, r3, r3)
+    const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)(odd ? sh[0] : sh[1]), (int)(odd ? sl[0] : sl[1]));
+}
+template <int KB>
+__device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, double ep, double &pdmin, double &nsum, double &rprod) {
+    constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
+    const double p11 = readlane_f64(m[kr], kg * 16 + k);
+    const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
+    const double p22 = readlane_f64(m[kr], (kg + 1) * 16 + k + 1);
+    const double t = fma(m[kr], em.tm[KB], em.wa[KB]);          // pivot rows, -I in the pivot block, zero elsewhere
+    const double other = row_partner(t, em.odd);
+    const double det = fma(p11, p22, -(p12 * p12));
+    const double idet = fast_rcp1(det);
+    pdmin = fmin(pdmin, fmin(p11, det));
+    nsum += det;
+    rprod *= det * ep;       // logdet(W M) = sum_k log(det P_k / (e_k e_k+1))  (:387): wave-uniform normalised running product
+    // -(Bk t) on the pivot-row lanes (Bk = adj(P) / det): row k: -(p22 t_k - p12 t_k+1) / det, row k+1: -(p11 t_k+1 - p12 t_k) / det
+    const double pd = em.e0[kg >> 1] * p22 + em.e1[kg >> 1] * p11;
+    const double nu = fma(p12, other, -(pd * t)) * idet;
+    d4 c;
+    c[0] = m[0] * (kr == 0 ? em.crm[KB] : em.cm[KB]);
+    c[1] = m[1] * (kr == 1 ? em.crm[KB] : em.cm[KB]);
+    c[2] = m[2] * (kr == 2 ? em.crm[KB] : em.cm[KB]);
+    c[3] = 0.0;
+    m = MFMA(t, nu, c);
+}
+
 __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base.isapprox, rtol = sqrt(eps), atol = 0
     if (x == y) return true;
     if (!isfinite(x) || !isfinite(y)) return false;

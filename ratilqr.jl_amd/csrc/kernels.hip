@@ -112,7 +112,6 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     double *__restrict__ Lout = st.L + (long)osel * st.l_half + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)osel * st.dl_half + (long)b * N * USTR;
 
-    __shared__ double rowbuf[2][2][16];
     __shared__ double lbuf[64];        // policy evaluation: the step's gain row block [L | dl], natural 4 x 16 layout
     __shared__ double ex[104];         // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0, [84..99] = s_vec
 #define HBUF(r_, c_) ex[(r_) * 16 + (c_)]
@@ -126,18 +125,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     double m12 = (j < 12) ? 1.0 : 0.0;                       // lanes holding a state column
     double nth12 = -st.theta[b] * m12;
     double mA = (g == 0 && j < 12) ? 1.0 : 0.0, mB = (g == 0 && j == 12) ? 1.0 : 0.0, mH = (j == 12 + g) ? 1.0 : 0.0;
-    // elimination round kb (pivot block {2kb, 2kb+1}): cm = 0 on the pivot columns, crm = 0 on pivot columns and (in the
-    // register that holds the pivot rows) on the pivot rows, wa = -1 in a row's own pivot slot (rows are exchanged as
-    // m*cm + wa, which puts -I into the pivot block)
-    double cm[6], crm[6], wa[6];
-#pragma unroll
-    for (int kb = 0; kb < 6; ++kb) {
-        const int k = 2 * kb, kg = k & 3;
-        const bool colk = (j == k) || (j == k + 1), rowk = (g == kg) || (g == kg + 1);
-        cm[kb] = colk ? 0.0 : 1.0;
-        crm[kb] = (colk || rowk) ? 0.0 : 1.0;
-        wa[kb] = (j == k + (g - kg)) ? -1.0 : 0.0;
-    }
+    ElimMasks em;
+    elim_masks(em, g, j);
     int hoff[4], foff[3], goff[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -232,32 +221,12 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                 //   m'_ij = base_ij - vi1 U1_j - vi2 U2_j,   U_j = Bk [v1_j; v2_j],   base = 0 on pivot rows/columns, m elsewhere.
                 // Leading minors p11 > 0, det P > 0 for every block  <=>  isposdef(M)  (:366); det P = d_k d_{k+1}.
                 double pdmin = 1.0, nsum = 0.0;                              // min over leading minors; NaN/Inf tripwire (fmin drops NaNs)
-#pragma unroll
-                for (int kb = 0; kb < 6; ++kb) {
-                    const int k = 2 * kb, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
-                    const double p11 = readlane_f64(m[kr], kg * 16 + k);
-                    const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
-                    const double p22 = readlane_f64(m[kr], (kg + 1) * 16 + k + 1);
-                    if (g == kg || g == kg + 1)                              // own pivot slot -> -1, the other -> 0
-                        rowbuf[kb & 1][g - kg][j] = fma(m[kr], cm[kb], wa[kb]);
-                    const double det = fma(p11, p22, -(p12 * p12));
-                    const double idet = fast_rcp1(det);                      // overlaps the LDS row exchange
-                    WAVE_SYNC();
-                    const double v1 = rowbuf[kb & 1][0][j], v2 = rowbuf[kb & 1][1][j];
-                    const double a10 = rowbuf[kb & 1][0][g], a20 = rowbuf[kb & 1][1][g];
-                    const double a11 = rowbuf[kb & 1][0][4 + g], a21 = rowbuf[kb & 1][1][4 + g];
-                    const double a12 = rowbuf[kb & 1][0][8 + g], a22 = rowbuf[kb & 1][1][8 + g];
-                    pdmin = fmin(pdmin, fmin(p11, det));
-                    nsum += det;
-                    // logdet(W M) = sum_k log(det P_k / (e_k e_k+1))  (:387): every lane carries the same normalised
-                    // running product (det is wave-uniform), so no lane select and no reduction is needed for it
-                    rprod *= det * ((kb == 0) ? ep0 : (kb == 1) ? ep1 : (kb == 2) ? ep2 : (kb == 3) ? ep3 : (kb == 4) ? ep4 : ep5);
-                    // U = Bk [v1; v2] with Bk = adj(P) / det: the adjugate products do not wait for the reciprocal
-                    const double u1 = fma(p22, v1, -(p12 * v2)) * idet, u2 = fma(p11, v2, -(p12 * v1)) * idet;
-                    m[0] = fma(-a20, u2, fma(-a10, u1, m[0] * (kr == 0 ? crm[kb] : cm[kb])));
-                    m[1] = fma(-a21, u2, fma(-a11, u1, m[1] * (kr == 1 ? crm[kb] : cm[kb])));
-                    m[2] = fma(-a22, u2, fma(-a12, u1, m[2] * (kr == 2 ? crm[kb] : cm[kb])));
-                }
+                elim_round<0>(m, em, ep0, pdmin, nsum, rprod);
+                elim_round<1>(m, em, ep1, pdmin, nsum, rprod);
+                elim_round<2>(m, em, ep2, pdmin, nsum, rprod);
+                elim_round<3>(m, em, ep3, pdmin, nsum, rprod);
+                elim_round<4>(m, em, ep4, pdmin, nsum, rprod);
+                elim_round<5>(m, em, ep5, pdmin, nsum, rprod);
                 DIAG_STAMP(1, m[0]);
                 if (!(pdmin > 0.0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
                 // theta M^-1 (the sweep left -M^-1); padded columns cleared

@@ -41,38 +41,8 @@ __device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, 
     tr.la = Lp[g * 12 + jc] * mL;
 }
 
-// one 2x2-block round of the symmetric sweep (see sweep_kernel) for BOTH recursions under a single fence: the two row
-// exchanges are issued back to back, so the two pivot chains (readlane -> adjugate -> rcp -> update) interleave.
-// Straight-line: the row exchange is an unconditional store to a per-lane offset (non-owner lanes hit a private dummy slot).
-template <int KB>
-__device__ __forceinline__ void elim_round2(d4 &mA, d4 &mB, double *__restrict__ rbA, double *__restrict__ rbB, int woff,
-                                            double cmk, double crmk, double wak, int j, int g, double ep,
-                                            double &pdA, double &nsA, double &rprodA, double &pdB, double &nsB, double &rprodB) {
-    constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;
-    const double pA11 = readlane_f64(mA[kr], kg * 16 + k), pB11 = readlane_f64(mB[kr], kg * 16 + k);
-    const double pA12 = readlane_f64(mA[kr], kg * 16 + k + 1), pB12 = readlane_f64(mB[kr], kg * 16 + k + 1);
-    const double pA22 = readlane_f64(mA[kr], (kg + 1) * 16 + k + 1), pB22 = readlane_f64(mB[kr], (kg + 1) * 16 + k + 1);
-    rbA[woff] = fma(mA[kr], cmk, wak);
-    rbB[woff] = fma(mB[kr], cmk, wak);
-    const double detA = fma(pA11, pA22, -(pA12 * pA12)), detB = fma(pB11, pB22, -(pB12 * pB12));
-    const double idA = fast_rcp1(detA), idB = fast_rcp1(detB);
-    WAVE_SYNC();
-    const double *__restrict__ a0 = rbA + (KB & 1) * 32, *__restrict__ a1 = a0 + 16;
-    const double *__restrict__ b0 = rbB + (KB & 1) * 32, *__restrict__ b1 = b0 + 16;
-    const double vA1 = a0[j], vA2 = a1[j], vB1 = b0[j], vB2 = b1[j];
-    const double aA10 = a0[g], aA20 = a1[g], aA11 = a0[4 + g], aA21 = a1[4 + g], aA12 = a0[8 + g], aA22 = a1[8 + g];
-    const double aB10 = b0[g], aB20 = b1[g], aB11 = b0[4 + g], aB21 = b1[4 + g], aB12 = b0[8 + g], aB22 = b1[8 + g];
-    pdA = fmin(pdA, fmin(pA11, detA)); pdB = fmin(pdB, fmin(pB11, detB));
-    nsA += detA; nsB += detB;
-    rprodA *= detA * ep; rprodB *= detB * ep;
-    const double uA1 = fma(pA22, vA1, -(pA12 * vA2)) * idA, uA2 = fma(pA11, vA2, -(pA12 * vA1)) * idA;
-    const double uB1 = fma(pB22, vB1, -(pB12 * vB2)) * idB, uB2 = fma(pB11, vB2, -(pB12 * vB1)) * idB;
-    const double k0 = (kr == 0 ? crmk : cmk), k1 = (kr == 1 ? crmk : cmk), k2 = (kr == 2 ? crmk : cmk);
-    mA[0] = fma(-aA20, uA2, fma(-aA10, uA1, mA[0] * k0)); mB[0] = fma(-aB20, uB2, fma(-aB10, uB1, mB[0] * k0));
-    mA[1] = fma(-aA21, uA2, fma(-aA11, uA1, mA[1] * k1)); mB[1] = fma(-aB21, uB2, fma(-aB11, uB1, mB[1] * k1));
-    mA[2] = fma(-aA22, uA2, fma(-aA12, uA1, mA[2] * k2)); mB[2] = fma(-aB22, uB2, fma(-aB12, uB1, mB[2] * k2));
-}
-
+// The elimination rounds of the two recursions are the shared elim_round (device_utils.h: rank-2 update on the matrix pipe, no LDS,
+// no fence), issued back to back: two independent pivot chains for the scheduler to interleave.
 template <bool WTV>
 __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b) {
     int lane_ = threadIdx.x;
@@ -103,7 +73,6 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     double *__restrict__ Lout = st.L + (long)(sel ^ 1) * st.l_half + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)(sel ^ 1) * st.dl_half + (long)b * N * USTR;
 
-    __shared__ double rbA[2 * 2 * 16 + 64], rbB[2 * 2 * 16 + 64];       // row exchange (+ 64 private dummy slots)
     __shared__ double exA[104], exB[104];                              // [G|H] 4x16, f 16, [80] = 0, [84..99] = s_vec
     if (l < 8) { exA[80 + l] = 0.0; exB[80 + l] = 0.0; }
 
@@ -111,17 +80,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     const double m12 = (j < 12) ? 1.0 : 0.0;
     const double nth12 = -theta * m12;
     const double mA_ = (g == 0 && j < 12) ? 1.0 : 0.0, mB_ = (g == 0 && j == 12) ? 1.0 : 0.0, mH = (j == 12 + g) ? 1.0 : 0.0;
-    double cm[6], crm[6], wa[6];
-    int woff[6];
-#pragma unroll
-    for (int kb = 0; kb < 6; ++kb) {
-        const int k = 2 * kb, kg = k & 3;
-        const bool colk = (j == k) || (j == k + 1), rowk = (g == kg) || (g == kg + 1);
-        cm[kb] = colk ? 0.0 : 1.0;
-        crm[kb] = (colk || rowk) ? 0.0 : 1.0;
-        wa[kb] = (j == k + (g - kg)) ? -1.0 : 0.0;
-        woff[kb] = rowk ? ((kb & 1) * 32 + (g - kg) * 16 + j) : (64 + l);
-    }
+    ElimMasks em;
+    elim_masks(em, g, j);
     int hoff[4], foff[3], goff[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -178,12 +138,18 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
             for (int r = 0; r < 3; ++r) { mA[r] = fma(nth12, vA[r], winv[r]); mB[r] = fma(nth12, vB[r], winv[r]); }
             mA[3] = 0.0; mB[3] = 0.0;
             double pdA = 1.0, nsA = 0.0, pdB = 1.0, nsB = 0.0;
-            elim_round2<0>(mA, mB, rbA, rbB, woff[0], cm[0], crm[0], wa[0], j, g, ep[0], pdA, nsA, rprodA, pdB, nsB, rprodB);
-            elim_round2<1>(mA, mB, rbA, rbB, woff[1], cm[1], crm[1], wa[1], j, g, ep[1], pdA, nsA, rprodA, pdB, nsB, rprodB);
-            elim_round2<2>(mA, mB, rbA, rbB, woff[2], cm[2], crm[2], wa[2], j, g, ep[2], pdA, nsA, rprodA, pdB, nsB, rprodB);
-            elim_round2<3>(mA, mB, rbA, rbB, woff[3], cm[3], crm[3], wa[3], j, g, ep[3], pdA, nsA, rprodA, pdB, nsB, rprodB);
-            elim_round2<4>(mA, mB, rbA, rbB, woff[4], cm[4], crm[4], wa[4], j, g, ep[4], pdA, nsA, rprodA, pdB, nsB, rprodB);
-            elim_round2<5>(mA, mB, rbA, rbB, woff[5], cm[5], crm[5], wa[5], j, g, ep[5], pdA, nsA, rprodA, pdB, nsB, rprodB);
+            elim_round<0>(mA, em, ep[0], pdA, nsA, rprodA);
+            elim_round<0>(mB, em, ep[0], pdB, nsB, rprodB);
+            elim_round<1>(mA, em, ep[1], pdA, nsA, rprodA);
+            elim_round<1>(mB, em, ep[1], pdB, nsB, rprodB);
+            elim_round<2>(mA, em, ep[2], pdA, nsA, rprodA);
+            elim_round<2>(mB, em, ep[2], pdB, nsB, rprodB);
+            elim_round<3>(mA, em, ep[3], pdA, nsA, rprodA);
+            elim_round<3>(mB, em, ep[3], pdB, nsB, rprodB);
+            elim_round<4>(mA, em, ep[4], pdA, nsA, rprodA);
+            elim_round<4>(mB, em, ep[4], pdB, nsB, rprodB);
+            elim_round<5>(mA, em, ep[5], pdA, nsA, rprodA);
+            elim_round<5>(mB, em, ep[5], pdB, nsB, rprodB);
             if (!(pdA > 0.0) || !(nsA * 0.0 == 0.0)) { failA = 1; return 1; }       // @assert isposdef(M) (:440)
             if (!deadB && (!(pdB > 0.0) || !(nsB * 0.0 == 0.0))) deadB = 2;         // @assert isposdef(M) (:366)
             d4 minvA, minvB;
