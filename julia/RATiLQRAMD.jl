@@ -1,6 +1,6 @@
 # RATiLQRAMD.jl -- thin `ccall` glue that keeps the reference's API surface
-# (OptimalControlProblem / ILEQGSolver / CrossEntropyBilevelOptimizationSolver / solve!) and sends the
-# iLEQG + Cross-Entropy hot path to libratilqr_hip.so (C ABI: include/ratilqr.h).
+# (OptimalControlProblem / ILEQGSolver / CrossEntropyBilevelOptimizationSolver / NelderMeadBilevelOptimizationSolver / solve!)
+# and sends the iLEQG + Cross-Entropy hot path to libratilqr_hip.so (C ABI: include/ratilqr.h).
 #
 # NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no `julia` binary.  The Python mirror
 # (ratilqr.jl_amd/*.py) binds exactly the same entry points and is what the test-suite runs.
@@ -178,6 +178,61 @@ function solve!(s::AMDCrossEntropyBilevelOptimizationSolver, problem::LQRiskSens
     return θ[], [x[:, t] for t in 1:N+1], [l[:, t] for t in 1:N], [L[:, :, t] for t in 1:N], val[], θmin[], θmax[]
 end
 
-export OptimalControlProblem, LQRiskSensitiveProblem, ILEQGSolver, AMDCrossEntropyBilevelOptimizationSolver, solve!, compute_cost,
-       simulate_dynamics_noisy
+# mirrors `struct rat_nm_solver` (nelder_mead_bilevel_optimization.jl:72-128); c_high / c_low persist across solve! calls as in
+# the reference (initialize! does not reset them, :164-168)
+mutable struct NmState
+    α::Float64; β::Float64; γ::Float64; ϵ::Float64; λ::Float64
+    iter_max::Int64
+    θ_high_init::Float64; θ_low_init::Float64
+    iter_current::Int64
+    θ_high::Float64; θ_low::Float64
+    has_c_high::Int32; has_c_low::Int32
+    c_high::Float64; c_low::Float64
+    n_solves::Int64; n_batches::Int64
+end
+
+"NelderMeadBilevelOptimizationSolver(; kwargs...) -- RAT iLQR++, nelder_mead_bilevel_optimization.jl:72-128"
+mutable struct AMDNelderMeadBilevelOptimizationSolver
+    opts::IleqgOpts
+    c::NmState
+    device::Int
+    h::Union{Nothing,Handle}
+end
+function AMDNelderMeadBilevelOptimizationSolver(; μ_min_ileqg=1e-6, Δ_0_ileqg=2.0, λ_ileqg=0.5, d_ileqg=1e-2, iter_max_ileqg=100,
+        adaptive_ϵ_init_ileqg=false, ϵ_init_ileqg=1.0, ϵ_min_ileqg=1e-6, α=1.0, β=2.0, γ=0.5, ϵ=1e-2, λ=0.5,
+        iter_max=100, θ_high_init=3.0, θ_low_init=1e-8, device=0)
+    o = IleqgOpts(μ_min_ileqg, Δ_0_ileqg, λ_ileqg, d_ileqg, iter_max_ileqg, ϵ_init_ileqg, ϵ_min_ileqg, adaptive_ϵ_init_ileqg)
+    c = NmState(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    ccall((:rat_nm_default, LIB), Cvoid, (Ref{NmState},), c)            # the constructor defaults of :102-128
+    c.α, c.β, c.γ, c.ϵ, c.λ, c.iter_max = α, β, γ, ϵ, λ, iter_max
+    c.θ_high_init = c.θ_high = θ_high_init
+    c.θ_low_init = c.θ_low = θ_low_init
+    AMDNelderMeadBilevelOptimizationSolver(o, c, device, nothing)
+end
+function handle!(s::AMDNelderMeadBilevelOptimizationSolver, problem)
+    if s.h === nothing
+        s.h = Handle(s.opts, 6, 1, s.device)                             # one step! asks for at most six vertices
+        problem_set!(s.h, problem)
+    end
+    s.h
+end
+
+"solve!(nm_solver, problem, x_0, u_array; kl_bound) -- nelder_mead_bilevel_optimization.jl:276-352"
+function solve!(s::AMDNelderMeadBilevelOptimizationSolver, problem::LQRiskSensitiveProblem, x_0::Vector{Float64},
+                u_array::Vector{Vector{Float64}}; kl_bound::Float64, verbose=false)
+    @assert kl_bound >= 0 "KL Divergence Bound must be non-negative"
+    h = handle!(s, problem); n, m = size(problem.B); N = problem.N
+    x = Matrix{Float64}(undef, n, N + 1); l = Matrix{Float64}(undef, m, N); L = Array{Float64}(undef, m, n, N)
+    θ = Ref(0.0); val = Ref(0.0); status = Ref(Int32(0))
+    check(ccall((:rat_nm_solve, LIB), Int32,
+                (Ptr{Cvoid}, Ref{NmState}, Ptr{Float64}, Ptr{Float64}, Float64, Ref{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}, Ref{Float64}, Ref{Int32}),
+                h.ptr, s.c, x_0, reduce(hcat, u_array), kl_bound, θ, x, l, L, val, status))
+    status[] in (1, 2) && throw(AssertionError("M: (inv(W) - θ*S) is not PSD"))
+    status[] in (0, 3) || error("final iLEQG solve failed with status $(status[])")
+    return θ[], [x[:, t] for t in 1:N+1], [l[:, t] for t in 1:N], [L[:, :, t] for t in 1:N], val[]
+end
+
+export OptimalControlProblem, LQRiskSensitiveProblem, ILEQGSolver, AMDCrossEntropyBilevelOptimizationSolver,
+       AMDNelderMeadBilevelOptimizationSolver, solve!, compute_cost, simulate_dynamics_noisy
 end
