@@ -345,3 +345,28 @@ def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
     for a, b, c in zip(fused, rounds, fused_plain):
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
         assert np.array_equal(np.asarray(a), np.asarray(c), equal_nan=True)
+
+
+@pytest.mark.parametrize("Nh", [1, 3, 7, 13, 60])
+def test_horizon_lengths_around_the_unroll_and_staging_limits(Nh):
+    """The closed-loop rollout unrolls its time loop by 5 (tail of N mod 5 steps) and, inside the fused solve, stages its operands in
+    LDS for N <= 52: horizons on both sides of those limits must agree with the oracle like any other."""
+    prob, x0, u = rat.synthetic_lq_problem(n=12, m=4, N=Nh, seed=4, kappa=0.02)
+    P = orc.Problem(prob)
+    theta = np.array([0.0, 0.7, 2.5])
+    ctx = rat.Context(prob, max_batch=theta.size)
+    check_batch(ctx, P, x0, u, theta)
+
+
+def test_batches_larger_than_the_machine():
+    """4096 samples on 1024 SIMDs: the fused solve runs its blocks in several waves; values equal the round-based path's."""
+    prob, x0, u = rat.synthetic_lq_problem()
+    theta = np.abs(1.0 + 2.0 * np.random.default_rng(9).standard_normal(4096))
+    v1, s1, i1, l1 = rat.Context(prob, max_batch=4096).solve_batch(x0, u, theta)
+    import os
+    os.environ["RATILQR_FUSED"] = "0"
+    try:
+        v0, s0, i0, l0 = rat.Context(prob, max_batch=4096).solve_batch(x0, u, theta)
+    finally:
+        del os.environ["RATILQR_FUSED"]
+    assert np.array_equal(v1, v0) and np.array_equal(s1, s0) and np.array_equal(i1, i0) and np.array_equal(l1, l0)
