@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
         PHASE_MARK();
         if (DUALF) {
             SweepArgs sa = fa.sw; sa.mode = 6;
-            sweep_dual_body<WTV>(sa, b);
+            sweep_dual_body<WTV, false>(sa, b);
             PHASE_MARK();
             PHASE_FENCE();
             if (threadIdx.x == 0) commit_init_body(st, b);
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
             }
             if (pair) {
                 SweepArgs sa = fa.sw; sa.mode = 7;
-                sweep_dual_body<WTV>(sa, b);
+                sweep_dual_body<WTV, true>(sa, b);
             } else {
                 SweepArgs sa = fa.sw; sa.mode = 1;
                 sweep_body<false, false, WTV, true>(sa, b);

@@ -21,10 +21,12 @@
 #include "layout.h"
 
 struct DTile {
-    d4 z, c, lc;
-    double x, la;          // x: lanes 0..15 = qr, lane 16 = q (register-image record, layout.h)
+    d4 z, c;
+    double x, la;          // x: lanes 0..15 = qr, lane 16 = q (register-image record, layout.h); la: own entry L[g][j] of the gain row block
 };
 
+// HASL: recursion A evaluates a given policy (mode 7); false for initialize!'s open-loop sweep (mode 6: all gains zero, nothing to load)
+template <bool HASL>
 __device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, int lx, int l, int j,
                                       const double *__restrict__ Lp, double mL, int g) {
     const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
@@ -34,16 +36,12 @@ __device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, 
     tr.c[3] = tp[TS_R6 + l];
     tr.x = tp[TS_QR + lx];
     const int jc = (j < 12) ? j : 11;
-    tr.lc[0] = Lp[jc] * mL;
-    tr.lc[1] = Lp[12 + jc] * mL;
-    tr.lc[2] = Lp[24 + jc] * mL;
-    tr.lc[3] = Lp[36 + jc] * mL;
-    tr.la = Lp[g * 12 + jc] * mL;
+    tr.la = HASL ? Lp[g * 12 + jc] * mL : 0.0;
 }
 
 // The elimination rounds of the two recursions are the shared elim_round (device_utils.h: rank-2 update on the matrix pipe, no LDS,
 // no fence), issued back to back: two independent pivot chains for the scheduler to interleave.
-template <bool WTV>
+template <bool WTV, bool HASL>
 __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b) {
     int lane_ = threadIdx.x;
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
@@ -73,6 +71,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     double *__restrict__ Lout = st.L + (long)(sel ^ 1) * st.l_half + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)(sel ^ 1) * st.dl_half + (long)b * N * USTR;
 
+    __shared__ double lbufA[64];
     __shared__ double exA[104], exB[104];                              // [G|H] 4x16, f 16, [80] = 0, [84..99] = s_vec
     if (l < 8) { exA[80 + l] = 0.0; exB[80 + l] = 0.0; }
 
@@ -175,11 +174,12 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         const double fvA = tmA[3] + cur.x, fvB = tmB[3] + cur.x;
         exA[g * 16 + j] = ghA; exB[g * 16 + j] = ghB;
         if (g == 0) { exA[64 + j] = fvA; exB[64 + j] = fvB; }
+        if (HASL) lbufA[l] = cur.la;                            // rows of [L | dl] of the given policy to every lane
         WAVE_SYNC();
         // ---- A: given policy (:446-451) ----
         const double hA0 = exA[hoff[0]], hA1 = exA[hoff[1]], hA2 = exA[hoff[2]], hA3 = exA[hoff[3]];
         const double gaA = fma(ghA, m12, exA[gaoff]);
-        const double uaA = hA0 * cur.lc[0] + hA1 * cur.lc[1] + hA2 * cur.lc[2] + hA3 * cur.lc[3] + gaA;
+        const double uaA = HASL ? hA0 * lbufA[j] + hA1 * lbufA[16 + j] + hA2 * lbufA[32 + j] + hA3 * lbufA[48 + j] + gaA : gaA;
         // ---- B: optimal gains (:372-382) ----
         const double hB0 = exB[hoff[0]], hB1 = exB[hoff[1]], hB2 = exB[hoff[2]], hB3 = exB[hoff[3]];
         const double gaB = fma(ghB, m12, exB[gaoff]);
@@ -213,28 +213,32 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         const double qc = readlane_f64(cur.x, 16);
         fxA[3] = fma(fvA, mA_, (2.0 * qc + vA[3]) * mB_);
         fxB[3] = fma(fvB, mA_, (2.0 * qc + vB[3]) * mB_);
-        d4 vnA = MFMA(cur.la, uaA, fxA);
         d4 vnB = MFMA(laB, uaB, fxB);
-        vnA = MFMA(gaA, cur.la, vnA);
         vnB = MFMA(gaB, laB, vnB);
-        vA = vnA; vB = vnB;
+        if (HASL) {
+            d4 vnA = MFMA(cur.la, uaA, fxA);
+            vA = MFMA(gaA, cur.la, vnA);
+        } else {
+            vA = fxA;                                           // zero gains: V = Fx
+        }
+        vB = vnB;
         WAVE_SYNC();
         return 0;
     };
 
     DTile ra, rb2;
-    dload(ra, tile0 + (long)(N - 1) * TSTRIDE, lx, l, j, Lb + (long)(N - 1) * LSTR, mL, g);
+    dload<HASL>(ra, tile0 + (long)(N - 1) * TSTRIDE, lx, l, j, Lb + (long)(N - 1) * LSTR, mL, g);
     BODY_MARK(a.dump, dgs + 1);
     for (int t = N - 1; t >= 0; t -= 2) {
         {
             const int tn = (t > 0) ? t - 1 : 0;
-            dload(rb2, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
+            dload<HASL>(rb2, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
         }
         if (step(t, ra)) break;
         if (t == 0) break;
         {
             const int tn = (t > 1) ? t - 2 : 0;
-            dload(ra, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
+            dload<HASL>(ra, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
         }
         if (step(t - 1, rb2)) break;
     }
