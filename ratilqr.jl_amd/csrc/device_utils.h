@@ -94,13 +94,24 @@ __device__ __forceinline__ void elim_masks(ElimMasks &em, int g, int j) {
     em.odd = (g & 1) != 0;
 }
 __device__ __forceinline__ double row_partner(double x, bool odd) {       // the same column of the adjacent row (0<->1, 2<->3)
+#ifdef RAT_PARTNER_PERMLANE
     const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
     const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [0] = (r0, r0, r2, r2), [1] = (r1, r1, r3, r3)
     const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     return __hiloint2double((int)(odd ? sh[0] : sh[1]), (int)(odd ? sl[0] : sl[1]));
+#else
+    // ds_swizzle bit mode, lane ^= 16 inside each half of the wave (and 0x1f, or 0, xor 0x10): the LDS crossbar without memory,
+    // one instruction per word and the result IS the partner (v_permlane16_swap needs two copies and a select per word)
+    (void)odd;
+    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F));
+#endif
 }
+// Leading minors p11 > 0 and det P > 0 of every block <=> isposdef(M) (:366).  A non-NaN double is > 0 iff its high word, read as a
+// signed integer, is > 0 (a positive subnormal below 2^-1022 * 2^-20 counts as singular), so the running minimum is an integer
+// minimum over high words: one SALU op for p11 (it lives in SGPRs) and one VALU op for det -- v_min_f64 would cost three with the
+// canonicalisation that fmin() carries.  NaNs are caught by the running sum nsum.
 template <int KB>
-__device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, double ep, double &pdmin, double &nsum, double &rprod) {
+__device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, double ep, int &pdmin, double &nsum, double &rprod) {
     constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
     const double p11 = readlane_f64(m[kr], kg * 16 + k);
     const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
@@ -109,18 +120,16 @@ __device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, double ep
     const double other = row_partner(t, em.odd);
     const double det = fma(p11, p22, -(p12 * p12));
     const double idet = fast_rcp1(det);
-    pdmin = fmin(pdmin, fmin(p11, det));
+    pdmin = min(pdmin, min(__double2hiint(p11), __double2hiint(det)));
     nsum += det;
     rprod *= det * ep;       // logdet(W M) = sum_k log(det P_k / (e_k e_k+1))  (:387): wave-uniform normalised running product
     // -(Bk t) on the pivot-row lanes (Bk = adj(P) / det): row k: -(p22 t_k - p12 t_k+1) / det, row k+1: -(p11 t_k+1 - p12 t_k) / det
     const double pd = em.e0[kg >> 1] * p22 + em.e1[kg >> 1] * p11;
     const double nu = fma(p12, other, -(pd * t)) * idet;
-    d4 c;
-    c[0] = m[0] * (kr == 0 ? em.crm[KB] : em.cm[KB]);
-    c[1] = m[1] * (kr == 1 ? em.crm[KB] : em.cm[KB]);
-    c[2] = m[2] * (kr == 2 ? em.crm[KB] : em.cm[KB]);
-    c[3] = 0.0;
-    m = MFMA(t, nu, c);
+    m[0] *= (kr == 0 ? em.crm[KB] : em.cm[KB]);                 // C operand in place (rows 12..15, register 3, stay zero)
+    m[1] *= (kr == 1 ? em.crm[KB] : em.cm[KB]);
+    m[2] *= (kr == 2 ? em.crm[KB] : em.cm[KB]);
+    m = MFMA(t, nu, m);
 }
 
 __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base.isapprox, rtol = sqrt(eps), atol = 0

@@ -220,7 +220,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                 // Rows k, k+1 are exchanged through LDS with -I in their pivot slots, so that every lane runs the one formula
                 //   m'_ij = base_ij - vi1 U1_j - vi2 U2_j,   U_j = Bk [v1_j; v2_j],   base = 0 on pivot rows/columns, m elsewhere.
                 // Leading minors p11 > 0, det P > 0 for every block  <=>  isposdef(M)  (:366); det P = d_k d_{k+1}.
-                double pdmin = 1.0, nsum = 0.0;                              // min over leading minors; NaN/Inf tripwire (fmin drops NaNs)
+                int pdmin = 1;                                               // min over the high words of the leading minors (elim_round)
+                double nsum = 0.0;                                           // NaN/Inf tripwire
                 elim_round<0>(m, em, ep0, pdmin, nsum, rprod);
                 elim_round<1>(m, em, ep1, pdmin, nsum, rprod);
                 elim_round<2>(m, em, ep2, pdmin, nsum, rprod);
@@ -228,7 +229,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                 elim_round<4>(m, em, ep4, pdmin, nsum, rprod);
                 elim_round<5>(m, em, ep5, pdmin, nsum, rprod);
                 DIAG_STAMP(1, m[0]);
-                if (!(pdmin > 0.0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
+                if (!(pdmin > 0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
                 // theta M^-1 (the sweep left -M^-1); padded columns cleared
                 d4 minv;
 #pragma unroll

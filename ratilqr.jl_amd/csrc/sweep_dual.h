@@ -136,7 +136,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
 #pragma unroll
             for (int r = 0; r < 3; ++r) { mA[r] = fma(nth12, vA[r], winv[r]); mB[r] = fma(nth12, vB[r], winv[r]); }
             mA[3] = 0.0; mB[3] = 0.0;
-            double pdA = 1.0, nsA = 0.0, pdB = 1.0, nsB = 0.0;
+            int pdA = 1, pdB = 1;
+            double nsA = 0.0, nsB = 0.0;
             elim_round<0>(mA, em, ep[0], pdA, nsA, rprodA);
             elim_round<0>(mB, em, ep[0], pdB, nsB, rprodB);
             elim_round<1>(mA, em, ep[1], pdA, nsA, rprodA);
@@ -149,8 +150,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
             elim_round<4>(mB, em, ep[4], pdB, nsB, rprodB);
             elim_round<5>(mA, em, ep[5], pdA, nsA, rprodA);
             elim_round<5>(mB, em, ep[5], pdB, nsB, rprodB);
-            if (!(pdA > 0.0) || !(nsA * 0.0 == 0.0)) { failA = 1; return 1; }       // @assert isposdef(M) (:440)
-            if (!deadB && (!(pdB > 0.0) || !(nsB * 0.0 == 0.0))) deadB = 2;         // @assert isposdef(M) (:366)
+            if (!(pdA > 0) || !(nsA * 0.0 == 0.0)) { failA = 1; return 1; }       // @assert isposdef(M) (:440)
+            if (!deadB && (!(pdB > 0) || !(nsB * 0.0 == 0.0))) deadB = 2;         // @assert isposdef(M) (:366)
             d4 minvA, minvB;
 #pragma unroll
             for (int r = 0; r < 3; ++r) { minvA[r] = nth12 * mA[r]; minvB[r] = nth12 * mB[r]; }
