@@ -111,7 +111,7 @@ __device__ __forceinline__ double row_partner(double x, bool odd) {       // the
 // minimum over high words: one SALU op for p11 (it lives in SGPRs) and one VALU op for det -- v_min_f64 would cost three with the
 // canonicalisation that fmin() carries.  NaNs are caught by the running sum nsum.
 template <int KB>
-__device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, double ep, int &pdmin, double &nsum, double &rprod) {
+__device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, int &pdmin, double &nsum, double &rprod) {
     constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
     const double p11 = readlane_f64(m[kr], kg * 16 + k);
     const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
@@ -122,7 +122,8 @@ __device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, double ep
     const double idet = fast_rcp1(det);
     pdmin = min(pdmin, min(__double2hiint(p11), __double2hiint(det)));
     nsum += det;
-    rprod *= det * ep;       // logdet(W M) = sum_k log(det P_k / (e_k e_k+1))  (:387): wave-uniform normalised running product
+    rprod *= det;            // logdet(W M) = sum_k log(det P_k / (e_k e_k+1))  (:387): wave-uniform running product; the caller
+                             // multiplies the step's prod_k 1/(e_k e_k+1) in once (before the rounds) and renormalises per step
     // -(Bk t) on the pivot-row lanes (Bk = adj(P) / det): row k: -(p22 t_k - p12 t_k+1) / det, row k+1: -(p11 t_k+1 - p12 t_k) / det
     const double pd = em.e0[kg >> 1] * p22 + em.e1[kg >> 1] * p11;
     const double nu = fma(p12, other, -(pd * t)) * idet;

@@ -142,14 +142,14 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
 
     // noise tables (time-invariant case is hoisted out of the time loop)
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
-    double ep0 = 1.0, ep1 = 1.0, ep2 = 1.0, ep3 = 1.0, ep4 = 1.0, ep5 = 1.0;   // 1/(e_k e_k+1) per pivot block (wave-uniform)
+    double epall = 1.0;                     // prod over the six pivot blocks of 1/(e_k e_k+1), e = pivots of inv(W) (wave-uniform)
     if (!WTV) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             winv[r] = pb.Winv[64 * r + l];
             wp[r] = pb.Wp[64 * r + l];
         }
-        ep0 = pb.epiv[0]; ep1 = pb.epiv[2]; ep2 = pb.epiv[4]; ep3 = pb.epiv[6]; ep4 = pb.epiv[8]; ep5 = pb.epiv[10];
+        epall = ((((pb.epiv[0] * pb.epiv[2]) * pb.epiv[4]) * pb.epiv[6]) * pb.epiv[8]) * pb.epiv[10];
     }
     const double coef = (theta != 0.0) ? -1.0 / (2.0 * theta) : 0.0;      // of logdet(W M); traces / quadratic forms carry 1/2
 
@@ -199,7 +199,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                     wp[r] = pb.Wp[(long)t * 192 + 64 * r + l];
                 }
                 const double *ept = pb.epiv + (long)t * 16;
-                ep0 = ept[0]; ep1 = ept[2]; ep2 = ept[4]; ep3 = ept[6]; ep4 = ept[8]; ep5 = ept[10];
+                epall = ((((ept[0] * ept[2]) * ept[4]) * ept[6]) * ept[8]) * ept[10];
             }
             // X = V[:, 0:12] [A|B] (rows 0..11 = S [A|B], row 12 = s_vec'[A|B]).  Issued first: it does not depend on the
             // inverse, so the matrix pipe works through it while the VALU runs the elimination below.
@@ -222,12 +222,13 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                 // Leading minors p11 > 0, det P > 0 for every block  <=>  isposdef(M)  (:366); det P = d_k d_{k+1}.
                 int pdmin = 1;                                               // min over the high words of the leading minors (elim_round)
                 double nsum = 0.0;                                           // NaN/Inf tripwire
-                elim_round<0>(m, em, ep0, pdmin, nsum, rprod);
-                elim_round<1>(m, em, ep1, pdmin, nsum, rprod);
-                elim_round<2>(m, em, ep2, pdmin, nsum, rprod);
-                elim_round<3>(m, em, ep3, pdmin, nsum, rprod);
-                elim_round<4>(m, em, ep4, pdmin, nsum, rprod);
-                elim_round<5>(m, em, ep5, pdmin, nsum, rprod);
+                rprod *= epall;
+                elim_round<0>(m, em, pdmin, nsum, rprod);
+                elim_round<1>(m, em, pdmin, nsum, rprod);
+                elim_round<2>(m, em, pdmin, nsum, rprod);
+                elim_round<3>(m, em, pdmin, nsum, rprod);
+                elim_round<4>(m, em, pdmin, nsum, rprod);
+                elim_round<5>(m, em, pdmin, nsum, rprod);
                 DIAG_STAMP(1, m[0]);
                 if (!(pdmin > 0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
                 // theta M^-1 (the sweep left -M^-1); padded columns cleared

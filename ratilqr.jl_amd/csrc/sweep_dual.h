@@ -93,12 +93,11 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     const int lx = (l < 17) ? l : 17;
 
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
-    double ep[6] = {1, 1, 1, 1, 1, 1};
+    double epall = 1.0;
     if (!WTV) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) { winv[r] = pb.Winv[64 * r + l]; wp[r] = pb.Wp[64 * r + l]; }
-#pragma unroll
-        for (int kb = 0; kb < 6; ++kb) ep[kb] = pb.epiv[2 * kb];
+        epall = ((((pb.epiv[0] * pb.epiv[2]) * pb.epiv[4]) * pb.epiv[6]) * pb.epiv[8]) * pb.epiv[10];
     }
     const double coef = (theta != 0.0) ? -1.0 / (2.0 * theta) : 0.0;
 
@@ -124,8 +123,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         if (WTV) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) { winv[r] = pb.Winv[(long)t * 192 + 64 * r + l]; wp[r] = pb.Wp[(long)t * 192 + 64 * r + l]; }
-#pragma unroll
-            for (int kb = 0; kb < 6; ++kb) ep[kb] = pb.epiv[(long)t * 16 + 2 * kb];
+            { const double *ept = pb.epiv + (long)t * 16; epall = ((((ept[0] * ept[2]) * ept[4]) * ept[6]) * ept[8]) * ept[10]; }
         }
         const d4 xzA = mm3(vA, cur.z, (d4){0, 0, 0, 0});
         const d4 xzB = mm3(vB, cur.z, (d4){0, 0, 0, 0});
@@ -138,18 +136,19 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
             mA[3] = 0.0; mB[3] = 0.0;
             int pdA = 1, pdB = 1;
             double nsA = 0.0, nsB = 0.0;
-            elim_round<0>(mA, em, ep[0], pdA, nsA, rprodA);
-            elim_round<0>(mB, em, ep[0], pdB, nsB, rprodB);
-            elim_round<1>(mA, em, ep[1], pdA, nsA, rprodA);
-            elim_round<1>(mB, em, ep[1], pdB, nsB, rprodB);
-            elim_round<2>(mA, em, ep[2], pdA, nsA, rprodA);
-            elim_round<2>(mB, em, ep[2], pdB, nsB, rprodB);
-            elim_round<3>(mA, em, ep[3], pdA, nsA, rprodA);
-            elim_round<3>(mB, em, ep[3], pdB, nsB, rprodB);
-            elim_round<4>(mA, em, ep[4], pdA, nsA, rprodA);
-            elim_round<4>(mB, em, ep[4], pdB, nsB, rprodB);
-            elim_round<5>(mA, em, ep[5], pdA, nsA, rprodA);
-            elim_round<5>(mB, em, ep[5], pdB, nsB, rprodB);
+            rprodA *= epall; rprodB *= epall;
+            elim_round<0>(mA, em, pdA, nsA, rprodA);
+            elim_round<0>(mB, em, pdB, nsB, rprodB);
+            elim_round<1>(mA, em, pdA, nsA, rprodA);
+            elim_round<1>(mB, em, pdB, nsB, rprodB);
+            elim_round<2>(mA, em, pdA, nsA, rprodA);
+            elim_round<2>(mB, em, pdB, nsB, rprodB);
+            elim_round<3>(mA, em, pdA, nsA, rprodA);
+            elim_round<3>(mB, em, pdB, nsB, rprodB);
+            elim_round<4>(mA, em, pdA, nsA, rprodA);
+            elim_round<4>(mB, em, pdB, nsB, rprodB);
+            elim_round<5>(mA, em, pdA, nsA, rprodA);
+            elim_round<5>(mB, em, pdB, nsB, rprodB);
             if (!(pdA > 0) || !(nsA * 0.0 == 0.0)) { failA = 1; return 1; }       // @assert isposdef(M) (:440)
             if (!deadB && (!(pdB > 0) || !(nsB * 0.0 == 0.0))) deadB = 2;         // @assert isposdef(M) (:366)
             d4 minvA, minvB;
