@@ -93,31 +93,33 @@ __device__ __forceinline__ void elim_masks(ElimMasks &em, int g, int j) {
     em.e0[1] = (g == 2) ? 1.0 : 0.0; em.e1[1] = (g == 3) ? 1.0 : 0.0;
     em.odd = (g & 1) != 0;
 }
-__device__ __forceinline__ double row_partner(double x, bool odd) {       // the same column of the adjacent row (0<->1, 2<->3)
-#ifdef RAT_PARTNER_PERMLANE
+// The same column of the adjacent row (0<->1, 2<->3), two ways with identical results:
+//   SWZ = true : ds_swizzle bit mode, lane ^= 16 inside each half of the wave (and 0x1f, or 0, xor 0x10) -- the LDS crossbar without
+//                memory: one instruction per word and the result IS the partner, but an LDS round trip of latency.  For the paired
+//                recursions, whose two chains hide each other's latency and which are short of issue slots.
+//   SWZ = false: v_permlane16_swap (gfx950) of the register with itself, then a select by row parity: two copies, a swap and a
+//                select per word, all VALU (short latency).  For the single recursion, which is bound by its dependency chain.
+template <bool SWZ>
+__device__ __forceinline__ double row_partner(double x, bool odd) {
+    if (SWZ)
+        return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F));
     const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
     const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [0] = (r0, r0, r2, r2), [1] = (r1, r1, r3, r3)
     const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     return __hiloint2double((int)(odd ? sh[0] : sh[1]), (int)(odd ? sl[0] : sl[1]));
-#else
-    // ds_swizzle bit mode, lane ^= 16 inside each half of the wave (and 0x1f, or 0, xor 0x10): the LDS crossbar without memory,
-    // one instruction per word and the result IS the partner (v_permlane16_swap needs two copies and a select per word)
-    (void)odd;
-    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F));
-#endif
 }
 // Leading minors p11 > 0 and det P > 0 of every block <=> isposdef(M) (:366).  A non-NaN double is > 0 iff its high word, read as a
 // signed integer, is > 0 (a positive subnormal below 2^-1022 * 2^-20 counts as singular), so the running minimum is an integer
 // minimum over high words: one SALU op for p11 (it lives in SGPRs) and one VALU op for det -- v_min_f64 would cost three with the
 // canonicalisation that fmin() carries.  NaNs are caught by the running sum nsum.
-template <int KB>
+template <int KB, bool SWZ>
 __device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, int &pdmin, double &nsum, double &rprod) {
     constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
     const double p11 = readlane_f64(m[kr], kg * 16 + k);
     const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
     const double p22 = readlane_f64(m[kr], (kg + 1) * 16 + k + 1);
     const double t = fma(m[kr], em.tm[KB], em.wa[KB]);          // pivot rows, -I in the pivot block, zero elsewhere
-    const double other = row_partner(t, em.odd);
+    const double other = row_partner<SWZ>(t, em.odd);
     const double det = fma(p11, p22, -(p12 * p12));
     const double idet = fast_rcp1(det);
     pdmin = min(pdmin, min(__double2hiint(p11), __double2hiint(det)));

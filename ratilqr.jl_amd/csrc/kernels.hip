@@ -223,12 +223,12 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                 int pdmin = 1;                                               // min over the high words of the leading minors (elim_round)
                 double nsum = 0.0;                                           // NaN/Inf tripwire
                 rprod *= epall;
-                elim_round<0>(m, em, pdmin, nsum, rprod);
-                elim_round<1>(m, em, pdmin, nsum, rprod);
-                elim_round<2>(m, em, pdmin, nsum, rprod);
-                elim_round<3>(m, em, pdmin, nsum, rprod);
-                elim_round<4>(m, em, pdmin, nsum, rprod);
-                elim_round<5>(m, em, pdmin, nsum, rprod);
+                elim_round<0, false>(m, em, pdmin, nsum, rprod);
+                elim_round<1, false>(m, em, pdmin, nsum, rprod);
+                elim_round<2, false>(m, em, pdmin, nsum, rprod);
+                elim_round<3, false>(m, em, pdmin, nsum, rprod);
+                elim_round<4, false>(m, em, pdmin, nsum, rprod);
+                elim_round<5, false>(m, em, pdmin, nsum, rprod);
                 DIAG_STAMP(1, m[0]);
                 if (!(pdmin > 0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
                 // theta M^-1 (the sweep left -M^-1); padded columns cleared

@@ -137,18 +137,18 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
             int pdA = 1, pdB = 1;
             double nsA = 0.0, nsB = 0.0;
             rprodA *= epall; rprodB *= epall;
-            elim_round<0>(mA, em, pdA, nsA, rprodA);
-            elim_round<0>(mB, em, pdB, nsB, rprodB);
-            elim_round<1>(mA, em, pdA, nsA, rprodA);
-            elim_round<1>(mB, em, pdB, nsB, rprodB);
-            elim_round<2>(mA, em, pdA, nsA, rprodA);
-            elim_round<2>(mB, em, pdB, nsB, rprodB);
-            elim_round<3>(mA, em, pdA, nsA, rprodA);
-            elim_round<3>(mB, em, pdB, nsB, rprodB);
-            elim_round<4>(mA, em, pdA, nsA, rprodA);
-            elim_round<4>(mB, em, pdB, nsB, rprodB);
-            elim_round<5>(mA, em, pdA, nsA, rprodA);
-            elim_round<5>(mB, em, pdB, nsB, rprodB);
+            elim_round<0, true>(mA, em, pdA, nsA, rprodA);
+            elim_round<0, true>(mB, em, pdB, nsB, rprodB);
+            elim_round<1, true>(mA, em, pdA, nsA, rprodA);
+            elim_round<1, true>(mB, em, pdB, nsB, rprodB);
+            elim_round<2, true>(mA, em, pdA, nsA, rprodA);
+            elim_round<2, true>(mB, em, pdB, nsB, rprodB);
+            elim_round<3, true>(mA, em, pdA, nsA, rprodA);
+            elim_round<3, true>(mB, em, pdB, nsB, rprodB);
+            elim_round<4, true>(mA, em, pdA, nsA, rprodA);
+            elim_round<4, true>(mB, em, pdB, nsB, rprodB);
+            elim_round<5, true>(mA, em, pdA, nsA, rprodA);
+            elim_round<5, true>(mB, em, pdB, nsB, rprodB);
             if (!(pdA > 0) || !(nsA * 0.0 == 0.0)) { failA = 1; return 1; }       // @assert isposdef(M) (:440)
             if (!deadB && (!(pdB > 0) || !(nsB * 0.0 == 0.0))) deadB = 2;         // @assert isposdef(M) (:366)
             d4 minvA, minvB;
