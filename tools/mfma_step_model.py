@@ -1,4 +1,4 @@
-"""NumPy model of the augmented 16x16 Riccati step that csrc/sweep_mfma.hip implements.
+"""NumPy model of the augmented 16x16 Riccati step that csrc/kernels.hip (sweep_body) implements.
 
 Design note (not product code): shows that one backward step of ileqg.jl:361-391 for n<=12, m<=4 is
 14 products of 16x16 tiles on the *augmented* value matrix V = [[S, sv],[sv', 2s]] plus one 12x12 SPD
