@@ -736,6 +736,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
 #pragma unroll
     for (int d = 0; d < RD - 1; ++d) {
         issue(buf[d], d);
+        if (staged) continue;                                   // operands come from LDS: no vmcnt wait in the loop to calibrate
 #pragma unroll
         for (int q = 0; q < kStoresPerStep; ++q) {              // (distinct pad slots: identical stores would be merged away)
             const int tq = d * kStoresPerStep + q;
