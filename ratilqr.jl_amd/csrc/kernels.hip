@@ -600,7 +600,8 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // a path-dependent number of loads between the prefetch and the tile stores and collapse every counted vmcnt wait.
 // STAGE (closed loop, N <= ROLLIN_NST): the operands of the whole trajectory -- L, xbar, l, dl: 27 KB -- are copied into LDS before the
 // time loop (57 loads in flight at once), so the loop issues no global loads at all and its tile stores never meet a vmcnt wait.
-template <int MODEL, int MODE, bool CTV, bool STAGE = false>
+// SEP (operand loads in the loop only): keep the steps of a group apart in the instruction schedule (see the time loop).
+template <int MODEL, int MODE, bool CTV, bool STAGE = false, bool SEP = true>
 __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     int lane_ = threadIdx.x;
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
@@ -668,6 +669,8 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const long sxu = (j < 3) ? XSTR : (j == 3 ? USTR : TSTRIDE);
     // [c_x | c_u] packed the same way; lane 4 carries c, the other idle lanes 0.0 for the pad slot
     const int qoff = (j < 4) ? TS_QR + 4 * j + g : (l == 4 ? TS_q : TS_PAD);
+    const double pm[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
+    const double m_j4 = (j < 4) ? 1.0 : 0.0, m_l4 = (l == 4) ? 1.0 : 0.0;
     double xb[3];                                               // x_t in B-form
 #pragma unroll
     for (int s = 0; s < 3; ++s) xb[s] = (MODE == 0) ? a.x0[4 * s + g] : xbar[4 * s + g];
@@ -797,7 +800,9 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
         }
         DIAG_STAMP(1, xn[0]);
         // ---- [x_t; u_t] packed on 16 lanes -> one store (idle lanes: 0.0 to the pad slot) ---------------------------------
-        const double pk = (j == 0) ? xb[0] : (j == 1 ? xb[1] : (j == 2 ? xb[2] : (j == 3 ? u : 0.0)));
+        // (0/1 multipliers instead of selects: a select between computed values compiles to a divergent branch, and one branch
+        //  splits the basic block the scheduler needs whole; exactly one term is non-zero, so the sum is exact)
+        const double pk = ((xb[0] * pm[0] + xb[1] * pm[1]) + xb[2] * pm[2]) + u * pm[3];
         pxu[(long)t * sxu] = pk;
         // ---- tile of step t: approximate_model at (x_t, u_t)   (ileqg.jl:294-313) ---------------------
         if (lq) {
@@ -814,11 +819,11 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
             cx = MFMA(cf[1], xb[1], cx);
             cx = MFMA(cf[2], xb[2], cx);
             cx = MFMA(cf[3], u, cx);
-            const double acc = (j == 0) ? cx[0] : (j == 1 ? cx[1] : (j == 2 ? cx[2] : cx[3]));      // packed (lanes j < 4)
+            const double acc = ((cx[0] * pm[0] + cx[1] * pm[1]) + cx[2] * pm[2]) + cx[3] * pm[3];    // packed (lanes j < 4), 0 elsewhere
             // c = [x;u]' (1/2 C [x;u] + lin) + q0  (:296): 16 packed terms, summed per row and then over the four rows
-            const double w = row_sum16((j < 4) ? pk * (0.5 * acc + clin) : 0.0);
+            const double w = row_sum16(pk * (0.5 * acc + clin));     // pk = 0 on the idle lanes
             const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
-            tp[qoff] = (j < 4) ? acc + clin : (l == 4 ? part + cq00 : 0.0);   // [c_x | c_u] = C [x;u] + [qv;rv]  (:297,:299), c, pad
+            tp[qoff] = fma(m_l4, part + cq00, m_j4 * (acc + clin));  // [c_x | c_u] = C [x;u] + [qv;rv]  (:297,:299), c, pad (0.0)
         } else {
             // power-law family (n == m <= 4): every derivative is diagonal, and row g's entries sit on the lanes of row g
             double val = 0.0, cv = 0.0;
@@ -859,6 +864,11 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     for (; t0 + RD <= N; t0 += RD) {
 #pragma unroll
         for (int d = 0; d < RD; ++d) {
+            // the group of RD steps is one basic block.  With the operands staged in LDS the scheduler may interleave the steps
+            // freely.  With operand loads in the loop it sinks every store of the group below the loads of the last step, which
+            // collapses the counted-vmcnt pipeline above: at one wave per SIMD (E = 1) that costs 15 % and nothing may cross a step
+            // boundary (SEP); with two waves per SIMD (E > 1) the other wave fills the gaps and the freer schedule measured 5 % faster.
+            if (!staged && SEP) __builtin_amdgcn_sched_barrier(0);
             issue(buf[(d + RD - 1) % RD], t0 + d + RD - 1);
             step(t0 + d, buf[d]);
         }
@@ -913,27 +923,28 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     BODY_MARK(a.dump, 12 + 4 * MODE + 3);
 }
 
-template <int MODEL, int MODE, bool CTV>
+template <int MODEL, int MODE, bool CTV, bool SEP>
 __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
-    rollin_body<MODEL, MODE, CTV>(a, blockIdx.x);
+    rollin_body<MODEL, MODE, CTV, false, SEP>(a, blockIdx.x);
 }
 
 void launch_rollin(const RolloutArgs &a, hipStream_t s) {
     const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
     if (ncand <= 0) return;
     const dim3 grid(ncand), block(64);
+    const bool sep = (a.mode == 0) || a.st.E == 1;            // one wave per SIMD: see rollin_body
     // one compact instantiation per (model family, mode): the LQ hot loop must not carry the inlined pow() expansions
     // of the power-law family through the instruction cache
+#define ROLLIN_LAUNCH(M, MD, C) do { if (sep) hipLaunchKernelGGL((rollin_kernel<M, MD, C, true>), grid, block, 0, s, a); \
+                                     else hipLaunchKernelGGL((rollin_kernel<M, MD, C, false>), grid, block, 0, s, a); } while (0)
     if (a.pb.model == 1 && a.pb.cost_tv) {
-        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<1, 0, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((rollin_kernel<1, 1, true>), grid, block, 0, s, a);
+        if (a.mode == 0) ROLLIN_LAUNCH(1, 0, true); else ROLLIN_LAUNCH(1, 1, true);
     } else if (a.pb.model == 1) {
-        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<1, 0, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((rollin_kernel<1, 1, false>), grid, block, 0, s, a);
+        if (a.mode == 0) ROLLIN_LAUNCH(1, 0, false); else ROLLIN_LAUNCH(1, 1, false);
     } else {
-        if (a.mode == 0) hipLaunchKernelGGL((rollin_kernel<2, 0, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((rollin_kernel<2, 1, false>), grid, block, 0, s, a);
+        if (a.mode == 0) ROLLIN_LAUNCH(2, 0, false); else ROLLIN_LAUNCH(2, 1, false);
     }
+#undef ROLLIN_LAUNCH
 }
 
 // =====================================================================================================
