@@ -228,7 +228,7 @@ static rat_rc alloc_state(rat_handle h) {
     AL(st.theta, B); AL(st.mu, B); AL(st.delta, B); AL(st.value, B); AL(st.d_cur, B); AL(st.eps_init, B); AL(st.ls_eps, B);
     AL(st.status, B); AL(st.iter, B); AL(st.ls_active, B); AL(st.ls_count, B); AL(st.slot_nom, B); AL(st.n_ls, B); AL(st.hist_n, B);
     AL(st.value_c, (size_t)B * E); AL(st.d_c, (size_t)B * E); AL(st.flag_c, (size_t)B * E);
-    AL(st.counters, 2 * CTR_RING);
+    AL(st.counters, 2 * CTR_RING); AL(st.sink, 64);
     st.hist = nullptr; st.hist_cap = 0;
     AL(h->d_x0, XSTR); AL(h->d_u0, (size_t)N * USTR); AL(h->d_theta, B); AL(h->d_val, B);
     AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);

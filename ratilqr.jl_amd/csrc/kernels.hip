@@ -113,7 +113,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     double *__restrict__ dlout = st.dl + (long)osel * st.dl_half + (long)b * N * USTR;
 
     __shared__ double lbuf[64];        // policy evaluation: the step's gain row block [L | dl], natural 4 x 16 layout
-    __shared__ double ex[104];         // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0, [84..99] = s_vec
+    __shared__ double ex[104 + 64];    // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0, [84..99] = s_vec,
+                                       // [104..167] dump slots: the row-0-only writes are unconditional, idle lanes write there
+                                       // (a lane-conditional write splits the basic block the scheduler works on)
 #define HBUF(r_, c_) ex[(r_) * 16 + (c_)]
 #define FBUF(c_) ex[64 + (c_)]
 #define SVB(c_) ex[84 + (c_)]
@@ -137,6 +139,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     for (int r = 0; r < 3; ++r) foff[r] = (j == 12) ? (64 + 4 * r + g) : 80;
     const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
 
+    const int svo = (g == 0) ? 84 + j : 104 + l, fbo = (g == 0) ? 64 + j : 104 + l;
+    double *const pgl = (j < 12) ? Lout + g * 12 + j : (j == 12 ? dlout + g : st.sink + l);
+    const long sgl = (j < 12) ? LSTR : (j == 12 ? USTR : 0);
     const int lx = (l < 17) ? l : 17;                        // [qr | q | pad] row: lanes past q read the (zero) pad slot
     const int lq = g * 12 + ((j < 12) ? j : 11);             // own entry of L_t (4 x 12 row-major), clamped
 
@@ -208,7 +213,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
             const double qc = readlane_f64(cur.x, 16);                      // c (ileqg.jl:296)
             d4 tm;
             if (theta != 0.0) {
-                if (g == 0) SVB(j) = v[3];                                  // s_vec (row 12 of V) to every lane, off the critical path
+                ex[svo] = v[3];                                             // s_vec (row 12 of V) to every lane, off the critical path
                 // M = Symmetric(inv(W) - theta S)   (ileqg.jl:365)
                 d4 m;
 #pragma unroll
@@ -258,7 +263,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
             const double fv = tm[3] + cur.x;      // lanes g == 0: [q_vec + A' D s_vec | r + B' D s_vec]  (:368, :389)
             DIAG_STAMP(3, gh);
             HBUF(g, j) = gh;
-            if (g == 0) FBUF(j) = fv;
+            ex[fbo] = fv;
             WAVE_SYNC();
             // row g of H = Symmetric(H) (upper triangle, :371) and this lane's entry of [G | g | 0]
             const double hg0 = ex[hoff[0]], hg1 = ex[hoff[1]], hg2 = ex[hoff[2]], hg3 = ex[hoff[3]];
@@ -297,8 +302,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
             const double ua = hg0 * x0 + hg1 * x1 + hg2 * x2 + hg3 * x3 + ga;         // H [L|dl] + [G|g]
             DIAG_STAMP(4, ua);
             if (GAIN) {
-                if (j < 12) Lout[(long)t * LSTR + g * 12 + j] = la;
-                else if (j == 12) dlout[(long)t * USTR + g] = la;
+                pgl[(long)t * sgl] = (j <= 12) ? la : 0.0;      // L_t (columns 0..11) | dl_t (column 12) | idle lanes: sink
             }
             // Fx = [[Q + A'DSA, f_x], [f_x', 2q + 2s + theta s'M^-1 s]]
             d4 fx;

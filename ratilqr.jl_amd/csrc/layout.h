@@ -93,6 +93,8 @@ struct StateDev {
     int *flag_c;                               // [B*E] 0 ok, 1 DP failed (M not PD), 2 domain failure
     double *hist; int hist_cap;                // [B][2*hist_cap] or null
     int *counters;                             // [CTR_RING][2]: per round {samples still in line search, samples running}
+    double *sink;                              // [64] write-only: idle lanes of unconditional stores (a lane-conditional store splits
+                                               // the basic block the scheduler works on)
 };
 
 struct OptsDev {

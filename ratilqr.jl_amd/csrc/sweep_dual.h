@@ -72,7 +72,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     double *__restrict__ dlout = st.dl + (long)(sel ^ 1) * st.dl_half + (long)b * N * USTR;
 
     __shared__ double lbufA[64];
-    __shared__ double exA[104], exB[104];                              // [G|H] 4x16, f 16, [80] = 0, [84..99] = s_vec
+    __shared__ double exA[104 + 64], exB[104 + 64];                    // [G|H] 4x16, f 16, [80] = 0, [84..99] = s_vec, [104..] dump slots
+                                                                       // of the idle lanes (unconditional writes: see sweep_body)
     if (l < 8) { exA[80 + l] = 0.0; exB[80 + l] = 0.0; }
 
     const double mL = (a.mode == 7 && j < 12) ? 1.0 : 0.0;
@@ -91,6 +92,9 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     for (int r = 0; r < 3; ++r) foff[r] = (j == 12) ? (64 + 4 * r + g) : 80;
     const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
     const int lx = (l < 17) ? l : 17;
+    const int svo = (g == 0) ? 84 + j : 104 + l, fbo = (g == 0) ? 64 + j : 104 + l;
+    double *const pgl = (j < 12) ? Lout + g * 12 + j : (j == 12 ? dlout + g : st.sink + l);
+    const long sgl = (j < 12) ? LSTR : (j == 12 ? USTR : 0);
 
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
     double epall = 1.0;
@@ -129,7 +133,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         const d4 xzB = mm3(vB, cur.z, (d4){0, 0, 0, 0});
         d4 tmA, tmB;
         if (theta != 0.0) {
-            if (g == 0) { exA[84 + j] = vA[3]; exB[84 + j] = vB[3]; }
+            exA[svo] = vA[3]; exB[svo] = vB[3];
             d4 mA, mB;
 #pragma unroll
             for (int r = 0; r < 3; ++r) { mA[r] = fma(nth12, vA[r], winv[r]); mB[r] = fma(nth12, vB[r], winv[r]); }
@@ -173,7 +177,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         const double ghA = fma(muA, mH, fA[3]), ghB = fma(muB, mH, fB[3]);
         const double fvA = tmA[3] + cur.x, fvB = tmB[3] + cur.x;
         exA[g * 16 + j] = ghA; exB[g * 16 + j] = ghB;
-        if (g == 0) { exA[64 + j] = fvA; exB[64 + j] = fvB; }
+        exA[fbo] = fvA; exB[fbo] = fvB;
         if (HASL) lbufA[l] = cur.la;                            // rows of [L | dl] of the given policy to every lane
         WAVE_SYNC();
         // ---- A: given policy (:446-451) ----
@@ -205,8 +209,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         const double x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
         const double laB = (g == 0) ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
         const double uaB = hB0 * x0 + hB1 * x1 + hB2 * x2 + hB3 * x3 + gaB;
-        if (j < 12) Lout[(long)t * LSTR + g * 12 + j] = laB;
-        else if (j == 12) dlout[(long)t * USTR + g] = laB;
+        pgl[(long)t * sgl] = (j <= 12) ? laB : 0.0;                // L_t | dl_t | idle lanes: sink
         d4 fxA, fxB;
 #pragma unroll
         for (int r = 0; r < 3; ++r) { fxA[r] = fma(fA[r], m12, exA[foff[r]]); fxB[r] = fma(fB[r], m12, exB[foff[r]]); }
