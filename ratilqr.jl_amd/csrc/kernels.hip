@@ -292,7 +292,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                 x2 = y2 * i2 - l32 * x3;
                 x1 = y1 * i1 - l21 * x2 - l31 * x3;
                 x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-                la = (g == 0) ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));             // [L | dl] natural rows
+                // [L | dl] natural rows: row g takes x_g (0/1 row selectors, not a select between computed values: that compiles
+                // to a chain of divergent branches)
+                la = ((x0 * em.e0[0] + x1 * em.e1[0]) + x2 * em.e0[1]) + x3 * em.e1[1];
             } else if (HASL) {
                 x0 = lbuf[j]; x1 = lbuf[16 + j]; x2 = lbuf[32 + j]; x3 = lbuf[48 + j];   // column j of [L | dl]
                 la = cur.la;

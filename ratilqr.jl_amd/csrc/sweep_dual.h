@@ -207,7 +207,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
         const double x2 = y2 * i2 - l32 * x3;
         const double x1 = y1 * i1 - l21 * x2 - l31 * x3;
         const double x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-        const double laB = (g == 0) ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
+        const double laB = ((x0 * em.e0[0] + x1 * em.e1[0]) + x2 * em.e0[1]) + x3 * em.e1[1];     // row g takes x_g (see sweep_body)
         const double uaB = hB0 * x0 + hB1 * x1 + hB2 * x2 + hB3 * x3 + gaB;
         pgl[(long)t * sgl] = (j <= 12) ? laB : 0.0;                // L_t | dl_t | idle lanes: sink
         d4 fxA, fxB;
