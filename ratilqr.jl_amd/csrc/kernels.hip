@@ -1142,33 +1142,39 @@ void launch_commit_init(const StateDev &st, hipStream_t s) {
 // Counters of round `slot`: [2*slot] samples still inside their line search, [2*slot+1] samples still running.
 // ctr: the round's counter pair, or null (fused solve: nobody polls)
 __device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev &op, const int b, int *ctr) {
-    if (!st.ls_active[b]) return;
-    double eps = st.ls_eps[b];
-    const double cur = st.value[b];
-    int count = st.ls_count[b];
+    // One lane runs this: every per-sample scalar it can need is fetched up front, so that the loads are in flight together (a
+    // chain of a dozen dependent L2 round trips otherwise: ~10k cycles per line-search decision inside the fused solve).
+    const int active = st.ls_active[b];
+    const int c0 = b * st.E;
+    const double eps_in = st.ls_eps[b], cur = st.value[b], mu_b = st.mu[b];
+    const int count_in = st.ls_count[b], nls_in = st.n_ls[b], spec = st.spec_st[b], nom = st.slot_nom[b], iter_b = st.iter[b];
+    const int hn_in = st.hist ? st.hist_n[b] : 0;
+    const int fl0 = st.flag_c[c0];
+    const double nv0 = st.value_c[c0], dc0 = st.d_c[c0];
+    if (!active) return;
+    double eps = eps_in;
+    int count = count_in, hn = hn_in;
     int chosen = -1;
     bool failed = false;
     for (int k = 0; k < st.E; ++k) {
-        const int c = b * st.E + k;
+        const int c = c0 + k;
         count++;                                               // :505
-        const int fl = st.flag_c[c];
+        const int fl = (k == 0) ? fl0 : st.flag_c[c];
         if (fl == 2) { failed = true; break; }                 // exception outside the try (App. B.8)
         if (fl == 1) { eps *= op.lambda; continue; }           // :529-535
-        const double nv = st.value_c[c];
+        const double nv = (k == 0) ? nv0 : st.value_c[c];
         if (st.hist) {
-            const int hn = st.hist_n[b];
             if (hn < st.hist_cap) {
                 st.hist[((long)b * st.hist_cap + hn) * 2] = eps;
                 st.hist[((long)b * st.hist_cap + hn) * 2 + 1] = nv - cur;          // :537
             }
-            st.hist_n[b] = hn + 1;
+            st.hist_n[b] = ++hn;
         }
         if (isapprox_default(nv, cur) || nv < cur) { chosen = k; break; }           // :538
         eps *= op.lambda;                                      // :557
         if (eps < op.eps_min) { chosen = k; break; }           // :558 forced accept of the candidate just evaluated
     }
-    st.n_ls[b] += (chosen >= 0 || failed) ? (count - st.ls_count[b]) : st.E;
-    const int spec = st.spec_st[b];
+    st.n_ls[b] = nls_in + ((chosen >= 0 || failed) ? (count - count_in) : st.E);
     if (failed) {
         st.status[b] = 4; st.value[b] = INFINITY; st.ls_active[b] = 0; st.spec_st[b] = 0;
         return;
@@ -1182,10 +1188,10 @@ __device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev
         return;
     }
     // accept (:539-555 / :559-575)
-    const int c = b * st.E + chosen;
-    const int nom = st.slot_nom[b];
-    st.d_cur[b] = st.d_c[c];
-    st.value[b] = st.value_c[c];
+    const int c = c0 + chosen;
+    const double d_new = (chosen == 0) ? dc0 : st.d_c[c];
+    st.d_cur[b] = d_new;
+    st.value[b] = (chosen == 0) ? nv0 : st.value_c[c];
     st.slot_nom[b] = (chosen < nom) ? chosen : chosen + 1;     // x_array, l_array (and their tiles) <- candidate
     st.ls_active[b] = 0;
     if (op.adaptive) {                                         // :582-591
@@ -1195,8 +1201,8 @@ __device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev
             st.eps_init[b] = eps;
         }
     }
-    if (op.d > st.d_cur[b] && st.mu[b] <= op.mu_min) { st.status[b] = 0; st.spec_st[b] = 0; }              // converged  (:642)
-    else if (st.iter[b] == op.iter_max) { st.status[b] = 3; st.spec_st[b] = 0; }                           // iter_max   (:648)
+    if (op.d > d_new && mu_b <= op.mu_min) { st.status[b] = 0; st.spec_st[b] = 0; }                         // converged  (:642)
+    else if (iter_b == op.iter_max) { st.status[b] = 3; st.spec_st[b] = 0; }                                // iter_max   (:648)
     else if (chosen == 0 && spec != 0) {
         if (commit_spec(st, b) && ctr) atomicAdd(&ctr[1], 1);  // next step! already has its gain sweep: straight to line search
     } else {
