@@ -79,34 +79,33 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     const ProblemDev &pb = a.pb;
     [[maybe_unused]] constexpr int dgs = (GAIN ? 0 : (HASL ? 4 : 8));
     BODY_MARK(a.dump, dgs + 0);
-    int b, slot, cidx = -1;
-    if (a.mode == 1) {
-        b = tid / st.E;
-        const int k = tid - b * st.E;
-        if (!st.ls_active[b]) return;
-        cidx = tid;
-        if (st.flag_c[cidx] == 2) return;
-        slot = cand_slot(b, k, st.slot_nom[b], st.E);
-    } else if (a.mode == 4) {          // speculative gain sweep of the NEXT iteration on line-search candidate 0
-        b = tid;
-        if (!st.ls_active[b]) return;
-        if (st.flag_c[b * st.E] == 2) return;
-        slot = cand_slot(b, 0, st.slot_nom[b], st.E);
-    } else if (a.mode == 5) {          // speculative first gain sweep on the nominal tiles, concurrent with initialize!'s sweep
-        b = tid;
-        slot = b * (st.E + 1) + st.slot_nom[b];
-    } else {
-        b = tid;
-        if (st.status[b] != ST_RUNNING) return;
-        if (a.mode == 0 && st.ls_active[b]) return;      // still inside line_search! of its current iteration
-        slot = b * (st.E + 1) + st.slot_nom[b];
-    }
-    const double theta = st.theta[b];
-    double mu = (a.mode == 2) ? 0.0 : (a.mode == 3 ? a.mu_op : st.mu[b]);
+    // (every per-sample scalar is fetched before the first test on any of them: issued back to back the loads are in flight
+    //  together; tested one by one they are a chain of dependent L2 round trips at every phase boundary of the fused solve)
+    int b, k = 0, slot, cidx = -1;
+    if (a.mode == 1) { b = tid / st.E; k = tid - b * st.E; } else b = tid;
+    const int fidx = (a.mode == 1) ? tid : b * st.E;
+    const int s_act = st.ls_active[b], s_flag = st.flag_c[fidx], s_nom = st.slot_nom[b], s_stat = st.status[b], sel = st.lsel[b];
+    const double theta = st.theta[b], mu_in = st.mu[b];
     double delta = st.delta[b];
+    if (a.mode == 1) {
+        if (!s_act) return;
+        cidx = tid;
+        if (s_flag == 2) return;
+        slot = cand_slot(b, k, s_nom, st.E);
+    } else if (a.mode == 4) {          // speculative gain sweep of the NEXT iteration on line-search candidate 0
+        if (!s_act) return;
+        if (s_flag == 2) return;
+        slot = cand_slot(b, 0, s_nom, st.E);
+    } else if (a.mode == 5) {          // speculative first gain sweep on the nominal tiles, concurrent with initialize!'s sweep
+        slot = b * (st.E + 1) + s_nom;
+    } else {
+        if (s_stat != ST_RUNNING) return;
+        if (a.mode == 0 && s_act) return;                 // still inside line_search! of its current iteration
+        slot = b * (st.E + 1) + s_nom;
+    }
+    double mu = (a.mode == 2) ? 0.0 : (a.mode == 3 ? a.mu_op : mu_in);
     const int N = st.N;
     const double *__restrict__ tile0 = st.tiles + (long)slot * st.tile_stride;
-    const int sel = st.lsel[b];
     const int osel = (a.mode >= 4) ? (sel ^ 1) : sel;      // speculative sweeps fill the other half; committed by select
     const double *__restrict__ Lb = st.L + (long)sel * st.l_half + (long)b * N * LSTR;
     double *__restrict__ Lout = st.L + (long)osel * st.l_half + (long)b * N * LSTR;
@@ -621,11 +620,15 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const int N = st.N;
     BODY_MARK(a.dump, 12 + 4 * MODE + 0);
     int b, k = 0;
-    if (MODE == 0) { b = c; if (st.status[b] != ST_RUNNING) return; }
-    else { b = c / st.E; k = c - b * st.E; if (!st.ls_active[b]) return; }
+    if (MODE == 0) b = c;
+    else { b = c / st.E; k = c - b * st.E; }
+    // (per-sample scalars fetched before the first test on any of them: see sweep_body)
+    const int s_stat = st.status[b], s_act = st.ls_active[b], nom = st.slot_nom[b], lsel = st.lsel[b];
+    const double eps_in = st.ls_eps[b];
+    if (MODE == 0) { if (s_stat != ST_RUNNING) return; }
+    else { if (!s_act) return; }
     __shared__ double shxu[16];                                  // terminal tile only
 
-    const int nom = st.slot_nom[b];
     const int slot_n = b * (st.E + 1) + nom;
     const int slot_o = (MODE == 0) ? slot_n : cand_slot(b, k, nom, st.E);
     const double *__restrict__ xbar = st.xs + (long)slot_n * st.x_stride;
@@ -633,7 +636,6 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     double *__restrict__ xo = st.xs + (long)slot_o * st.x_stride;
     double *__restrict__ uo = st.us + (long)slot_o * st.u_stride;
     double *__restrict__ tile0 = st.tiles + (long)slot_o * st.tile_stride;
-    const int lsel = st.lsel[b];
     const double *__restrict__ Lb = st.L + (long)lsel * st.l_half + (long)b * N * LSTR;
     const double *__restrict__ dlb = st.dl + (long)lsel * st.dl_half + (long)b * N * USTR;
     constexpr bool lq = (MODEL == 1);
@@ -641,7 +643,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
 
     double eps = 0.0;
     if (MODE == 1) {
-        eps = st.ls_eps[b];
+        eps = eps_in;
         for (int q = 0; q < k; ++q) eps *= a.op.lambda;        // eps_k = eps * lambda^k by repeated multiplication (:530,:557)
     }
     // per-lane constants (dynamics are time-invariant; cost tables only when !CTV).  The tile is a register image

@@ -51,22 +51,22 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     const ProblemDev &pb = a.pb;
     [[maybe_unused]] const int dgs = 20 + 4 * (a.mode - 6);
     BODY_MARK(a.dump, dgs + 0);
+    // (per-sample scalars fetched before the first test on any of them: see sweep_body)
     int slot, cidx = -1;
+    const int s_act = st.ls_active[b], s_flag = st.flag_c[b * st.E], s_nom = st.slot_nom[b], s_stat = st.status[b], sel = st.lsel[b];
+    const double theta = st.theta[b], muB = st.mu[b];          // initialize! leaves mu = 0 (set by init_state_kernel)
     if (a.mode == 7) {
-        if (!st.ls_active[b]) return;
+        if (!s_act) return;
         cidx = b * st.E;
-        if (st.flag_c[cidx] == 2) return;
-        slot = cand_slot(b, 0, st.slot_nom[b], st.E);
+        if (s_flag == 2) return;
+        slot = cand_slot(b, 0, s_nom, st.E);
     } else {
-        if (st.status[b] != ST_RUNNING) return;
-        slot = b * (st.E + 1) + st.slot_nom[b];
+        if (s_stat != ST_RUNNING) return;
+        slot = b * (st.E + 1) + s_nom;
     }
-    const double theta = st.theta[b];
-    const double muA = (a.mode == 6) ? 0.0 : st.mu[b];
-    const double muB = st.mu[b];                              // initialize! leaves mu = 0 (set by init_state_kernel)
+    const double muA = (a.mode == 6) ? 0.0 : muB;
     const int N = st.N;
     const double *__restrict__ tile0 = st.tiles + (long)slot * st.tile_stride;
-    const int sel = st.lsel[b];
     const double *__restrict__ Lb = st.L + (long)sel * st.l_half + (long)b * N * LSTR;
     double *__restrict__ Lout = st.L + (long)(sel ^ 1) * st.l_half + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)(sel ^ 1) * st.dl_half + (long)b * N * USTR;
