@@ -1,26 +1,33 @@
 // kernels.hip -- gfx950 (CDNA4) kernels of the iLEQG hot path.
 //
-//   rollout_kernel    simulate_dynamics, open loop and closed loop        (ileqg.jl:18-38, 62-87) + d_current reduction (:539)
-//   linearize_kernel  approximate_model -> tile bundles in HBM            (ileqg.jl:258-322)
-//   sweep_kernel      risk-sensitive Riccati sweep, gain / policy-eval    (ileqg.jl:341-406 / 412-465)
-//   ls_select_kernel / init_state_kernel (+ the epilogue of the gain sweep)  per-sample control flow of step!/line_search!/solve!
+//   solve_fused_kernel  the COMPLETE solve! of one theta-sample in one persistent wavefront (default, E = 1): the phases below as
+//                       device functions (rollin_body, sweep_body, sweep_dual_body, ls_select_body)          (ileqg.jl:635-659)
+//   rollin_kernel       simulate_dynamics + approximate_model fused: rollout on the matrix pipe, tile records streamed to HBM
+//                                                                                                (ileqg.jl:18-38, 62-87, 258-322)
+//   sweep_kernel        risk-sensitive Riccati sweep, gain / policy evaluation                   (ileqg.jl:341-406 / 412-465)
+//   rollout_kernel, linearize_kernel   the same two reference functions unfused (operator entry points)
+//   noisy_rollout_kernel               simulate_dynamics with process noise + integrate_cost     (ileqg.jl:44-55, 94-109, 115-124)
+//   ls_select_kernel / init_state_kernel / commit_init_kernel   per-sample control flow of step! / line_search! / solve!
 //                                                                          (ileqg.jl:494-592, 598-613, 635-659) replayed on device
+//   pets_rollout_kernel, pets_mean_kernel   PETS stochastic rollouts                             (pets.jl:76-157)
 //
-// sweep_kernel: ONE WAVEFRONT PER TRAJECTORY.  The value function is carried as the augmented
+// Sweep: ONE WAVEFRONT PER TRAJECTORY.  The value function is carried as the augmented
 // symmetric matrix V = [[S, s_vec], [s_vec', 2 s]] (13 x 13 inside a 16 x 16 tile) held in the
 // accumulator layout of v_mfma_f64_16x16x4_f64 (4 doubles per lane: col = lane & 15,
 // row = 4*reg + (lane >> 4)).  In that layout register s of a matrix X is at once
 //   - the B operand of K-slice s of  (.) * X, and
 //   - the A operand of K-slice s of  X' * (.)
 // so every product of one backward step chains through registers with no data movement:
-//     X  = V [A|B]            3 MFMA      (independent of the inverse: runs on the matrix pipe under the elimination)
-//     Y  = theta M^-1 X       3 MFMA      (M = W^-1 - theta S, inverted by a symmetric sweep with 2x2 block pivots)
+//     X  = V [A|B]            3 MFMA      (independent of the inverse)
+//     M^-1                    6 MFMA      (M = W^-1 - theta S: symmetric sweep with 2x2 block pivots, one rank-2 MFMA per round;
+//                                          elim_round in device_utils.h)
+//     Y  = theta M^-1 X       3 MFMA
 //     T  = X + V Y            3 MFMA      (= (D S)[A|B]; row 12 of T is (D s_vec)'[A|B])
 //     F  = [A|B]' T + C       3 MFMA      (C = [[Q,P'],[P,R]] enters as the accumulator input)
 //     V  = Fx + La' Ua + Ga' La   2 MFMA  (La = [L|dl], Ga = [G|g], Ua = H La + Ga: 4 x 16 "natural" rows)
 // The 4x4 system H X = -[G|g] is solved redundantly by every lane for its own column (LDL').
-// logdet(W M) is accumulated per lane as sum_k log(d_k / e_k) (pivots of M over pivots of W^-1) and
-// reduced once per sweep.  See tools/mfma_step_model.py for the NumPy model of this step.
+// logdet(W M) is accumulated as a wave-uniform normalised running product of det(P_k) / (e_k e_k+1) (pivot blocks of M over
+// pivots of W^-1) and reduced once per sweep.  See tools/mfma_step_model.py for the NumPy model of this step.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -221,7 +228,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                 DIAG_STAMP(0, m[0]);
                 // symmetric sweep operator with 2x2 block pivots K = {k, k+1}, k = 0, 2, .., 10:  m <- -M^-1.
                 // With P = M_KK, Bk = P^-1:  M'_KK = -Bk, M'_Kj = Bk M_Kj, M'_iK = M_iK Bk, M'_ij = M_ij - M_iK Bk M_Kj.
-                // Rows k, k+1 are exchanged through LDS with -I in their pivot slots, so that every lane runs the one formula
+                // Rows k, k+1 (with -I in their pivot slots) are their own A operand, so that every entry obeys the one formula
                 //   m'_ij = base_ij - vi1 U1_j - vi2 U2_j,   U_j = Bk [v1_j; v2_j],   base = 0 on pivot rows/columns, m elsewhere.
                 // Leading minors p11 > 0, det P > 0 for every block  <=>  isposdef(M)  (:366); det P = d_k d_{k+1}.
                 int pdmin = 1;                                               // min over the high words of the leading minors (elim_round)
@@ -956,7 +963,7 @@ void launch_rollin(const RolloutArgs &a, hipStream_t s) {
 }
 
 // =====================================================================================================
-// linearize_kernel: one wavefront per (trajectory, time step); writes the 417-double tile.
+// linearize_kernel: one wavefront per (trajectory, time step); writes the tile record (layout.h).
 // =====================================================================================================
 __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15;
