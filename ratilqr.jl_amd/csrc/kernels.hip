@@ -27,7 +27,7 @@
 //     V  = Fx + La' Ua + Ga' La   2 MFMA  (La = [L|dl], Ga = [G|g], Ua = H La + Ga: 4 x 16 "natural" rows)
 // The 4x4 system H X = -[G|g] is solved redundantly by every lane for its own column (LDL').
 // logdet(W M) is accumulated as a wave-uniform normalised running product of det(P_k) / (e_k e_k+1) (pivot blocks of M over
-// pivots of W^-1) and reduced once per sweep.  See tools/mfma_step_model.py for the NumPy model of this step.
+// pivots of W^-1) and reduced once per sweep.  See tests/step_model.py for the NumPy model of this step.
 #include <hip/hip_runtime.h>
 #include <math.h>
 

@@ -2,7 +2,7 @@
 
 Design note (not product code): shows that one backward step of ileqg.jl:361-391 for n<=12, m<=4 is
 14 products of 16x16 tiles on the *augmented* value matrix V = [[S, sv],[sv', 2s]] plus one 12x12 SPD
-inverse and one 4x4 solve.  Run: python tools/mfma_step_model.py  (compares with the CPU oracle).
+inverse and one 4x4 solve.  Checked against the CPU oracle by tests/test_cpu_step_model.py.
 """
 import sys, os
 import numpy as np
@@ -72,26 +72,3 @@ def sweep(a, n, m, N, W, theta, mu, L=None):
         assert ok1 and ok2
         Ls[t] = Laug[:m, :n]; dls[t] = Laug[:m, AUG]; s[t] = V[AUG, AUG] / 2
     return Ls, dls, s, V
-
-
-if __name__ == "__main__":
-    import ratilqr.jl_amd as rat
-    from oracle import oracle as orc
-    for (n, m, N, kappa) in [(12, 4, 50, 0.02), (4, 2, 20, 0.0), (2, 2, 10, 0.0)]:
-        prob, x0, _ = rat.synthetic_lq_problem(n=n, m=m, N=N, seed=3, kappa=kappa)
-        P = orc.Problem(prob)
-        u = 0.1 * np.random.default_rng(1).standard_normal((N, m))
-        _, x = orc.simulate_open(P, x0, u)
-        _, ap = orc.approximate_model(P, u, x)
-        a = ap.arrays()
-        for theta in (0.0, 2.0, 6.0):
-            _, Lo, dlo, dpo, _, _ = orc.dp_gain(P, ap, theta)
-            Lm, dlm, sm, _ = sweep(a, n, m, N, prob.W(0), theta, 0.0)
-            e1 = np.abs(Lm - Lo).max() / np.abs(Lo).max(); e2 = np.abs(dlm - dlo).max() / np.abs(dlo).max()
-            e3 = np.abs(sm - dpo["s"]).max() / np.abs(dpo["s"]).max()
-            _, dpe = orc.dp_eval(P, ap, Lo * 0.9, None, theta, 1e-6)
-            _, _, se, _ = sweep(a, n, m, N, prob.W(0), theta, 1e-6, L=Lo * 0.9)
-            e4 = abs(se[0] - dpe["s"][0]) / abs(dpe["s"][0])
-            print(f"n={n} m={m} theta={theta}: gain L {e1:.1e} dl {e2:.1e} s {e3:.1e} | eval s0 {e4:.1e}")
-            assert max(e1, e2, e3, e4) < 1e-10
-    print("augmented-step model matches the oracle")
