@@ -102,3 +102,29 @@ def test_kl_zero_is_ilqg():                                   # ce.jl:386-389, 4
     solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=3)
     th, x, l, L, val, tmin, tmax = ce.solve_(solver, prob, x0, u, 1, kl_bound=0.0)
     assert th == 0.0 and tmin == 0.0 and tmax == 0.0 and abs(val - 1.0029075497782471) < 1e-9
+
+
+def test_config3_full_size_ce_matches_the_oracle():
+    """BASELINE config 3: the full RAT iLQR solve -- 1024 CE samples, 100 elites, 5 CE iterations, N = 50, n = 12, m = 4 -- with one
+    (fused solve kernel) and with 8 speculative line-search step sizes per sample, against the oracle run live on the same injected
+    N(0,1) stream (5120 iLEQG solves on the host cores): same draws, same elite sets (hence mu, sigma to 1e-9), same theta_opt."""
+    import os
+    prob, x0, u = rat.synthetic_lq_problem()
+    z = np.random.default_rng(31).standard_normal(40000)
+    kw = dict(num_samples=1024, num_elite=100)
+    oc = orc.CrossEntropyBilevelOptimizationSolver(z, nthreads=os.cpu_count() or 8, **kw)
+    rc, th_o, x_o, l_o, L_o, val_o, tmin_o, tmax_o = oc.solve(orc.Problem(prob), x0, u, 0.1)
+    assert rc == 0
+    res = []
+    for E in (1, 8):
+        solver = rat.CrossEntropyBilevelOptimizationSolver(spec_eps=E, **kw)
+        th, x, l, L, val, tmin, tmax = ce.solve_(solver, prob, x0, u, z, kl_bound=0.1)
+        assert abs(th - th_o) <= 1e-9 * th_o and abs(val - val_o) <= 1e-9 * abs(val_o)
+        assert tmin == tmin_o and tmax == tmax_o                                   # extreme samples: identical draws
+        assert abs(solver.c.mu - oc.c.mu) <= 1e-9 * oc.c.mu and abs(solver.c.sigma - oc.c.sigma) <= 1e-6 * oc.c.sigma + 1e-12
+        assert solver.c.mu_init == oc.c.mu_init and solver.c.sigma_init == oc.c.sigma_init
+        assert solver.c.n_solves == 5 * 1024
+        assert np.abs(x - x_o).max() < 1e-9 and np.abs(L - L_o).max() < 1e-9
+        res.append((th, val, solver.c.mu, solver.c.sigma, x, l, L))
+    for a, b in zip(res[0], res[1]):                                               # speculation width does not change a bit
+        assert np.array_equal(np.asarray(a), np.asarray(b))
