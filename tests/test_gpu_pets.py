@@ -115,3 +115,22 @@ def test_device_generator_is_statistically_sane():
     se = np.std(c1 - c2) / np.sqrt(2)                      # per-sample Monte-Carlo standard error of a K-rollout mean
     assert abs(np.mean(c1 - cref)) < 5 * se / np.sqrt(S) * np.sqrt(2) + 1e-9
     assert abs(np.mean(c1) / np.mean(cref) - 1) < 0.02
+
+
+def test_config5_ten_thousand_trajectories():
+    """BASELINE config 5: 10k stochastic trajectories (100 control samples x 100 rollouts), N = 30, n = 12, m = 4, one call.
+    Injected noise: every sample's mean cost equals the oracle's; device noise: finite, reproducible, and a Monte-Carlo estimate of the
+    same mean (the K = 100 rollouts of a sample average out to within a few standard errors)."""
+    prob, r = rich_problem()
+    S, K = 100, 100
+    ds = rat.CrossEntropyDirectOptimizationSolver(np.zeros((30, 4)), np.stack([np.eye(4)] * 30), num_control_samples=S, num_trajectory_samples=K)
+    ctrl = 0.3 * r.standard_normal((S, 30, 4))
+    x0 = r.standard_normal(12)
+    zn = r.standard_normal(S * K * 30 * 12)
+    got = pets.compute_cost_serial(ds, prob, x0, ctrl, None, False, streams=(zn, None))
+    ref = orc.pets_compute_cost(orc.GenProblem(prob), x0, ctrl, K, False, zn, None)
+    assert np.all(np.isfinite(ref)) and np.all(np.abs(got - ref) <= 1e-11 * np.abs(ref))
+    dev = pets.compute_cost_serial(ds, prob, x0, ctrl, None, False, seed=11)
+    dev2 = pets.compute_cost_serial(ds, prob, x0, ctrl, None, False, seed=11)
+    assert np.all(np.isfinite(dev)) and np.array_equal(dev, dev2)
+    assert np.median(np.abs(dev - got) / np.abs(got)) < 0.05          # two independent K = 100 estimates of the same means
