@@ -702,7 +702,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     // the prologue is followed by as many (pad) stores as a step issues, (3) the loads are unconditional (clamped step index).
     // A register set is refilled at the top of the step AFTER the one that consumed it: its old value is dead by then, so
     // the loop-carried sets need no copies (a copy of a just-loaded register would wait for the load and drain the queue).
-    constexpr int RD = ROLLIN_PREFETCH;
+    constexpr int RD = (MODEL == 1) ? ROLLIN_PREFETCH : 2;     // (power-law family: pow() expansions are large -- keep its loop short)
     constexpr int kStoresPerStep = 6;
     struct StepIn { double l, dl, xb[3], La[3]; };
     StepIn buf[RD];
