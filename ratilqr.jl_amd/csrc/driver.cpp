@@ -457,14 +457,17 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     return RAT_OK;
 }
 
-static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
+// outputs of a batch (device pointers, any may be null); cost = value + kl_bound / theta  (cross_entropy...jl:193)
+struct BatchOut { double *value = nullptr; int *status = nullptr, *iters = nullptr, *ls = nullptr; double *cost = nullptr; double kl_bound = 0.0; };
+
+static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const BatchOut &out = BatchOut()) {
     if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
     if (!h->have_initial) return fail(RAT_ERR_ARG, "rat_set_initial was not called");
     if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");
     HIPCHK(hipSetDevice(h->device));
     StateDev st = h->st;
     st.B = B;
-    launch_init_state(st, h->opd, theta_dev, h->stream);
+    if (!h->fused) launch_init_state(st, h->opd, theta_dev, h->stream);     // (the fused solve initialises each sample in its own wave)
     // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation; the first gain
     // sweep (step! number 1 re-linearises the same trajectory, App. B.1) runs speculatively beside it.
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
@@ -474,6 +477,9 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B) {
         fa.ro = ra;
         fa.max_rounds = (int)std::min<int64_t>(((int64_t)h->opd.iter_max + 1) * 4002, 2000000000);
         fa.dual = h->fused_dual ? 1 : 0;
+        fa.theta_in = theta_dev;
+        fa.out_value = out.value; fa.out_status = out.status; fa.out_iters = out.iters; fa.out_ls = out.ls;
+        fa.out_cost = out.cost; fa.kl_bound = out.kl_bound;
         prof_begin(h, RAT_K_SOLVE_FUSED, B); launch_solve_fused(fa, h->stream); prof_end(h);
         return RAT_OK;
     }
@@ -540,10 +546,28 @@ extern "C" rat_rc rat_set_initial(rat_handle h, const double *x0, const double *
 extern "C" rat_rc rat_ileqg_solve_batch_dev(rat_handle h, const double *theta_dev, int64_t B, double *value_dev,
                                             int32_t *status_dev, int32_t *iters_dev, int32_t *ls_evals_dev) {
     if (!h || !theta_dev) return fail(RAT_ERR_ARG, "null");
-    rat_rc rc = run_batch(h, theta_dev, (int)B);
+    BatchOut out; out.value = value_dev; out.status = status_dev; out.iters = iters_dev; out.ls = ls_evals_dev;
+    rat_rc rc = run_batch(h, theta_dev, (int)B, out);
     if (rc) return rc;
-    StateDev st = h->st; st.B = (int)B;
-    launch_gather(st, value_dev, status_dev, iters_dev, ls_evals_dev, h->stream);
+    if (!h->fused) {                                   // (the fused solve has written the outputs itself)
+        StateDev st = h->st; st.B = (int)B;
+        launch_gather(st, value_dev, status_dev, iters_dev, ls_evals_dev, nullptr, 0.0, h->stream);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RAT_OK;
+}
+
+// compute_cost (cross_entropy_bilevel_optimization.jl:173-195) with theta and cost resident in HBM: cost = value + kl_bound / theta,
+// +Inf for failed samples (:163-165).  One launch per batch on the fused path.
+extern "C" rat_rc rat_ce_compute_cost_dev(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev) {
+    if (!h || !theta_dev || !cost_dev) return fail(RAT_ERR_ARG, "null");
+    BatchOut out; out.cost = cost_dev; out.kl_bound = kl_bound;
+    rat_rc rc = run_batch(h, theta_dev, (int)B, out);
+    if (rc) return rc;
+    if (!h->fused) {
+        StateDev st = h->st; st.B = (int)B;
+        launch_gather(st, nullptr, nullptr, nullptr, nullptr, cost_dev, kl_bound, h->stream);
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     return RAT_OK;
 }

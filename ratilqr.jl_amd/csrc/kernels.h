@@ -33,6 +33,11 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     RolloutArgs ro;
     int max_rounds;        // guard on phases per sample
     int dual;              // pair each policy evaluation with the gain sweep that would follow it (sweep_dual_body)
+    // the batch's input and outputs, handled by the sample's own wave (no init / gather launches around the solve):
+    const double *theta_in;            // [B]; per-sample state is initialised from it (what init_state_kernel does)
+    double *out_value;                 // [B] value (Inf for failures) or null
+    int *out_status, *out_iters, *out_ls;   // [B] or null
+    double *out_cost; double kl_bound; // [B] cost = value + kl_bound / theta  (cross_entropy_bilevel_optimization.jl:193) or null
 };
 
 struct LinArgs {
@@ -83,4 +88,4 @@ void launch_init_state(const StateDev &st, const OptsDev &op, const double *thet
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s);   // modes 6 (initialize! + first gain sweep), 7 (candidate 0 + next gain sweep)
 void launch_commit_init(const StateDev &st, hipStream_t s);
-void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, hipStream_t s);
+void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, double *cost, double kl_bound, hipStream_t s);

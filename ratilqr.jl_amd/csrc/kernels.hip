@@ -1089,10 +1089,14 @@ void launch_linearize(const LinArgs &a, hipStream_t s) {
 // =====================================================================================================
 // per-sample control flow (one thread per sample)
 // =====================================================================================================
+__device__ __forceinline__ void init_state_body(const StateDev &st, const OptsDev &op, const double *theta_in, const int b);
 __global__ void init_state_kernel(StateDev st, OptsDev op, const double *theta_in) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < 2 * CTR_RING) st.counters[b] = 0;
     if (b >= st.B) return;
+    init_state_body(st, op, theta_in, b);
+}
+__device__ __forceinline__ void init_state_body(const StateDev &st, const OptsDev &op, const double *theta_in, const int b) {
     st.theta[b] = theta_in[b];
     st.mu[b] = 0.0;                       // initialize! sets mu = 0.0, Delta = Delta_0   (ileqg.jl:216)
     st.delta[b] = op.delta_0;
@@ -1260,6 +1264,9 @@ __device__ __forceinline__ double uniform_load_f64(const double *p) { return rea
 // of the separate sweeps, so results are bit-identical).  The gains of the second recursion are committed by the accept rule
 // (commit_spec) or dropped.  A candidate whose acceptance would END the solve (d < d_tol with mu at its floor, or iter_max) gets the
 // plain policy evaluation: nothing would consume the gains.
+__device__ __forceinline__ void gather_body(const StateDev &st, const int b, double *value, int *status, int *iters, int *ls_evals,
+                                            double *cost, double kl_bound);
+
 template <int MODEL, bool CTV, bool WTV, bool DUALF, bool STG>
 __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
     const int b = blockIdx.x;
@@ -1268,6 +1275,9 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
     const unsigned long long dg_t0 = __builtin_readcyclecounter();
     int dg_pi = 0;
 #endif
+    // the sample's own wave initialises its state and, at the end, writes its outputs: a batch is ONE launch
+    if (threadIdx.x == 0) init_state_body(st, fa.sw.op, fa.theta_in, b);
+    PHASE_FENCE();
     {
         RolloutArgs ra = fa.ro; ra.mode = 0;
         rollin_body<MODEL, 0, CTV>(ra, b);
@@ -1326,7 +1336,10 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
             PHASE_MARK();
         }
     }
+    PHASE_FENCE();
+    if (threadIdx.x == 0) gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
 }
+
 
 void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
     const int B = fa.sw.st.B;
@@ -1356,17 +1369,24 @@ void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream
 }
 
 // gather the outputs of a batch: value (Inf for failures), status, iters, ls_evals
-__global__ void gather_kernel(StateDev st, double *value, int *status, int *iters, int *ls_evals) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= st.B) return;
+// the outputs of sample b: value (Inf for failures), status, iters, ls_evals, cost = value + kl / theta (cross_entropy...jl:193)
+__device__ __forceinline__ void gather_body(const StateDev &st, const int b, double *value, int *status, int *iters, int *ls_evals,
+                                            double *cost, double kl_bound) {
     const int s = st.status[b];
-    if (value) value[b] = (s == 0 || s == 3) ? st.value[b] : INFINITY;
+    const double v = (s == 0 || s == 3) ? st.value[b] : INFINITY;
+    if (value) value[b] = v;
     if (status) status[b] = s;
     if (iters) iters[b] = st.iter[b];
     if (ls_evals) ls_evals[b] = st.n_ls[b];
+    if (cost) cost[b] = v + kl_bound / st.theta[b];
 }
-void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, hipStream_t s) {
-    hipLaunchKernelGGL(gather_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, value, status, iters, ls_evals);
+__global__ void gather_kernel(StateDev st, double *value, int *status, int *iters, int *ls_evals, double *cost, double kl_bound) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= st.B) return;
+    gather_body(st, b, value, status, iters, ls_evals, cost, kl_bound);
+}
+void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, double *cost, double kl_bound, hipStream_t s) {
+    hipLaunchKernelGGL(gather_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, value, status, iters, ls_evals, cost, kl_bound);
 }
 
 // =====================================================================================================

@@ -159,6 +159,11 @@ class Context:
         nv.check(nv.lib().rat_ileqg_solve_batch_dev(self.h, C.c_void_p(theta_ptr), C.c_int64(B), C.c_void_p(value_ptr),
                                                     C.c_void_p(status_ptr), C.c_void_p(iters_ptr), C.c_void_p(ls_ptr)))
 
+    def compute_cost_dev(self, theta_ptr, B, kl_bound, cost_ptr):
+        """compute_cost (cross_entropy...jl:173-195), device-pointer form: cost = value + kl_bound / theta stays in HBM."""
+        nv.check(nv.lib().rat_ce_compute_cost_dev(self.h, C.c_void_p(theta_ptr), C.c_int64(B), C.c_double(kl_bound),
+                                                  C.c_void_p(cost_ptr)))
+
     # ---- measurement -----------------------------------------------------------------------------
     def profile(self, on=True, kinds=None):
         """HIP-event timing of kernel launches; ``kinds`` (names from _native.K_NAMES) restricts what is recorded."""

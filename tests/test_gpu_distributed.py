@@ -61,3 +61,24 @@ def test_pets_sharded_cost_equals_the_single_call():
     a, b = ev2(ctrl[:8], 0).numpy(), ev2(ctrl[:8], 0).numpy()
     c = ev2(ctrl[:8], 8).numpy()
     assert np.all(np.isfinite(a)) and np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_compute_cost_dev_is_value_plus_kl_over_theta(monkeypatch):
+    """rat_ce_compute_cost_dev (theta and costs stay in HBM; on the fused path the sample's own wave writes its cost: one launch per
+    batch) equals value + kl/theta of the host-pointer entry point bit for bit, Inf for infeasible samples, on every execution path."""
+    prob, x0, u = rat.synthetic_lq_problem()
+    theta_h = np.concatenate([np.abs(1.0 + 2.0 * np.random.default_rng(3).standard_normal(200)), [30.0, 50.0]])
+    theta = torch.as_tensor(theta_h, dtype=torch.float64, device="cuda")
+    for env in ({}, {"RATILQR_FUSED_DUAL": "0"}, {"RATILQR_FUSED": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for E in (1, 4):
+            ctx = rat.Context(prob, max_batch=theta_h.size, spec_eps=E)
+            ctx.set_initial(x0, u)
+            cost = torch.empty_like(theta)
+            ctx.compute_cost_dev(theta.data_ptr(), theta_h.size, 0.1, cost.data_ptr())
+            v, st, _, _ = ctx.solve_batch(x0, u, theta_h)
+            assert np.array_equal(cost.cpu().numpy(), v + 0.1 / theta_h)
+            assert np.isposinf(cost.cpu().numpy()[-1]) and st[-1] == 1
+        for k in env:
+            monkeypatch.delenv(k)
