@@ -102,12 +102,17 @@ def main():
     cost_all = torch.empty(world * B, dtype=torch.float64, device=dev) if world > 1 else cost
     torch.cuda.synchronize()
 
+    # the handle's own HIP stream, seen by torch: the batch, the cost all-gather and the next batch are ordered on it on the device,
+    # with no host round trip between steps (the timed region ends with a device synchronisation)
+    hstream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+
     def step():
         # compute_cost (cross_entropy...jl:173-195): B complete solves and cost = value + kl/theta (:193), all on the device
         # (one kernel launch on the fused path), then the per-sample costs go to every rank
-        ctx.compute_cost_dev(theta.data_ptr(), B, kl_bound, cost.data_ptr())
+        ctx.compute_cost_enqueue(theta.data_ptr(), B, kl_bound, cost.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(cost_all, cost)       # RCCL
+            with torch.cuda.stream(hstream):                  # RCCL waits for the batch and the next batch waits for RCCL
+                dist.all_gather_into_tensor(cost_all, cost)
 
     for _ in range(W):
         step()

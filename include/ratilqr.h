@@ -202,6 +202,10 @@ rat_rc rat_ce_compute_cost(rat_handle h, const double *x0, const double *u0, con
 /* compute_cost with theta_dev / cost_dev resident in device (HBM) memory; x0/u0 from the last rat_set_initial() call.
  * cost = value + kl_bound / theta (:193), +Inf for samples whose solve failed (:163-165).  Returns after the batch has finished. */
 rat_rc rat_ce_compute_cost_dev(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev);
+/* the same, stream-ordered: returns once the batch is enqueued on rat_stream(h) (single-launch path; otherwise it behaves like
+ * rat_ce_compute_cost_dev).  theta_dev / cost_dev must stay valid, and cost_dev unread, until work ordered after it on that stream
+ * (or a synchronisation of it) has passed -- lets a caller chain batch -> cost all-gather -> next batch without host round trips. */
+rat_rc rat_ce_compute_cost_enqueue(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev);
 /* The bookkeeping half of step! (:291-334) for hosts that evaluate costs themselves (multi-GPU: the
  * host all-gathers cost shards between rat_ce_draw and rat_ce_update).
  *   rat_ce_draw   : theta[num_samples] for the current iteration (uses mu_init/sigma_init in iteration 1)

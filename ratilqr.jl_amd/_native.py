@@ -75,7 +75,7 @@ EXPORTS = [
     "rat_problem_set", "rat_ileqg_solve_batch", "rat_set_initial", "rat_ileqg_solve_batch_dev", "rat_ileqg_solve",
     "rat_rollout_open", "rat_rollout_feedback", "rat_rollout_noisy", "rat_integrate_cost", "rat_approximate_model", "rat_dp_gain_sweep",
     "rat_dp_policy_eval", "rat_ce_default", "rat_ce_initialize", "rat_ce_set_stream", "rat_ce_seed",
-    "rat_ce_stream_pos", "rat_ce_get_positive_samples", "rat_ce_compute_cost", "rat_ce_compute_cost_dev", "rat_ce_begin_step", "rat_ce_draw",
+    "rat_ce_stream_pos", "rat_ce_get_positive_samples", "rat_ce_compute_cost", "rat_ce_compute_cost_dev", "rat_ce_compute_cost_enqueue", "rat_ce_begin_step", "rat_ce_draw",
     "rat_ce_update", "rat_ce_draw_stream", "rat_ce_step", "rat_ce_solve", "rat_nm_default", "rat_nm_initialize",
     "rat_nm_compute_cost", "rat_nm_step", "rat_nm_solve", "rat_pets_problem_set", "rat_pets_initialize",
     "rat_pets_compute_cost", "rat_pets_sample_controls", "rat_pets_update", "rat_pets_step", "rat_pets_solve", "rat_profile_enable", "rat_profile_reset", "rat_profile_get",

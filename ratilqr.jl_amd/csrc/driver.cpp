@@ -572,6 +572,13 @@ extern "C" rat_rc rat_ce_compute_cost_dev(rat_handle h, const double *theta_dev,
     return RAT_OK;
 }
 
+extern "C" rat_rc rat_ce_compute_cost_enqueue(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev) {
+    if (!h || !theta_dev || !cost_dev) return fail(RAT_ERR_ARG, "null");
+    if (!h->fused) return rat_ce_compute_cost_dev(h, theta_dev, B, kl_bound, cost_dev);   // the round-based path polls its round counters
+    BatchOut out; out.cost = cost_dev; out.kl_bound = kl_bound;
+    return run_batch(h, theta_dev, (int)B, out);          // one launch on the handle's stream; no host wait
+}
+
 extern "C" rat_rc rat_ileqg_solve_batch(rat_handle h, const double *x0, const double *u0, const double *theta, int64_t B,
                                         double *value, int32_t *status, int32_t *iters, int32_t *ls_evals) {
     if (!h || !theta || !value) return fail(RAT_ERR_ARG, "null");

@@ -164,6 +164,16 @@ class Context:
         nv.check(nv.lib().rat_ce_compute_cost_dev(self.h, C.c_void_p(theta_ptr), C.c_int64(B), C.c_double(kl_bound),
                                                   C.c_void_p(cost_ptr)))
 
+    def compute_cost_enqueue(self, theta_ptr, B, kl_bound, cost_ptr):
+        """Stream-ordered compute_cost_dev: returns once the batch is enqueued on ``self.stream`` (hipStream_t as int)."""
+        nv.check(nv.lib().rat_ce_compute_cost_enqueue(self.h, C.c_void_p(theta_ptr), C.c_int64(B), C.c_double(kl_bound),
+                                                      C.c_void_p(cost_ptr)))
+
+    @property
+    def stream(self):
+        """The handle's HIP stream (hipStream_t) as an integer, e.g. for ``torch.cuda.ExternalStream``."""
+        return int(nv.lib().rat_stream(self.h) or 0)
+
     # ---- measurement -----------------------------------------------------------------------------
     def profile(self, on=True, kinds=None):
         """HIP-event timing of kernel launches; ``kinds`` (names from _native.K_NAMES) restricts what is recorded."""

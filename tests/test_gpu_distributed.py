@@ -80,5 +80,15 @@ def test_compute_cost_dev_is_value_plus_kl_over_theta(monkeypatch):
             v, st, _, _ = ctx.solve_batch(x0, u, theta_h)
             assert np.array_equal(cost.cpu().numpy(), v + 0.1 / theta_h)
             assert np.isposinf(cost.cpu().numpy()[-1]) and st[-1] == 1
+            # stream-ordered form: three batches chained on the handle's stream without a host wait, consumed by torch work
+            # ordered on the same stream
+            hs = torch.cuda.ExternalStream(ctx.stream)
+            costs = [torch.zeros_like(theta) for _ in range(3)]
+            for c in costs:
+                ctx.compute_cost_enqueue(theta.data_ptr(), theta_h.size, 0.1, c.data_ptr())
+            with torch.cuda.stream(hs):
+                stacked = torch.stack(costs)
+            hs.synchronize()
+            assert all(np.array_equal(row, v + 0.1 / theta_h) for row in stacked.cpu().numpy())
         for k in env:
             monkeypatch.delenv(k)
