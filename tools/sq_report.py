@@ -27,9 +27,11 @@ md += f"""
 * VALU issuing {fused['SQ_ACTIVE_INST_VALU']/wc*100:.0f} % of the wave's life (SQ_ACTIVE_INST_VALU), any instruction issuing {fused['SQ_ACTIVE_INST_ANY']/wc*100:.0f} % (SQ_ACTIVE_INST_ANY),
   waiting on `s_waitcnt` {fused['SQ_WAIT_INST_ANY']/wc*100:.0f} % (SQ_WAIT_INST_ANY); the rest are dependency stalls of the in-order wave.
   MFMA pipe busy {fused['SQ_VALU_MFMA_BUSY_CYCLES']:,.0f} clocks = {fused['SQ_INSTS_MFMA']:,.0f} MFMAs x 64 = {fused['SQ_VALU_MFMA_BUSY_CYCLES']/(wc*4)*100:.0f} %.
-* With one wave per SIMD (1024 samples on 1024 SIMDs) nothing else can fill those slots: the solve is bound by the latency of its own
-  dependency chain (elimination of M: a third of the time), which is why the work went into shortening that chain, pairing two
-  recursions in one wave, and removing every wait that is not a true dependency -- not into bandwidth.
+* An f64 MFMA and vector instructions do not overlap on this hardware (profiles/r01_ubench_fp64_pipe.md: MFMA + VALU costs the sum of
+  the two at every occupancy), so VALU issue + MFMA busy = {(fused['SQ_ACTIVE_INST_VALU']*4+fused['SQ_VALU_MFMA_BUSY_CYCLES'])/(wc*4)*100:.0f} % of the wave's life is a serial FP64-datapath floor.
+  With one wave per SIMD (1024 samples on 1024 SIMDs) the rest are dependency stalls of the in-order wave (elimination of M) and the
+  write-bound rollout phases: the work went into shortening that chain, pairing two recursions in one wave, removing every wait that
+  is not a true dependency, and trimming vector/matrix instructions per step -- not into bandwidth.
 """
 open(os.path.join(ROOT, "profiles", "r01_pmc_sq_E1.md"), "w").write(md)
 print(md[-900:])
