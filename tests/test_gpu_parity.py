@@ -370,3 +370,39 @@ def test_batches_larger_than_the_machine():
     finally:
         del os.environ["RATILQR_FUSED"]
     assert np.array_equal(v1, v0) and np.array_equal(s1, s0) and np.array_equal(i1, i0) and np.array_equal(l1, l0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_and_tables_against_the_oracle(seed, monkeypatch):
+    """Fuzz over the shape envelope of the device path (1 <= n <= 12, 1 <= m <= 4, 1 <= N <= 60): random LQ problems with random
+    time-varying / time-invariant tables, linear cost terms, cross terms, non-diagonal W and the cubic drift; theta from 0 through
+    infeasible; on the default execution path and (odd seeds) on the round-based path with a random speculation width.  Status,
+    iteration and line-search counts identical to the oracle's, values to 1e-9."""
+    rng = np.random.default_rng(1000 + seed)
+    n, m, N = int(rng.integers(1, 13)), int(rng.integers(1, 5)), int(rng.integers(1, 61))
+    tv = bool(rng.integers(0, 2))
+    A = (0.7 + 0.3 * rng.random()) * np.linalg.qr(rng.standard_normal((n, n)))[0]
+    B = rng.standard_normal((n, m)) / np.sqrt(n)
+    def spd(k, scale):
+        G = rng.standard_normal((k, k))
+        return scale * (np.eye(k) + 0.2 * G @ G.T / k)
+    if tv:
+        Q = np.stack([spd(n, 0.5 + rng.random()) for _ in range(N)])
+        R = np.stack([spd(m, 0.1 + 0.3 * rng.random()) for _ in range(N)])
+        Pm = 0.03 * rng.standard_normal((N, m, n))
+        qv, rv, q0 = 0.1 * rng.standard_normal((N, n)), 0.1 * rng.standard_normal((N, m)), rng.standard_normal(N)
+        W = np.stack([spd(n, 1e-3 * (0.5 + rng.random())) for _ in range(N)])
+    else:
+        Q, R, Pm = spd(n, 1.0), spd(m, 0.2), 0.03 * rng.standard_normal((m, n))
+        qv, rv, q0 = 0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(m), float(rng.standard_normal())
+        W = spd(n, 1e-3)
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=Q, R=R, P=Pm, qv=qv, rv=rv, q0=q0, N=N, W=W, Qf=spd(n, 1.0),
+                                      qvf=0.2 * rng.standard_normal(n), q0f=float(rng.standard_normal()),
+                                      kappa=(0.0 if seed % 3 else 0.02))
+    x0, u = rng.standard_normal(n), 0.1 * rng.standard_normal((N, m))
+    theta = np.concatenate([[0.0], np.sort(10.0 ** rng.uniform(-2, 2.5, 9))])
+    if seed % 2:
+        monkeypatch.setenv("RATILQR_FUSED", "0")
+    ctx = rat.Context(prob, max_batch=theta.size, spec_eps=(int(rng.integers(1, 6)) if seed % 2 else 1))
+    v, st, it, ls = check_batch(ctx, orc.Problem(prob), x0, u, theta)
+    assert st[0] == 0                                             # theta = 0 (iLQG) is always feasible
