@@ -53,6 +53,18 @@ def algo_bytes_of_solves(iters, ls_evals):
     return float(len(iters)) * a["init"] + float(np.sum(iters)) * a["sweep_gain"] + float(np.sum(ls_evals)) * a["candidate"]
 
 
+FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak (they are one datapath, profiles/r01_ubench_fp64_pipe.md)
+
+
+def algo_flops_of_solves(iters, ls_evals, N=50):
+    """SURVEY.md section 8(d) "algorithmic flops per unit" (factored form, App. D): 22.2 kflop per backward step, rollout 24 kflop and
+    linearise 20 kflop per trajectory; a solve runs 1 + iters + ls_evals sweeps and 1 + ls_evals rollouts / linearisations
+    (5.7 Mflop for the 2-iteration, 2-evaluation LQ solve)."""
+    sweeps = float(len(iters)) + float(np.sum(iters)) + float(np.sum(ls_evals))
+    trajs = float(len(iters)) + float(np.sum(ls_evals))
+    return sweeps * 22.2e3 * N + trajs * (24e3 + 20e3)
+
+
 def draw_theta(B, seed):
     """Positive samples of N(1, 2) -- the CE solver's first-iteration distribution (mu_init=1, sigma_init=2)."""
     rng = np.random.default_rng(seed)
@@ -265,8 +277,14 @@ def main():
                 "trajectories_per_launch": traj_per_launch,
                 "avg_launch_ms": avg_ms, "launches": pe["launches"],
             },
-            "kernel_ms_per_step": {k: v["ms"] / n_all for k, v in prof_all.items()},
         }
+        if fused:           # the sweep sits at the fp64 ridge -- report the FP64 fraction of the same launches beside the HBM one
+            fl = algo_flops_of_solves(it_h, ls_h)
+            out["roofline"]["fp64"] = {"achieved": fl / (avg_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": fl / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_per_solve": fl / B}
+        out.update({
+            "kernel_ms_per_step": {k: v["ms"] / n_all for k, v in prof_all.items()},
+        })
         if unfused is not None:
             out["round_based_path"] = unfused
         if second is not None:
