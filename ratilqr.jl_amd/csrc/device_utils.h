@@ -108,10 +108,6 @@ __device__ __forceinline__ double row_partner(double x, bool odd) {
     const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     return __hiloint2double((int)(odd ? sh[0] : sh[1]), (int)(odd ? sl[0] : sl[1]));
 }
-// lane_gather: x of the lane whose byte address (4 * lane) is given -- ds_bpermute, the LDS crossbar without memory (no VALU/MFMA slot)
-__device__ __forceinline__ double lane_gather(double x, int addr4) {
-    return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr4, __double2hiint(x)), __builtin_amdgcn_ds_bpermute(addr4, __double2loint(x)));
-}
 // Leading minors p11 > 0 and det P > 0 of every block <=> isposdef(M) (:366).  A non-NaN double is > 0 iff its high word, read as a
 // signed integer, is > 0 (a positive subnormal below 2^-1022 * 2^-20 counts as singular), so the running minimum is an integer
 // minimum over high words: one SALU op for p11 (it lives in SGPRs) and one VALU op for det -- v_min_f64 would cost three with the

@@ -684,7 +684,6 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const long sxu = (j < 3) ? XSTR : (j == 3 ? USTR : TSTRIDE);
     // [c_x | c_u] packed the same way; lane 4 carries c, the other idle lanes 0.0 for the pad slot
     const int qoff = (j < 4) ? TS_QR + 4 * j + g : (l == 4 ? TS_q : TS_PAD);
-    const int gsrc = 4 * ((4 * j3 + g) & 15);                   // byte address of lane (0, 4 j + g): column of this lane's packed component
     const double pm[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
     const double m_j4 = (j < 4) ? 1.0 : 0.0, m_l4 = (l == 4) ? 1.0 : 0.0;
     double xb[3];                                               // x_t in B-form
@@ -831,17 +830,11 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
             t2[64 + l] = make_double2(z2, cq0);
             t2[128 + l] = make_double2(cq1, cq2);
             tp[TS_R6 + l] = cpr;
-            // C [x;u] without the matrix pipe (a matrix-vector product uses 1/16 of an MFMA, and on gfx950 an f64 MFMA blocks the
-            // vector ALU for its 64 cycles, profiles/r01_ubench_fp64_pipe.md; this product is off the recursion's critical path):
-            // C is symmetric and lane (g, j) holds C[4 s + g][j] beside [x;u]_{4 s + g} (B-form), so four FMAs give the
-            // contribution of rows = g (mod 4) to component j; the four 16-lane rows are summed and the packed component
-            // 4 j + g is fetched through the LDS crossbar (ds_swizzle / ds_bpermute: no memory, no vector-ALU slot).
-            double cp = cf[0] * xb[0];
-            cp = fma(cf[1], xb[1], cp);
-            cp = fma(cf[2], xb[2], cp);
-            cp = fma(cf[3], u, cp);
-            cp += row_partner<true>(cp, false);                                  // rows 0+1 | 2+3
-            const double acc = lane_gather(cp, gsrc) + lane_gather(cp, gsrc + 128);       // packed (lanes j < 4); idle lanes: a copy
+            d4 cx = MFMA(cf[0], xb[0], zero4);                      // C [x;u] in B-form
+            cx = MFMA(cf[1], xb[1], cx);
+            cx = MFMA(cf[2], xb[2], cx);
+            cx = MFMA(cf[3], u, cx);
+            const double acc = ((cx[0] * pm[0] + cx[1] * pm[1]) + cx[2] * pm[2]) + cx[3] * pm[3];    // packed (lanes j < 4), 0 elsewhere
             // c = [x;u]' (1/2 C [x;u] + lin) + q0  (:296): 16 packed terms, summed per row and then over the four rows
             const double w = row_sum16(pk * (0.5 * acc + clin));     // pk = 0 on the idle lanes
             const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
