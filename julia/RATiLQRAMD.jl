@@ -160,6 +160,26 @@ function compute_cost(s::AMDCrossEntropyBilevelOptimizationSolver, problem, x::V
     cost
 end
 
+"set_initial!(ce_solver, problem, x, u_array): uploads the initial state and nominal controls used by the device-pointer entry points"
+function set_initial!(s::AMDCrossEntropyBilevelOptimizationSolver, problem, x::Vector{Float64}, u_array)
+    h = handle!(s, problem)
+    check(ccall((:rat_set_initial, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h.ptr, x, reduce(hcat, u_array)))
+end
+
+"""compute_cost with θ and the costs resident in HBM (device pointers, e.g. `pointer(::ROCArray{Float64})` of AMDGPU.jl); the initial
+state / controls are the ones of the last `compute_cost` / `set_initial!`.  `enqueue = true` returns after the launch: the batch is
+ordered on the handle's HIP stream (`ccall((:rat_stream, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), h.ptr)`)."""
+function compute_cost_dev!(s::AMDCrossEntropyBilevelOptimizationSolver, problem, θ_dev::Ptr{Float64}, B::Integer, kl_bound::Float64,
+                           cost_dev::Ptr{Float64}; enqueue::Bool=false)
+    h = handle!(s, problem)
+    if enqueue
+        check(ccall((:rat_ce_compute_cost_enqueue, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Ptr{Float64}), h.ptr, θ_dev, B, kl_bound, cost_dev))
+    else
+        check(ccall((:rat_ce_compute_cost_dev, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Ptr{Float64}), h.ptr, θ_dev, B, kl_bound, cost_dev))
+    end
+    nothing
+end
+
 "solve!(ce_solver, problem, x_0, u_array, rng; kl_bound) -- :364-415.  `rng` supplies the N(0,1) stream (randn(rng, k))."
 function solve!(s::AMDCrossEntropyBilevelOptimizationSolver, problem::LQRiskSensitiveProblem, x_0::Vector{Float64},
                 u_array::Vector{Vector{Float64}}, rng::AbstractRNG; kl_bound::Float64, verbose=false, stream_len=1 << 20)
