@@ -44,6 +44,10 @@ __device__ __forceinline__ double fast_rcp1(double p) {
     return fma(x, e, x);
 }
 
+// A per-sample index every lane loaded from the same address: telling the compiler it is wave-uniform (v_readfirstlane) moves the
+// slot / pointer arithmetic built on it, and the per-step address updates of the time loops, from the vector ALU to the scalar unit.
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);

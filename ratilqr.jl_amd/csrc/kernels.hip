@@ -91,7 +91,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     int b, k = 0, slot, cidx = -1;
     if (a.mode == 1) { b = tid / st.E; k = tid - b * st.E; } else b = tid;
     const int fidx = (a.mode == 1) ? tid : b * st.E;
-    const int s_act = st.ls_active[b], s_flag = st.flag_c[fidx], s_nom = st.slot_nom[b], s_stat = st.status[b], sel = st.lsel[b];
+    const int v_act = st.ls_active[b], v_flag = st.flag_c[fidx], v_nom = st.slot_nom[b], v_stat = st.status[b], v_sel = st.lsel[b];
+    const int s_act = wave_uniform(v_act), s_flag = wave_uniform(v_flag), s_nom = wave_uniform(v_nom), s_stat = wave_uniform(v_stat), sel = wave_uniform(v_sel);
     const double theta = st.theta[b], mu_in = st.mu[b];
     double delta = st.delta[b];
     if (a.mode == 1) {
@@ -630,7 +631,8 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     if (MODE == 0) b = c;
     else { b = c / st.E; k = c - b * st.E; }
     // (per-sample scalars fetched before the first test on any of them: see sweep_body)
-    const int s_stat = st.status[b], s_act = st.ls_active[b], nom = st.slot_nom[b], lsel = st.lsel[b];
+    const int v_stat = st.status[b], v_act = st.ls_active[b], v_nom = st.slot_nom[b], v_lsel = st.lsel[b];
+    const int s_stat = wave_uniform(v_stat), s_act = wave_uniform(v_act), nom = wave_uniform(v_nom), lsel = wave_uniform(v_lsel);
     const double eps_in = st.ls_eps[b];
     if (MODE == 0) { if (s_stat != ST_RUNNING) return; }
     else { if (!s_act) return; }

@@ -53,7 +53,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     BODY_MARK(a.dump, dgs + 0);
     // (per-sample scalars fetched before the first test on any of them: see sweep_body)
     int slot, cidx = -1;
-    const int s_act = st.ls_active[b], s_flag = st.flag_c[b * st.E], s_nom = st.slot_nom[b], s_stat = st.status[b], sel = st.lsel[b];
+    const int v_act = st.ls_active[b], v_flag = st.flag_c[b * st.E], v_nom = st.slot_nom[b], v_stat = st.status[b], v_sel = st.lsel[b];
+    const int s_act = wave_uniform(v_act), s_flag = wave_uniform(v_flag), s_nom = wave_uniform(v_nom), s_stat = wave_uniform(v_stat), sel = wave_uniform(v_sel);
     const double theta = st.theta[b], muB = st.mu[b];          // initialize! leaves mu = 0 (set by init_state_kernel)
     if (a.mode == 7) {
         if (!s_act) return;
