@@ -406,3 +406,14 @@ def test_random_shapes_and_tables_against_the_oracle(seed, monkeypatch):
     ctx = rat.Context(prob, max_batch=theta.size, spec_eps=(int(rng.integers(1, 6)) if seed % 2 else 1))
     v, st, it, ls = check_batch(ctx, orc.Problem(prob), x0, u, theta)
     assert st[0] == 0                                             # theta = 0 (iLQG) is always feasible
+
+
+@pytest.mark.parametrize("w", [1e-16, 1e-9, 1.0, 1e2])
+def test_noise_scales_from_1e_minus_16_to_1e2(w):
+    """W = w I over 18 decades with theta scaled to the same fraction of the breakdown value (theta w = const): the pivot products of
+    the elimination and the logdet accumulation neither overflow nor lose the oracle's digits."""
+    prob, x0, u = rat.synthetic_lq_problem(w=w)
+    theta = np.array([0.0, 1e-4, 1e-3, 5e-3, 1e-2, 2e-2]) / w
+    ctx = rat.Context(prob, max_batch=theta.size)
+    v, st, it, ls = check_batch(ctx, orc.Problem(prob), x0, u, theta)
+    assert st.tolist() == [0, 0, 0, 0, 0, 1]
