@@ -1429,10 +1429,17 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
     double x = (j < 12) ? a.x0[j] : 0.0;
     double cacc = 0.0;
     const double *__restrict__ uc = a.controls + ii * N * USTR;
-    for (int t = 0; t < N; ++t) {
-        const int kc = g.cost_tv ? t : 0;
+    const bool need_sel = a.use_true && g.tw2 > 0.0;          // the mixture selector is only drawn when a second component exists
+    double lin = g.lin[j], q0t = g.q0[0];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) crow[q] = g.Ctab[(long)kc * 256 + j * 16 + q];
+    for (int q = 0; q < 16; ++q) crow[q] = g.Ctab[j * 16 + q];   // time-invariant cost tables stay in registers
+    for (int t = 0; t < N; ++t) {
+        if (g.cost_tv) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) crow[q] = g.Ctab[(long)t * 256 + j * 16 + q];
+            lin = g.lin[(long)t * 16 + j];
+            q0t = g.q0[t];
+        }
         const double u = uc[(long)t * USTR + (j & 3)];
         // draws of this (trajectory, step): zn (per state lane) and the mixture selector
         double z = 0.0, zsel = 1.0;
@@ -1444,9 +1451,11 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
             philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)t, (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
             const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
             z = (g.noise_kind == 1 && !(a.use_true && g.tw2 > 0.0)) ? u1 : sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925286766559 * u2);
-            unsigned rs[4];
-            philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)t, 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);
-            zsel = u01(rs[0], rs[1]);
+            if (need_sel) {
+                unsigned rs[4];
+                philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)t, 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);
+                zsel = u01(rs[0], rs[1]);
+            }
         }
         if (j < 12) shxu[row][j] = x;
         if (j < 4) shxu[row][12 + j] = u;
@@ -1456,11 +1465,10 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
         double acc = 0.0, dyn = 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { acc = fma(crow[q], shxu[row][q], acc); dyn = fma(zr[q], shxu[row][q], dyn); }
-        const double lin = g.lin[(long)kc * 16 + j];
         const double xuj = (j < 12) ? x : u;
         double part = xuj * (0.5 * acc + lin) + ((j >= 12 && j - 12 < g.m) ? g.l1u * fabs(u) : 0.0);
         part = row_sum16(part);
-        cacc += part + g.q0[kc];
+        cacc += part + q0t;
         // stochastic transition x <- f_stochastic(x, u, rng, use_true_model)     (pets.jl:144)
         if (g.kappa != 0.0) dyn += g.kappa * (x * x * x);
         double w;
