@@ -1307,6 +1307,8 @@ extern "C" rat_rc rat_pets_problem_set(rat_handle h, const rat_gen_problem_desc 
     if (!q.A || !q.B || !q.Q || !q.R || !q.P || !q.qv || !q.rv || !q.q0 || !q.Qf || !q.qvf) return fail(RAT_ERR_ARG, "a table pointer is null");
     if (d->noise_kind == 0 && (!d->nmean || !d->nchol)) return fail(RAT_ERR_ARG, "Gaussian noise needs nmean / nchol");
     if (d->tw2 > 0 && (!d->tmean2 || !d->tchol2)) return fail(RAT_ERR_ARG, "mixture noise needs tmean2 / tchol2");
+    if (d->tw2 > 0 && d->noise_kind != 0)
+        return fail(RAT_ERR_UNSUPPORTED, "the true-model mixture is defined over Gaussian model noise (one N(0,1) stream feeds both components)");
     HIPCHK(hipStreamSynchronize(h->stream));
     free_list(h->gen_allocs);
     GenDev g;

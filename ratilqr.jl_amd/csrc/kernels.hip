@@ -1427,7 +1427,7 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
     for (int q = 0; q < 12; ++q) { nrow[q] = g.nchol[jx * 16 + q]; trow[q] = g.tchol2 ? g.tchol2[jx * 16 + q] : 0.0; }
     const double nmean = g.nmean[jx], tmean = g.tmean2 ? g.tmean2[jx] : 0.0;
     double x = (j < 12) ? a.x0[j] : 0.0;
-    double cacc = 0.0;
+    double cacc = 0.0, znext = 0.0;
     const double *__restrict__ uc = a.controls + ii * N * USTR;
     const bool need_sel = a.use_true && g.tw2 > 0.0;          // the mixture selector is only drawn when a second component exists
     double lin = g.lin[j], q0t = g.q0[0];
@@ -1447,10 +1447,19 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
             if (j < n && live) z = a.zn[((tj * N + t) * (long)n) + j];
             if (a.zu && live) zsel = a.zu[tj * N + t];
         } else {
-            unsigned r[4];
-            philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)t, (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
-            const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
-            z = (g.noise_kind == 1 && !(a.use_true && g.tw2 > 0.0)) ? u1 : sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925286766559 * u2);
+            // one Philox block and one Box-Muller transform serve two consecutive steps (both outputs of the transform are used)
+            if ((t & 1) == 0) {
+                unsigned r[4];
+                philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)(t >> 1), (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+                const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+                if (g.noise_kind == 1 && !need_sel) { z = u1; znext = u2; }
+                else {
+                    const double rad = sqrt(-2.0 * log(1.0 - u1));
+                    double sn, cs;
+                    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+                    z = rad * cs; znext = rad * sn;
+                }
+            } else z = znext;
             if (need_sel) {
                 unsigned rs[4];
                 philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)t, 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);

@@ -222,6 +222,8 @@ class LQGenerativeProblem(FiniteHorizonGenerativeOptimalControlProblem):
         else:
             raise ValueError(noise[0])
         if true_noise is not None:
+            if self.noise_kind != 0 and float(true_noise[0]) > 0:
+                raise ValueError("the true-model mixture is defined over Gaussian model noise")
             self.tw2, self.tmean2 = float(true_noise[0]), np.asarray(true_noise[1], float)
             self.tchol2 = np.linalg.cholesky(np.asarray(true_noise[2], float))
         else:
