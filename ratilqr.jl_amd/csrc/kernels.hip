@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(64) void noisy_rollout_kernel(NoisyArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) zr[q] = lq ? pb.Zt[jx * 16 + q] : 0.0;
     double x = (j < 12) ? a.xnom[j] : 0.0;
-    double cacc = 0.0;
+    double cacc = 0.0, znext = 0.0;
     int dom = 0;
     for (int t = 0; t < N; ++t) {
         const int kc = pb.cost_tv ? t : 0, kw = pb.W_tv ? t : 0;
@@ -1541,9 +1541,14 @@ __global__ __launch_bounds__(64) void noisy_rollout_kernel(NoisyArgs a) {
         double z = 0.0;
         if (a.z) { if (live && j < n) z = a.z[(k * N + t) * (long)n + j]; }
         else {
-            unsigned r[4];
-            philox4x32_10((unsigned)k, (unsigned)(k >> 32), (unsigned)t, (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
-            z = sqrt(-2.0 * log(1.0 - u01(r[0], r[1]))) * cos(6.283185307179586476925286766559 * u01(r[2], r[3]));
+            if ((t & 1) == 0) {                                      // both outputs of one Box-Muller transform: steps t and t + 1
+                unsigned r[4];
+                philox4x32_10((unsigned)k, (unsigned)(k >> 32), (unsigned)(t >> 1), (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+                const double rad = sqrt(-2.0 * log(1.0 - u01(r[0], r[1])));
+                double sn, cs;
+                sincos(6.283185307179586476925286766559 * u01(r[2], r[3]), &sn, &cs);
+                z = rad * cs; znext = rad * sn;
+            } else z = znext;
         }
         if (j < 12) shxu[row][j] = x;
         if (j < 4) shxu[row][12 + j] = u;
