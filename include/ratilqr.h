@@ -289,7 +289,7 @@ void   rat_pets_initialize(rat_pets_solver *s);                               /*
  *   controls[S][N][m] (time-major, m fastest), cost[S] = mean over K stochastic rollouts of sum c + h.
  * Randomness, serial semantics: trajectory j = ii*K + kk consumes zn[(j*N + t)*n .. +n) at step t (N(0,1) draws for Gaussian
  * noise, U[0,1) draws for uniform noise) and zu[j*N + t] (mixture choice; may be NULL when tw2 = 0).  zn = NULL selects the
- * device generator (Philox4x32-10 keyed by `seed`, counter = (trajectory, step, lane)): statistical parity only. */
+ * device generator (Philox4x32-10 keyed by `seed`, counter = (trajectory, step / 2, lane); both Box-Muller outputs are used, for steps 2i and 2i + 1): statistical parity only. */
 rat_rc rat_pets_compute_cost(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K,
                              int32_t use_true_model, const double *zn, const double *zu, uint64_t seed, double *cost);
 /* draw the control sequences of one step! (pets.jl:206-216): controls[ii][t] = mu_t + chol(Sigma_t) * zc[(ii*N + t)*m ..] */
