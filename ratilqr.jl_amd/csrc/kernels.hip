@@ -59,10 +59,11 @@ template <bool HASL, bool DUMP>
 __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict__ tp, int l, int lx, int lq,
                                           const double *__restrict__ Lp, const double *__restrict__ dlp, double mL, int g, int j) {
     const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
-    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = t2[128 + l];
+    const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);            // (loop-invariant per lane; dead lanes: the record's zero pair)
+    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = *reinterpret_cast<const double2 *>(tp + c34);
     tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
-    tr.c[0] = w1.y; tr.c[1] = w2.x; tr.c[2] = w2.y;
-    tr.c[3] = tp[TS_R6 + l];
+    tr.c[0] = w2.x; tr.c[1] = w2.y; tr.c[2] = tp[r5];
+    tr.c[3] = w1.y;
     tr.x = tp[TS_QR + lx];
     tr.la = 0.0;
     if (HASL) {
@@ -149,7 +150,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     const int svo = (g == 0) ? 84 + j : 104 + l, fbo = (g == 0) ? 64 + j : 104 + l;
     double *const pgl = (j < 12) ? Lout + g * 12 + j : (j == 12 ? dlout + g : st.sink + l);
     const long sgl = (j < 12) ? LSTR : (j == 12 ? USTR : 0);
-    const int lx = (l < 17) ? l : 17;                        // [qr | q | pad] row: lanes past q read the (zero) pad slot
+    const int lx = (l < 17) ? l : TS_PAD - TS_QR;            // [qr | q] row: lanes past q read the record's zero slot
     const int lq = g * 12 + ((j < 12) ? j : 11);             // own entry of L_t (4 x 12 row-major), clamped
 
     // noise tables (time-invariant case is hoisted out of the time loop)
@@ -686,6 +687,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const long sxu = (j < 3) ? XSTR : (j == 3 ? USTR : TSTRIDE);
     // [c_x | c_u] packed the same way; lane 4 carries c, the other idle lanes 0.0 for the pad slot
     const int qoff = (j < 4) ? TS_QR + 4 * j + g : (l == 4 ? TS_q : TS_PAD);
+    const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);            // C rows 0..11: live lanes compact, dead lanes (j >= 12) to the zero pair
     const double pm[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
     const double m_j4 = (j < 4) ? 1.0 : 0.0, m_l4 = (l == 4) ? 1.0 : 0.0;
     double xb[3];                                               // x_t in B-form
@@ -829,9 +831,9 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
             const double z2 = zt2 + dgz[2] * (3.0 * pb.kappa * (xb[2] * xb[2]));
             double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
             t2[l] = make_double2(z0, z1);
-            t2[64 + l] = make_double2(z2, cq0);
-            t2[128 + l] = make_double2(cq1, cq2);
-            tp[TS_R6 + l] = cpr;
+            t2[64 + l] = make_double2(z2, cpr);
+            *reinterpret_cast<double2 *>(tp + c34) = make_double2(cq0, cq1);     // dead lanes: (0, 0) to the zero pair
+            tp[r5] = cq2;
             d4 cx = MFMA(cf[0], xb[0], zero4);                      // C [x;u] in B-form
             cx = MFMA(cf[1], xb[1], cx);
             cx = MFMA(cf[2], xb[2], cx);
@@ -851,14 +853,12 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
                 } else if (j == 12 + g) val = pb.pl_b * powchk(u, pb.pl_b - 1.0, dom);
             }
             double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
+            double rv = 0.0;
+            if (j == 12 + g) rv = (g < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(u, pb.pl_pu - 2.0, dom) : 1.0;
             t2[l] = make_double2(val, 0.0);
-            t2[64 + l] = make_double2(0.0, cv);
-            t2[128 + l] = make_double2(0.0, 0.0);
-            {
-                double rv = 0.0;
-                if (j == 12 + g) rv = (g < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(u, pb.pl_pu - 2.0, dom) : 1.0;
-                tp[TS_R6 + l] = rv;
-            }
+            t2[64 + l] = make_double2(0.0, rv);
+            *reinterpret_cast<double2 *>(tp + c34) = make_double2(cv, 0.0);      // cv != 0 only on the diagonal lane j == g (live)
+            tp[r5] = 0.0;
             double part = 0.0, qv = 0.0;                            // packed: x_g on lane (g, 0), u_g on lane (g, 3)
             if (j == 0 && g < pb.n) {
                 qv = pb.pl_cx * pb.pl_p * powchk(pk, pb.pl_p - 1.0, dom);
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
             tp[TS_REG(r, l)] = val;
             tp[TS_REG(3 + r, l)] = (j < 12) ? C[e] : 0.0;            // c_xx   (:298); columns 12..15 are dead slots
         }
-        tp[TS_R6 + l] = C[192 + l];                                  // [c_ux | c_uu]   (:300-301)
+        tp[TS_REG(6, l)] = C[192 + l];                               // [c_ux | c_uu]   (:300-301)
         double part = 0.0;
         if (l < 16) {                                                // [c_x | c_u] = C [x;u] + [qv;rv]   (:297, :299)
             double acc = 0.0;
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
             const int gg = l >> 4;
             double val = 0.0;
             if (j == 12 + gg) val = (gg < pb.m) ? pb.pl_cu * pb.pl_pu * (pb.pl_pu - 1.0) * powchk(up[gg], pb.pl_pu - 2.0, dom) : 1.0;
-            tp[TS_R6 + l] = val;
+            tp[TS_REG(6, l)] = val;
         }
         double part = 0.0;
         if (l < 16) {

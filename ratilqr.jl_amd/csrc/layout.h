@@ -12,15 +12,18 @@
 //     R0..R2  Z = [A | B]              12 x 16   (f_x | f_u)
 //     R3..R6  C = [[Q, *], [P, R]]     16 x 16   (c_xx | unused ; c_ux | c_uu); the 48 slots of rows 0..11, columns 12..15
 //                                                are never consumed by the sweep (written as zeros)
-//   physical record, step t = 0..N-1, stride TSTRIDE = 466 doubles:
-//     [  0 .. 384)  three 128-double chunks; chunk c holds registers 2c and 2c+1 interleaved per lane:
-//                   position 128 c + 2 l + h  <->  register 2 c + h, lane l      (one global_load_dwordx4 per chunk)
-//     [384 .. 448)  register R6 (rows 12..15 of C = [P | R]), position 384 + l
-//     [448 .. 464)  qr = [q_vec | r]  (c_x | c_u)
-//     [464]         q  = c            [465] pad (keeps every record 16-B aligned)
+//   physical record, step t = 0..N-1, stride TSTRIDE = 420 doubles:
+//     [  0 .. 128)  registers R0, R1 interleaved per lane: position 2 l + h                (one global_load_dwordx4)
+//     [128 .. 256)  registers R2, R6 interleaved per lane: position 128 + 2 l + h          (one global_load_dwordx4)
+//     [256 .. 352)  registers R3, R4 (rows 0..7 of C), live lanes only, interleaved: position 256 + 2 (12 g + j) + h for
+//                   lane (g, j), j < 12                                                     (one global_load_dwordx4)
+//     [352 .. 400)  register R5 (rows 8..11 of C), live lanes only: position 352 + 12 g + j  (one global_load_dwordx2)
+//     [400 .. 416)  qr = [q_vec | r]  (c_x | c_u)          [416] q = c          [417] unused
+//     [418 .. 420)  two zeros: what the dead lanes (columns 12..15 of R3..R5) load and store, so that every access stays
+//                   unconditional and full-width (16-B aligned)
 //   terminal block at N*TSTRIDE: Qf 12x12 row-major (144), q_vec (12), q (1), pad (1)  -> TTERM = 158
 // The information content is SURVEY.md section 8's n^2 + nm + n^2 + m^2 + mn + n + m + 1 = 417 doubles per step
-// (+157 terminal = 168,056 B at N = 50); the physical record carries 49 dead doubles per step on top (+11.7 %).
+// (+157 terminal = 168,056 B at N = 50); the physical record carries 3 more (+0.7 %).
 #pragma once
 
 #define RAT_NP 12
@@ -28,11 +31,12 @@
 #define RAT_PD 16
 #define RAT_AUG 12          /* index of the homogeneous coordinate in the augmented value matrix */
 
-#define TS_R6  384
-#define TS_QR  448
-#define TS_q   464
-#define TS_PAD 465
-#define TSTRIDE 466
+#define TS_C34 256
+#define TS_R5  352
+#define TS_QR  400
+#define TS_q   416
+#define TS_PAD 418          /* two zeros (16-B aligned): target of the dead lanes and of idle-lane stores */
+#define TSTRIDE 420
 #define TS_INFO 417         /* doubles of information per step */
 #define TT_Q   0
 #define TT_QV  144
@@ -40,8 +44,12 @@
 #define TTERM  158
 #define TT_INFO 157
 
-/* physical position of lane l of logical register R (0..6) */
-#define TS_REG(R, l) ((R) < 6 ? 128 * ((R) >> 1) + 2 * (l) + ((R) & 1) : TS_R6 + (l))
+/* physical position of lane l of logical register R (0..6); dead lanes of R3..R5 map to the zero pair */
+#define TS_LIVE(l) (((l) & 15) < 12)
+#define TS_CL(l) (((l) >> 4) * 12 + ((l) & 15))
+#define TS_REG(R, l) ((R) < 2 ? 2 * (l) + (R) : (R) == 2 ? 128 + 2 * (l) : (R) == 6 ? 129 + 2 * (l) : \
+                      (R) < 5 ? (TS_LIVE(l) ? TS_C34 + 2 * TS_CL(l) + ((R) - 3) : TS_PAD + ((R) - 3)) : \
+                                (TS_LIVE(l) ? TS_R5 + TS_CL(l) : TS_PAD))
 /* [A|B] row i (0..11), column c (0..15);  C row i (0..15), column c (0..15) */
 #define TS_ZPOS(i, c) TS_REG(((i) * 16 + (c)) >> 6, ((i) * 16 + (c)) & 63)
 #define TS_CPOS(i, c) TS_REG(3 + (((i) * 16 + (c)) >> 6), ((i) * 16 + (c)) & 63)

@@ -30,10 +30,11 @@ template <bool HASL>
 __device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, int lx, int l, int j,
                                       const double *__restrict__ Lp, double mL, int g) {
     const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
-    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = t2[128 + l];
+    const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);            // (loop-invariant per lane; dead lanes: the record's zero pair)
+    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = *reinterpret_cast<const double2 *>(tp + c34);
     tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
-    tr.c[0] = w1.y; tr.c[1] = w2.x; tr.c[2] = w2.y;
-    tr.c[3] = tp[TS_R6 + l];
+    tr.c[0] = w2.x; tr.c[1] = w2.y; tr.c[2] = tp[r5];
+    tr.c[3] = w1.y;
     tr.x = tp[TS_QR + lx];
     const int jc = (j < 12) ? j : 11;
     tr.la = HASL ? Lp[g * 12 + jc] * mL : 0.0;
@@ -92,7 +93,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
 #pragma unroll
     for (int r = 0; r < 3; ++r) foff[r] = (j == 12) ? (64 + 4 * r + g) : 80;
     const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
-    const int lx = (l < 17) ? l : 17;
+    const int lx = (l < 17) ? l : TS_PAD - TS_QR;
     const int svo = (g == 0) ? 84 + j : 104 + l, fbo = (g == 0) ? 64 + j : 104 + l;
     double *const pgl = (j < 12) ? Lout + g * 12 + j : (j == 12 ? dlout + g : st.sink + l);
     const long sgl = (j < 12) ? LSTR : (j == 12 ? USTR : 0);

@@ -31,7 +31,7 @@ summarised by `python tools/pmc_summary.py FETCH=... WRITE=... kernel`; this fil
 
 Units: KB per dispatch as reported. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests at 64 B, so
 read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.  Calibration on this access pattern: the gain sweep reads each byte of its
-1024 tile bundles exactly once -- physical record 466 doubles/step (layout.h): 1024 x 187,664 B = 192.2 MB -- and
+1024 tile bundles exactly once -- physical record 420 doubles/step (layout.h): 1024 x 169,264 B = 173.3 MB -- and
 2 x FETCH_SIZE = 193.3 MB reproduces that, so the 2x correction holds here.
 
 The default E = 1 path is ONE launch per batch (`solve_fused_kernel`); the per-phase kernels in the E = 1 table come from
@@ -47,12 +47,12 @@ out += f'''## Reading
 
 * `solve_fused_kernel` (1024 complete 2-iteration solves per launch): {fs/1e6:.1f} MB of HBM traffic per launch = {fs/1024/1e6:.3f} MB per solve,
   against 1.537 MB of algorithmic bytes per solve (SURVEY.md section 8d, unfused three-kernel formulation: initialize! 368.3 KB +
-  2 gain sweeps x 188.9 KB + 2 candidates x 395.6 KB) = {(fs/1024/1537256-1)*100:+.1f} %.  Two effects against each other: the padded
-  register-image tile record (466 instead of 417 doubles per step, +11.7 % on every tile pass) and the paired recursions, which
+  2 gain sweeps x 188.9 KB + 2 candidates x 395.6 KB) = {(fs/1024/1537256-1)*100:+.1f} %: the register-image tile record is
+  within 0.7 % of the information content (420 vs 417 doubles per step) and the paired recursions
   read the tiles of `initialize!` and of the first candidate ONCE for the policy evaluation and the gain sweep that follows it
   (the three-kernel formulation reads them twice).  No re-reads.
 * policy-evaluation sweep, round-based path: {tr["sweep_eval_E1_B1024"]/1e6:.1f} MB per launch at E = 1 (1024 candidates), {tr["sweep_eval_E8_B1024"]/1e6:.1f} MB at E = 8 (8192);
-  algorithmic 187,264 B per candidate = 191.8 MB / 1,534 MB (+11 %: the padded record).
+  algorithmic 187,264 B per candidate = 191.8 MB / 1,534 MB.
 '''
 open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.md"), "w").write(out)
 print(tr)
