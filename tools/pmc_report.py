@@ -23,6 +23,8 @@ for E in (1, 8):
         if "sweep_kernel<false, false, false, true>" in k:
             tr[f"sweep_eval_E{E}_B1024"] = t
 json.dump(tr, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+f1 = load(f"{O}/pmc_fetch_e1/runc_counter_collection.csv")
+CAL = 2 * max(v for k, vs in f1.items() if "sweep_kernel<false, false, false, false>" in k for v in vs) * 1024 / 1e6
 out = '''# r01 HBM traffic per launch from rocprofv3 PMC counters (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes)
 
 Commands (tools/profile_round.sh, one counter per pass, no trace domains in the same run):
@@ -30,14 +32,14 @@ Commands (tools/profile_round.sh, one counter per pass, no trace domains in the 
 summarised by `python tools/pmc_summary.py FETCH=... WRITE=... kernel`; this file is written by tools/pmc_report.py.
 
 Units: KB per dispatch as reported. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests at 64 B, so
-read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.  Calibration on this access pattern: the gain sweep reads each byte of its
+read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.  Calibration on this access pattern: the open-loop policy evaluation of `initialize!` reads each byte of its
 1024 tile bundles exactly once -- physical record 420 doubles/step (layout.h): 1024 x 169,264 B = 173.3 MB -- and
-2 x FETCH_SIZE = 193.3 MB reproduces that, so the 2x correction holds here.
+2 x FETCH_SIZE = {CAL:.1f} MB reproduces that, so the 2x correction holds here.
 
 The default E = 1 path is ONE launch per batch (`solve_fused_kernel`); the per-phase kernels in the E = 1 table come from
 bench.py's secondary `round_based_path` measurement (RATILQR_FUSED=0), the E = 8 table is the round-based path throughout.
 
-'''
+'''.replace('{CAL:.1f}', f'{CAL:.1f}')
 for E in (1, 8):
     t = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f"FETCH={O}/pmc_fetch_e{E}/runc_counter_collection.csv",
                         f"WRITE={O}/pmc_write_e{E}/runc_counter_collection.csv", "kernel<", "_kernel("], capture_output=True, text=True).stdout
