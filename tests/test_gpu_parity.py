@@ -417,3 +417,25 @@ def test_noise_scales_from_1e_minus_16_to_1e2(w):
     ctx = rat.Context(prob, max_batch=theta.size)
     v, st, it, ls = check_batch(ctx, orc.Problem(prob), x0, u, theta)
     assert st.tolist() == [0, 0, 0, 0, 0, 1]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_solver_options(seed, monkeypatch):
+    """Fuzz over the ILEQGSolver options (lambda, eps_init < 1, eps_min, d, mu_min, Delta_0, iter_max, adaptive eps_init) on cubic-drift
+    problems (3 to 15 iterations, iter_max reached, infeasible theta); both execution paths; decisions identical to the oracle's."""
+    rng = np.random.default_rng(2000 + seed)
+    prob, x0, u = rat.synthetic_lq_problem(seed=int(rng.integers(1, 50)), kappa=float(rng.choice([0.02, 0.04, -0.03])), N=int(rng.integers(8, 41)))
+    x0 = x0 * float(rng.uniform(0.4, 1.0))
+    kw = dict(lam=float(rng.uniform(0.2, 0.8)), eps_init=float(rng.uniform(0.3, 1.0)), eps_min=float(10.0 ** rng.uniform(-6, -2)),
+              d=float(10.0 ** rng.uniform(-4, -1)), mu_min=float(10.0 ** rng.uniform(-8, -4)), Delta_0=float(rng.uniform(1.5, 4.0)),
+              iter_max=int(rng.integers(2, 30)), adaptive_eps_init=bool(rng.integers(0, 2)))
+    theta = np.concatenate([[0.0], np.sort(10.0 ** rng.uniform(-1, 1.3, 7))])
+    E = 1
+    if seed % 2:
+        monkeypatch.setenv("RATILQR_FUSED", "0")
+        E = int(rng.integers(1, 5))
+    ctx = rat.Context(prob, rat.ileqg.make_opts(**kw), max_batch=theta.size, spec_eps=E)
+    okw = dict(kw)
+    okw["adaptive_eps_init"] = int(okw["adaptive_eps_init"])
+    v, st, it, ls = check_batch(ctx, orc.Problem(prob), x0, u, theta, **okw)
+    assert (ls >= it).all()
