@@ -260,8 +260,12 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
                 tm = mm3(v, y2, xz);
                 DIAG_STAMP(2, tm[0]);
             } else {
-                // theta == 0: D = I ; 0.5 tr(W S)   (ileqg.jl:385)
-                racc += m12 * (wp[0] * v[0] + wp[1] * v[1] + wp[2] * v[2]);
+                // theta == 0: D = I ; 0.5 tr(W S)   (ileqg.jl:385).  The reference still forms M = inv(W) - 0 S and asserts
+                // isposdef(M) (:365-366 / :439-440): a non-finite entry of S makes M NaN, i.e. not PD (0 x Inf = NaN).
+                const double nf = fma(v[2], 0.0, fma(v[1], 0.0, v[0] * 0.0));
+                if (__ballot(nf != nf) & 0x0FFF0FFF0FFF0FFFull) { fail = 1; return 1; }      // lanes j < 12 hold S
+                // (explicit fma: the same contraction in every instantiation and in sweep_dual_body -- the paths are tested bit for bit)
+                racc = fma(m12, fma(wp[2], v[2], fma(wp[1], v[1], wp[0] * v[0])), racc);
                 tm = xz;
             }
             // F = [A|B]' T + [[Q,P'],[P,R]]  (:369-370 and the Q + A'DSA term of :390)

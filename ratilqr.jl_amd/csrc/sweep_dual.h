@@ -170,8 +170,12 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
             tmA = mm3(vA, y2A, xzA);
             tmB = mm3(vB, y2B, xzB);
         } else {
-            raccA += m12 * (wp[0] * vA[0] + wp[1] * vA[1] + wp[2] * vA[2]);
-            raccB += m12 * (wp[0] * vB[0] + wp[1] * vB[1] + wp[2] * vB[2]);
+            // theta == 0: the reference still asserts isposdef(inv(W) - 0 S) (:365-366 / :439-440): a non-finite S fails it
+            const double nfA = fma(vA[2], 0.0, fma(vA[1], 0.0, vA[0] * 0.0)), nfB = fma(vB[2], 0.0, fma(vB[1], 0.0, vB[0] * 0.0));
+            if (__ballot(nfA != nfA) & 0x0FFF0FFF0FFF0FFFull) { failA = 1; return 1; }
+            if (!deadB && (__ballot(nfB != nfB) & 0x0FFF0FFF0FFF0FFFull)) deadB = 2;
+            raccA = fma(m12, fma(wp[2], vA[2], fma(wp[1], vA[1], wp[0] * vA[0])), raccA);
+            raccB = fma(m12, fma(wp[2], vB[2], fma(wp[1], vB[1], wp[0] * vB[0])), raccB);
             tmA = xzA; tmB = xzB;
         }
         d4 fA = mm3(cur.z, tmA, cur.c);

@@ -439,3 +439,18 @@ def test_random_solver_options(seed, monkeypatch):
     okw["adaptive_eps_init"] = int(okw["adaptive_eps_init"])
     v, st, it, ls = check_batch(ctx, orc.Problem(prob), x0, u, theta, **okw)
     assert (ls >= it).all()
+
+
+def test_trajectory_that_overflows_fails_like_the_reference():
+    """Cubic drift strong enough that the open-loop rollout overflows to Inf / NaN: the reference forms M = inv(W) - theta S and asserts
+    isposdef(M) at every theta, 0 included (ileqg.jl:439-440; 0 x Inf = NaN), so initialize! throws -> status 1 and Inf, no hang in the
+    regularisation loop.  Both execution paths."""
+    prob, x0, u = rat.synthetic_lq_problem(seed=1, kappa=0.1, N=15)
+    x0 = 1.4 * x0
+    _, xo = orc.simulate_open(orc.Problem(prob), x0, u)
+    assert not np.all(np.isfinite(xo))
+    theta = np.array([0.0, 0.5, 2.0])
+    for E in (1, 3):
+        ctx = rat.Context(prob, max_batch=3, spec_eps=E)
+        v, st, it, ls = check_batch(ctx, orc.Problem(prob), x0, u, theta)
+        assert st.tolist() == [1, 1, 1] and np.all(np.isposinf(v))
