@@ -215,9 +215,10 @@ static rat_rc alloc_state(rat_handle h) {
     st.x_stride = (long)(N + 1) * XSTR;
     st.u_stride = (long)N * USTR;
     const size_t slots = (size_t)B * (E + 1);
+    st.tile_alias = h->fused ? 1 : 0;          // (layout.h: candidates are linearised over the dead tiles of their nominal trajectory)
     rat_rc rc;
 #define AL(ptr, cnt) if ((rc = dev_alloc(h->st_allocs, &(ptr), (cnt)))) return rc
-    AL(st.tiles, slots * st.tile_stride);
+    AL(st.tiles, (st.tile_alias ? (size_t)B : slots) * st.tile_stride);
     AL(st.xs, slots * st.x_stride);
     AL(st.us, slots * st.u_stride);
     st.l_half = (long)B * N * LSTR;
@@ -626,7 +627,7 @@ static rat_rc fetch_slot(rat_handle h, int slot, std::vector<double> *xp, std::v
     const StateDev &st = h->st;
     if (xp) { xp->resize(st.x_stride); HIPCHK(hipMemcpy(xp->data(), st.xs + (size_t)slot * st.x_stride, st.x_stride * 8, hipMemcpyDeviceToHost)); }
     if (up) { up->resize(st.u_stride); HIPCHK(hipMemcpy(up->data(), st.us + (size_t)slot * st.u_stride, st.u_stride * 8, hipMemcpyDeviceToHost)); }
-    if (tp) { tp->resize(st.tile_stride); HIPCHK(hipMemcpy(tp->data(), st.tiles + (size_t)slot * st.tile_stride, st.tile_stride * 8, hipMemcpyDeviceToHost)); }
+    if (tp) { tp->resize(st.tile_stride); HIPCHK(hipMemcpy(tp->data(), st.tiles + (size_t)tile_slot(st, slot / (st.E + 1), slot) * st.tile_stride, st.tile_stride * 8, hipMemcpyDeviceToHost)); }
     return RAT_OK;
 }
 

@@ -114,7 +114,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     }
     double mu = (a.mode == 2) ? 0.0 : (a.mode == 3 ? a.mu_op : mu_in);
     const int N = st.N;
-    const double *__restrict__ tile0 = st.tiles + (long)slot * st.tile_stride;
+    const double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot) * st.tile_stride;
     const int osel = (a.mode >= 4) ? (sel ^ 1) : sel;      // speculative sweeps fill the other half; committed by select
     const double *__restrict__ Lb = st.L + (long)sel * st.l_half + (long)b * N * LSTR;
     double *__restrict__ Lout = st.L + (long)osel * st.l_half + (long)b * N * LSTR;
@@ -649,7 +649,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const double *__restrict__ lnom = (MODE == 0) ? a.u0 : st.us + (long)slot_n * st.u_stride;
     double *__restrict__ xo = st.xs + (long)slot_o * st.x_stride;
     double *__restrict__ uo = st.us + (long)slot_o * st.u_stride;
-    double *__restrict__ tile0 = st.tiles + (long)slot_o * st.tile_stride;
+    double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot_o) * st.tile_stride;
     const double *__restrict__ Lb = st.L + (long)lsel * st.l_half + (long)b * N * LSTR;
     const double *__restrict__ dlb = st.dl + (long)lsel * st.dl_half + (long)b * N * USTR;
     constexpr bool lq = (MODEL == 1);
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LinArgs a) {
     }
     const double *__restrict__ xp = st.xs + (long)slot * st.x_stride + (long)t * XSTR;
     const double *__restrict__ up = st.us + (long)slot * st.u_stride + (long)t * USTR;
-    double *__restrict__ tp = st.tiles + (long)slot * st.tile_stride + (long)t * TSTRIDE;
+    double *__restrict__ tp = st.tiles + tile_slot(st, b, slot) * st.tile_stride + (long)t * TSTRIDE;
     int dom = 0;
     if (t == N) {                                                    // terminal: h, h_x, h_xx   (ileqg.jl:314-316)
         if (pb.model == 1) {

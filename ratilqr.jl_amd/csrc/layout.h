@@ -88,8 +88,13 @@ struct ProblemDev {
 // All per-sample / per-slot device state of one handle.
 struct StateDev {
     int B, E, N;
+    int tile_alias;                            // 1: one tile bundle per SAMPLE instead of per slot (single-launch E = 1 path).  The
+                                               // nominal trajectory's tiles are dead once the gain sweep of its iteration has run
+                                               // (line_search! never reads them, ileqg.jl:494-592; step! re-linearises what was
+                                               // accepted, :604), so every candidate is linearised over them in place: the tile
+                                               // traffic of a whole batch (173 MB at B = 1024) stays inside the 256 MB MALL
     long tile_stride, x_stride, u_stride;      // doubles per slot
-    double *tiles, *xs, *us;                   // slot pools: B*(E+1) slots
+    double *tiles, *xs, *us;                   // slot pools: B*(E+1) slots (tiles: B bundles when tile_alias)
     double *L, *dl;                            // [2][Bmax][N*48], [2][Bmax][N*4]: double-buffered gains (lsel[b] = live half)
     long l_half, dl_half;                      // doubles per half
     int *lsel;                                 // [B] which half holds the committed L_array / dl of sample b
@@ -110,6 +115,7 @@ struct OptsDev {
     int iter_max, adaptive;
 };
 
+__host__ __device__ inline long tile_slot(const StateDev &st, int b, int slot) { return st.tile_alias ? (long)b : (long)slot; }
 __host__ __device__ inline int cand_slot(int b, int k, int nom, int E) {
     int s = (k < nom) ? k : k + 1;
     return b * (E + 1) + s;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     }
     const double muA = (a.mode == 6) ? 0.0 : muB;
     const int N = st.N;
-    const double *__restrict__ tile0 = st.tiles + (long)slot * st.tile_stride;
+    const double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot) * st.tile_stride;
     const double *__restrict__ Lb = st.L + (long)sel * st.l_half + (long)b * N * LSTR;
     double *__restrict__ Lout = st.L + (long)(sel ^ 1) * st.l_half + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)(sel ^ 1) * st.dl_half + (long)b * N * USTR;
