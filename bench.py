@@ -90,9 +90,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_distributed.py runs two ranks on ONE GPU): the collective backend, and all ranks on device 0
+    backend = os.environ.get("RATILQR_BENCH_BACKEND", "nccl")
+    if os.environ.get("RATILQR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # RCCL
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -122,9 +129,14 @@ def main():
         # compute_cost (cross_entropy...jl:173-195): B complete solves and cost = value + kl/theta (:193), all on the device
         # (one kernel launch on the fused path), then the per-sample costs go to every rank
         ctx.compute_cost_enqueue(theta.data_ptr(), B, kl_bound, cost.data_ptr())
-        if world > 1:
+        if world > 1 and backend == "nccl":
             with torch.cuda.stream(hstream):                  # RCCL waits for the batch and the next batch waits for RCCL
                 dist.all_gather_into_tensor(cost_all, cost)
+        elif world > 1:                                       # host-staged collective (test hook)
+            hstream.synchronize()
+            parts = [torch.empty(B, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, cost.cpu())
+            cost_all.copy_(torch.cat(parts))
 
     for _ in range(W):
         step()
@@ -156,7 +168,7 @@ def main():
     prof = ctx.profile_get()
     ctx.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -1,5 +1,7 @@
 """Device path of the theta-sharding layer on one GPU (world size 1; N > 1 ranks are covered by the gloo test on CPU and
 run by the driver's multi-GPU bench): theta and values stay in HBM, CE result equals the single-call C-ABI solve."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -92,3 +94,27 @@ def test_compute_cost_dev_is_value_plus_kl_over_theta(monkeypatch):
             assert all(np.array_equal(row, v + 0.1 / theta_h) for row in stacked.cpu().numpy())
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_bench_runs_as_two_ranks():
+    """bench.py's multi-rank flow end to end -- torch.distributed.run launch, per-rank contexts and theta shards, barrier-bracketed timing,
+    max over ranks, the cost gather, rank 0's JSON line -- with two ranks sharing this box's single GPU and a host-staged collective
+    (test hooks of bench.py; on a multi-GPU node the same flow runs one rank per GPU over RCCL)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RATILQR_BENCH_BACKEND="gloo", RATILQR_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu",
+           "--batch", "256"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["value"] > 0 and abs(d["value"] - 512 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["config"]["feasible_fraction"] == 1.0 and d["roofline"]["launches"] == 3
