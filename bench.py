@@ -94,7 +94,9 @@ def main():
     backend = os.environ.get("RATILQR_BENCH_BACKEND", "nccl")
     if os.environ.get("RATILQR_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
-    if world > 1:
+    # (test hook: run the collective path even with one rank -- RCCL on the handle's stream on a single-GPU box)
+    multi = world > 1 or os.environ.get("RATILQR_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # RCCL
@@ -118,7 +120,7 @@ def main():
     iters = torch.empty(B, dtype=torch.int32, device=dev)
     ls = torch.empty(B, dtype=torch.int32, device=dev)
     cost = torch.empty(B, dtype=torch.float64, device=dev)
-    cost_all = torch.empty(world * B, dtype=torch.float64, device=dev) if world > 1 else cost
+    cost_all = torch.empty(world * B, dtype=torch.float64, device=dev) if multi else cost
     torch.cuda.synchronize()
 
     # the handle's own HIP stream, seen by torch: the batch, the cost all-gather and the next batch are ordered on it on the device,
@@ -129,10 +131,10 @@ def main():
         # compute_cost (cross_entropy...jl:173-195): B complete solves and cost = value + kl/theta (:193), all on the device
         # (one kernel launch on the fused path), then the per-sample costs go to every rank
         ctx.compute_cost_enqueue(theta.data_ptr(), B, kl_bound, cost.data_ptr())
-        if world > 1 and backend == "nccl":
+        if multi and backend == "nccl":
             with torch.cuda.stream(hstream):                  # RCCL waits for the batch and the next batch waits for RCCL
                 dist.all_gather_into_tensor(cost_all, cost)
-        elif world > 1:                                       # host-staged collective (test hook)
+        elif multi:                                           # host-staged collective (test hook)
             hstream.synchronize()
             parts = [torch.empty(B, dtype=torch.float64) for _ in range(world)]
             dist.all_gather(parts, cost.cpu())
@@ -154,20 +156,20 @@ def main():
     main_kind = "solve_fused" if fused else "sweep_eval"
     ctx.profile(True, kinds=[main_kind])
     ctx.profile_reset()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
     ctx.profile(False)
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -328,7 +330,7 @@ def main():
                           f"thread on {cores} threads, {t_cpu:.1f} s; " + julia_note,
             }
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -96,10 +96,7 @@ def test_compute_cost_dev_is_value_plus_kl_over_theta(monkeypatch):
             monkeypatch.delenv(k)
 
 
-def test_bench_runs_as_two_ranks():
-    """bench.py's multi-rank flow end to end -- torch.distributed.run launch, per-rank contexts and theta shards, barrier-bracketed timing,
-    max over ranks, the cost gather, rank 0's JSON line -- with two ranks sharing this box's single GPU and a host-staged collective
-    (test hooks of bench.py; on a multi-GPU node the same flow runs one rank per GPU over RCCL)."""
+def _run_bench(nproc, extra_env, *args):
     import json
     import socket
     import subprocess
@@ -108,13 +105,27 @@ def test_bench_runs_as_two_ranks():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, RATILQR_BENCH_BACKEND="gloo", RATILQR_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu",
-           "--batch", "256"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), *args]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_collective_path_over_rccl_on_the_solver_stream():
+    """The N > 1 step of bench.py -- batch enqueued on the handle's HIP stream, RCCL all-gather ordered behind it on that stream, next
+    batch ordered behind the gather -- run with a one-rank RCCL communicator (test hook), costs checked by bench.py itself."""
+    d = _run_bench(1, {"RATILQR_BENCH_FORCE_DIST": "1"}, "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu", "--no-second", "--batch", "512")
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["roofline"]["launches"] == 4
+
+
+def test_bench_runs_as_two_ranks():
+    """bench.py's multi-rank flow end to end -- torch.distributed.run launch, per-rank contexts and theta shards, barrier-bracketed timing,
+    max over ranks, the cost gather, rank 0's JSON line -- with two ranks sharing this box's single GPU and a host-staged collective
+    (test hooks of bench.py; on a multi-GPU node the same flow runs one rank per GPU over RCCL)."""
+    d = _run_bench(2, {"RATILQR_BENCH_BACKEND": "gloo", "RATILQR_BENCH_ONE_DEVICE": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1",
+                   "--no-cpu", "--batch", "256")
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak" and d["steps"] == 3
     assert d["value"] > 0 and abs(d["value"] - 512 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert d["config"]["feasible_fraction"] == 1.0 and d["roofline"]["launches"] == 3
