@@ -40,6 +40,7 @@ struct rat_handle_s {
     bool dual = false;               // RATILQR_DUAL=1: fused evaluation + next-gain-sweep wavefronts (E = 1 only)
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
     bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
+    std::vector<double> x0_host, u0_host;   // padded copies of what d_x0 / d_u0 hold (rat_set_initial skips identical uploads)
     bool fused_dual = true;          // ... with policy evaluation + following gain sweep paired in one pass (RATILQR_FUSED_DUAL=0: separate)
     rat_ileqg_opts opts;
     OptsDev opd;
@@ -537,9 +538,12 @@ extern "C" rat_rc rat_set_initial(rat_handle h, const double *x0, const double *
     std::vector<double> xp(XSTR, 0.0), up((size_t)h->N * USTR, 0.0);
     for (int i = 0; i < h->n; ++i) xp[i] = x0[i];
     for (int t = 0; t < h->N; ++t) for (int g = 0; g < h->m; ++g) up[(size_t)t * USTR + g] = u0[(size_t)t * h->m + g];
+    // (the bilevel drivers pass the same x_0 / u_array for every batch of a solve: upload only what changed)
+    if (h->have_initial && xp == h->x0_host && up == h->u0_host) return RAT_OK;
     HIPCHK(hipMemcpyAsync(h->d_x0, xp.data(), xp.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_u0, up.data(), up.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->x0_host.swap(xp); h->u0_host.swap(up);
     h->have_initial = true;
     return RAT_OK;
 }
