@@ -621,7 +621,7 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // SEP (operand loads in the loop only): keep the steps of a group apart in the instruction schedule (see the time loop).
 template <int MODEL, int MODE, bool CTV, bool STAGE = false, bool SEP = true>
 __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
-    int lane_ = threadIdx.x;
+    int lane_ = threadIdx.x & 63;        // (rollin_stage_kernel runs the E candidates of a sample as the waves of one workgroup)
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
     const int l = lane_, j = l & 15, g = l >> 4;
 #ifdef RAT_DIAG
@@ -641,7 +641,8 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const double eps_in = st.ls_eps[b];
     if (MODE == 0) { if (s_stat != ST_RUNNING) return; }
     else { if (!s_act) return; }
-    __shared__ double shxu[16];                                  // terminal tile only
+    __shared__ double shxu_all[8][16];                           // terminal tile only; one row per wave of the workgroup
+    double *const shxu = shxu_all[(threadIdx.x >> 6) & 7];
 
     const int slot_n = b * (st.E + 1) + nom;
     const int slot_o = (MODE == 0) ? slot_n : cand_slot(b, k, nom, st.E);
@@ -949,9 +950,24 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     rollin_body<MODEL, MODE, CTV, false, SEP>(a, blockIdx.x);
 }
 
+// The E line-search candidates of a sample as the E waves of ONE workgroup (E <= 8, N <= ROLLIN_NST): they share the sample's operands
+// (L, xbar, l, dl), so the staged variant of rollin_body applies -- every wave copies the operands of the whole trajectory into the
+// workgroup's LDS area (identical values: benign overlap, each wave reads back what it wrote itself) and its time loop issues no
+// global load.  The unstaged kernel spends 60 % of its cycles in s_waitcnt on those loads (tools/profile_rollin.sh).
+template <int MODEL, bool CTV>
+__global__ __launch_bounds__(512) void rollin_stage_kernel(RolloutArgs a) {
+    rollin_body<MODEL, 1, CTV, true, false>(a, blockIdx.x * a.st.E + (threadIdx.x >> 6));
+}
+
 void launch_rollin(const RolloutArgs &a, hipStream_t s) {
     const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
     if (ncand <= 0) return;
+    if (a.mode == 1 && a.pb.model == 1 && a.st.E > 1 && a.st.E <= 8 && a.st.N <= ROLLIN_NST) {
+        const dim3 g2(a.st.B), b2(64 * a.st.E);
+        if (a.pb.cost_tv) hipLaunchKernelGGL((rollin_stage_kernel<1, true>), g2, b2, 0, s, a);
+        else hipLaunchKernelGGL((rollin_stage_kernel<1, false>), g2, b2, 0, s, a);
+        return;
+    }
     const dim3 grid(ncand), block(64);
     const bool sep = (a.mode == 0) || a.st.E == 1;            // one wave per SIMD: see rollin_body
     // one compact instantiation per (model family, mode): the LQ hot loop must not carry the inlined pow() expansions
