@@ -37,7 +37,7 @@ struct rat_handle_s {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // speculative gain sweeps run here, concurrently with the evaluation sweep
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    bool dual = false;               // RATILQR_DUAL=1: fused evaluation + next-gain-sweep wavefronts (E = 1 only)
+    bool dual = false;               // paired evaluation + next-gain-sweep wavefronts on the round-based path (default for E > 1; RATILQR_DUAL)
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
     bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
     std::vector<double> x0_host, u0_host;   // padded copies of what d_x0 / d_u0 hold (rat_set_initial skips identical uploads)
@@ -119,7 +119,8 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     HIPCHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
     if (const char *e = getenv("RATILQR_SPECULATE")) h->speculate = (e[0] == '1');
-    if (const char *e = getenv("RATILQR_DUAL")) h->dual = (e[0] == '1') && spec_eps == 1;
+    h->dual = spec_eps > 1;          // E > 1: candidate 0 in paired wavefronts beside the other candidates' evaluation (+3.5 % at E = 8)
+    if (const char *e = getenv("RATILQR_DUAL")) h->dual = (e[0] == '1');
     if (const char *e = getenv("RATILQR_FUSED")) h->fused = (e[0] != '0');
     if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
     if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
@@ -409,7 +410,7 @@ extern "C" rat_rc rat_layout_info(rat_handle h, int64_t *tile_bytes, int64_t *L_
 // ---- the batched solve state machine ------------------------------------------------------------------
 static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     SweepArgs a;
-    a.st = st; a.pb = h->pb; a.op = h->opd; a.mode = mode; a.dl_in = nullptr; a.mu_op = 0.0; a.op_out = nullptr; a.dump = nullptr;
+    a.st = st; a.pb = h->pb; a.op = h->opd; a.mode = mode; a.k_first = 0; a.dl_in = nullptr; a.mu_op = 0.0; a.op_out = nullptr; a.dump = nullptr;
 #if defined(RAT_DIAG) || defined(RAT_DIAG_PHASES)
     a.dump = h->d_dump;
 #endif
@@ -435,7 +436,17 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
         // fused path (E = 1): the plain gain sweep only serves samples whose fused gain recursion was abandoned (H not PD)
         prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
         prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);
+        if (st.E > 1) {              // candidates 1 .. E-1: plain policy evaluation, beside candidate 0's paired wavefronts (second stream)
+            HIPCHK(hipEventRecord(h->ev_a, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_a, 0));
+            SweepArgs se = sweep_args(h, st, 1);
+            se.k_first = 1;
+            const int64_t n1 = (int64_t)st.B * (st.E - 1);
+            prof_begin(h, RAT_K_SWEEP_EVAL, n1, h->stream2); launch_sweep(se, (int)n1, false, false, h->stream2); prof_end(h, h->stream2);
+            HIPCHK(hipEventRecord(h->ev_b, h->stream2));
+        }
         prof_begin(h, RAT_K_SWEEP_DUAL, st.B); launch_sweep_dual(sweep_args(h, st, 7), st.B, h->stream); prof_end(h);
+        if (st.E > 1) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
         prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
         HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));

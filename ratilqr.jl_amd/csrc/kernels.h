@@ -12,6 +12,7 @@ struct SweepArgs {
                            // 2 policy evaluation of nominal slots with L = 0, mu = 0 (initialize!);
                            // 3 operator form of policy evaluation (sample 0, L/dl given, mu = mu_op)
                            // 4 speculative gain sweep on line-search candidate 0; 5 speculative gain sweep on nominal slots
+    int k_first;           // mode 1: first candidate of each sample this launch evaluates (1 when candidate 0 runs in sweep_dual_kernel)
     const double *dl_in;   // mode 3: dl_array or null
     double mu_op;          // mode 3
     double *op_out;        // modes 0/3 operator forms: [0] = s_1, [1] = status ; else null

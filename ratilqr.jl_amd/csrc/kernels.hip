@@ -90,15 +90,15 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     // (every per-sample scalar is fetched before the first test on any of them: issued back to back the loads are in flight
     //  together; tested one by one they are a chain of dependent L2 round trips at every phase boundary of the fused solve)
     int b, k = 0, slot, cidx = -1;
-    if (a.mode == 1) { b = tid / st.E; k = tid - b * st.E; } else b = tid;
-    const int fidx = (a.mode == 1) ? tid : b * st.E;
+    if (a.mode == 1) { const int Ek = st.E - a.k_first; b = tid / Ek; k = a.k_first + (tid - b * Ek); } else b = tid;
+    const int fidx = b * st.E + k;
     const int v_act = st.ls_active[b], v_flag = st.flag_c[fidx], v_nom = st.slot_nom[b], v_stat = st.status[b], v_sel = st.lsel[b];
     const int s_act = wave_uniform(v_act), s_flag = wave_uniform(v_flag), s_nom = wave_uniform(v_nom), s_stat = wave_uniform(v_stat), sel = wave_uniform(v_sel);
     const double theta = st.theta[b], mu_in = st.mu[b];
     double delta = st.delta[b];
     if (a.mode == 1) {
         if (!s_act) return;
-        cidx = tid;
+        cidx = fidx;
         if (s_flag == 2) return;
         slot = cand_slot(b, k, s_nom, st.E);
     } else if (a.mode == 4) {          // speculative gain sweep of the NEXT iteration on line-search candidate 0

@@ -308,6 +308,30 @@ def test_dual_sweep_wavefronts_are_result_identical(monkeypatch):
     assert np.array_equal(r0["eps_history"], r1["eps_history"])
 
 
+@pytest.mark.parametrize("E", [2, 8])
+def test_dual_wavefronts_with_speculative_step_sizes(E, monkeypatch):
+    """E > 1 (default; RATILQR_DUAL=0 switches it off): candidate 0 runs in the paired wavefronts (its evaluation + the next gain sweep), candidates 1 .. E-1 in
+    the plain evaluation kernel on a second stream.  Bit-identical to the default path, including samples whose accepted candidate
+    is not candidate 0 (the speculative gain sweep is then void) and infeasible ones."""
+    prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
+    theta = np.array([0.0, 1.0, 4.0, 5.0, 5.9, 6.3, 6.6, 9.0, 30.0])
+    sprob, sx0, su = stress_problem(2, kappa=0.03)
+    pl = rat.PowerLawRiskSensitiveProblem(2, 10, 0.01 * np.eye(2))
+    px0, pu = np.zeros(2), 0.1 * np.ones((10, 2))
+    def run():
+        out = rat.Context(prob, max_batch=theta.size, spec_eps=E).solve_batch(x0, u, theta)
+        out += rat.Context(sprob, rat.ileqg.make_opts(iter_max=8), max_batch=3, spec_eps=E).solve_batch(sx0, su, np.array([0.0, 1.0, 4.0]))
+        out += rat.Context(pl, max_batch=3, spec_eps=E).solve_batch(px0, pu, np.array([0.0, 0.5, 2.0]))
+        return out
+    got = run()                                             # default for E > 1
+    monkeypatch.setenv("RATILQR_DUAL", "0")
+    ref = run()                                             # every candidate in the plain evaluation kernel, separate gain sweeps
+    monkeypatch.delenv("RATILQR_DUAL")
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    assert ref[3].max() > ref[2].max()                      # some line search really backtracked
+
+
 def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
     """Default for E = 1: one persistent wavefront per theta-sample runs the whole solve! in one launch, pairing each policy
     evaluation with the gain sweep that would follow it (RATILQR_FUSED_DUAL=0: separate passes).  It calls the same device
