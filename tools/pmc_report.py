@@ -53,8 +53,9 @@ out += f'''## Reading
   within 0.7 % of the information content (420 vs 417 doubles per step) and the paired recursions
   read the tiles of `initialize!` and of the first candidate ONCE for the policy evaluation and the gain sweep that follows it
   (the three-kernel formulation reads them twice).  No re-reads.
-* policy-evaluation sweep, round-based path: {tr["sweep_eval_E1_B1024"]/1e6:.1f} MB per launch at E = 1 (1024 candidates), {tr["sweep_eval_E8_B1024"]/1e6:.1f} MB at E = 8 (8192);
-  algorithmic 187,264 B per candidate = 191.8 MB / 1,534 MB.
+* policy-evaluation sweep, round-based path: {tr["sweep_eval_E1_B1024"]/1e6:.1f} MB per launch at E = 1 (1024 candidates), {tr["sweep_eval_E8_B1024"]/1e6:.1f} MB at E = 8
+  (7168 candidates: candidate 0 of every sample runs in the paired wavefronts of `sweep_dual_kernel`); algorithmic 187,264 B per candidate =
+  191.8 MB / 1,342 MB.
 '''
 open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.md"), "w").write(out)
 print(tr)
