@@ -56,6 +56,7 @@ struct rat_handle_s {
            *d_dlin = nullptr;
     int *d_ist = nullptr, *d_iit = nullptr, *d_ils = nullptr;
     int *h_counters = nullptr;       // pinned, [CTR_RING][2]
+    char *h_io = nullptr;            // pinned staging of the host-pointer batch entry point: theta | value | status | iters | ls_evals, [Bmax] each
     hipEvent_t round_ev[CTR_RING] = {};
     bool have_initial = false;
     int pred_rounds = 1;             // rounds the previous batch needed: that many are enqueued before the host first polls
@@ -125,6 +126,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
     if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
     HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_io, (size_t)max_batch * 28, hipHostMallocDefault));
     for (int i = 0; i < CTR_RING; ++i) HIPCHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->pb, 0, sizeof(h->pb));
@@ -147,6 +149,7 @@ extern "C" void rat_destroy(rat_handle h) {
     for (double *q : {h->d_px0, h->d_pctrl, h->d_pzn, h->d_pzu, h->d_ptraj, h->d_pcost}) if (q) (void)hipFree(q);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->h_counters) (void)hipHostFree(h->h_counters);
+    if (h->h_io) (void)hipHostFree(h->h_io);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -601,13 +604,29 @@ extern "C" rat_rc rat_ileqg_solve_batch(rat_handle h, const double *x0, const do
     if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");
     rat_rc rc = rat_set_initial(h, x0, u0);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_theta, theta, B * 8, hipMemcpyHostToDevice, h->stream));
-    rc = rat_ileqg_solve_batch_dev(h, h->d_theta, B, h->d_val, h->d_ist, h->d_iit, h->d_ils);
+    // theta in and the per-sample outputs back through one pinned staging area: asynchronous copies ordered on the handle's stream and
+    // ONE host wait per batch (pageable-memory copies cost a staging round trip and a synchronisation each)
+    const size_t M = (size_t)h->Bmax;
+    double *p_theta = reinterpret_cast<double *>(h->h_io), *p_val = p_theta + M;
+    int32_t *p_st = reinterpret_cast<int32_t *>(p_val + M), *p_it = p_st + M, *p_ls = p_it + M;
+    memcpy(p_theta, theta, B * 8);
+    HIPCHK(hipMemcpyAsync(h->d_theta, p_theta, B * 8, hipMemcpyHostToDevice, h->stream));
+    BatchOut out; out.value = h->d_val; out.status = h->d_ist; out.iters = h->d_iit; out.ls = h->d_ils;
+    rc = run_batch(h, h->d_theta, (int)B, out);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(value, h->d_val, B * 8, hipMemcpyDeviceToHost));
-    if (status) HIPCHK(hipMemcpy(status, h->d_ist, B * 4, hipMemcpyDeviceToHost));
-    if (iters) HIPCHK(hipMemcpy(iters, h->d_iit, B * 4, hipMemcpyDeviceToHost));
-    if (ls_evals) HIPCHK(hipMemcpy(ls_evals, h->d_ils, B * 4, hipMemcpyDeviceToHost));
+    if (!h->fused) {
+        StateDev st = h->st; st.B = (int)B;
+        launch_gather(st, h->d_val, h->d_ist, h->d_iit, h->d_ils, nullptr, 0.0, h->stream);
+    }
+    HIPCHK(hipMemcpyAsync(p_val, h->d_val, B * 8, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIPCHK(hipMemcpyAsync(p_st, h->d_ist, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIPCHK(hipMemcpyAsync(p_it, h->d_iit, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (ls_evals) HIPCHK(hipMemcpyAsync(p_ls, h->d_ils, B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(value, p_val, B * 8);
+    if (status) memcpy(status, p_st, B * 4);
+    if (iters) memcpy(iters, p_it, B * 4);
+    if (ls_evals) memcpy(ls_evals, p_ls, B * 4);
     return RAT_OK;
 }
 
