@@ -56,6 +56,7 @@ struct rat_handle_s {
            *d_dlin = nullptr;
     int *d_ist = nullptr, *d_iit = nullptr, *d_ils = nullptr;
     int *h_counters = nullptr;       // pinned, [CTR_RING][2]
+    double *d_hist = nullptr; int hist_dev_cap = 0;   // eps-history of single solves (rat_ileqg_solve), grown on demand
     char *h_io = nullptr;            // pinned staging of the host-pointer batch entry point: theta | value | status | iters | ls_evals, [Bmax] each
     hipEvent_t round_ev[CTR_RING] = {};
     bool have_initial = false;
@@ -126,7 +127,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
     if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
     HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->h_io, (size_t)max_batch * 28, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_io, std::max<size_t>((size_t)max_batch * 28, 64), hipHostMallocDefault));
     for (int i = 0; i < CTR_RING; ++i) HIPCHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->pb, 0, sizeof(h->pb));
@@ -150,6 +151,7 @@ extern "C" void rat_destroy(rat_handle h) {
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->h_io) (void)hipHostFree(h->h_io);
+    if (h->d_hist) (void)hipFree(h->d_hist);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -684,34 +686,45 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     if (!h || !x0 || !u0) return fail(RAT_ERR_ARG, "null");
     rat_rc rc = rat_set_initial(h, x0, u0);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_theta, &theta, 8, hipMemcpyHostToDevice, h->stream));
-    double *d_hist = nullptr;
+    // pinned staging (h_io, >= 28 bytes): theta in, the sample's scalars back; asynchronous copies, two host waits per solve
+    double *p_d = reinterpret_cast<double *>(h->h_io);            // [0] theta, then value
+    int32_t *p_i = reinterpret_cast<int32_t *>(h->h_io + 16);     // status, iter, slot_nom (+ lsel, hist_n in the theta slot afterwards)
+    p_d[0] = theta;
+    HIPCHK(hipMemcpyAsync(h->d_theta, p_d, 8, hipMemcpyHostToDevice, h->stream));
     const int cap = (int)std::min<int64_t>(std::max<int64_t>(hist_cap, 0), 1 << 20);
-    if (eps_hist && cap > 0) { HIPCHK(hipMalloc((void **)&d_hist, (size_t)cap * 16)); }
-    h->st.hist = d_hist; h->st.hist_cap = cap;
+    if (eps_hist && cap > 0 && cap > h->hist_dev_cap) {            // the eps-history buffer is kept (and only grown) across calls
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_hist) (void)hipFree(h->d_hist);
+        h->d_hist = nullptr; h->hist_dev_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->d_hist, (size_t)cap * 16));
+        h->hist_dev_cap = cap;
+    }
+    const bool want_hist = eps_hist && cap > 0;
+    h->st.hist = want_hist ? h->d_hist : nullptr; h->st.hist_cap = want_hist ? cap : 0;
     rc = run_batch(h, h->d_theta, 1);
-    if (!rc) HIPCHK(hipStreamSynchronize(h->stream));       // the fused solve returns with its launch still in flight
     h->st.hist = nullptr; h->st.hist_cap = 0;
-    if (rc) { if (d_hist) (void)hipFree(d_hist); return rc; }
-    int st_h = 0, it_h = 0, nom = 0, hn = 0; double val = 0;
-    HIPCHK(hipMemcpy(&st_h, h->st.status, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&it_h, h->st.iter, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&nom, h->st.slot_nom, 4, hipMemcpyDeviceToHost));
-    int lsel = 0;
-    HIPCHK(hipMemcpy(&lsel, h->st.lsel, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&hn, h->st.hist_n, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&val, h->st.value, 8, hipMemcpyDeviceToHost));
+    if (rc) return rc;
+    int32_t *p_j = reinterpret_cast<int32_t *>(h->h_io);          // (the theta slot is free once the batch is enqueued behind its upload)
+    HIPCHK(hipMemcpyAsync(p_d + 1, h->st.value, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 0, h->st.status, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 1, h->st.iter, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 2, h->st.slot_nom, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_j + 0, h->st.lsel, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_j + 1, h->st.hist_n, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int st_h = p_i[0], it_h = p_i[1], nom = p_i[2], lsel = p_j[0], hn = p_j[1];
+    const double val = p_d[1];
     if (status) *status = st_h;
     if (iters) *iters = it_h;
     if (value) *value = (st_h == 0 || st_h == 3) ? val : INFINITY;
     if (hist_n) *hist_n = hn;
-    if (d_hist) {
-        HIPCHK(hipMemcpy(eps_hist, d_hist, (size_t)std::min(hn, cap) * 16, hipMemcpyDeviceToHost));
-        (void)hipFree(d_hist);
-    }
-    std::vector<double> xp, up, Lp((size_t)h->N * LSTR);
-    if ((rc = fetch_slot(h, nom, &xp, &up, nullptr))) return rc;
-    HIPCHK(hipMemcpy(Lp.data(), h->st.L + (size_t)lsel * h->st.l_half, Lp.size() * 8, hipMemcpyDeviceToHost));
+    const StateDev &st = h->st;
+    std::vector<double> xp(st.x_stride), up(st.u_stride), Lp((size_t)h->N * LSTR);
+    if (want_hist && hn > 0) HIPCHK(hipMemcpyAsync(eps_hist, h->d_hist, (size_t)std::min(hn, cap) * 16, hipMemcpyDeviceToHost, h->stream));
+    if (x) HIPCHK(hipMemcpyAsync(xp.data(), st.xs + (size_t)nom * st.x_stride, st.x_stride * 8, hipMemcpyDeviceToHost, h->stream));
+    if (l) HIPCHK(hipMemcpyAsync(up.data(), st.us + (size_t)nom * st.u_stride, st.u_stride * 8, hipMemcpyDeviceToHost, h->stream));
+    if (L) HIPCHK(hipMemcpyAsync(Lp.data(), st.L + (size_t)lsel * st.l_half, Lp.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     if (x) unpad_x(h, xp, x);
     if (l) unpad_u(h, up, l);
     if (L) unpad_L(h, Lp, L);
