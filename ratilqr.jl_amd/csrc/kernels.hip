@@ -950,20 +950,23 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     rollin_body<MODEL, MODE, CTV, false, SEP>(a, blockIdx.x);
 }
 
-// The E line-search candidates of a sample as the E waves of ONE workgroup (E <= 8, N <= ROLLIN_NST): they share the sample's operands
+// The E line-search candidates of a sample as the waves of ONE workgroup (eight per workgroup; N <= ROLLIN_NST): they share the sample's operands
 // (L, xbar, l, dl), so the staged variant of rollin_body applies -- every wave copies the operands of the whole trajectory into the
 // workgroup's LDS area (identical values: benign overlap, each wave reads back what it wrote itself) and its time loop issues no
 // global load.  The unstaged kernel spends 60 % of its cycles in s_waitcnt on those loads (tools/profile_rollin.sh).
 template <int MODEL, bool CTV>
 __global__ __launch_bounds__(512) void rollin_stage_kernel(RolloutArgs a) {
-    rollin_body<MODEL, 1, CTV, true, false>(a, blockIdx.x * a.st.E + (threadIdx.x >> 6));
+    const int nb = (a.st.E + 7) >> 3;                           // workgroups per sample: eight candidates each
+    const int b = blockIdx.x / nb, k = (blockIdx.x - b * nb) * 8 + (threadIdx.x >> 6);
+    if (k >= a.st.E) return;
+    rollin_body<MODEL, 1, CTV, true, false>(a, b * a.st.E + k);
 }
 
 void launch_rollin(const RolloutArgs &a, hipStream_t s) {
     const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
     if (ncand <= 0) return;
-    if (a.mode == 1 && a.pb.model == 1 && a.st.E > 1 && a.st.E <= 8 && a.st.N <= ROLLIN_NST) {
-        const dim3 g2(a.st.B), b2(64 * a.st.E);
+    if (a.mode == 1 && a.pb.model == 1 && a.st.E > 1 && a.st.N <= ROLLIN_NST) {
+        const dim3 g2(a.st.B * ((a.st.E + 7) / 8)), b2(64 * (a.st.E < 8 ? a.st.E : 8));
         if (a.pb.cost_tv) hipLaunchKernelGGL((rollin_stage_kernel<1, true>), g2, b2, 0, s, a);
         else hipLaunchKernelGGL((rollin_stage_kernel<1, false>), g2, b2, 0, s, a);
         return;

@@ -67,7 +67,7 @@ def test_first_gain_sweep_policy_against_oracle():
         assert np.array_equal(r["eps_history"][:, 0], so.eps_history[:, 0])
 
 
-@pytest.mark.parametrize("E", [1, 2, 4, 8])
+@pytest.mark.parametrize("E", [1, 2, 4, 8, 11])
 def test_speculation_width_does_not_change_results(E):
     """App. B.17: evaluating E step sizes at once and replaying the sequential rule is result-identical."""
     prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
