@@ -210,6 +210,34 @@ def main():
                                "avg_launch_ms": p8["ms"] / max(p8["launches"], 1)}}
         del ctx8
 
+    # second secondary: a nonlinear workload (cubic drift kappa x^3 on the same tables): more iterations per solve and
+    # theta-dependent iteration counts, i.e. divergent per-sample control flow inside one launch
+    nonlin = None
+    if world == 1 and not args.no_second:
+        probn, x0n, u0n = rat.synthetic_lq_problem(n=12, m=4, N=50, seed=0, kappa=0.05)
+        ctxn = rat.Context(probn, max_batch=B, spec_eps=E, device=local_rank)
+        ctxn.set_initial(x0n, u0n)
+        vn = torch.empty(B, dtype=torch.float64, device=dev)
+        stn = torch.empty(B, dtype=torch.int32, device=dev)
+        itn = torch.empty(B, dtype=torch.int32, device=dev)
+        lsn = torch.empty(B, dtype=torch.int32, device=dev)
+        for _ in range(3):
+            ctxn.solve_batch_dev(theta.data_ptr(), B, vn.data_ptr(), stn.data_ptr(), itn.data_ptr(), lsn.data_ptr())
+        torch.cuda.synchronize()
+        tn = time.perf_counter()
+        Kn = max(3, K // 3)
+        for _ in range(Kn):
+            ctxn.solve_batch_dev(theta.data_ptr(), B, vn.data_ptr(), stn.data_ptr(), itn.data_ptr(), lsn.data_ptr())
+        torch.cuda.synchronize()
+        en = time.perf_counter() - tn
+        sn = stn.cpu().numpy()
+        nonlin = {"workload": "the same problem with cubic drift kappa = 0.05 (f = A x + B u + kappa x^3)", "value": B * Kn / en,
+                  "unit": "solves/s", "ms_per_step": en / Kn * 1e3, "steps": Kn,
+                  "feasible_fraction": float(np.mean((sn == 0) | (sn == 3))), "mean_iters": float(itn.float().mean().item()),
+                  "mean_ls_evals": float(lsn.float().mean().item()),
+                  "algorithmic_GBps": algo_bytes_of_solves(itn.cpu().numpy(), lsn.cpu().numpy()) * Kn / en / 1e9}
+        del ctxn
+
     # per-phase breakdown of the same batch on the round-based path (one launch per phase; what the fused kernel replaces)
     unfused = None
     if fused and world == 1:
@@ -303,6 +331,8 @@ def main():
             out["round_based_path"] = unfused
         if second is not None:
             out["secondary_spec_eps8"] = second
+        if nonlin is not None:
+            out["secondary_nonlinear"] = nonlin
         if world == 1 and not args.no_cpu:
             from oracle import oracle as orc
 
