@@ -37,6 +37,7 @@ from .cross_entropy import (  # noqa: F401,E402
     CrossEntropyBilevelOptimizationSolver,
     compute_cost,
     compute_cost_serial,
+    compute_value_worker,
     get_positive_samples,
 )
 from . import nelder_mead  # noqa: F401,E402

@@ -75,6 +75,14 @@ def initialize_(ce_solver: CrossEntropyBilevelOptimizationSolver):           # i
     nv.lib().rat_ce_initialize(C.byref(ce_solver.c))
 
 
+def compute_value_worker(ce_solver, problem, x, u_array, theta):             # compute_value_worker  :144-167
+    """Value of one fresh iLEQG solve at ``theta``; any failure of the solve (M not PD, DomainError, ...) gives Inf (:163-165).
+    The reference runs this on a worker process per sample; here it is a batch of one on the device."""
+    ctx = ce_solver.context(problem)
+    value, _, _, _ = ctx.solve_batch(x, u_array, np.array([float(theta)]))
+    return float(value[0])
+
+
 def compute_cost(ce_solver, problem, x, u_array, theta_array, kl_bound):     # compute_cost  :173-195
     theta = nv.f64(theta_array)
     ctx = ce_solver.context(problem)

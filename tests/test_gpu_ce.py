@@ -32,6 +32,16 @@ def test_compute_cost_equals_serial():                        # :27-32
     assert np.allclose(costs, [11.002908466254208, 4.33624364124029, 3.3284929065983375], rtol=1e-9)
 
 
+def test_compute_value_worker_is_value_or_inf():              # ce.jl:144-167
+    prob, x0, u = nonlinear()
+    solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=3)
+    costs = ce.compute_cost(solver, prob, x0, u, [0.1, 0.3, 0.43], 1.0)
+    vals = [rat.compute_value_worker(solver, prob, x0, u, th) for th in (0.1, 0.3, 0.43)]
+    assert np.array_equal(np.array(vals) + 1.0 / np.array([0.1, 0.3, 0.43]), costs)
+    lq, lx0, lu = rat.synthetic_lq_problem()
+    assert np.isposinf(rat.compute_value_worker(rat.CrossEntropyBilevelOptimizationSolver(), lq, lx0, lu, 60.0))   # exception -> Inf (:163-165)
+
+
 def test_get_positive_samples():                              # :34-35
     z = np.random.default_rng(123).standard_normal(200)
     th = rat.get_positive_samples(0.0, 1.0, 10, z)
