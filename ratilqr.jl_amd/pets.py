@@ -119,6 +119,23 @@ def compute_cost_serial(direct_solver, problem, x, control_sequence_array, rng, 
 compute_cost = compute_cost_serial            # the reference's distributed twin differs only in its RNG jumps (pets.jl:100-126)
 
 
+def compute_cost_worker(direct_solver, problem, x, u_array, rng, use_true_model=False, streams=None, seed=None):   # pets.jl:76-98
+    """Mean cost of ONE control sequence over num_trajectory_samples stochastic rollouts (what a worker computes per sample)."""
+    ctrl = nv.f64(u_array)[None]
+    assert ctrl.shape[1] == direct_solver.N
+    K = int(direct_solver.c.num_trajectory_samples)
+    ctx = direct_solver.context(problem)
+    zn = zu = None
+    if seed is None:
+        zn, zu = streams if streams is not None else draw_noise(problem, rng, 1, K, use_true_model)
+        zn = nv.f64(zn)
+        zu = None if zu is None else nv.f64(zu)
+    cost = np.zeros(1)
+    nv.check(nv.lib().rat_pets_compute_cost(ctx.h, nv.P(nv.f64(x)), nv.P(ctrl), C.c_int64(1), C.c_int64(K), int(use_true_model),
+                                            nv.P(zn), nv.P(zu), C.c_uint64(0 if seed is None else int(seed)), nv.P(cost)))
+    return float(cost[0])
+
+
 def get_elite_samples(direct_solver, control_sequence_array, cost_array):          # pets.jl:159-171
     ctrl = nv.f64(control_sequence_array)
     order = np.argsort(nv.f64(cost_array), kind="stable")[: direct_solver.c.num_elite]

@@ -55,6 +55,18 @@ def test_reference_pets_test():                               # pets_test.jl:22-
     assert np.abs(mu).mean() < 0.25 and Sig.max() < 0.5       # c = sum|u|: the CE distribution contracts towards u = 0
 
 
+def test_compute_cost_worker_is_one_row_of_compute_cost():    # pets.jl:76-98
+    prob = ref_problem()
+    ds = rat.CrossEntropyDirectOptimizationSolver(np.zeros((N, 2)), np.stack([np.eye(2)] * N), num_control_samples=4, num_trajectory_samples=50)
+    rng = np.random.default_rng(5)
+    ctrl = rng.random((4, N, 2))
+    zn, _ = pets.draw_noise(prob, rng, 4, 50)
+    cost = pets.compute_cost_serial(ds, prob, np.zeros(2), ctrl, None, streams=(zn, None))
+    per = N * 2 * 50
+    for ii in range(4):
+        assert pets.compute_cost_worker(ds, prob, np.zeros(2), ctrl[ii], None, streams=(zn[ii * per:(ii + 1) * per], None)) == cost[ii]
+
+
 def rich_problem(n=12, m=4, Nh=30, kappa=-0.01):
     r = np.random.default_rng(8)
     A = 0.9 * np.linalg.qr(r.standard_normal((n, n)))[0]
