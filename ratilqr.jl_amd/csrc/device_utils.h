@@ -156,7 +156,7 @@ __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base
 #endif
 
 #ifdef RAT_DIAG
-#define DIAG_DECL unsigned long long dg_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long dg_prev = 0, dg_gap = 0;
+#define DIAG_DECL unsigned long long dg_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long dg_prev = 0; [[maybe_unused]] unsigned long long dg_gap = 0;
 #define DIAG_START() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         { unsigned long long now_ = __builtin_readcyclecounter(); if (dg_prev) dg_gap += now_ - dg_prev; dg_prev = now_; } __builtin_amdgcn_sched_barrier(0); } while (0)
 #define DIAG_STAMP(i, val) do { asm volatile("" :: "v"(val)); __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
