@@ -1326,8 +1326,10 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
         }
     }
     for (int guard = 0; guard < fa.max_rounds; ++guard) {
-        if (uniform_load(&st.status[b]) != ST_RUNNING) break;
-        if (!uniform_load(&st.ls_active[b])) {               // step!: solve_approximate_dp!  (ileqg.jl:598-613)
+        // (both control words are requested before either is waited for: one L2 round trip per loop turn instead of two)
+        const int v_stat = __atomic_load_n(&st.status[b], __ATOMIC_RELAXED), v_act = __atomic_load_n(&st.ls_active[b], __ATOMIC_RELAXED);
+        if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
+        if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp!  (ileqg.jl:598-613)
             SweepArgs sa = fa.sw; sa.mode = 0;
             sweep_body<true, false, WTV, false>(sa, b);
             PHASE_MARK();
@@ -1343,8 +1345,10 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
             PHASE_MARK();
             bool pair = DUALF;
             if (DUALF) {                                     // would accepting this candidate end solve!?  (ileqg.jl:642-653)
-                const double dc = uniform_load_f64(&st.d_c[b]), mu = uniform_load_f64(&st.mu[b]);
-                const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || uniform_load(&st.iter[b]) == fa.sw.op.iter_max;
+                const double v_dc = *(const volatile double *)&st.d_c[b], v_mu = *(const volatile double *)&st.mu[b];
+                const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);            // (three loads in flight together)
+                const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
+                const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
                 pair = !ends;
             }
             if (pair) {
