@@ -47,14 +47,37 @@ def allgather_values(local: torch.Tensor, B: int, group=None) -> torch.Tensor:
 
 
 def compute_cost_sharded(theta: np.ndarray, kl_bound: float, evaluate_shard: Callable[[torch.Tensor], torch.Tensor],
-                         device="cpu", group=None) -> np.ndarray:
+                         device="cpu", group=None, assignment="contiguous") -> np.ndarray:
     """compute_cost (:173-195) with the value fan-out sharded over the ranks of ``group``.
 
     ``evaluate_shard(theta_shard)`` returns the iLEQG values (Inf on failure) of this rank's block as a tensor
-    on ``device``; product code passes Context.solve_batch_dev wrapped by ``gpu_evaluator``."""
+    on ``device``; product code passes Context.solve_batch_dev wrapped by ``gpu_evaluator``.
+    ``assignment``: "contiguous" blocks, or "interleaved" -- the samples sorted by theta are dealt round-robin (rank r takes every
+    world-th one), the reference's own pattern (:181).  Iteration counts grow with theta on nonlinear problems and infeasible samples
+    stop at initialize!, so dealing the sorted samples evens out the work per rank; results do not depend on the assignment."""
     B = int(theta.size)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if assignment == "interleaved" and world > 1:
+        order = np.argsort(theta, kind="stable")
+        mine = order[rank::world]
+        th = torch.as_tensor(np.ascontiguousarray(theta[mine]), dtype=torch.float64, device=device)
+        val = evaluate_shard(th)
+        chunk = -(-B // world)
+        buf = torch.full((chunk,), float("nan"), dtype=torch.float64, device=val.device)
+        buf[: val.numel()] = val
+        out = torch.empty((world * chunk,), dtype=torch.float64, device=val.device)
+        if val.is_cuda:
+            dist.all_gather_into_tensor(out, buf, group=group)
+        else:
+            dist.all_gather(list(out.view(world, chunk).unbind(0)), buf, group=group)
+        out = out.cpu().numpy().reshape(world, chunk)
+        allv = np.empty(B)
+        for r in range(world):
+            idx = order[r::world]
+            allv[idx] = out[r, : idx.size]
+        return allv + kl_bound / theta                                              # :193
+    assert assignment in ("contiguous", "interleaved")
     lo, hi = shard_bounds(B, world, rank)
     th = torch.as_tensor(np.ascontiguousarray(theta[lo:hi]), dtype=torch.float64, device=device)
     val = evaluate_shard(th)

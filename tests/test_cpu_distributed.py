@@ -120,3 +120,38 @@ def test_two_rank_pets_cost_matches_single_process(tmp_path):
     prob, ctrl, zn, S, K = _pets_setup()
     ref = orc.pets_compute_cost(orc.GenProblem(prob), np.zeros(2), ctrl, K, False, zn)
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], ref)
+
+
+def _worker_interleaved(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob, x0, u = _problem()
+    P = orc.Problem(prob)
+    seen = []
+
+    def evaluate(th):
+        seen.append(th.numpy().copy())
+        v, _, _, _ = orc.compute_value_batch(P, x0, u, th.numpy(), nthreads=1)
+        return torch.as_tensor(v, dtype=torch.float64)
+
+    theta = np.abs(1.0 + 2.0 * np.random.default_rng(5).standard_normal(13)) + 0.01      # ragged: 13 samples on 3 ranks
+    theta[4] = 500.0                                                                      # infeasible -> Inf
+    a = rd.compute_cost_sharded(theta, 0.1, evaluate, assignment="interleaved")
+    b = rd.compute_cost_sharded(theta, 0.1, evaluate, assignment="contiguous")
+    assert np.array_equal(a, b) and np.isposinf(a[4])
+    assert np.array_equal(seen[0], np.sort(theta)[rank::world])                           # sorted samples dealt round-robin
+    np.save(os.path.join(out_dir, f"i{rank}.npy"), a)
+    dist.destroy_process_group()
+
+
+def test_interleaved_assignment_gives_the_same_costs(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_interleaved, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    got = [np.load(os.path.join(str(tmp_path), f"i{r}.npy")) for r in range(3)]
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+    prob, x0, u = _problem()
+    theta = np.abs(1.0 + 2.0 * np.random.default_rng(5).standard_normal(13)) + 0.01
+    theta[4] = 500.0
+    v, _, _, _ = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=1)
+    assert np.array_equal(got[0], v + 0.1 / theta)
