@@ -1,30 +1,46 @@
 #!/usr/bin/env python3
-"""bench.py -- iLEQG solves/sec (N=50, n=12, m=4) at CE batch = 1024 per GPU.
+"""bench.py -- iLEQG solves/sec (N=50, n=12, m=4) at CE batch = 1024, on 1/2/4/8 MI355X.
 
-A "step" is one compute_cost-equivalent pass (cross_entropy_bilevel_optimization.jl:173-195) over a CE batch of
-1024 theta-samples on every rank: 1024 complete iLEQG solves (initialize! + iterations with line search) on the
-synthetic LQ-plus-noise problem of SURVEY.md section 8(d), followed -- when N > 1 -- by the all-gather of the
-per-sample costs (RCCL).  theta, x0, u0 and the problem tables are resident in HBM before the timed region.
-Weak scaling: every rank owns its own 1024-sample CE batch; value = N * 1024 * K / max-over-ranks time.
+A "step" is one compute_cost-equivalent pass (cross_entropy_bilevel_optimization.jl:173-195) over ONE Cross-Entropy batch of
+1024 theta-samples: 1024 complete iLEQG solves (initialize! + iterations with line search) on the synthetic LQ-plus-noise
+problem of SURVEY.md section 8(d).  theta, x0, u0 and the problem tables are resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--spec-eps E] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--spec-eps E] [--no-cpu] [--no-second]
+
+N > 1 (one process per GPU over RCCL):
+  * started by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE is set), or
+  * started plainly as `python bench.py --gpus N`: this process then launches the N ranks itself -- BEFORE any GPU call -- and
+    exits with their exit code; it fails (non-zero) when fewer than N devices are visible.
+  `value` is the BASELINE.json configuration: the ONE CE batch of 1024 samples sharded over the N ranks in contiguous theta blocks
+  (1024 / N solves per GPU) followed by the RCCL all-gather of the per-sample costs, i.e. STRONG scaling ("scaling": "strong").
+  The same JSON line carries `weak` (1024 samples per GPU) and `strong_spec_eps8` (BASELINE config 3: 8 speculative line-search step
+  sizes per sample) measured in the same run.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
+
+# (the CPU baseline leg binds the oracle's OpenMP threads; libgomp reads these when it is first loaded -- before torch pulls it in)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "threads")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak (one datapath, profiles/r01_ubench_fp64_pipe.md)
+KERNEL_SOURCES = ("kernels.hip", "sweep_dual.h", "device_utils.h", "layout.h", "kernels.h")
 
 
+# ---- the byte / flop model of SURVEY.md section 8(d) (pinned by tests/test_cpu_bench_model.py) --------------------------------
 def algo_bytes(n=12, m=4, N=50):
     """SURVEY.md section 8(d) "algorithmic bytes per unit" (unfused three-kernel formulation), in bytes.
     tile bundle = N (2n^2 + 2nm + m^2 + n + m + 1) + n^2 + n + 1 doubles; x = (N+1) n; l, dl = N m; L = N m n."""
@@ -53,9 +69,6 @@ def algo_bytes_of_solves(iters, ls_evals):
     return float(len(iters)) * a["init"] + float(np.sum(iters)) * a["sweep_gain"] + float(np.sum(ls_evals)) * a["candidate"]
 
 
-FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak (they are one datapath, profiles/r01_ubench_fp64_pipe.md)
-
-
 def algo_flops_of_solves(iters, ls_evals, N=50):
     """SURVEY.md section 8(d) "algorithmic flops per unit" (factored form, App. D): 22.2 kflop per backward step, rollout 24 kflop and
     linearise 20 kflop per trajectory; a solve runs 1 + iters + ls_evals sweeps and 1 + ls_evals rollouts / linearisations
@@ -75,123 +88,432 @@ def draw_theta(B, seed):
     return np.array(out[:B])
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--spec-eps", type=int, default=1, help="E speculative line-search step sizes per sample")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-second", action="store_true", help="skip the secondary E=8 measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+def shard_bounds(B, world, rank):
+    """Contiguous theta block [lo, hi) of a rank (ratilqr.jl_amd.distributed.shard_bounds; blocks differ by at most one sample)."""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hooks (tests/test_gpu_distributed.py runs two ranks on ONE GPU): the collective backend, and all ranks on device 0
-    backend = os.environ.get("RATILQR_BENCH_BACKEND", "nccl")
-    if os.environ.get("RATILQR_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    # (test hook: run the collective path even with one rank -- RCCL on the handle's stream on a single-GPU box)
-    multi = world > 1 or os.environ.get("RATILQR_BENCH_FORCE_DIST") == "1"
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # RCCL
-        else:
-            dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    import ratilqr.jl_amd as rat
+def kernel_source_hash():
+    """sha256 over the kernel sources: stamps profiles/traffic.json, so that a PMC figure measured on other kernels reads as null."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "ratilqr.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
-    B, E, K, W = args.batch, args.spec_eps, args.steps, args.warmup
-    prob, x0, u0 = rat.synthetic_lq_problem(n=12, m=4, N=50, seed=0)
-    ctx = rat.Context(prob, max_batch=B, spec_eps=E, device=local_rank)
-    ctx.set_initial(x0, u0)
-    kl_bound = 0.1
-    theta_h = draw_theta(B, seed=1000 + rank)
-    theta = torch.as_tensor(theta_h, dtype=torch.float64, device=dev)
-    value = torch.empty(B, dtype=torch.float64, device=dev)
-    status = torch.empty(B, dtype=torch.int32, device=dev)
-    iters = torch.empty(B, dtype=torch.int32, device=dev)
-    ls = torch.empty(B, dtype=torch.int32, device=dev)
-    cost = torch.empty(B, dtype=torch.float64, device=dev)
-    cost_all = torch.empty(world * B, dtype=torch.float64, device=dev) if multi else cost
-    torch.cuda.synchronize()
 
-    # the handle's own HIP stream, seen by torch: the batch, the cost all-gather and the next batch are ordered on it on the device,
-    # with no host round trip between steps (the timed region ends with a device synchronisation)
-    hstream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+def traffic_for(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or (None, why)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tpath))
+    except Exception:
+        return None, "profiles/traffic.json missing"
+    if key not in tj:
+        return None, f"no PMC pass recorded for {key}"
+    if tj.get("kernels_sha") != kernel_source_hash():
+        return None, f"profiles/traffic.json was measured on kernel sources {tj.get('kernels_sha')}, this tree is {kernel_source_hash()}"
+    return float(tj[key]), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {tj.get('kernels_sha')} ({tj.get('round', '?')})"
+
+
+# ---- host cores the CPU baseline may use ---------------------------------------------------------------------------------------
+def cgroup_cpu_limit():
+    for p in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(p).read().split()[:2]
+            if q != "max":
+                return float(q) / float(per)
+        except Exception:
+            pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except Exception:
+        pass
+    return None
+
+
+def host_cpu_info():
+    """Hardware threads this process may run on (affinity mask clipped by the cgroup CPU quota) and the physical cores behind them."""
+    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    lim = cgroup_cpu_limit()
+    threads = len(aff) if lim is None else max(1, min(len(aff), int(math.floor(lim + 1e-9))))
+    sib = set()
+    for c in aff:
+        try:
+            sib.add(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip())
+        except Exception:
+            sib.add(str(c))
+    phys = max(1, min(len(sib), threads))
+    return {"affinity_threads": len(aff), "cgroup_cpu_limit": lim, "threads": threads, "physical_cores": phys,
+            "os_cpu_count": os.cpu_count()}
+
+
+def cpu_baseline(prob, x0, u0, seconds):
+    """The C oracle (reference operation order, -O2, no FMA contraction) on the host cores, one theta-sample per OpenMP thread
+    (the reference's one-sample-per-worker layout, cross_entropy...jl:180-191): thread-count sweep, best reported."""
+    from oracle import oracle as orc
+
+    P = orc.Problem(prob)
+    info = host_cpu_info()
+    th1 = draw_theta(24, seed=55)
+    t1 = time.perf_counter()
+    orc.compute_value_batch(P, x0, u0, th1, nthreads=1)
+    v1 = th1.size / (time.perf_counter() - t1)
+    cand = sorted({c for c in (info["physical_cores"] // 2, info["physical_cores"], info["threads"]) if c >= 2})
+    sweep, per_point = [{"threads": 1, "solves_per_s": v1}], max(1.0, 0.25 * seconds / max(len(cand), 1))
+
+    def run(T, budget, seed0):
+        n_done, t_cpu = 0, 0.0
+        chunk = max(64, 16 * T)
+        while t_cpu < budget:
+            th = draw_theta(chunk, seed=seed0 + n_done)
+            t0 = time.perf_counter()
+            orc.compute_value_batch(P, x0, u0, th, nthreads=T)
+            t_cpu += time.perf_counter() - t0
+            n_done += chunk
+        return n_done, t_cpu
+
+    for T in cand:
+        n_done, t_cpu = run(T, per_point, 1000 * T)
+        sweep.append({"threads": T, "solves_per_s": n_done / t_cpu})
+    best = max(sweep, key=lambda r: r["solves_per_s"])
+    n_done, t_cpu = (th1.size, th1.size / v1) if best["threads"] == 1 else run(best["threads"], max(2.0, 0.7 * seconds), 77)
+    value = max(best["solves_per_s"], n_done / t_cpu)
+    import shutil
+    jl = shutil.which("julia")                          # probed at run time: the reference itself is never on the GPU box
+    julia_note = ("the Julia reference is not runnable (no julia binary)" if jl is None else
+                  f"a julia binary exists ({jl}) but the reference package and its dependencies do not travel to this box")
+    return {
+        "value": value, "unit": "solves/s", "cores": best["threads"], "kind": "port", "value_1thread": v1,
+        "parallel_efficiency": value / (v1 * best["threads"]), "thread_sweep": sweep, "host": info,
+        "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+        "sample": f"{n_done} solves of the same workload (theta ~ N(1,2)>0) by the C oracle, OpenMP one sample per thread, best of the "
+                  f"thread sweep = {best['threads']} threads ({info['threads']} usable hardware threads on {info['physical_cores']} "
+                  f"physical cores: affinity mask clipped by the cgroup quota), {t_cpu:.1f} s; " + julia_note,
+    }
+
+
+# ---- launching ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (torch.distributed.run, one process per GPU) from this
+    process, which never touches the GPU itself (device_count() does not initialise it), and hand their exit code back."""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    shared = os.environ.get("RATILQR_BENCH_ONE_DEVICE") == "1" or os.environ.get("RATILQR_BENCH_DRY") == "1"    # test hooks
+    if ndev < args.gpus and not shared:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} HIP devices, {ndev} visible", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RATILQR_BENCH_SELF_LAUNCHED="1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Dist:
+    """Process-group plumbing of one rank (RCCL = backend "nccl" on ROCm; gloo and a one-device mapping as test hooks)."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("RATILQR_BENCH_BACKEND", "nccl")
+        self.dry = os.environ.get("RATILQR_BENCH_DRY") == "1"       # CPU test hook: launch / collective plumbing only, no solver
+        if os.environ.get("RATILQR_BENCH_ONE_DEVICE") == "1":
+            self.local_rank = 0
+        self.multi = self.world > 1 or os.environ.get("RATILQR_BENCH_FORCE_DIST") == "1"
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not self.dry:
+            if torch.cuda.device_count() <= self.local_rank:
+                raise SystemExit(f"bench.py: rank {self.rank} needs HIP device {self.local_rank}, {torch.cuda.device_count()} visible")
+            torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cpu") if self.dry else torch.device("cuda", self.local_rank)
+        self.rccl_ranks = 1
+        if self.multi:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)      # RCCL
+            else:
+                dist.init_process_group(self.backend)
+            # a real collective: every rank contributes its rank id, every rank must see 0 .. world-1
+            cdev = self.dev if self.backend == "nccl" else torch.device("cpu")
+            ids = torch.empty(self.world, dtype=torch.int64, device=cdev)
+            mine = torch.tensor([self.rank], dtype=torch.int64, device=cdev)
+            if self.backend == "nccl":
+                dist.all_gather_into_tensor(ids, mine)
+            else:
+                dist.all_gather(list(ids.unbind(0)), mine[0])
+            if ids.cpu().tolist() != list(range(self.world)):
+                raise SystemExit(f"bench.py: rank census failed: {ids.cpu().tolist()}")
+            self.rccl_ranks = dist.get_world_size()
+
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.multi:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if not self.multi:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, K, W):
+        """W untimed steps, then EXACTLY K steps bracketed by barrier + device synchronisation on both sides; max over ranks."""
+        for _ in range(W):
+            step()
+        self.sync()
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        self.sync()
+        self.barrier()
+        self.sync()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+
+class Workload:
+    """One CE batch on this rank: `nloc` theta-samples of a (global) batch `G`, solved by one rat_handle with E speculative step
+    sizes, followed -- when there is more than one rank -- by the all-gather of the per-sample costs."""
+
+    def __init__(self, D, prob, x0, u0, theta_local, G, E, kl_bound=0.1):
+        import ratilqr.jl_amd as rat
+        torch = D.torch
+        self.D, self.G, self.E, self.kl = D, G, E, kl_bound
+        self.nloc = int(theta_local.size)
+        self.theta_h = theta_local
+        self.ctx = rat.Context(prob, max_batch=max(self.nloc, 1), spec_eps=E, device=D.local_rank)
+        self.ctx.set_initial(x0, u0)
+        self.theta = torch.as_tensor(theta_local, dtype=torch.float64, device=D.dev)
+        self.chunk = -(-G // D.world)                     # padded shard length of the gather
+        self.cost = torch.full((self.chunk,), float("nan"), dtype=torch.float64, device=D.dev)
+        self.cost_all = torch.empty(D.world * self.chunk, dtype=torch.float64, device=D.dev) if D.multi else self.cost
+        # the handle's own HIP stream, seen by torch: the batch, the cost all-gather and the next batch are ordered on it on the
+        # device, with no host round trip between steps (the timed region ends with a device synchronisation)
+        self.hstream = torch.cuda.ExternalStream(self.ctx.stream, device=D.dev)
+        self.fused = None
+
+    def step(self):
+        # compute_cost (cross_entropy...jl:173-195): the shard's complete solves and cost = value + kl/theta (:193), all on the
+        # device (one kernel launch on the fused path), then the per-sample costs go to every rank
+        D, torch = self.D, self.D.torch
+        if self.nloc:
+            self.ctx.compute_cost_enqueue(self.theta.data_ptr(), self.nloc, self.kl, self.cost.data_ptr())
+        if D.multi and D.backend == "nccl":
+            with torch.cuda.stream(self.hstream):             # RCCL waits for the batch and the next batch waits for RCCL
+                D.dist.all_gather_into_tensor(self.cost_all, self.cost)
+        elif D.multi:                                         # host-staged collective (test hook)
+            self.hstream.synchronize()
+            parts = [torch.empty(self.chunk, dtype=torch.float64) for _ in range(D.world)]
+            D.dist.all_gather(parts, self.cost.cpu())
+            self.cost_all.copy_(torch.cat(parts))
+
+    def outputs(self):
+        """Untimed: per-sample value / status / iteration and line-search counts of the same shard (also checks the timed path's costs)."""
+        torch = self.D.torch
+        n = max(self.nloc, 1)
+        value = torch.empty(n, dtype=torch.float64, device=self.D.dev)
+        status, iters, ls = (torch.empty(n, dtype=torch.int32, device=self.D.dev) for _ in range(3))
+        if self.nloc:
+            self.ctx.solve_batch_dev(self.theta.data_ptr(), self.nloc, value.data_ptr(), status.data_ptr(), iters.data_ptr(), ls.data_ptr())
+        torch.cuda.synchronize()
+        v = value.cpu().numpy()[: self.nloc]
+        assert np.array_equal(self.cost.cpu().numpy()[: self.nloc], v + self.kl / self.theta_h), "compute_cost disagrees with value + kl/theta"
+        self.value_t = value
+        return v, status.cpu().numpy()[: self.nloc], iters.cpu().numpy()[: self.nloc], ls.cpu().numpy()[: self.nloc]
+
+    def check_gather(self):
+        """Every rank holds every shard's costs after the gather: rank r's block at [r * chunk, r * chunk + its shard length)."""
+        D = self.D
+        got = self.cost_all.cpu().numpy()
+        for r in range(D.world):
+            lo, hi = shard_bounds(self.G, D.world, r)
+            blk = got[r * self.chunk: r * self.chunk + (hi - lo)]
+            assert not np.any(np.isnan(blk)), f"rank {r}'s block of the gathered costs was never written"
+            if r == D.rank:
+                assert np.array_equal(blk, self.cost.cpu().numpy()[: self.nloc]), "all-gather lost this rank's block"
+
+
+def roofline_of(w, prof_main, main_kind, iters_h, ls_h):
+    """`roofline` of the dominant kernel of workload w from the HIP events recorded inside the timed region."""
+    lay = w.ctx.layout_info()
+    avg_ms = prof_main["ms"] / max(prof_main["launches"], 1)
+    traj_per_launch = prof_main["trajectories"] / max(prof_main["launches"], 1)
+    fused = main_kind == "solve_fused"
+    if fused:
+        bytes_per_launch = algo_bytes_of_solves(iters_h, ls_h)
+        bytes_per_traj = bytes_per_launch / max(len(iters_h), 1)
+        kernel_name = "solve_fused_kernel (one persistent wavefront group per theta-sample: whole solve!)"
+    else:
+        bytes_per_traj = algo_bytes_per_candidate()
+        bytes_per_launch = bytes_per_traj * traj_per_launch
+        kernel_name = "sweep_kernel<eval> (policy-evaluation Riccati sweep of line-search candidates)"
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, tnote = traffic_for(f"{main_kind}_E{w.E}_B{w.nloc}")
+    r = {
+        "bound": "hbm", "kernel": kernel_name,
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": tnote,
+        "bytes_per_trajectory": bytes_per_traj, "hbm_record_bytes_per_trajectory": lay["tile_bytes"] + lay["L_bytes"] + 8,
+        "trajectories_per_launch": traj_per_launch,
+        "avg_launch_ms": avg_ms, "launches": prof_main["launches"],
+    }
+    if fused:           # SURVEY 8(d): the sweep sits at the fp64 ridge -- report the FP64 fraction of the same launches beside the HBM one
+        fl = algo_flops_of_solves(iters_h, ls_h)
+        r["fp64"] = {"achieved": fl / (avg_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": fl / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_per_solve": fl / max(len(iters_h), 1)}
+    return r
+
+
+def dry_rank(args, D):
+    """CPU test hook (RATILQR_BENCH_DRY=1): the launch, rank census, shard arithmetic, barrier-bracketed timing, max over ranks and
+    the cost gather of the N-rank flow with a stand-in for the solver (no GPU in this process; nothing here is a measurement)."""
+    torch = D.torch
+    G, K, W = args.batch, args.steps, args.warmup
+    lo, hi = shard_bounds(G, D.world, D.rank)
+    theta = draw_theta(G, seed=1000)
+    chunk = -(-G // D.world)
+    gathered = {}
 
     def step():
-        # compute_cost (cross_entropy...jl:173-195): B complete solves and cost = value + kl/theta (:193), all on the device
-        # (one kernel launch on the fused path), then the per-sample costs go to every rank
-        ctx.compute_cost_enqueue(theta.data_ptr(), B, kl_bound, cost.data_ptr())
-        if multi and backend == "nccl":
-            with torch.cuda.stream(hstream):                  # RCCL waits for the batch and the next batch waits for RCCL
-                dist.all_gather_into_tensor(cost_all, cost)
-        elif multi:                                           # host-staged collective (test hook)
-            hstream.synchronize()
-            parts = [torch.empty(B, dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(parts, cost.cpu())
-            cost_all.copy_(torch.cat(parts))
+        cost = torch.full((chunk,), float("nan"), dtype=torch.float64)
+        cost[: hi - lo] = torch.as_tensor(0.1 / theta[lo:hi])
+        parts = [torch.empty(chunk, dtype=torch.float64) for _ in range(D.world)]
+        if D.multi:
+            D.dist.all_gather(parts, cost)
+        else:
+            parts = [cost]
+        gathered["all"] = torch.cat([p[: shard_bounds(G, D.world, r)[1] - shard_bounds(G, D.world, r)[0]] for r, p in enumerate(parts)])
 
+    elapsed = D.timed(step, K, W)
+    assert np.array_equal(gathered["all"].numpy(), 0.1 / theta), "gathered costs are not the global batch in order"
+    if D.rank == 0:
+        print(json.dumps({"metric": "iLEQG solves/sec (N=50, n=12, m=4) at CE batch=1024", "value": G * K / elapsed, "unit": "solves/s",
+                          "n_gpus": D.world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "DRY RUN (no GPU, no solver): launch and "
+                          "collective plumbing only", "dry_run": True, "rccl_ranks": D.rccl_ranks, "collective_backend": D.backend,
+                          "self_launched": os.environ.get("RATILQR_BENCH_SELF_LAUNCHED") == "1",
+                          "config": {"workload": "dry run", "global_batch": G, "shard_sizes": [shard_bounds(G, D.world, r)[1] - shard_bounds(G, D.world, r)[0] for r in range(D.world)]}}))
+
+
+def rank_main(args):
+    D = Dist(args)
+    if D.dry:
+        dry_rank(args, D)
+        if D.multi:
+            D.dist.destroy_process_group()
+        return
+    torch = D.torch
+    import ratilqr.jl_amd as rat
+
+    G, E, K, W = args.batch, args.spec_eps, args.steps, args.warmup
+    world, rank = D.world, D.rank
+    prob, x0, u0 = rat.synthetic_lq_problem(n=12, m=4, N=50, seed=0)
+    theta_global = draw_theta(G, seed=1000)                  # the ONE CE batch every rank knows (same N(0,1) stream on every rank)
+    lo, hi = shard_bounds(G, world, rank)
+
+    # ---- primary: the BASELINE configuration -- one CE batch of G = 1024 samples over all ranks (strong scaling) -------------
+    w = Workload(D, prob, x0, u0, theta_global[lo:hi], G, E)
     for _ in range(W):
-        step()
-    torch.cuda.synchronize()
-    # untimed pass with HIP events around every kernel kind: per-kernel breakdown (events perturb the stream, so the
-    # timed region below only brackets the dominant kernel, whose duration feeds the roofline object)
-    ctx.profile(True)
-    ctx.profile_reset()
-    for _ in range(max(2, min(K, 5))):
-        step()
-    torch.cuda.synchronize()
-    prof_all = ctx.profile_get()
+        w.step()
+    D.sync()
+    # untimed pass with HIP events around every kernel kind: per-kernel breakdown (events perturb the stream, so the timed region
+    # below only brackets the dominant kernel, whose duration feeds the roofline object)
+    w.ctx.profile(True)
+    w.ctx.profile_reset()
     n_all = max(2, min(K, 5))
+    for _ in range(n_all):
+        w.step()
+    D.sync()
+    prof_all = w.ctx.profile_get()
     fused = prof_all["solve_fused"]["launches"] > 0
     main_kind = "solve_fused" if fused else "sweep_eval"
-    ctx.profile(True, kinds=[main_kind])
-    ctx.profile_reset()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        step()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_get()
-    ctx.profile(False)
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    w.ctx.profile(True, kinds=[main_kind])
+    w.ctx.profile_reset()
+    elapsed = D.timed(w.step, K, 0)
+    prof = w.ctx.profile_get()
+    w.ctx.profile(False)
+    v_h, st_h, it_h, ls_h = w.outputs()
+    if D.multi:
+        w.check_gather()
+    feasible = float(np.mean((st_h == 0) | (st_h == 3))) if st_h.size else 1.0
+    strong = {"value": G * K / elapsed, "unit": "solves/s", "ms_per_step": elapsed / K * 1e3, "global_batch": G,
+              "solves_per_gpu": [shard_bounds(G, world, r)[1] - shard_bounds(G, world, r)[0] for r in range(world)], "spec_eps": E}
 
-    # untimed: the per-sample outputs of the same batch (statuses, iteration and line-search counts for the report; the costs of
-    # the timed path are checked against them)
-    ctx.solve_batch_dev(theta.data_ptr(), B, value.data_ptr(), status.data_ptr(), iters.data_ptr(), ls.data_ptr())
-    torch.cuda.synchronize()
-    assert np.array_equal(cost.cpu().numpy(), value.cpu().numpy() + kl_bound / theta_h), "compute_cost_dev disagrees with value + kl/theta"
-    st_h, it_h, ls_h = status.cpu().numpy(), iters.cpu().numpy(), ls.cpu().numpy()
-    feasible = float(np.mean((st_h == 0) | (st_h == 3)))
+    # ---- weak scaling and BASELINE config 3 (E = 8) in the same run, N > 1 ---------------------------------------------------------
+    weak = strong8 = None
+    if world > 1:
+        ww = Workload(D, prob, x0, u0, draw_theta(G, seed=1000 + rank), G * world, E)
+        ew = D.timed(ww.step, K, W)
+        weak = {"value": world * G * K / ew, "unit": "solves/s", "ms_per_step": ew / K * 1e3, "global_batch": world * G,
+                "solves_per_gpu": G, "spec_eps": E}
+        del ww
+        if E != 8 and not args.no_second:
+            w8 = Workload(D, prob, x0, u0, theta_global[lo:hi], G, 8)
+            K8 = max(3, K // 3)
+            e8 = D.timed(w8.step, K8, max(2, W))
+            strong8 = {"value": G * K8 / e8, "unit": "solves/s", "ms_per_step": e8 / K8 * 1e3, "steps": K8, "global_batch": G,
+                       "spec_eps": 8, "costs_identical_to_primary": bool(torch.equal(w8.cost, w.cost))}
+            del w8
 
-    # secondary measurement in the same run: E = 8 speculative step sizes per sample (BASELINE config 3's "x 8 line-search
-    # eps"); identical results, 8x the candidate work on this problem (every first candidate is accepted).
-    second = None
+    # ---- single-GPU secondaries ---------------------------------------------------------------------------------------------------
+    second = nonlin = unfused = steady = large = None
+    value = w.value_t
+    theta = w.theta
+    B = w.nloc
+    dev = D.dev
+    if world == 1 and not args.no_second:
+        # steady state: >= 1 s of back-to-back batches, one HIP event per batch on the handle's stream
+        n_ss = int(min(20000, max(200, 1.15 / max(elapsed / K, 1e-5))))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ss + 1)]
+        D.sync()
+        t0 = time.perf_counter()
+        evs[0].record(w.hstream)
+        for i in range(n_ss):
+            w.step()
+            evs[i + 1].record(w.hstream)
+        D.sync()
+        wall = time.perf_counter() - t0
+        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_ss)])
+        steady = {"batches": n_ss, "wall_s": wall, "value": B * n_ss / wall, "unit": "solves/s",
+                  "per_batch_ms": {"median": float(np.median(per)), "min": float(per.min()), "mean": float(per.mean()),
+                                   "p95": float(np.percentile(per, 95)), "max": float(per.max())},
+                  "value_from_median": B / (float(np.median(per)) * 1e-3),
+                  "note": "per-batch times are HIP-event intervals on the library's stream (launch gaps included); the headline `value` "
+                          "is the driver-contract figure over `steps` batches"}
+        del evs
+
     if world == 1 and E != 8 and not args.no_second:
-        ctx8 = rat.Context(prob, max_batch=B, spec_eps=8, device=local_rank)
+        # E = 8 speculative step sizes per sample (BASELINE config 3's "x 8 line-search eps"); identical results, 8x the candidate
+        # work on this problem (every first candidate is accepted).
+        ctx8 = rat.Context(prob, max_batch=B, spec_eps=8, device=D.local_rank)
         ctx8.set_initial(x0, u0)
         v8 = torch.empty(B, dtype=torch.float64, device=dev)
         for _ in range(6):                  # (as many untimed batches as the primary measurement has behind it when its timing starts)
             ctx8.solve_batch_dev(theta.data_ptr(), B, v8.data_ptr())
-        ctx8.profile(True, kinds=["sweep_eval"])
+        ctx8.profile(True)
         ctx8.profile_reset()
         torch.cuda.synchronize()
         t8 = time.perf_counter()
@@ -200,27 +522,34 @@ def main():
             ctx8.solve_batch_dev(theta.data_ptr(), B, v8.data_ptr())
         torch.cuda.synchronize()
         e8 = time.perf_counter() - t8
-        p8 = ctx8.profile_get()["sweep_eval"]
-        bpt = algo_bytes_per_candidate(prob)
-        ach8 = bpt * (p8["trajectories"] / max(p8["launches"], 1)) / (p8["ms"] / max(p8["launches"], 1) * 1e-3) / 1e9
+        p8all = ctx8.profile_get()
+        k8 = "solve_fused" if p8all["solve_fused"]["launches"] else "sweep_eval"
+        p8 = p8all[k8]
+        a = algo_bytes()
+        # algorithmic bytes of the E = 8 batch: every line-search round evaluates 8 candidates per sample (7.08 MB/solve)
+        rounds = float(np.sum(np.ceil(ls_h / 1.0)))          # E = 1 accepted-candidate count = number of rounds on this workload
+        bytes8 = float(B) * a["init"] + float(np.sum(it_h)) * a["sweep_gain"] + 8.0 * rounds * a["candidate"]
         second = {"spec_eps": 8, "value": B * K8 / e8, "unit": "solves/s", "ms_per_step": e8 / K8 * 1e3, "steps": K8,
                   "values_identical_to_primary": bool(torch.equal(v8, value)),
-                  "roofline": {"bound": "hbm", "achieved": ach8, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach8 / HBM_PEAK_GBS,
-                               "trajectories_per_launch": p8["trajectories"] / max(p8["launches"], 1),
-                               "avg_launch_ms": p8["ms"] / max(p8["launches"], 1)}}
+                  "algorithmic_GBps": bytes8 * K8 / e8 / 1e9, "algorithmic_bytes_per_solve": bytes8 / B,
+                  "kernel_ms_per_step": {k: v["ms"] / K8 for k, v in p8all.items() if v["launches"]},
+                  "dominant_kernel": k8}
+        if k8 == "sweep_eval":
+            bpt = algo_bytes_per_candidate(prob)
+            ach8 = bpt * (p8["trajectories"] / max(p8["launches"], 1)) / (p8["ms"] / max(p8["launches"], 1) * 1e-3) / 1e9
+            second["roofline"] = {"bound": "hbm", "achieved": ach8, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach8 / HBM_PEAK_GBS,
+                                  "trajectories_per_launch": p8["trajectories"] / max(p8["launches"], 1),
+                                  "avg_launch_ms": p8["ms"] / max(p8["launches"], 1)}
         del ctx8
 
-    # second secondary: a nonlinear workload (cubic drift kappa x^3 on the same tables): more iterations per solve and
-    # theta-dependent iteration counts, i.e. divergent per-sample control flow inside one launch
-    nonlin = None
     if world == 1 and not args.no_second:
+        # a nonlinear workload (cubic drift kappa x^3 on the same tables): more iterations per solve and theta-dependent
+        # iteration counts, i.e. divergent per-sample control flow inside one launch
         probn, x0n, u0n = rat.synthetic_lq_problem(n=12, m=4, N=50, seed=0, kappa=0.05)
-        ctxn = rat.Context(probn, max_batch=B, spec_eps=E, device=local_rank)
+        ctxn = rat.Context(probn, max_batch=B, spec_eps=E, device=D.local_rank)
         ctxn.set_initial(x0n, u0n)
         vn = torch.empty(B, dtype=torch.float64, device=dev)
-        stn = torch.empty(B, dtype=torch.int32, device=dev)
-        itn = torch.empty(B, dtype=torch.int32, device=dev)
-        lsn = torch.empty(B, dtype=torch.int32, device=dev)
+        stn, itn, lsn = (torch.empty(B, dtype=torch.int32, device=dev) for _ in range(3))
         for _ in range(3):
             ctxn.solve_batch_dev(theta.data_ptr(), B, vn.data_ptr(), stn.data_ptr(), itn.data_ptr(), lsn.data_ptr())
         torch.cuda.synchronize()
@@ -238,11 +567,29 @@ def main():
                   "algorithmic_GBps": algo_bytes_of_solves(itn.cpu().numpy(), lsn.cpu().numpy()) * Kn / en / 1e9}
         del ctxn
 
-    # per-phase breakdown of the same batch on the round-based path (one launch per phase; what the fused kernel replaces)
-    unfused = None
-    if fused and world == 1:
+        # CE batches larger than the chip's 1024 SIMDs (two waves per SIMD hide each other's dependency stalls)
+        large = {}
+        for Bl in (2048, 4096, 8192):
+            ctxl = rat.Context(prob, max_batch=Bl, spec_eps=E, device=D.local_rank)
+            ctxl.set_initial(x0, u0)
+            thl = torch.as_tensor(draw_theta(Bl, seed=4242), dtype=torch.float64, device=dev)
+            cl = torch.empty(Bl, dtype=torch.float64, device=dev)
+            for _ in range(3):
+                ctxl.compute_cost_enqueue(thl.data_ptr(), Bl, 0.1, cl.data_ptr())
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            Kl = max(5, K // 2)
+            for _ in range(Kl):
+                ctxl.compute_cost_enqueue(thl.data_ptr(), Bl, 0.1, cl.data_ptr())
+            torch.cuda.synchronize()
+            el = time.perf_counter() - tl
+            large[str(Bl)] = {"value": Bl * Kl / el, "unit": "solves/s", "ms_per_step": el / Kl * 1e3, "steps": Kl}
+            del ctxl
+
+    if fused and world == 1 and not args.no_second:
+        # per-phase breakdown of the same batch on the round-based path (one launch per phase; what the fused kernel replaces)
         os.environ["RATILQR_FUSED"] = "0"
-        ctxu = rat.Context(prob, max_batch=B, spec_eps=E, device=local_rank)
+        ctxu = rat.Context(prob, max_batch=B, spec_eps=E, device=D.local_rank)
         del os.environ["RATILQR_FUSED"]
         ctxu.set_initial(x0, u0)
         vu = torch.empty(B, dtype=torch.float64, device=dev)
@@ -266,102 +613,77 @@ def main():
         del ctxu
 
     if rank == 0:
-        lay = ctx.layout_info()
-        # Algorithmic bytes (information content, not the padded HBM records).
-        #  fused path: the dominant kernel is the whole solve -- initialize! + iters gain sweeps + ls_evals candidates
-        #              per sample (1.54 MB for this workload's 2-iteration solves), summed over the launch's samples;
-        #  round-based path: the policy-evaluation sweep, 187.3 KB per candidate.
-        pe = prof[main_kind]
-        avg_ms = pe["ms"] / max(pe["launches"], 1)
-        traj_per_launch = pe["trajectories"] / max(pe["launches"], 1)
-        if fused:
-            bytes_per_launch = algo_bytes_of_solves(it_h, ls_h)
-            bytes_per_traj = bytes_per_launch / B
-            kernel_name = "solve_fused_kernel (one persistent wavefront per theta-sample: whole solve!)"
-        else:
-            bytes_per_traj = algo_bytes_per_candidate(prob)
-            bytes_per_launch = bytes_per_traj * traj_per_launch
-            kernel_name = "sweep_kernel<eval> (policy-evaluation Riccati sweep of line-search candidates)"
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f"{main_kind}_E{E}_B{B}", None)
-            except Exception:
-                traffic = None
         out = {
             "metric": "iLEQG solves/sec (N=50, n=12, m=4) at CE batch=1024",
-            "value": world * B * K / elapsed,
+            "value": strong["value"],
             "unit": "solves/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
+            "ms_per_step": strong["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
+            "value_is": "strong: ONE CE batch of 1024 theta-samples (BASELINE.json metric) sharded over the ranks in contiguous blocks, "
+                        "cost all-gather included; `weak` = 1024 samples per GPU",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "rccl_ranks": D.rccl_ranks,
+            "collective_backend": ("rccl (torch.distributed nccl)" if D.backend == "nccl" else D.backend) if D.multi else None,
+            "self_launched": os.environ.get("RATILQR_BENCH_SELF_LAUNCHED") == "1",
             "config": {
                 "workload": "batched iLEQG solves of one CE batch (compute_cost): synthetic LQ-plus-noise, N=50, n=12, m=4, "
                             "W=1e-3 I, theta ~ N(1,2)>0, kl=0.1, iLEQG defaults",
-                "ce_batch_per_gpu": B, "global_batch": world * B, "spec_eps": E,
-                "parallelism": f"theta-shards x{world}, cost all-gather" if world > 1 else "single GPU",
+                "global_batch": G, "ce_batch_per_gpu": strong["solves_per_gpu"], "spec_eps": E,
+                "parallelism": f"theta-shards x{world} (contiguous blocks), one cost all-gather per batch" if world > 1 else "single GPU",
                 "feasible_fraction": feasible, "mean_iters": float(it_h.mean()), "mean_ls_evals": float(ls_h.mean()),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": kernel_name,
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "bytes_per_trajectory": bytes_per_traj, "hbm_record_bytes_per_trajectory": lay["tile_bytes"] + lay["L_bytes"] + 8,
-                "trajectories_per_launch": traj_per_launch,
-                "avg_launch_ms": avg_ms, "launches": pe["launches"],
-            },
-        }
-        if fused:           # the sweep sits at the fp64 ridge -- report the FP64 fraction of the same launches beside the HBM one
-            fl = algo_flops_of_solves(it_h, ls_h)
-            out["roofline"]["fp64"] = {"achieved": fl / (avg_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": fl / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_per_solve": fl / B}
-        out.update({
+            "strong": strong,
+            "roofline": roofline_of(w, prof[main_kind], main_kind, it_h, ls_h),
             "kernel_ms_per_step": {k: v["ms"] / n_all for k, v in prof_all.items()},
-        })
+        }
+        if weak is not None:
+            out["weak"] = weak
+        if strong8 is not None:
+            out["strong_spec_eps8"] = strong8
+        if steady is not None:
+            out["steady_state"] = steady
         if unfused is not None:
             out["round_based_path"] = unfused
         if second is not None:
             out["secondary_spec_eps8"] = second
         if nonlin is not None:
             out["secondary_nonlinear"] = nonlin
+        if large:
+            out["secondary_large_batch"] = large
         if world == 1 and not args.no_cpu:
-            from oracle import oracle as orc
-
-            P = orc.Problem(prob)
-            cores = os.cpu_count() or 1
-            n_done, t_cpu = 0, 0.0
-            chunk = max(64, 32 * cores)
-            while t_cpu < args.cpu_seconds:
-                th = draw_theta(chunk, seed=77 + n_done)
-                t1 = time.perf_counter()
-                orc.compute_value_batch(P, x0, u0, th, nthreads=cores)
-                t_cpu += time.perf_counter() - t1
-                n_done += chunk
-            import shutil
-            jl = shutil.which("julia")                          # probed at run time: the reference itself is never on the GPU box
-            julia_note = ("the Julia reference is not runnable (no julia binary)" if jl is None else
-                          f"a julia binary exists ({jl}) but the reference package and its dependencies do not travel to this box")
-            th1 = draw_theta(32, seed=55)                       # the same oracle on one thread
-            t1 = time.perf_counter()
-            orc.compute_value_batch(P, x0, u0, th1, nthreads=1)
-            t_one = time.perf_counter() - t1
-            out["cpu_baseline"] = {
-                "value": n_done / t_cpu, "unit": "solves/s", "cores": cores, "kind": "port", "value_1thread": 32 / t_one,
-                "sample": f"{n_done} solves of the same workload (theta ~ N(1,2)>0) by the C oracle, OpenMP one sample per "
-                          f"thread on {cores} threads, {t_cpu:.1f} s; " + julia_note,
-            }
+            out["cpu_baseline"] = cpu_baseline(prob, x0, u0, args.cpu_seconds)
         print(json.dumps(out))
-    if multi:
-        dist.destroy_process_group()
+    if D.multi:
+        D.dist.destroy_process_group()
+
+
+def parse(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="the CE batch (global: sharded over the ranks)")
+    ap.add_argument("--spec-eps", type=int, default=1, help="E speculative line-search step sizes per sample")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-second", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv))             # (nothing has touched the GPU in this process)
+    rank_main(args)
 
 
 if __name__ == "__main__":

@@ -96,7 +96,8 @@ def test_compute_cost_dev_is_value_plus_kl_over_theta(monkeypatch):
             monkeypatch.delenv(k)
 
 
-def _run_bench(nproc, extra_env, *args):
+def _run_bench(nproc, extra_env, *args, launcher=True):
+    """bench.py under torch.distributed.run (the driver's command) or, launcher=False, started plainly: it then launches its ranks itself."""
     import json
     import socket
     import subprocess
@@ -105,10 +106,14 @@ def _run_bench(nproc, extra_env, *args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), *args]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", **extra_env)
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), *args]
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py"), *args]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
 
@@ -118,14 +123,25 @@ def test_bench_collective_path_over_rccl_on_the_solver_stream():
     batch ordered behind the gather -- run with a one-rank RCCL communicator (test hook), costs checked by bench.py itself."""
     d = _run_bench(1, {"RATILQR_BENCH_FORCE_DIST": "1"}, "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu", "--no-second", "--batch", "512")
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["roofline"]["launches"] == 4
+    assert d["rccl_ranks"] == 1 and d["collective_backend"].startswith("rccl")
 
 
-def test_bench_runs_as_two_ranks():
-    """bench.py's multi-rank flow end to end -- torch.distributed.run launch, per-rank contexts and theta shards, barrier-bracketed timing,
-    max over ranks, the cost gather, rank 0's JSON line -- with two ranks sharing this box's single GPU and a host-staged collective
-    (test hooks of bench.py; on a multi-GPU node the same flow runs one rank per GPU over RCCL)."""
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts its two ranks itself (before touching the GPU), they shard
+    the ONE global CE batch (strong scaling, `value`), run the barrier-bracketed timing with the max over ranks and the cost gather, and
+    rank 0 prints the JSON line with `weak` and `strong_spec_eps8` beside it.  Two ranks share this box's single GPU and the collective
+    is host-staged (test hooks of bench.py; on a multi-GPU node the same flow runs one rank per GPU over RCCL)."""
     d = _run_bench(2, {"RATILQR_BENCH_BACKEND": "gloo", "RATILQR_BENCH_ONE_DEVICE": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1",
-                   "--no-cpu", "--batch", "256")
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak" and d["steps"] == 3
-    assert d["value"] > 0 and abs(d["value"] - 512 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
-    assert d["config"]["feasible_fraction"] == 1.0 and d["roofline"]["launches"] == 3
+                   "--no-cpu", "--batch", "256", launcher=False)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["self_launched"] is True and d["scaling"] == "strong" and d["steps"] == 3
+    assert d["config"]["global_batch"] == 256 and d["strong"]["solves_per_gpu"] == [128, 128]
+    assert d["value"] == d["strong"]["value"] > 0 and abs(d["value"] - 256 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["config"]["feasible_fraction"] == 1.0 and d["roofline"]["launches"] == 3 and d["roofline"]["trajectories_per_launch"] == 128
+    assert d["weak"]["global_batch"] == 512 and d["weak"]["value"] > 0
+    assert d["strong_spec_eps8"]["costs_identical_to_primary"] is True and d["strong_spec_eps8"]["value"] > 0
+
+
+def test_bench_runs_as_two_ranks_under_the_drivers_launcher():
+    d = _run_bench(2, {"RATILQR_BENCH_BACKEND": "gloo", "RATILQR_BENCH_ONE_DEVICE": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                   "--no-cpu", "--no-second", "--batch", "64")
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["self_launched"] is False and d["strong"]["solves_per_gpu"] == [32, 32]
