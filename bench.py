@@ -26,6 +26,9 @@ import subprocess
 import sys
 import time
 
+# The hardware threads this process may use, read BEFORE any OpenMP runtime is loaded: with OMP_PROC_BIND set, the runtime pins the
+# initial thread to its first place, after which the affinity mask of this thread reads as one CPU.
+_AFFINITY0 = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
 # (the CPU baseline leg binds the oracle's OpenMP threads; libgomp reads these when it is first loaded -- before torch pulls it in)
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "threads")
@@ -139,7 +142,7 @@ def cgroup_cpu_limit():
 
 def host_cpu_info():
     """Hardware threads this process may run on (affinity mask clipped by the cgroup CPU quota) and the physical cores behind them."""
-    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    aff = list(_AFFINITY0)
     lim = cgroup_cpu_limit()
     threads = len(aff) if lim is None else max(1, min(len(aff), int(math.floor(lim + 1e-9))))
     sib = set()
@@ -436,6 +439,14 @@ def rank_main(args):
 
     # ---- primary: the BASELINE configuration -- one CE batch of G = 1024 samples over all ranks (strong scaling) -------------
     w = Workload(D, prob, x0, u0, theta_global[lo:hi], G, E)
+    # conditioning (untimed, before the W warm-up steps): a batch is < 0.5 ms, so W = 3 steps after an idle period are over before the
+    # chip has left its idle clocks -- `steady_state` below (>= 1 s of batches) showed the first ~10 ms running 5 % slow.  0.3 s of the
+    # same batches first; the timed region is still EXACTLY `steps` batches.
+    t_c = time.perf_counter()
+    while time.perf_counter() - t_c < args.condition_seconds:
+        for _ in range(16):
+            w.step()
+        D.sync()
     for _ in range(W):
         w.step()
     D.sync()
@@ -673,6 +684,7 @@ def parse(argv):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-second", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--condition-seconds", type=float, default=0.3, help="untimed batches before the warm-up steps (clock ramp)")
     return ap.parse_args(argv)
 
 

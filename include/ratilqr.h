@@ -182,6 +182,7 @@ typedef struct rat_ce_solver {
     int64_t iter_current;
     /* bookkeeping (not in the reference) */
     int64_t n_solves, n_redraws;
+    int64_t n_final_retries;     /* times the final solve of solve! failed and theta_opt was lowered by sigma (:410-413) */
 } rat_ce_solver;
 
 void   rat_ce_default(rat_ce_solver *c);                                     /* ctor defaults :100-127 */

@@ -48,7 +48,7 @@ end
 mutable struct CeState
     num_samples::Int64; num_elite::Int64; iter_max::Int64; λ::Float64; use_θ_max::Int32
     μ_init::Float64; σ_init::Float64; μ::Float64; σ::Float64; θ_max::Float64; θ_min::Float64
-    iter_current::Int64; n_solves::Int64; n_redraws::Int64
+    iter_current::Int64; n_solves::Int64; n_redraws::Int64; n_final_retries::Int64
 end
 
 check(rc) = rc == 0 || error("libratilqr_hip: rc=$rc: " * unsafe_string(ccall((:rat_last_error, LIB), Cstring, ())))
@@ -140,7 +140,7 @@ function AMDCrossEntropyBilevelOptimizationSolver(; μ_min_ileqg=1e-6, Δ_0_ileq
         adaptive_ϵ_init_ileqg=false, ϵ_init_ileqg=1.0, ϵ_min_ileqg=1e-6, μ_init=1.0, σ_init=2.0, num_samples=10, num_elite=3,
         iter_max=5, λ=0.5, use_θ_max=false, spec_eps=1, device=0)
     o = IleqgOpts(μ_min_ileqg, Δ_0_ileqg, λ_ileqg, d_ileqg, iter_max_ileqg, ϵ_init_ileqg, ϵ_min_ileqg, adaptive_ϵ_init_ileqg)
-    c = CeState(num_samples, num_elite, iter_max, λ, use_θ_max, μ_init, σ_init, μ_init, σ_init, 0.0, Inf, 0, 0, 0)
+    c = CeState(num_samples, num_elite, iter_max, λ, use_θ_max, μ_init, σ_init, μ_init, σ_init, 0.0, Inf, 0, 0, 0, 0)
     AMDCrossEntropyBilevelOptimizationSolver(o, c, spec_eps, device, nothing)
 end
 

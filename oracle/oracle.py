@@ -58,7 +58,8 @@ class _Ce(C.Structure):
                 ("mu_init", C.c_double), ("sigma_init", C.c_double), ("mu", C.c_double), ("sigma", C.c_double),
                 ("theta_max", C.c_double), ("theta_min", C.c_double), ("iter_current", C.c_int64),
                 ("z", _dp), ("nz", C.c_int64), ("zpos", C.c_int64),
-                ("n_solves", C.c_int64), ("n_redraws", C.c_int64), ("nthreads", C.c_int)]
+                ("n_solves", C.c_int64), ("n_redraws", C.c_int64), ("nthreads", C.c_int),
+                ("n_final_retries", C.c_int64)]
 
 
 _lib = None

@@ -837,6 +837,7 @@ int orc_ce_solve(orc_ce *c, const orc_problem *p, const double *x0, const double
                  double *theta_min_out, double *theta_max_out) {
     if (!(kl_bound >= 0)) return -3;                                            /* :368 */
     orc_ce_initialize(c);                                                       /* :369 */
+    c->n_final_retries = 0;
     double theta_opt, theta_min = 0.0, theta_max = 0.0;
     if (kl_bound > 0) {
         while (c->iter_current < c->iter_max) {                                 /* :371 */
@@ -865,6 +866,7 @@ int orc_ce_solve(orc_ce *c, const orc_problem *p, const double *x0, const double
         }
         orc_solver_free(s);
         theta_opt = fmax(0.0, theta_opt - c->sigma);                            /* :412 */
+        c->n_final_retries++;
     }
 }
 

@@ -158,6 +158,7 @@ typedef struct orc_ce {
     /* bookkeeping for tests/bench */
     int64_t n_solves, n_redraws;
     int nthreads;
+    int64_t n_final_retries;     /* final-solve retries of solve! (:410-413) */
 } orc_ce;
 void orc_ce_default(orc_ce *c);
 void orc_ce_initialize(orc_ce *c);                                   /* :133-138 */

@@ -48,7 +48,7 @@ class CeSolver(C.Structure):
                 ("lam", C.c_double), ("use_theta_max", C.c_int32),
                 ("mu_init", C.c_double), ("sigma_init", C.c_double), ("mu", C.c_double), ("sigma", C.c_double),
                 ("theta_max", C.c_double), ("theta_min", C.c_double), ("iter_current", C.c_int64),
-                ("n_solves", C.c_int64), ("n_redraws", C.c_int64)]
+                ("n_solves", C.c_int64), ("n_redraws", C.c_int64), ("n_final_retries", C.c_int64)]
 
 
 class GenProblemDesc(C.Structure):

@@ -1189,6 +1189,7 @@ extern "C" rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0,
     if (!h || !c || !theta_opt || !value) return fail(RAT_ERR_ARG, "null");
     if (!(kl_bound >= 0)) return fail(RAT_ERR_ARG, "KL Divergence Bound must be non-negative (:368)");
     rat_ce_initialize(c);                                                           // :369
+    c->n_final_retries = 0;
     double th_opt, tmin = 0.0, tmax = 0.0;
     if (kl_bound > 0) {
         while (c->iter_current < c->iter_max) {                                     // :371-373
@@ -1212,6 +1213,7 @@ extern "C" rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0,
             return RAT_OK;
         }
         th_opt = std::max(0.0, th_opt - c->sigma);                                   // :412
+        c->n_final_retries++;
     }
 }
 

@@ -54,6 +54,12 @@ def _colmajor(a: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(a.transpose(0, 2, 1)).ravel()
 
 
+def _timemajor(a: np.ndarray) -> np.ndarray:
+    """Flat buffer of a (possibly time-varying) VECTOR table: a Vector{Vector} of Julia, time slowest -- entry (k, i) at k * len + i.
+    (A 2-D (N, len) table is NOT a matrix: _colmajor would transpose it.)"""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64)).ravel()
+
+
 class LQRiskSensitiveProblem(FiniteHorizonRiskSensitiveOptimalControlProblem):
     r"""x' = A x + B u + kappa x.^3 + w,  w ~ N(0, W(k)).
 
@@ -124,7 +130,7 @@ class LQRiskSensitiveProblem(FiniteHorizonRiskSensitiveOptimalControlProblem):
     def c_tables(self) -> dict:
         return dict(model=MODEL_LQ, n=self.n, m=self.m, N=self.N, cost_tv=int(self.cost_tv), W_tv=int(self.W_tv),
                     A=_colmajor(self.A), B=_colmajor(self.B), Q=_colmajor(self.Q), R=_colmajor(self.R),
-                    P=_colmajor(self.P), qv=_colmajor(self.qv), rv=_colmajor(self.rv),
+                    P=_colmajor(self.P), qv=_timemajor(self.qv), rv=_timemajor(self.rv),
                     q0=_colmajor(np.atleast_1d(self.q0)), Qf=_colmajor(self.Qf), qvf=_colmajor(self.qvf),
                     q0f=self.q0f, kappa=self.kappa, W=_colmajor(self.Wtab),
                     pl_a=0.0, pl_b=0.0, pl_p=0.0, pl_pu=0.0, pl_cx=0.0, pl_cu=0.0, pl_h=0.0)

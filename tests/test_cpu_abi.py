@@ -107,3 +107,25 @@ def test_stream_exhaustion_is_an_error():
     zp = C.c_int64(0)
     rc = L.rat_ce_draw_stream(C.byref(c), nv.P(z), C.c_int64(z.size), C.byref(zp), nv.P(th))
     assert rc == 5 and b"exhausted" in L.rat_last_error()
+
+
+def test_ce_update_has_the_if_elseif_theta_max_quirk():
+    """rat_ce_update (device-free): the first valid sample only sets theta_min (cross_entropy...jl:318-322), as the oracle does."""
+    L = nv.lib()
+    c = nv.CeSolver()
+    L.rat_ce_default(C.byref(c))
+    c.num_samples, c.num_elite = 3, 3
+    L.rat_ce_initialize(C.byref(c))
+    nv.check(L.rat_ce_begin_step(C.byref(c)))
+    theta, cost = np.array([0.45, 0.1, 0.3]), np.array([3.0, 11.0, 4.3])
+    redraw = C.c_int32()
+    nv.check(L.rat_ce_update(C.byref(c), nv.P(theta), nv.P(cost), C.byref(redraw)))
+    assert redraw.value == 0 and c.theta_min == 0.1 and c.theta_max == 0.3
+    assert (c.mu_init, c.sigma_init) == (2.0, 4.0) and abs(c.mu - theta.mean()) < 1e-15
+    # an infeasible first sample is skipped: the next valid one takes its place as "first"
+    L.rat_ce_initialize(C.byref(c))
+    c.num_elite = 2                                            # 2 valid of 3 >= max(num_elite, num_samples * lambda): no redraw (:306)
+    nv.check(L.rat_ce_begin_step(C.byref(c)))
+    theta, cost = np.array([9.0, 0.45, 0.3]), np.array([np.inf, 3.0, 4.3])
+    nv.check(L.rat_ce_update(C.byref(c), nv.P(theta), nv.P(cost), C.byref(redraw)))
+    assert redraw.value == 0 and c.theta_min == 0.3 and c.theta_max == 0.0 and (c.mu_init, c.sigma_init) == (2.0, 4.0)

@@ -64,14 +64,9 @@ def test_host_cpu_info_respects_affinity_and_quota(monkeypatch):
     assert 1 <= info["threads"] <= info["affinity_threads"] <= (os.cpu_count() or 1) and 1 <= info["physical_cores"] <= info["threads"]
     monkeypatch.setattr(bench, "cgroup_cpu_limit", lambda: 2.5)
     assert bench.host_cpu_info()["threads"] == min(2, info["affinity_threads"])
-    if hasattr(os, "sched_setaffinity") and info["affinity_threads"] >= 2:
-        old = os.sched_getaffinity(0)
-        try:
-            os.sched_setaffinity(0, {min(old)})
-            monkeypatch.setattr(bench, "cgroup_cpu_limit", lambda: None)
-            assert bench.host_cpu_info()["threads"] == 1
-        finally:
-            os.sched_setaffinity(0, old)
+    monkeypatch.setattr(bench, "cgroup_cpu_limit", lambda: None)
+    monkeypatch.setattr(bench, "_AFFINITY0", [bench._AFFINITY0[0]])
+    assert bench.host_cpu_info()["threads"] == 1
 
 
 def test_traffic_is_null_when_the_kernels_changed(tmp_path, monkeypatch):

@@ -138,3 +138,30 @@ def test_config3_full_size_ce_matches_the_oracle():
         res.append((th, val, solver.c.mu, solver.c.sigma, x, l, L))
     for a, b in zip(res[0], res[1]):                                               # speculation width does not change a bit
         assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+# ---- the two solve! branches the reference's own tests never reach (VERDICT r01 missing #5), GPU vs oracle ------------------------
+def test_use_theta_max_with_the_if_elseif_quirk_matches_the_oracle():        # :318-322, :375-379
+    prob, x0, u = nonlinear()
+    for thetas, iw in (([0.45, 0.1, 0.3], 2), ([0.1, 0.3, 0.45], 2)):
+        z = (np.array(thetas) - 1.0) / 2.0
+        want, low = (1.0 + 2.0 * z)[iw], (1.0 + 2.0 * z).min()
+        solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=3, iter_max=1, use_theta_max=True)
+        got = ce.solve_(solver, prob, x0, u, z, kl_bound=1.0)
+        oc = orc.CrossEntropyBilevelOptimizationSolver(z, num_samples=3, iter_max=1, use_theta_max=True)
+        rc, th, x, l, L, val, tmin, tmax = oc.solve(orc.Problem(prob), x0, u, 1.0)
+        assert rc == 0 and got[0] == th == want and got[5] == tmin == low and got[6] == tmax == want
+        assert abs(got[4] - val) <= 1e-9 * abs(val) and np.abs(got[3] - L).max() < 1e-9
+        assert solver.c.n_final_retries == oc.c.n_final_retries == 0
+
+
+def test_final_solve_retry_matches_the_oracle():                              # :410-413
+    prob, x0, u = rat.synthetic_lq_problem()
+    for mu0, s0 in ((40.0, 10.0), (40.0, 100.0), (25.0, 6.0)):
+        solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=3, iter_max=0, mu_init=mu0, sigma_init=s0)
+        got = ce.solve_(solver, prob, x0, u, np.zeros(1), kl_bound=0.1)
+        oc = orc.CrossEntropyBilevelOptimizationSolver(np.zeros(1), num_samples=3, iter_max=0, mu_init=mu0, sigma_init=s0)
+        rc, th, x, l, L, val, tmin, tmax = oc.solve(orc.Problem(prob), x0, u, 0.1)
+        assert rc == 0 and got[0] == th and solver.c.n_final_retries == oc.c.n_final_retries >= 1
+        assert (np.isinf(val) and np.isinf(got[4])) or abs(got[4] - val) <= 1e-9 * abs(val)
+        assert np.isinf(got[5]) and got[6] == 0.0 and np.abs(got[1] - x).max() < 1e-9
