@@ -36,7 +36,11 @@ class CrossEntropyBilevelOptimizationSolver:
         self.f_returns_jacobian = f_returns_jacobian
         self.spec_eps, self.device = int(spec_eps), int(device)
         self._ctx = None
-        self._stream_keep = None
+        self._rng_key = None          # what is bound to the handle of self._rng_ctx: ("seed", value) / ("gen", id) / ("stream", id)
+        self._rng_ctx = None
+        self._stream = None           # converted (contiguous f64) copy of the caller's stream object, made once
+        self._stream_src = None
+        self._stream_off = 0          # absolute position in the caller's stream of the view bound to the handle
 
     # mutable fields of the reference struct
     mu_init = property(lambda s: s.c.mu_init)
@@ -57,18 +61,38 @@ class CrossEntropyBilevelOptimizationSolver:
         return self._ctx
 
     def _bind_rng(self, ctx, rng):
+        """`rng` stands for the reference's stateful AbstractRNG argument: it is bound to the handle ONCE and then advances.
+        * an integer seed / a numpy Generator seeds the library's generator the first time it is seen (a hand-driven loop
+          ``step_(..., rng=42)`` continues the sequence instead of replaying it every CE iteration);
+        * an array-like stream of N(0,1) draws is converted once and keyed on the caller's object, so the same list / view passed
+          again continues where the last call stopped;
+        * when the Context is recreated (another problem, a larger batch) the binding moves with it: a stream resumes at its
+          current position, a seeded generator is re-seeded (its state lives in the dropped handle)."""
         L = nv.lib()
         if rng is None:
             return
         if isinstance(rng, np.random.Generator):
-            nv.check(L.rat_ce_seed(ctx.h, C.c_uint64(int(rng.integers(0, 2 ** 63 - 1)))))
+            key = ("gen", id(rng))
         elif isinstance(rng, (int, np.integer)):
-            nv.check(L.rat_ce_seed(ctx.h, C.c_uint64(int(rng))))
+            key = ("seed", int(rng))
         else:
-            z = nv.f64(rng)
-            if self._stream_keep is None or self._stream_keep is not z:
-                self._stream_keep = z
-                nv.check(L.rat_ce_set_stream(ctx.h, nv.P(z), C.c_int64(z.size)))
+            key = ("stream", id(rng))
+        if key == self._rng_key and ctx is self._rng_ctx:
+            return
+        if key[0] == "stream":
+            pos = 0
+            if key == self._rng_key and self._rng_ctx is not None:          # same stream, new handle: resume where the old one stopped
+                pos = self._stream_off + int(L.rat_ce_stream_pos(self._rng_ctx.h))
+            if self._stream_src is not rng:
+                self._stream, self._stream_src = nv.f64(rng).ravel(), rng
+            z = self._stream[pos:]
+            self._stream_view, self._stream_off = z, pos                    # (the view keeps the memory the handle points into alive)
+            nv.check(L.rat_ce_set_stream(ctx.h, nv.P(z), C.c_int64(z.size)))
+        elif key[0] == "gen":
+            nv.check(L.rat_ce_seed(ctx.h, C.c_uint64(int(rng.integers(0, 2 ** 63 - 1)))))
+        else:
+            nv.check(L.rat_ce_seed(ctx.h, C.c_uint64(key[1])))
+        self._rng_key, self._rng_ctx = key, ctx
 
 
 def initialize_(ce_solver: CrossEntropyBilevelOptimizationSolver):           # initialize!  :133-138

@@ -116,21 +116,25 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     rat_handle h = new rat_handle_s();
     h->device = device; h->opts = o; h->Bmax = max_batch; h->E = spec_eps;
     set_opd(h);
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
+    memset(&h->st, 0, sizeof(h->st));
+    memset(&h->pb, 0, sizeof(h->pb));
+    // (a failure from here on must not leak the handle: rat_destroy copes with partially built ones)
+#define CREATECHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rat_destroy(h); \
+        return fail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    CREATECHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATECHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    CREATECHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
+    CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
     if (const char *e = getenv("RATILQR_SPECULATE")) h->speculate = (e[0] == '1');
     h->dual = spec_eps > 1;          // E > 1: candidate 0 in paired wavefronts beside the other candidates' evaluation (+3.5 % at E = 8)
     if (const char *e = getenv("RATILQR_DUAL")) h->dual = (e[0] == '1');
     if (const char *e = getenv("RATILQR_FUSED")) h->fused = (e[0] != '0');
     if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
     if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
-    HIPCHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->h_io, std::max<size_t>((size_t)max_batch * 28, 64), hipHostMallocDefault));
-    for (int i = 0; i < CTR_RING; ++i) HIPCHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
-    memset(&h->st, 0, sizeof(h->st));
-    memset(&h->pb, 0, sizeof(h->pb));
+    CREATECHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
+    CREATECHK(hipHostMalloc((void **)&h->h_io, std::max<size_t>((size_t)max_batch * 28, 64), hipHostMallocDefault));
+    for (int i = 0; i < CTR_RING; ++i) CREATECHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
+#undef CREATECHK
     *out = h;
     return RAT_OK;
 }
@@ -143,7 +147,8 @@ static void free_list(std::vector<void *> &v) {
 extern "C" void rat_destroy(rat_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);       // (speculative sweeps of the round-based path run there)
     free_list(h->pb_allocs);
     free_list(h->st_allocs);
     free_list(h->gen_allocs);
@@ -156,7 +161,7 @@ extern "C" void rat_destroy(rat_handle h) {
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    (void)hipStreamDestroy(h->stream);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -335,7 +340,11 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
     UP(Zt, Zt); UP(Ctab, Ctab); UP(lin, lin); UP(q0, q0); UP(Qf, Qf); UP(qvf, qvf);
     UP(Winv, Winv); UP(Wp, Wp); UP(epiv, epiv); UP(logdetW, ldw);
 #undef UP
-    const bool realloc_state = !h->have_problem || h->N != N;
+    // The slot pools rely on their padded lanes (states n..11, controls m..3 of x / u / L / dl) being exact zeros.  A problem with the
+    // same N but smaller n or m would find the previous problem's values there, so the pools are rebuilt (and re-zeroed by
+    // alloc_state) whenever ANY dimension changes; a problem of the same shape (a receding-horizon caller re-setting its tables every
+    // control step) keeps its buffers: every live lane is rewritten by the next solve.
+    const bool realloc_state = !h->have_problem || h->N != N || h->n != n || h->m != m;
     h->pb = pb; h->n = n; h->m = m; h->N = N;
     h->have_problem = true; h->have_initial = false;
     if (realloc_state && (rc = alloc_state(h))) return rc;

@@ -129,3 +129,27 @@ class GenericContext(il.Context):
 
     def solve(self, x0, u, theta, hist_cap=4096):
         raise NotImplementedError("generic closures are solved by ileqg.solve_ (host-driven initialize!/step! loop)")
+
+    # The remaining device-family entry points of Context would run on the CARRIER (A = 0, B = 0, R = I), not on the user's f, c, h:
+    # they fail loudly instead.
+    def _carrier_only(self, name):
+        raise NotImplementedError(f"{name} runs a compiled-in model family on the device; a generic-closure problem has none "
+                                  "(use ileqg.solve_ / solve_closure_batch, or a LQ / power-law family)")
+
+    def rollout_noisy(self, *a, **k):
+        self._carrier_only("rollout_noisy (simulate_dynamics with rng)")
+
+    def solve_batch(self, *a, **k):
+        self._carrier_only("solve_batch")
+
+    def solve_batch_dev(self, *a, **k):
+        self._carrier_only("solve_batch_dev")
+
+    def compute_cost_dev(self, *a, **k):
+        self._carrier_only("compute_cost_dev")
+
+    def compute_cost_enqueue(self, *a, **k):
+        self._carrier_only("compute_cost_enqueue")
+
+    def set_initial(self, *a, **k):
+        self._carrier_only("set_initial")

@@ -41,6 +41,14 @@ class Context:
     def set_opts(self, opts):
         nv.check(nv.lib().rat_set_ileqg_opts(self.h, C.byref(opts)))
 
+    def set_problem(self, problem):
+        """Re-bind the handle to another problem of the same model families (rat_problem_set on the live handle: device buffers are
+        kept when n, m, N are unchanged -- the receding-horizon pattern of re-setting the tables every control step)."""
+        desc, keep = nv.make_desc(problem)
+        nv.check(nv.lib().rat_problem_set(self.h, C.byref(desc)))
+        self.problem, self._keep = problem, keep
+        self.n, self.m, self.N = problem.n, problem.m, problem.N
+
     # ---- operator forms --------------------------------------------------------------------------
     def rollout_open(self, x0, u):
         x = np.zeros((self.N + 1, self.n))
@@ -276,7 +284,17 @@ class ILEQGSolver:
         self.eps_history = []
         self.eps_init_init = eps_init
         self.status = None
-        self.ctx = make_context(problem, self.opts, max_batch=max_batch, spec_eps=spec_eps, device=device)
+        self._ctx_args = dict(max_batch=max_batch, spec_eps=spec_eps, device=device)
+        self.ctx = make_context(problem, self.opts, **self._ctx_args)
+
+    def context(self, problem) -> "Context":
+        """The device context of `problem`.  The reference's solve!/initialize!/step!/line_search! take every table from their
+        `problem` argument (ileqg.jl:214, 494, 598, 635), so a solver built on one problem and called with another must follow the
+        argument: the context (device tables) is rebuilt when the problem object differs from the one it was made for."""
+        bound = getattr(self.ctx, "generic", None) or self.ctx.problem
+        if problem is not bound:
+            self.ctx = make_context(problem, self.opts, **self._ctx_args)
+        return self.ctx
 
 
 # ---- the reference's free functions ----------------------------------------------------------------
@@ -309,7 +327,7 @@ def approximate_model(problem, u_array, x_array, A_array_input=None, B_array_inp
 
 
 def initialize_(ileqg: ILEQGSolver, problem, x_0, u_array, theta):          # initialize!  ileqg.jl:214-236
-    ctx = ileqg.ctx
+    ctx = ileqg.context(problem)
     ileqg.mu, ileqg.Delta = 0.0, ileqg.Delta_0
     ileqg.d_current, ileqg.iter_current = np.inf, 0
     ileqg.eps_init = ileqg.eps_init_init
@@ -364,7 +382,7 @@ def _isapprox(x, y):
 
 
 def line_search_(ileqg: ILEQGSolver, problem, dl_array_new, theta, verbose=False):      # line_search!  ileqg.jl:494-592
-    ctx = ileqg.ctx
+    ctx = ileqg.context(problem)
     cur = ileqg.value_current
     eps = ileqg.eps_init
     count = 0
@@ -400,7 +418,7 @@ def line_search_(ileqg: ILEQGSolver, problem, dl_array_new, theta, verbose=False
 
 def step_(ileqg: ILEQGSolver, problem, theta, verbose=False):                 # step!  ileqg.jl:598-613
     ileqg.iter_current += 1
-    ap = ileqg.ctx.approximate_model(ileqg.l_array, ileqg.x_array)            # :604
+    ap = ileqg.context(problem).approximate_model(ileqg.l_array, ileqg.x_array)            # :604
     _, dl = solve_approximate_dp_(ileqg, ap, verbose, theta=theta)            # :610-611
     line_search_(ileqg, problem, dl, theta, verbose)                          # :612
 
@@ -411,7 +429,7 @@ def solve_(ileqg: ILEQGSolver, problem, x_0, u_array, theta, verbose=False):
     Returns (x_array, l_array, L_array, value, ϵ_history).  Raises where the reference throws."""
     if getattr(problem, "model", 0) == 0:            # generic closures: host rollouts + linearisation, device sweeps
         return solve_stepwise_(ileqg, problem, x_0, u_array, theta)
-    r = ileqg.ctx.solve(x_0, u_array, theta)
+    r = ileqg.context(problem).solve(x_0, u_array, theta)
     ileqg.status = r["status"]
     ileqg.iter_current = r["iters"]
     ileqg.eps_history = [tuple(p) for p in r["eps_history"]]

@@ -1,0 +1,106 @@
+"""State the host mirrors carry between calls: solvers follow their `problem` argument, a handle can be re-bound to
+another problem, the CE `rng` argument behaves like the reference's stateful AbstractRNG, generic-closure contexts refuse the
+device-family entry points."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ratilqr.jl_amd as rat
+from ratilqr.jl_amd import cross_entropy as ce
+from ratilqr.jl_amd import _native as nv
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ileqg_solver_follows_the_problem_argument():
+    """solve!(ileqg, problem, ...) takes every table from `problem` (ileqg.jl:635-659): a solver constructed on one problem and called
+    with another solves the other one (round 1 silently solved the constructor's)."""
+    pa, x0a, ua = rat.synthetic_lq_problem(seed=0)
+    pb, x0b, ub = rat.synthetic_lq_problem(n=6, m=2, N=30, seed=3)
+    s = rat.ILEQGSolver(pa)
+    ra = rat.solve_(s, pa, x0a, ua, 1.5)
+    rb = rat.solve_(s, pb, x0b, ub, 1.5)                     # same solver object, other problem
+    fresh = rat.solve_(rat.ILEQGSolver(pb), pb, x0b, ub, 1.5)
+    assert rb[3] == fresh[3] and np.array_equal(rb[0], fresh[0]) and np.array_equal(rb[2], fresh[2])
+    assert rb[0].shape == (31, 6) and ra[0].shape == (51, 12)
+    ra2 = rat.solve_(s, pa, x0a, ua, 1.5)                    # and back
+    assert ra2[3] == ra[3] and np.array_equal(ra2[2], ra[2])
+    # the stepwise operators follow it too
+    s2 = rat.ILEQGSolver(pa)
+    rat.initialize_ileqg_(s2, pb, x0b, ub, 0.7)
+    s3 = rat.ILEQGSolver(pb)
+    rat.initialize_ileqg_(s3, pb, x0b, ub, 0.7)
+    assert s2.value_current == s3.value_current
+
+
+def test_handle_rebound_to_a_smaller_problem_with_the_same_horizon():
+    """rat_problem_set on a live handle: same N, smaller n and m -- the padded lanes of the slot pools must read as zeros again."""
+    big, x0, u = rat.synthetic_lq_problem(n=12, m=4, N=50, seed=0)
+    small, x0s, us = rat.synthetic_lq_problem(n=5, m=2, N=50, seed=4, w=1e-2)
+    theta = np.array([0.0, 0.4, 1.0, 2.0])
+    for E in (1, 2):
+        ctx = rat.Context(big, max_batch=8, spec_eps=E)
+        vb = ctx.solve_batch(x0, u, theta)
+        ctx.set_problem(small)
+        got = ctx.solve_batch(x0s, us, theta)
+        want = rat.Context(small, max_batch=8, spec_eps=E).solve_batch(x0s, us, theta)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        r, rw = ctx.solve(x0s, us, 0.4), rat.Context(small, spec_eps=E).solve(x0s, us, 0.4)
+        assert r["value"] == rw["value"] and np.array_equal(r["L"], rw["L"]) and np.array_equal(r["x"], rw["x"])
+        ctx.set_problem(big)                                   # and back to the large one
+        vb2 = ctx.solve_batch(x0, u, theta)
+        for a, b in zip(vb, vb2):
+            assert np.array_equal(a, b)
+
+
+def test_ce_rng_argument_is_stateful():
+    prob, x0, u = rat.synthetic_lq_problem(n=4, m=2, N=20, seed=1)
+    # (a) an integer seed names ONE generator: a hand-driven step_ loop advances it instead of replaying it
+    s = rat.CrossEntropyBilevelOptimizationSolver(num_samples=8, num_elite=3)
+    ce.initialize_(s)
+    th1, _ = ce.step_(s, prob, x0, u, 0.1, 42)
+    th2, _ = ce.step_(s, prob, x0, u, 0.1, 42)
+    assert not np.array_equal((th1 - s.c.mu_init), (th2 - s.c.mu_init)) and s.c.iter_current == 2
+    s_b = rat.CrossEntropyBilevelOptimizationSolver(num_samples=8, num_elite=3)
+    ce.initialize_(s_b)
+    th1b, _ = ce.step_(s_b, prob, x0, u, 0.1, 42)
+    assert np.array_equal(th1, th1b)                           # same seed, same first batch
+    # (b) a Python list is converted once and keyed on the caller's object: the second step_ continues in it
+    z = np.random.default_rng(3).standard_normal(4000)
+    zl = z.tolist()
+    sl = rat.CrossEntropyBilevelOptimizationSolver(num_samples=8, num_elite=3)
+    ce.initialize_(sl)
+    a1, _ = ce.step_(sl, prob, x0, u, 0.1, zl)
+    a2, _ = ce.step_(sl, prob, x0, u, 0.1, zl)
+    sa = rat.CrossEntropyBilevelOptimizationSolver(num_samples=8, num_elite=3)
+    ce.initialize_(sa)
+    b1, _ = ce.step_(sa, prob, x0, u, 0.1, z)
+    b2, _ = ce.step_(sa, prob, x0, u, 0.1, z)
+    assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and not np.array_equal(a1, a2)
+    # (c) the Context is recreated between two steps (a compute_cost batch larger than max_batch): the stream resumes, it is neither
+    #     lost (RAT_ERR_STREAM_DRY in round 1) nor restarted
+    sc = rat.CrossEntropyBilevelOptimizationSolver(num_samples=8, num_elite=3)
+    ce.initialize_(sc)
+    c1, _ = ce.step_(sc, prob, x0, u, 0.1, z)
+    old = sc.context(prob)
+    ce.compute_cost(sc, prob, x0, u, np.linspace(0.1, 1.0, 20), 0.1)      # 20 > 8: new Context
+    assert sc.context(prob) is not old
+    c2, _ = ce.step_(sc, prob, x0, u, 0.1, z)
+    assert np.array_equal(c1, b1) and np.array_equal(c2, b2)
+    assert sc._stream_off + nv.lib().rat_ce_stream_pos(sc.context(prob).h) == nv.lib().rat_ce_stream_pos(sa.context(prob).h)
+
+
+def test_generic_context_refuses_device_family_entry_points():
+    n, m, N = 2, 1, 8
+    A, B = np.array([[1.0, 0.1], [0.0, 1.0]]), np.array([[0.0], [0.1]])
+    gp = rat.GenericRiskSensitiveProblem(lambda x, u: A @ x + B @ u, lambda k, x, u: 0.5 * x @ x + 0.5 * u @ u, lambda x: 0.5 * x @ x,
+                                         lambda k: 0.01 * np.eye(n), N, n, m)
+    ctx = rat.ileqg.make_context(gp)
+    for call in (lambda: ctx.rollout_noisy(np.zeros(n), np.zeros((N, m)), K=2), lambda: ctx.solve_batch(np.zeros(n), np.zeros((N, m)), [0.1]),
+                 lambda: ctx.solve_batch_dev(0, 1, 0), lambda: ctx.compute_cost_dev(0, 1, 0.1, 0), lambda: ctx.set_initial(np.zeros(n), np.zeros((N, m)))):
+        with pytest.raises(NotImplementedError):
+            call()
+    with pytest.raises(NotImplementedError):
+        rat.simulate_dynamics_noisy(gp, np.zeros(n), np.zeros((N, m)), K=2)
