@@ -31,7 +31,7 @@ import time
 _AFFINITY0 = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
 # (the CPU baseline leg binds the oracle's OpenMP threads; libgomp reads these when it is first loaded -- before torch pulls it in)
 os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "threads")
+os.environ.setdefault("OMP_PLACES", "cores")       # one thread per PHYSICAL core first (hardware threads 0 and 1 may be SMT siblings)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -364,11 +364,12 @@ def roofline_of(w, prof_main, main_kind, iters_h, ls_h):
     lay = w.ctx.layout_info()
     avg_ms = prof_main["ms"] / max(prof_main["launches"], 1)
     traj_per_launch = prof_main["trajectories"] / max(prof_main["launches"], 1)
-    fused = main_kind == "solve_fused"
+    fused = main_kind in ("solve_fused", "solve_block")
     if fused:
         bytes_per_launch = algo_bytes_of_solves(iters_h, ls_h)
         bytes_per_traj = bytes_per_launch / max(len(iters_h), 1)
-        kernel_name = "solve_fused_kernel (one persistent wavefront group per theta-sample: whole solve!)"
+        kernel_name = ("solve_fused_kernel (one persistent wavefront per theta-sample: whole solve!)" if main_kind == "solve_fused" else
+                       "solve_block_kernel (one workgroup per theta-sample -- a wavefront per line-search candidate + a gain-sweep wavefront: whole solve!)")
     else:
         bytes_per_traj = algo_bytes_per_candidate()
         bytes_per_launch = bytes_per_traj * traj_per_launch
@@ -459,8 +460,8 @@ def rank_main(args):
         w.step()
     D.sync()
     prof_all = w.ctx.profile_get()
-    fused = prof_all["solve_fused"]["launches"] > 0
-    main_kind = "solve_fused" if fused else "sweep_eval"
+    main_kind = next((k for k in ("solve_fused", "solve_block") if prof_all[k]["launches"] > 0), "sweep_eval")
+    fused = main_kind != "sweep_eval"
     w.ctx.profile(True, kinds=[main_kind])
     w.ctx.profile_reset()
     elapsed = D.timed(w.step, K, 0)
@@ -534,7 +535,7 @@ def rank_main(args):
         torch.cuda.synchronize()
         e8 = time.perf_counter() - t8
         p8all = ctx8.profile_get()
-        k8 = "solve_fused" if p8all["solve_fused"]["launches"] else "sweep_eval"
+        k8 = next((k for k in ("solve_fused", "solve_block") if p8all[k]["launches"] > 0), "sweep_eval")
         p8 = p8all[k8]
         a = algo_bytes()
         # algorithmic bytes of the E = 8 batch: every line-search round evaluates 8 candidates per sample (7.08 MB/solve)

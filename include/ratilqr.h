@@ -314,7 +314,8 @@ rat_rc rat_pets_solve(rat_handle h, rat_pets_solver *s, const double *x0, int32_
 #define RAT_K_SWEEP_INIT 5   /* open-loop policy evaluation of initialize! (no gains read) */
 #define RAT_K_SWEEP_DUAL 6   /* fused wavefront: policy evaluation + the next step!'s gain sweep over one pass of the tiles */
 #define RAT_K_SOLVE_FUSED 7  /* one persistent wavefront per sample runs the whole solve! (E = 1): every phase above in one launch */
-#define RAT_K_COUNT     8
+#define RAT_K_SOLVE_BLOCK 8  /* one workgroup per sample runs the whole solve!: a wavefront per line-search candidate + a gain-sweep wavefront */
+#define RAT_K_COUNT     9
 /* When enabled, kernel launches are bracketed by HIP events on the handle's stream.
  * on = 0: off; on = 1: every kernel kind; otherwise on = (mask << 1) | 1 with bit k of mask selecting kind RAT_K_k.
  * Launches of a surplus round (no live sample left) are not counted. */

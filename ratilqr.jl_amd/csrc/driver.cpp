@@ -42,6 +42,8 @@ struct rat_handle_s {
     bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
     std::vector<double> x0_host, u0_host;   // padded copies of what d_x0 / d_u0 hold (rat_set_initial skips identical uploads)
     bool fused_dual = true;          // ... with policy evaluation + following gain sweep paired in one pass (RATILQR_FUSED_DUAL=0: separate)
+    int block_mode = -1;             // workgroup-per-sample solve kernel (solve_block_kernel): -1 auto, 0 never, 1 whenever it is supported (RATILQR_BLOCK)
+    int block_max_b = 512;           // auto, E = 1: used for batches up to this size (RATILQR_BLOCK_MAX_B)
     rat_ileqg_opts opts;
     OptsDev opd;
     int Bmax = 0, E = 1;
@@ -131,6 +133,9 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_FUSED")) h->fused = (e[0] != '0');
     if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
     if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
+    if (const char *e = getenv("RATILQR_BLOCK")) h->block_mode = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
+    if (const char *e = getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = atoi(e);
+    if (const char *e = getenv("RATILQR_FUSED")) { if (e[0] == '0') h->block_mode = 0; }     // "round-based path": no single-launch solve at all
     CREATECHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
     CREATECHK(hipHostMalloc((void **)&h->h_io, std::max<size_t>((size_t)max_batch * 28, 64), hipHostMallocDefault));
     for (int i = 0; i < CTR_RING; ++i) CREATECHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
@@ -484,6 +489,24 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     return RAT_OK;
 }
 
+// Which execution path runs a batch of B samples (results are bit-identical on all of them):
+//   PATH_FUSED   solve_fused_kernel: one persistent wavefront per sample, evaluation + gain recursions paired in-wave  (E = 1)
+//   PATH_BLOCK   solve_block_kernel: one workgroup per sample, a wave per candidate + a gain wave                      (E = 1, 2, 4, 8)
+//   PATH_ROUNDS  one launch per phase, host-polled rounds                                                              (any E, operators)
+// E = 1: the chip has 1024 SIMDs.  Up to 512 samples the block kernel gives every sample two SIMDs (its evaluation and gain
+// recursions run side by side); from there on the in-wave pairing of the fused kernel is the better use of a SIMD (measured).
+enum Path { PATH_ROUNDS, PATH_FUSED, PATH_BLOCK };
+static Path pick_path(const rat_handle h, int B) {
+    const bool block_ok = solve_block_supported(h->E) && h->block_mode != 0 && (h->E > 1 || h->fused) && !h->speculate &&
+                          (h->E == 1 || getenv("RATILQR_DUAL") == nullptr);
+    if (h->E == 1) {
+        if (!h->fused) return PATH_ROUNDS;
+        if (block_ok && (h->block_mode == 1 || B <= h->block_max_b)) return PATH_BLOCK;
+        return PATH_FUSED;
+    }
+    return block_ok ? PATH_BLOCK : PATH_ROUNDS;
+}
+
 // outputs of a batch (device pointers, any may be null); cost = value + kl_bound / theta  (cross_entropy...jl:193)
 struct BatchOut { double *value = nullptr; int *status = nullptr, *iters = nullptr, *ls = nullptr; double *cost = nullptr; double kl_bound = 0.0; };
 
@@ -494,11 +517,12 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
     HIPCHK(hipSetDevice(h->device));
     StateDev st = h->st;
     st.B = B;
-    if (!h->fused) launch_init_state(st, h->opd, theta_dev, h->stream);     // (the fused solve initialises each sample in its own wave)
+    const Path path = pick_path(h, B);
+    if (path == PATH_ROUNDS) launch_init_state(st, h->opd, theta_dev, h->stream);     // (the single-launch solves initialise each sample themselves)
     // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation; the first gain
     // sweep (step! number 1 re-linearises the same trajectory, App. B.1) runs speculatively beside it.
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
-    if (h->fused) {                  // the whole state machine below, per sample, inside one launch
+    if (path != PATH_ROUNDS) {       // the whole state machine below, per sample, inside one launch
         FusedArgs fa;
         fa.sw = sweep_args(h, st, 0);
         fa.ro = ra;
@@ -507,7 +531,9 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.theta_in = theta_dev;
         fa.out_value = out.value; fa.out_status = out.status; fa.out_iters = out.iters; fa.out_ls = out.ls;
         fa.out_cost = out.cost; fa.kl_bound = out.kl_bound;
-        prof_begin(h, RAT_K_SOLVE_FUSED, B); launch_solve_fused(fa, h->stream); prof_end(h);
+        prof_begin(h, path == PATH_BLOCK ? RAT_K_SOLVE_BLOCK : RAT_K_SOLVE_FUSED, B);
+        if (path == PATH_BLOCK) launch_solve_block(fa, h->stream); else launch_solve_fused(fa, h->stream);
+        prof_end(h);
         return RAT_OK;
     }
     prof_begin(h, RAT_K_ROLLOUT, B); launch_rollin(ra, h->stream); prof_end(h);         // fused rollout + linearise
@@ -579,7 +605,7 @@ extern "C" rat_rc rat_ileqg_solve_batch_dev(rat_handle h, const double *theta_de
     BatchOut out; out.value = value_dev; out.status = status_dev; out.iters = iters_dev; out.ls = ls_evals_dev;
     rat_rc rc = run_batch(h, theta_dev, (int)B, out);
     if (rc) return rc;
-    if (!h->fused) {                                   // (the fused solve has written the outputs itself)
+    if (pick_path(h, (int)B) == PATH_ROUNDS) {         // (the single-launch solves have written the outputs themselves)
         StateDev st = h->st; st.B = (int)B;
         launch_gather(st, value_dev, status_dev, iters_dev, ls_evals_dev, nullptr, 0.0, h->stream);
     }
@@ -594,7 +620,7 @@ extern "C" rat_rc rat_ce_compute_cost_dev(rat_handle h, const double *theta_dev,
     BatchOut out; out.cost = cost_dev; out.kl_bound = kl_bound;
     rat_rc rc = run_batch(h, theta_dev, (int)B, out);
     if (rc) return rc;
-    if (!h->fused) {
+    if (pick_path(h, (int)B) == PATH_ROUNDS) {
         StateDev st = h->st; st.B = (int)B;
         launch_gather(st, nullptr, nullptr, nullptr, nullptr, cost_dev, kl_bound, h->stream);
     }
@@ -604,7 +630,8 @@ extern "C" rat_rc rat_ce_compute_cost_dev(rat_handle h, const double *theta_dev,
 
 extern "C" rat_rc rat_ce_compute_cost_enqueue(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev) {
     if (!h || !theta_dev || !cost_dev) return fail(RAT_ERR_ARG, "null");
-    if (!h->fused) return rat_ce_compute_cost_dev(h, theta_dev, B, kl_bound, cost_dev);   // the round-based path polls its round counters
+    if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");
+    if (pick_path(h, (int)B) == PATH_ROUNDS) return rat_ce_compute_cost_dev(h, theta_dev, B, kl_bound, cost_dev);   // the round-based path polls its round counters
     BatchOut out; out.cost = cost_dev; out.kl_bound = kl_bound;
     return run_batch(h, theta_dev, (int)B, out);          // one launch on the handle's stream; no host wait
 }
@@ -625,7 +652,7 @@ extern "C" rat_rc rat_ileqg_solve_batch(rat_handle h, const double *x0, const do
     BatchOut out; out.value = h->d_val; out.status = h->d_ist; out.iters = h->d_iit; out.ls = h->d_ils;
     rc = run_batch(h, h->d_theta, (int)B, out);
     if (rc) return rc;
-    if (!h->fused) {
+    if (pick_path(h, (int)B) == PATH_ROUNDS) {
         StateDev st = h->st; st.B = (int)B;
         launch_gather(st, h->d_val, h->d_ist, h->d_iit, h->d_ils, nullptr, 0.0, h->stream);
     }

@@ -85,6 +85,8 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s);
 void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout + linearise (solver hot loop)
 void launch_linearize(const LinArgs &a, hipStream_t s);
 void launch_solve_fused(const FusedArgs &a, hipStream_t s);   // complete solve! per sample in one launch (E = 1)
+void launch_solve_block(const FusedArgs &a, hipStream_t s);   // complete solve! per sample by a workgroup of wavefronts (E = 1, 2, 4, 8)
+bool solve_block_supported(int E);
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s);   // modes 6 (initialize! + first gain sweep), 7 (candidate 0 + next gain sweep)

@@ -40,7 +40,6 @@
 #ifndef ROLLIN_PREFETCH
 #define ROLLIN_PREFETCH 5          /* rotating operand sets of rollin_body: prefetch distance ROLLIN_PREFETCH - 1 steps */
 #endif
-#define ROLLIN_NST 52              /* longest horizon whose closed-loop operands are staged in LDS by the fused solve (28.5 KB) */
 
 // =====================================================================================================
 // sweep_kernel
@@ -76,9 +75,10 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
 // are all zero: no gain loads and V = Fx without the two rank-4 updates.
 // sweep_body is the whole sweep of ONE wavefront (trajectory `tid` of the launch); sweep_kernel wraps it one block per
 // trajectory, solve_fused_kernel calls it as one phase of a sample's complete solve.
+// wls: this wavefront's LDS scratch (WLS_SWEEP doubles).
 template <bool GAIN, bool DUMP, bool WTV, bool HASL>
-__device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
-    int lane_ = threadIdx.x;
+__device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, double *const wls) {
+    int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase: keeps the per-lane constants of one phase from being shared with
                                          // (and kept live across) the other phases inlined into solve_fused_kernel
     const int l_ = lane_, g_ = l_ >> 4, j_ = l_ & 15;
@@ -120,8 +120,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
     double *__restrict__ Lout = st.L + (long)osel * st.l_half + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)osel * st.dl_half + (long)b * N * USTR;
 
-    __shared__ double lbuf[64];        // policy evaluation: the step's gain row block [L | dl], natural 4 x 16 layout
-    __shared__ double ex[104 + 64];    // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0, [84..99] = s_vec,
+    double *const lbuf = wls;          // policy evaluation: the step's gain row block [L | dl], natural 4 x 16 layout
+    double *const ex = wls + 64;       // exchange area: rows 0..3 = [G | H] (4 x 16), row 4 = f (16), [80] = 0.0, [84..99] = s_vec,
                                        // [104..167] dump slots: the row-0-only writes are unconditional, idle lanes write there
                                        // (a lane-conditional write splits the basic block the scheduler works on)
 #define HBUF(r_, c_) ex[(r_) * 16 + (c_)]
@@ -422,7 +422,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid) {
 
 template <bool GAIN, bool DUMP, bool WTV, bool HASL>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
-    sweep_body<GAIN, DUMP, WTV, HASL>(a, blockIdx.x);
+    __shared__ double wls[WLS_SWEEP];
+    sweep_body<GAIN, DUMP, WTV, HASL>(a, blockIdx.x, wls);
 }
 
 template <bool GAIN, bool DUMP, bool HASL>
@@ -619,8 +620,9 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // STAGE (closed loop, N <= ROLLIN_NST): the operands of the whole trajectory -- L, xbar, l, dl: 27 KB -- are copied into LDS before the
 // time loop (57 loads in flight at once), so the loop issues no global loads at all and its tile stores never meet a vmcnt wait.
 // SEP (operand loads in the loop only): keep the steps of a group apart in the instruction schedule (see the time loop).
+// shxu: 16 doubles of this wavefront's LDS (terminal tile); stg: STG_DOUBLES of LDS shared by the waves of the workgroup (STAGE), else null
 template <int MODEL, int MODE, bool CTV, bool STAGE = false, bool SEP = true>
-__device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
+__device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, double *const shxu, double *const stg = nullptr) {
     int lane_ = threadIdx.x & 63;        // (rollin_stage_kernel runs the E candidates of a sample as the waves of one workgroup)
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
     const int l = lane_, j = l & 15, g = l >> 4;
@@ -641,8 +643,6 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     const double eps_in = st.ls_eps[b];
     if (MODE == 0) { if (s_stat != ST_RUNNING) return; }
     else { if (!s_act) return; }
-    __shared__ double shxu_all[8][16];                           // terminal tile only; one row per wave of the workgroup
-    double *const shxu = shxu_all[(threadIdx.x >> 6) & 7];
 
     const int slot_n = b * (st.E + 1) + nom;
     const int slot_o = (MODE == 0) ? slot_n : cand_slot(b, k, nom, st.E);
@@ -716,8 +716,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
     struct StepIn { double l, dl, xb[3], La[3]; };
     StepIn buf[RD];
     constexpr bool staged = STAGE && MODE == 1;
-    constexpr int cL = (ROLLIN_NST * LSTR + 63) / 64, cX = ((ROLLIN_NST + 1) * XSTR + 63) / 64, cU = (ROLLIN_NST * USTR + 63) / 64;
-    __shared__ double stg[staged ? (cL + cX + 2 * cU) * 64 : 1];
+    constexpr int cL = STG_CL, cX = STG_CX, cU = STG_CU;
     double *const sL = stg, *const sX = stg + (staged ? cL * 64 : 0), *const sl = sX + (staged ? cX * 64 : 0), *const sdl = sl + (staged ? cU * 64 : 0);
     if (staged) {
         double tL[cL], tX[cX], tl[cU], tdl[cU];
@@ -947,7 +946,8 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c) {
 
 template <int MODEL, int MODE, bool CTV, bool SEP>
 __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
-    rollin_body<MODEL, MODE, CTV, false, SEP>(a, blockIdx.x);
+    __shared__ double shxu[16];
+    rollin_body<MODEL, MODE, CTV, false, SEP>(a, blockIdx.x, shxu);
 }
 
 // The E line-search candidates of a sample as the waves of ONE workgroup (eight per workgroup; N <= ROLLIN_NST): they share the sample's operands
@@ -959,7 +959,9 @@ __global__ __launch_bounds__(512) void rollin_stage_kernel(RolloutArgs a) {
     const int nb = (a.st.E + 7) >> 3;                           // workgroups per sample: eight candidates each
     const int b = blockIdx.x / nb, k = (blockIdx.x - b * nb) * 8 + (threadIdx.x >> 6);
     if (k >= a.st.E) return;
-    rollin_body<MODEL, 1, CTV, true, false>(a, b * a.st.E + k);
+    __shared__ double shxu[8][16];
+    __shared__ double stg[STG_DOUBLES];
+    rollin_body<MODEL, 1, CTV, true, false>(a, b * a.st.E + k, shxu[(threadIdx.x >> 6) & 7], stg);
 }
 
 void launch_rollin(const RolloutArgs &a, hipStream_t s) {
@@ -1300,18 +1302,21 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
     const unsigned long long dg_t0 = __builtin_readcyclecounter();
     int dg_pi = 0;
 #endif
+    __shared__ double wls[DUALF ? WLS_DUAL : WLS_SWEEP];
+    __shared__ double shxu[16];
+    __shared__ double stg[STG ? STG_DOUBLES : 1];
     // the sample's own wave initialises its state and, at the end, writes its outputs: a batch is ONE launch
     if (threadIdx.x == 0) init_state_body(st, fa.sw.op, fa.theta_in, b);
     PHASE_FENCE();
     {
         RolloutArgs ra = fa.ro; ra.mode = 0;
-        rollin_body<MODEL, 0, CTV>(ra, b);
+        rollin_body<MODEL, 0, CTV>(ra, b, shxu);
         PHASE_MARK();
         PHASE_FENCE();
         PHASE_MARK();
         if (DUALF) {
             SweepArgs sa = fa.sw; sa.mode = 6;
-            sweep_dual_body<WTV, false>(sa, b);
+            sweep_dual_body<WTV, false>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             if (threadIdx.x == 0) commit_init_body(st, b);
@@ -1319,7 +1324,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
             PHASE_MARK();
         } else {
             SweepArgs sa = fa.sw; sa.mode = 2;
-            sweep_body<false, false, WTV, false>(sa, b);
+            sweep_body<false, false, WTV, false>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1331,7 +1336,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp!  (ileqg.jl:598-613)
             SweepArgs sa = fa.sw; sa.mode = 0;
-            sweep_body<true, false, WTV, false>(sa, b);
+            sweep_body<true, false, WTV, false>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1339,7 +1344,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
         }
         {                                                    // one candidate of line_search!  (ileqg.jl:504-581)
             RolloutArgs ra = fa.ro; ra.mode = 1;
-            rollin_body<MODEL, 1, CTV, STG>(ra, b);
+            rollin_body<MODEL, 1, CTV, STG>(ra, b, shxu, stg);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1353,10 +1358,10 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
             }
             if (pair) {
                 SweepArgs sa = fa.sw; sa.mode = 7;
-                sweep_dual_body<WTV, true>(sa, b);
+                sweep_dual_body<WTV, true>(sa, b, wls);
             } else {
                 SweepArgs sa = fa.sw; sa.mode = 1;
-                sweep_body<false, false, WTV, true>(sa, b);
+                sweep_body<false, false, WTV, true>(sa, b, wls);
             }
             PHASE_MARK();
             PHASE_FENCE();
@@ -1387,6 +1392,124 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
         if (wtv) FUSED_LAUNCH(2, false, true); else FUSED_LAUNCH(2, false, false);
     }
 #undef FUSED_LAUNCH
+}
+
+// =====================================================================================================
+// solve_block_kernel: the complete solve! of one theta-sample by a WORKGROUP of wavefronts -- one wave per speculative line-search
+// candidate (E of them) plus, when GW, one wave that runs the gain sweeps:
+//   wave 0        initialize!'s rollout + open-loop policy evaluation; candidate 0 of every line-search round; the accept rule
+//   waves 1..E-1  candidates 1..E-1 (eps_k = eps lambda^k): rollout + linearise, policy evaluation       (ileqg.jl:504-536)
+//   wave E (GW)   solve_approximate_dp! of the NEXT step!, speculatively on candidate 0's tiles while the candidates are evaluated
+//                 (what step! would compute if candidate 0 is accepted, App. B.1; dropped otherwise), the first gain sweep beside
+//                 initialize!'s sweep, and the plain gain sweep whenever no speculative one is valid
+// The phases are the SAME device functions as everywhere else (rollin_body, sweep_body, ls_select_body): results are bit-identical
+// to solve_fused_kernel and to the round-based path.  Where solve_fused_kernel pairs a policy evaluation with the following gain
+// sweep as two recursions inside ONE wave (sweep_dual_body, 342 registers: one wave per SIMD), this kernel puts them on two waves
+// of <= 256 registers each, so that
+//   * a sample's evaluation and gain recursions run CONCURRENTLY on two SIMDs when the batch leaves SIMDs free (strong scaling:
+//     1024 / N samples per GPU) -- the critical path of a 2-iteration solve drops from 5 sweeps' worth to 3;
+//   * two waves per SIMD fit, so at a full batch the hardware interleaves two independent waves per SIMD;
+//   * E > 1 candidates are evaluated inside the launch (line searches that really backtrack, BASELINE config 3).
+// Waves meet at workgroup barriers between phases; per-sample control state stays in the StateDev arrays as in the fused kernel.
+// =====================================================================================================
+template <int MODEL, bool CTV, bool WTV, int NW, bool GW, bool STG>
+__global__ __launch_bounds__(64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
+    constexpr int E = GW ? NW - 1 : NW;          // candidate waves
+    constexpr int WG = GW ? NW - 1 : 0;          // the wave that runs gain sweeps
+    const int b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const StateDev &st = fa.sw.st;
+    __shared__ double wls_all[NW][WLS_SWEEP];
+    __shared__ double shxu_all[NW][16];
+    __shared__ double stg[STG ? STG_DOUBLES : 1];
+    double *const wls = wls_all[wave], *const shxu = shxu_all[wave];
+    if (threadIdx.x == 0) init_state_body(st, fa.sw.op, fa.theta_in, b);
+    __syncthreads();
+    if (wave == 0) {                             // initialize!: open-loop rollout + linearise   (ileqg.jl:214-233)
+        RolloutArgs ra = fa.ro; ra.mode = 0;
+        rollin_body<MODEL, 0, CTV>(ra, b, shxu);
+    }
+    __syncthreads();
+    if (wave == 0) {                             // open-loop policy evaluation (:234) ...
+        SweepArgs sa = fa.sw; sa.mode = 2;
+        sweep_body<false, false, WTV, false>(sa, b, wls);
+    } else if (GW && wave == WG) {               // ... beside the first step!'s gain sweep on the same tiles (speculative until initialize! succeeds)
+        SweepArgs sa = fa.sw; sa.mode = 5;
+        sweep_body<true, false, WTV, false>(sa, b, wls);
+    }
+    __syncthreads();
+    if (GW) {
+        if (threadIdx.x == 0) commit_init_body(st, b);
+        __syncthreads();
+    }
+    for (int guard = 0; guard < fa.max_rounds; ++guard) {
+        const int v_stat = __atomic_load_n(&st.status[b], __ATOMIC_RELAXED), v_act = __atomic_load_n(&st.ls_active[b], __ATOMIC_RELAXED);
+        if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
+        if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp! with no valid speculative sweep  (ileqg.jl:598-613)
+            if (wave == WG) {
+                SweepArgs sa = fa.sw; sa.mode = 0;
+                sweep_body<true, false, WTV, false>(sa, b, wls);
+            }
+            __syncthreads();
+            continue;
+        }
+        if (wave < E) {                                       // candidates of this line-search round  (ileqg.jl:504-521)
+            RolloutArgs ra = fa.ro; ra.mode = 1;
+            rollin_body<MODEL, 1, CTV, STG, false>(ra, b * E + wave, shxu, stg);
+        }
+        __syncthreads();
+        if (wave < E) {                                       // their policy evaluations  (:522-536)
+            SweepArgs sa = fa.sw; sa.mode = 1;
+            sweep_body<false, false, WTV, true>(sa, b * E + wave, wls);
+        } else {                                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
+            const double v_dc = *(const volatile double *)&st.d_c[b * E], v_mu = *(const volatile double *)&st.mu[b];   // it ends solve! (:642-653)
+            const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
+            const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
+            const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
+            if (!ends) {
+                SweepArgs sa = fa.sw; sa.mode = 4;
+                sweep_body<true, false, WTV, false>(sa, b, wls);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) ls_select_body(st, fa.sw.op, b, nullptr);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
+}
+
+template <int NW, bool GW>
+static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {
+    const dim3 grid(fa.sw.st.B), block(64 * NW);
+    const bool wtv = fa.sw.pb.W_tv != 0;
+    const bool stg = fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST;
+#define BLOCK_LAUNCH(M, C, W, S) hipLaunchKernelGGL((solve_block_kernel<M, C, W, NW, GW, S>), grid, block, 0, s, fa)
+    if (fa.sw.pb.model == 1) {
+        if (stg) {
+            if (fa.sw.pb.cost_tv) { if (wtv) BLOCK_LAUNCH(1, true, true, true); else BLOCK_LAUNCH(1, true, false, true); }
+            else { if (wtv) BLOCK_LAUNCH(1, false, true, true); else BLOCK_LAUNCH(1, false, false, true); }
+        } else {
+            if (fa.sw.pb.cost_tv) { if (wtv) BLOCK_LAUNCH(1, true, true, false); else BLOCK_LAUNCH(1, true, false, false); }
+            else { if (wtv) BLOCK_LAUNCH(1, false, true, false); else BLOCK_LAUNCH(1, false, false, false); }
+        }
+    } else {
+        if (wtv) BLOCK_LAUNCH(2, false, true, false); else BLOCK_LAUNCH(2, false, false, false);
+    }
+#undef BLOCK_LAUNCH
+}
+
+// E = st.E speculative candidates per sample: E + 1 waves (the last one runs the gain sweeps) for E <= 7, E waves for E = 8
+bool solve_block_supported(int E) { return E == 1 || E == 2 || E == 4 || E == 8; }
+void launch_solve_block(const FusedArgs &fa, hipStream_t s) {
+    if (fa.sw.st.B <= 0) return;
+    switch (fa.sw.st.E) {
+        case 1: launch_solve_block_n<2, true>(fa, s); break;
+        case 2: launch_solve_block_n<3, true>(fa, s); break;
+        case 4: launch_solve_block_n<5, true>(fa, s); break;
+        case 8: launch_solve_block_n<8, false>(fa, s); break;
+        default: break;
+    }
 }
 
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s) {

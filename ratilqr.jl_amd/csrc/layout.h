@@ -66,6 +66,16 @@
 #define DUMP_H   209        /* 4 x 4 row-major  */
 #define DUMP_STRIDE 225
 
+/* LDS scratch of the phase bodies, in doubles.  The bodies take pointers (no static __shared__ of their own): a kernel that inlines
+ * several of them -- or runs them on several wavefronts of one workgroup -- declares ONE area per wave instead of one per instantiation. */
+#define WLS_SWEEP 232       /* sweep_body: gain rows [L|dl] 64 + exchange area 168 */
+#define WLS_DUAL  400       /* sweep_dual_body: 64 + 2 x 168 */
+#define ROLLIN_NST 52       /* longest horizon whose closed-loop operands are staged in LDS by the fused solves */
+#define STG_CL ((ROLLIN_NST * LSTR + 63) / 64)
+#define STG_CX (((ROLLIN_NST + 1) * XSTR + 63) / 64)
+#define STG_CU ((ROLLIN_NST * USTR + 63) / 64)
+#define STG_DOUBLES ((STG_CL + STG_CX + 2 * STG_CU) * 64)   /* L, xbar, l, dl of one trajectory: 29,184 B */
+
 #define ST_RUNNING (-1)
 #define CTR_RING 8          /* per-round counter pairs kept in a ring (host polls one round behind) */
 

@@ -42,9 +42,10 @@ __device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, 
 
 // The elimination rounds of the two recursions are the shared elim_round (device_utils.h: rank-2 update on the matrix pipe, no LDS,
 // no fence), issued back to back: two independent pivot chains for the scheduler to interleave.
+// wls: this wavefront's LDS scratch (WLS_DUAL doubles)
 template <bool WTV, bool HASL>
-__device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b) {
-    int lane_ = threadIdx.x;
+__device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b, double *const wls) {
+    int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
     const int l_ = lane_, g_ = l_ >> 4, j_ = l_ & 15;
     const int l = l_, g = g_, j = j_;
@@ -73,8 +74,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b)
     double *__restrict__ Lout = st.L + (long)(sel ^ 1) * st.l_half + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)(sel ^ 1) * st.dl_half + (long)b * N * USTR;
 
-    __shared__ double lbufA[64];
-    __shared__ double exA[104 + 64], exB[104 + 64];                    // [G|H] 4x16, f 16, [80] = 0, [84..99] = s_vec, [104..] dump slots
+    double *const lbufA = wls;
+    double *const exA = wls + 64, *const exB = wls + 64 + 168;         // [G|H] 4x16, f 16, [80] = 0, [84..99] = s_vec, [104..] dump slots
                                                                        // of the idle lanes (unconditional writes: see sweep_body)
     if (l < 8) { exA[80 + l] = 0.0; exB[80 + l] = 0.0; }
 

@@ -3,7 +3,8 @@
 
 template <bool WTV, bool HASL>
 __global__ __launch_bounds__(64) void sweep_dual_kernel(SweepArgs a) {
-    sweep_dual_body<WTV, HASL>(a, blockIdx.x);
+    __shared__ double wls[WLS_DUAL];
+    sweep_dual_body<WTV, HASL>(a, blockIdx.x, wls);
 }
 
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s) {

@@ -1,0 +1,93 @@
+"""solve_block_kernel -- the whole solve! of a theta-sample by ONE WORKGROUP (a wavefront per speculative line-search candidate plus a
+gain-sweep wavefront) -- against the other execution paths (bit for bit: it calls the same device functions) and against the oracle
+(counts identical, values 1e-9), on workloads whose line search really backtracks."""
+import numpy as np
+import pytest
+
+import ratilqr.jl_amd as rat
+from oracle import oracle as orc
+from test_gpu_parity import check_batch, stress_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _workloads():
+    back, bx0, bu = rat.synthetic_lq_problem(kappa=0.06)                      # 5 iterations, 6..13 line-search evaluations
+    th_b = np.array([0.0, 0.5, 2.0, 5.0, 6.5, 8.0, 30.0])
+    lq, lx0, lu = rat.synthetic_lq_problem()
+    th_l = np.concatenate([[0.0], np.linspace(0.01, 14.0, 30), [50.0]])
+    stress = [stress_problem(i, kappa=0.03) for i in range(4)]
+    th_s = np.array([0.0, 0.3, 1.0, 4.0])
+    pl = rat.PowerLawRiskSensitiveProblem(2, 10, 0.01 * np.eye(2), a=1.3, b=1.5, p=2.5, hconst=1.0)
+    return back, bx0, bu, th_b, lq, lx0, lu, th_l, stress, th_s, pl
+
+
+def _run_all(E):
+    back, bx0, bu, th_b, lq, lx0, lu, th_l, stress, th_s, pl = _workloads()
+    out = []
+    out += rat.Context(back, max_batch=th_b.size, spec_eps=E).solve_batch(bx0, bu, th_b)
+    out += rat.Context(lq, max_batch=32, spec_eps=E).solve_batch(lx0, lu, th_l)
+    for sp, sx, su in stress:
+        out += rat.Context(sp, rat.ileqg.make_opts(iter_max=8), max_batch=4, spec_eps=E).solve_batch(sx, su, th_s)
+    out += rat.Context(pl, max_batch=3, spec_eps=E).solve_batch(np.zeros(2), 0.1 * np.ones((10, 2)), np.array([0.0, 0.5, 2.0]))
+    r = rat.Context(back, spec_eps=E).solve(bx0, bu, 5.0)
+    out += [r["L"], r["x"], r["l"], np.array([r["value"], r["status"], r["iters"]]), np.asarray(r["eps_history"], dtype=float)]
+    return out
+
+
+@pytest.mark.parametrize("E", [1, 2, 4, 8])
+def test_block_kernel_is_bit_identical_to_the_other_paths(E, monkeypatch):
+    monkeypatch.setenv("RATILQR_BLOCK", "1")
+    block = _run_all(E)
+    monkeypatch.setenv("RATILQR_BLOCK", "0")
+    other = _run_all(E)                                        # E = 1: solve_fused_kernel; E > 1: round-based path
+    monkeypatch.setenv("RATILQR_FUSED", "0")
+    rounds = _run_all(E)
+    assert len(block) == len(other) == len(rounds)
+    for a, b, c in zip(block, other, rounds):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+        assert np.array_equal(np.asarray(a), np.asarray(c), equal_nan=True)
+
+
+@pytest.mark.parametrize("E", [1, 2, 4, 8])
+def test_block_kernel_against_the_oracle_on_a_backtracking_workload(E, monkeypatch):
+    monkeypatch.setenv("RATILQR_BLOCK", "1")
+    prob, x0, u = rat.synthetic_lq_problem(kappa=0.06)
+    P = orc.Problem(prob)
+    theta = np.array([0.0, 0.5, 2.0, 3.5, 5.0, 6.0, 7.5, 8.0, 20.0])
+    ctx = rat.Context(prob, max_batch=theta.size, spec_eps=E)
+    assert ctx.profile_get()["solve_block"]["launches"] == 0
+    ctx.profile(True)
+    vg, sg, ig, lg = check_batch(ctx, P, x0, u, theta)
+    assert ctx.profile_get()["solve_block"]["launches"] == 1 and ctx.profile_get()["solve_fused"]["launches"] == 0
+    ctx.profile(False)
+    assert lg.max() >= 10 and (lg > ig).any()                  # the line search really backtracks on this problem
+    # eps history of a single solve: the sequence of accepted / rejected step sizes is the sequential one
+    r = ctx.solve(x0, u, 5.0)
+    s = orc.ILEQGSolver(P)
+    assert s.solve(x0, u, 5.0) == r["status"] == 0
+    ho = s.eps_history
+    assert r["eps_history"].shape == ho.shape and np.array_equal(r["eps_history"][:, 0], ho[:, 0])
+    assert np.abs(r["eps_history"][:, 1] - ho[:, 1]).max() <= 1e-9 * max(1.0, np.abs(ho[:, 1]).max())
+    assert np.abs(r["L"] - s.L_array).max() < 1e-9 and np.abs(r["x"] - s.x_array).max() < 1e-9
+
+
+def test_block_kernel_default_policy_and_several_generations(monkeypatch):
+    """E = 1: batches up to 512 samples run on the block kernel (two SIMDs per sample), larger ones on the fused kernel; forced, a batch
+    larger than the chip runs its workgroups in several generations with unchanged results."""
+    prob, x0, u = rat.synthetic_lq_problem()
+    theta = np.abs(1.0 + 2.0 * np.random.default_rng(9).standard_normal(2500))
+    ctx = rat.Context(prob, max_batch=2500)
+    ctx.profile(True)
+    small = ctx.solve_batch(x0, u, theta[:512])
+    p1 = ctx.profile_get()
+    assert p1["solve_block"]["launches"] == 1 and p1["solve_fused"]["launches"] == 0
+    big = ctx.solve_batch(x0, u, theta)
+    p2 = ctx.profile_get()
+    assert p2["solve_block"]["launches"] == 1 and p2["solve_fused"]["launches"] == 1
+    monkeypatch.setenv("RATILQR_BLOCK", "1")
+    forced = rat.Context(prob, max_batch=2500).solve_batch(x0, u, theta)
+    for a, b in zip(big, forced):
+        assert np.array_equal(a, b)
+    for a, b in zip(small, big):
+        assert np.array_equal(a, b[:512])

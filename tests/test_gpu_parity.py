@@ -358,13 +358,15 @@ def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
         out += [r["L"], r["x"], r["l"], np.array([r["value"]]), np.asarray(r["eps_history"], dtype=float)]
         return out
 
-    fused = run_all()                                # default: fused, policy evaluation paired with the following gain sweep
+    monkeypatch.setenv("RATILQR_BLOCK", "0")         # (small batches default to the workgroup-per-sample kernel: tests/test_gpu_block.py)
+    fused = run_all()                                # fused, policy evaluation paired with the following gain sweep
     monkeypatch.setenv("RATILQR_FUSED_DUAL", "0")
     fused_plain = run_all()                          # fused, one recursion per pass
     monkeypatch.delenv("RATILQR_FUSED_DUAL")
     monkeypatch.setenv("RATILQR_FUSED", "0")
     rounds = run_all()                               # one launch per phase
     monkeypatch.delenv("RATILQR_FUSED")
+    monkeypatch.delenv("RATILQR_BLOCK")
     assert len(fused) == len(rounds) == len(fused_plain)
     for a, b, c in zip(fused, rounds, fused_plain):
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
