@@ -16,7 +16,8 @@
  *   - no exceptions cross the ABI: functions return a rat_rc (API misuse / HIP errors), and every
  *     trajectory carries a per-sample status (RAT_ST_*) with value = +Inf where the reference
  *     would have thrown (cross_entropy_bilevel_optimization.jl:161-165);
- *   - call from one host thread per handle; a handle owns one HIP device and one stream.
+ *   - call from one host thread per handle; a handle owns one HIP device and one stream; a rat_multi owns one handle per
+ *     device and is driven from one host thread as well (no callbacks, no thread-local state of the caller: @threadcall-safe);
  *   - user closures f/c/h/W cannot cross the ABI: problems are instances of compiled-in model
  *     families (rat_problem_desc.model).
  */
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RAT_VERSION 100
+#define RAT_VERSION 200
 
 /* ---- return codes (API level) ---------------------------------------------------------------- */
 typedef int32_t rat_rc;
@@ -304,6 +305,36 @@ rat_rc rat_pets_step(rat_handle h, rat_pets_solver *s, const double *x0, int32_t
  * (zc may not be NULL; zn NULL -> device generator with seed + iteration). */
 rat_rc rat_pets_solve(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc,
                       const double *zn, const double *zu, uint64_t seed);
+
+/* ---- several devices behind one object -----------------------------------------------------------------
+ * Replaces the process fan-out of compute_cost (cross_entropy_bilevel_optimization.jl:180-192: `@sync ... @async remotecall_fetch(
+ * compute_value_worker, 2 + mod(i, nprocs - 1), ...)` over `addprocs` workers) and of the PETS cost (pets.jl:108-124): ONE host
+ * thread drives n_devices GPUs.  theta-samples are split in contiguous blocks (rat_shard_bounds), every device solves its block in
+ * one launch on its own HIP stream, and ONE ncclAllGather (RCCL over xGMI) of the per-sample costs, ordered on those streams, leaves
+ * cost[B] on every device; device 0's copy returns to the host.  Elite selection stays host arithmetic (rat_ce_update), the final
+ * solve at theta_opt runs on device 0.  Results do not depend on n_devices. */
+typedef struct rat_multi_s *rat_multi;
+/* contiguous block [lo, hi) of `rank` among `world` (blocks differ by at most one sample; device-free) */
+rat_rc  rat_shard_bounds(int64_t B, int32_t world, int32_t rank, int64_t *lo, int64_t *hi);
+/* devices: n_devices distinct HIP device indices, or NULL for 0 .. n_devices-1.  max_batch is the whole CE batch. */
+rat_rc  rat_create_multi(const rat_ileqg_opts *opts, int32_t max_batch, int32_t spec_eps, int32_t n_devices,
+                         const int32_t *devices, rat_multi *out);
+void    rat_multi_destroy(rat_multi m);
+int32_t rat_multi_n_devices(rat_multi m);
+rat_handle rat_multi_handle(rat_multi m, int32_t i);        /* the single-device handle of device i (e.g. rat_ce_set_stream on i = 0) */
+int32_t rat_multi_uses_rccl(rat_multi m);                   /* 1 when the costs travel through ncclAllGather */
+int64_t rat_multi_allgathers(rat_multi m);                  /* collectives issued so far (one per compute_cost batch) */
+rat_rc  rat_multi_problem_set(rat_multi m, const rat_problem_desc *desc);
+rat_rc  rat_multi_set_initial(rat_multi m, const double *x0, const double *u0);
+/* compute_cost (:173-195) on all devices; x0/u0 may be NULL (keep the last rat_multi_set_initial) */
+rat_rc  rat_multi_ce_compute_cost(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B,
+                                  double kl_bound, double *cost);
+/* step! (:252-335) / solve! (:364-415) with the cost evaluation on all devices; draws come from rat_multi_handle(m, 0) */
+rat_rc  rat_multi_ce_step(rat_multi m, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
+                          double *theta_out, double *cost_out);
+rat_rc  rat_multi_ce_solve(rat_multi m, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
+                           double *theta_opt, double *x, double *l, double *L, double *value,
+                           double *theta_min, double *theta_max);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 #define RAT_K_ROLLOUT   0

@@ -40,6 +40,8 @@ from .cross_entropy import (  # noqa: F401,E402
     compute_value_worker,
     get_positive_samples,
 )
+from . import multi  # noqa: F401,E402
+from .multi import MultiContext  # noqa: F401,E402
 from . import nelder_mead  # noqa: F401,E402
 from .nelder_mead import NelderMeadBilevelOptimizationSolver, compute_cost_worker  # noqa: F401,E402
 from .problems import FiniteHorizonGenerativeOptimalControlProblem, LQGenerativeProblem  # noqa: F401,E402

@@ -80,6 +80,9 @@ EXPORTS = [
     "rat_nm_compute_cost", "rat_nm_step", "rat_nm_solve", "rat_pets_problem_set", "rat_pets_initialize",
     "rat_pets_compute_cost", "rat_pets_sample_controls", "rat_pets_update", "rat_pets_step", "rat_pets_solve", "rat_profile_enable", "rat_profile_reset", "rat_profile_get",
     "rat_stream", "rat_layout_info",
+    "rat_shard_bounds", "rat_create_multi", "rat_multi_destroy", "rat_multi_n_devices", "rat_multi_handle", "rat_multi_uses_rccl",
+    "rat_multi_allgathers", "rat_multi_problem_set", "rat_multi_set_initial", "rat_multi_ce_compute_cost", "rat_multi_ce_step",
+    "rat_multi_ce_solve",
 ]
 
 _lib = None
@@ -99,6 +102,12 @@ def lib():
         _lib.rat_stream.argtypes = [C.c_void_p]
         _lib.rat_destroy.argtypes = [C.c_void_p]
         _lib.rat_destroy.restype = None
+        _lib.rat_multi_destroy.argtypes = [C.c_void_p]
+        _lib.rat_multi_destroy.restype = None
+        _lib.rat_multi_handle.argtypes = [C.c_void_p, C.c_int32]
+        _lib.rat_multi_handle.restype = C.c_void_p
+        _lib.rat_multi_allgathers.argtypes = [C.c_void_p]
+        _lib.rat_multi_allgathers.restype = C.c_int64
     return _lib
 
 

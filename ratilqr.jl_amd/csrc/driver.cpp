@@ -22,6 +22,7 @@
 
 static thread_local std::string g_err;
 static rat_rc fail(rat_rc rc, const std::string &msg) { g_err = msg; return rc; }
+void rat_set_error(const char *msg) { g_err = msg; }          // (multi.cpp reports through the same rat_last_error)
 
 #define HIPCHK(expr)                                                                                         \
     do {                                                                                                     \
@@ -44,6 +45,9 @@ struct rat_handle_s {
     bool fused_dual = true;          // ... with policy evaluation + following gain sweep paired in one pass (RATILQR_FUSED_DUAL=0: separate)
     int block_mode = -1;             // workgroup-per-sample solve kernel (solve_block_kernel): -1 auto, 0 never, 1 whenever it is supported (RATILQR_BLOCK)
     int block_max_b = 512;           // auto, E = 1: used for batches up to this size (RATILQR_BLOCK_MAX_B)
+    int n_cu = 256;                  // compute units of the device
+    int *d_census = nullptr;         // solve_block_kernel's (CU, SIMD) census of candidate waves (zero between launches)
+    bool block_shape = true;         // RATILQR_BLOCK_SHAPE=0: no census-based role assignment, no LDS-shaped workgroup spreading
     rat_ileqg_opts opts;
     OptsDev opd;
     int Bmax = 0, E = 1;
@@ -135,6 +139,10 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
     if (const char *e = getenv("RATILQR_BLOCK")) h->block_mode = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
     if (const char *e = getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = atoi(e);
+    if (const char *e = getenv("RATILQR_BLOCK_SHAPE")) h->block_shape = (e[0] != '0');
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
+    CREATECHK(hipMalloc((void **)&h->d_census, sizeof(int) * CENSUS_SLOTS * 4));
+    CREATECHK(hipMemset(h->d_census, 0, sizeof(int) * CENSUS_SLOTS * 4));
     if (const char *e = getenv("RATILQR_FUSED")) { if (e[0] == '0') h->block_mode = 0; }     // "round-based path": no single-launch solve at all
     CREATECHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
     CREATECHK(hipHostMalloc((void **)&h->h_io, std::max<size_t>((size_t)max_batch * 28, 64), hipHostMallocDefault));
@@ -162,6 +170,7 @@ extern "C" void rat_destroy(rat_handle h) {
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->d_hist) (void)hipFree(h->d_hist);
+    if (h->d_census) (void)hipFree(h->d_census);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -504,7 +513,12 @@ static Path pick_path(const rat_handle h, int B) {
         if (block_ok && (h->block_mode == 1 || B <= h->block_max_b)) return PATH_BLOCK;
         return PATH_FUSED;
     }
-    return block_ok ? PATH_BLOCK : PATH_ROUNDS;
+    // E > 1: a workgroup of NW waves per sample; the chip holds n_cu * (8 / NW) of them at once (two waves per SIMD).  Within one such
+    // generation the block kernel wins (no launches between phases, candidates side by side on idle SIMDs); beyond it the single-wave
+    // phases of a workgroup (gain sweeps) leave SIMDs idle that the round-based path fills with other samples (measured).
+    const int nw = h->E == 2 ? 3 : (h->E == 4 ? 5 : 8);
+    if (block_ok && (h->block_mode == 1 || B <= h->n_cu * (8 / nw))) return PATH_BLOCK;
+    return PATH_ROUNDS;
 }
 
 // outputs of a batch (device pointers, any may be null); cost = value + kl_bound / theta  (cross_entropy...jl:193)
@@ -531,6 +545,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.theta_in = theta_dev;
         fa.out_value = out.value; fa.out_status = out.status; fa.out_iters = out.iters; fa.out_ls = out.ls;
         fa.out_cost = out.cost; fa.kl_bound = out.kl_bound;
+        fa.census = h->block_shape ? h->d_census : nullptr; fa.n_cu = h->n_cu;
         prof_begin(h, path == PATH_BLOCK ? RAT_K_SOLVE_BLOCK : RAT_K_SOLVE_FUSED, B);
         if (path == PATH_BLOCK) launch_solve_block(fa, h->stream); else launch_solve_fused(fa, h->stream);
         prof_end(h);

@@ -39,7 +39,11 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     double *out_value;                 // [B] value (Inf for failures) or null
     int *out_status, *out_iters, *out_ls;   // [B] or null
     double *out_cost; double kl_bound; // [B] cost = value + kl_bound / theta  (cross_entropy_bilevel_optimization.jl:193) or null
+    // solve_block_kernel only:
+    int *census;                       // [CENSUS_SLOTS][4] heavy (candidate-0) waves resident per (CU, SIMD), or null: see solve_block_kernel
+    int n_cu;                          // compute units of the device (launch geometry: workgroups per CU by LDS size)
 };
+#define CENSUS_SLOTS 4096              /* (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID / HW_REG_XCC_ID: 4 + 3 + 1 + 4 bits */
 
 struct LinArgs {
     StateDev st;

@@ -1412,19 +1412,51 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
 //   * E > 1 candidates are evaluated inside the launch (line searches that really backtrack, BASELINE config 3).
 // Waves meet at workgroup barriers between phases; per-sample control state stays in the StateDev arrays as in the fused kernel.
 // =====================================================================================================
+// Which wave is which (E = 1, two waves): the wave of candidate 0 issues about twice the instructions of the gain wave (three rollouts
+// and three policy evaluations against two gain sweeps).  A workgroup's waves land on two different SIMDs, and at a full batch every SIMD
+// holds two waves of two different samples: if the dispatcher happens to put two candidate waves on one SIMD and two gain waves on
+// another (it does: consecutive workgroups start on the same SIMD), the first SIMD carries twice the work of the second and sets the
+// pace.  So the roles are handed out at run time: each workgroup looks up how many candidate waves its two SIMDs already host (a census
+// table indexed by the hardware CU / SIMD ids, kept with relaxed atomics: a heuristic, never a correctness matter) and gives the
+// candidate role to the wave on the less loaded SIMD.
+__device__ __forceinline__ int hw_cu_key() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // HW_REG_XCC_ID [3:0]
+    return (int)(((xcc & 15u) << 8) | ((hw >> 8) & 255u));                // < CENSUS_SLOTS
+}
+__device__ __forceinline__ int hw_simd_id() { return (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u); }
+
 template <int MODEL, bool CTV, bool WTV, int NW, bool GW, bool STG>
 __global__ __launch_bounds__(64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
     constexpr int E = GW ? NW - 1 : NW;          // candidate waves
     constexpr int WG = GW ? NW - 1 : 0;          // the wave that runs gain sweeps
     const int b = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const StateDev &st = fa.sw.st;
     __shared__ double wls_all[NW][WLS_SWEEP];
     __shared__ double shxu_all[NW][16];
     __shared__ double stg[STG ? STG_DOUBLES : 1];
-    double *const wls = wls_all[wave], *const shxu = shxu_all[wave];
-    if (threadIdx.x == 0) init_state_body(st, fa.sw.op, fa.theta_in, b);
+    __shared__ int s_simd[NW], s_swap;
+    double *const wls = wls_all[hwave], *const shxu = shxu_all[hwave];
+    int census_slot = -1;
+    if (NW == 2 && fa.census) {
+        if ((threadIdx.x & 63) == 0) s_simd[hwave] = hw_simd_id();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        init_state_body(st, fa.sw.op, fa.theta_in, b);
+        int swap = 0;
+        if (NW == 2 && fa.census) {
+            const int key = hw_cu_key() * 4;
+            const int c0 = __atomic_load_n(&fa.census[key + s_simd[0]], __ATOMIC_RELAXED), c1 = __atomic_load_n(&fa.census[key + s_simd[1]], __ATOMIC_RELAXED);
+            swap = (c1 < c0) ? 1 : 0;
+            census_slot = key + s_simd[swap];
+            atomicAdd(&fa.census[census_slot], 1);
+        }
+        s_swap = swap;
+    }
     __syncthreads();
+    const int wave = (NW == 2) ? (hwave ^ __builtin_amdgcn_readfirstlane(s_swap)) : hwave;      // role: 0 .. E-1 candidates, WG gain sweeps
     if (wave == 0) {                             // initialize!: open-loop rollout + linearise   (ileqg.jl:214-233)
         RolloutArgs ra = fa.ro; ra.mode = 0;
         rollin_body<MODEL, 0, CTV>(ra, b, shxu);
@@ -1476,7 +1508,25 @@ __global__ __launch_bounds__(64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
         __syncthreads();
     }
     __syncthreads();
-    if (threadIdx.x == 0) gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
+    if (threadIdx.x == 0) {
+        gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
+        if (census_slot >= 0) atomicSub(&fa.census[census_slot], 1);
+    }
+}
+
+// Workgroups per CU.  The register budget admits 8 / NW workgroups per CU, and the dispatcher fills a CU before it moves on only as
+// far as resources allow -- so a batch that needs fewer workgroups per CU than fit would crowd some CUs (two waves per SIMD) and leave
+// others empty.  The launch therefore asks for just enough extra (unused) dynamic LDS that ceil(B / n_cu) workgroups fit per CU and
+// no more: the batch spreads over the whole chip, one wave per SIMD as long as B * NW <= 4 n_cu.
+static unsigned shaping_lds_bytes(int B, int n_cu, int nw, size_t static_lds) {
+    const int kmax = 8 / nw;                                     // two waves per SIMD: 8 waves per CU
+    int k = (B + n_cu - 1) / (n_cu > 0 ? n_cu : 256);
+    if (k < 1) k = 1;
+    if (k >= kmax) return 0;
+    const size_t lds_cu = 160 * 1024;
+    size_t want = lds_cu / (size_t)(k + 1) + 512;                // k + 1 workgroups of this size do not fit ...
+    if (want > lds_cu / (size_t)k) want = lds_cu / (size_t)k;   // ... k do
+    return want > static_lds ? (unsigned)(want - static_lds) : 0u;
 }
 
 template <int NW, bool GW>
@@ -1484,7 +1534,16 @@ static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {
     const dim3 grid(fa.sw.st.B), block(64 * NW);
     const bool wtv = fa.sw.pb.W_tv != 0;
     const bool stg = fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST;
-#define BLOCK_LAUNCH(M, C, W, S) hipLaunchKernelGGL((solve_block_kernel<M, C, W, NW, GW, S>), grid, block, 0, s, fa)
+#define BLOCK_LAUNCH(M, C, W, S) do { \
+        auto kfn = solve_block_kernel<M, C, W, NW, GW, S>; \
+        static size_t static_lds = (size_t)-1; \
+        if (static_lds == (size_t)-1) { \
+            hipFuncAttributes at; \
+            static_lds = (hipFuncGetAttributes(&at, (const void *)kfn) == hipSuccess) ? at.sharedSizeBytes : 48 * 1024; \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)static_lds); \
+        } \
+        const unsigned dyn = fa.census ? shaping_lds_bytes(fa.sw.st.B, fa.n_cu, NW, static_lds) : 0u; \
+        hipLaunchKernelGGL(kfn, grid, block, dyn, s, fa); } while (0)
     if (fa.sw.pb.model == 1) {
         if (stg) {
             if (fa.sw.pb.cost_tv) { if (wtv) BLOCK_LAUNCH(1, true, true, true); else BLOCK_LAUNCH(1, true, false, true); }

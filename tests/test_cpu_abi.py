@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/ratilqr.h but not exported"
     assert declared == set(nv.EXPORTS)
-    assert lib.rat_version() == 100
+    assert lib.rat_version() == 200
 
 
 def test_defaults_match_reference_constructor():                    # ileqg.jl:191-194, ce.jl:100-116
@@ -129,3 +129,27 @@ def test_ce_update_has_the_if_elseif_theta_max_quirk():
     theta, cost = np.array([9.0, 0.45, 0.3]), np.array([np.inf, 3.0, 4.3])
     nv.check(L.rat_ce_update(C.byref(c), nv.P(theta), nv.P(cost), C.byref(redraw)))
     assert redraw.value == 0 and c.theta_min == 0.3 and c.theta_max == 0.0 and (c.mu_init, c.sigma_init) == (2.0, 4.0)
+
+
+def test_shard_bounds_in_c_match_the_python_layer():
+    """rat_shard_bounds (the block arithmetic rat_multi_* uses on the device side) == ratilqr.jl_amd.distributed.shard_bounds (what the
+    gloo world-size-2/3 tests exercise): contiguous, exhaustive, blocks differ by at most one sample."""
+    from ratilqr.jl_amd import distributed as rd
+    from ratilqr.jl_amd import multi
+    for B in (0, 1, 5, 7, 1000, 1024, 10000):
+        for world in (1, 2, 3, 8):
+            blocks = [multi.shard_bounds(B, world, r) for r in range(world)]
+            assert blocks == [rd.shard_bounds(B, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == B
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1 and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    L = nv.lib()
+    lo, hi = C.c_int64(), C.c_int64()
+    assert L.rat_shard_bounds(C.c_int64(10), C.c_int32(4), C.c_int32(4), C.byref(lo), C.byref(hi)) == 1      # rank out of range
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
+def test_create_multi_without_devices_fails_loudly():
+    m = C.c_void_p()
+    rc = nv.lib().rat_create_multi(None, 64, 1, 2, None, C.byref(m))
+    assert rc != 0 and not m.value
