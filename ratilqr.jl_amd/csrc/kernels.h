@@ -40,8 +40,7 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     int *out_status, *out_iters, *out_ls;   // [B] or null
     double *out_cost; double kl_bound; // [B] cost = value + kl_bound / theta  (cross_entropy_bilevel_optimization.jl:193) or null
     // solve_block_kernel only:
-    int *census;                       // [CENSUS_SLOTS][4] heavy (candidate-0) waves resident per (CU, SIMD), or null: see solve_block_kernel
-    int n_cu;                          // compute units of the device (launch geometry: workgroups per CU by LDS size)
+    int *census;                       // [CENSUS_SLOTS] per-CU workgroup tickets of the two-wave geometry, or null: see solve_block_kernel
 };
 #define CENSUS_SLOTS 4096              /* (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID / HW_REG_XCC_ID: 4 + 3 + 1 + 4 bits */
 

@@ -1412,13 +1412,14 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
 //   * E > 1 candidates are evaluated inside the launch (line searches that really backtrack, BASELINE config 3).
 // Waves meet at workgroup barriers between phases; per-sample control state stays in the StateDev arrays as in the fused kernel.
 // =====================================================================================================
-// Which wave is which (E = 1, two waves): the wave of candidate 0 issues about twice the instructions of the gain wave (three rollouts
-// and three policy evaluations against two gain sweeps).  A workgroup's waves land on two different SIMDs, and at a full batch every SIMD
-// holds two waves of two different samples: if the dispatcher happens to put two candidate waves on one SIMD and two gain waves on
-// another (it does: consecutive workgroups start on the same SIMD), the first SIMD carries twice the work of the second and sets the
-// pace.  So the roles are handed out at run time: each workgroup looks up how many candidate waves its two SIMDs already host (a census
-// table indexed by the hardware CU / SIMD ids, kept with relaxed atomics: a heuristic, never a correctness matter) and gives the
-// candidate role to the wave on the less loaded SIMD.
+// Where the waves of a two-wave workgroup land (E = 1; tools/ubench/placement.hip, profiles/r02_wave_placement.md).  The dispatcher deals
+// workgroups evenly over the CUs and puts a workgroup's waves on consecutive SIMDs of the cyclic order 0 -> 2 -> 1 -> 3, but the NEXT
+// workgroup on the same CU starts on the SIMD the previous one's wave 1 sits on: with two two-wave workgroups per CU (512 samples) one
+// SIMD hosts two waves and one hosts none.  PAD4 launches four waves per workgroup instead -- one per SIMD, always -- draws a ticket
+// from a per-CU counter (hardware CU id, one relaxed atomic per workgroup) and keeps the pair of SIMDs the ticket's parity names
+// ({0, 2} / {1, 3}); the other two waves exit at once.  Consecutive workgroups of a CU so use complementary SIMD pairs: 512 samples run
+// in 0.339 ms instead of 0.413 ms.  (The host uses it up to two workgroups per CU: the register slots of the waves that exit stay
+// charged to their workgroup until it ends.)  The ticket is a placement heuristic: whatever it returns, results are the same.
 __device__ __forceinline__ int hw_cu_key() {
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // HW_REG_XCC_ID [3:0]
@@ -1426,37 +1427,41 @@ __device__ __forceinline__ int hw_cu_key() {
 }
 __device__ __forceinline__ int hw_simd_id() { return (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u); }
 
-template <int MODEL, bool CTV, bool WTV, int NW, bool GW, bool STG>
-__global__ __launch_bounds__(64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
+template <int MODEL, bool CTV, bool WTV, int NW, bool GW, bool STG, bool PAD4>
+__global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
+    static_assert(!PAD4 || NW == 2, "PAD4 is the two-wave (E = 1) geometry");
     constexpr int E = GW ? NW - 1 : NW;          // candidate waves
     constexpr int WG = GW ? NW - 1 : 0;          // the wave that runs gain sweeps
+    constexpr int HWAVES = PAD4 ? 4 : NW;
     const int b = blockIdx.x;
     const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const StateDev &st = fa.sw.st;
-    __shared__ double wls_all[NW][WLS_SWEEP];
-    __shared__ double shxu_all[NW][16];
+    __shared__ double wls_all[HWAVES][WLS_SWEEP];
+    __shared__ double shxu_all[HWAVES][16];
     __shared__ double stg[STG ? STG_DOUBLES : 1];
-    __shared__ int s_simd[NW], s_swap;
     double *const wls = wls_all[hwave], *const shxu = shxu_all[hwave];
-    int census_slot = -1;
-    if (NW == 2 && fa.census) {
+    int wave = hwave;                            // role: 0 .. E-1 candidates, WG gain sweeps
+    if (PAD4) {
+        __shared__ int s_simd[4], s_role[4];
         if ((threadIdx.x & 63) == 0) s_simd[hwave] = hw_simd_id();
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        init_state_body(st, fa.sw.op, fa.theta_in, b);
-        int swap = 0;
-        if (NW == 2 && fa.census) {
-            const int key = hw_cu_key() * 4;
-            const int c0 = __atomic_load_n(&fa.census[key + s_simd[0]], __ATOMIC_RELAXED), c1 = __atomic_load_n(&fa.census[key + s_simd[1]], __ATOMIC_RELAXED);
-            swap = (c1 < c0) ? 1 : 0;
-            census_slot = key + s_simd[swap];
-            atomicAdd(&fa.census[census_slot], 1);
+        if (threadIdx.x == 0) {
+            const int ticket = atomicAdd(&fa.census[hw_cu_key()], 1);
+            const int odd = ticket & 1, flip = (ticket >> 1) & 1;
+            for (int w = 0; w < 4; ++w) {
+                const int sid = s_simd[w];
+                const bool in_pair = odd ? (sid == 1 || sid == 3) : (sid == 0 || sid == 2);
+                const bool first = odd ? (sid == 1) : (sid == 0);
+                s_role[w] = in_pair ? ((first != (flip != 0)) ? 0 : 1) : -1;
+            }
         }
-        s_swap = swap;
+        __syncthreads();
+        wave = __builtin_amdgcn_readfirstlane(s_role[hwave]);
+        if (wave < 0) return;                    // (an ended wave no longer takes part in the workgroup's barriers)
     }
+    const bool leader = (wave == 0) && ((threadIdx.x & 63) == 0);
+    if (leader) init_state_body(st, fa.sw.op, fa.theta_in, b);
     __syncthreads();
-    const int wave = (NW == 2) ? (hwave ^ __builtin_amdgcn_readfirstlane(s_swap)) : hwave;      // role: 0 .. E-1 candidates, WG gain sweeps
     if (wave == 0) {                             // initialize!: open-loop rollout + linearise   (ileqg.jl:214-233)
         RolloutArgs ra = fa.ro; ra.mode = 0;
         rollin_body<MODEL, 0, CTV>(ra, b, shxu);
@@ -1471,7 +1476,7 @@ __global__ __launch_bounds__(64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
     }
     __syncthreads();
     if (GW) {
-        if (threadIdx.x == 0) commit_init_body(st, b);
+        if (leader) commit_init_body(st, b);
         __syncthreads();
     }
     for (int guard = 0; guard < fa.max_rounds; ++guard) {
@@ -1504,29 +1509,11 @@ __global__ __launch_bounds__(64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) ls_select_body(st, fa.sw.op, b, nullptr);
+        if (leader) ls_select_body(st, fa.sw.op, b, nullptr);
         __syncthreads();
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
-        if (census_slot >= 0) atomicSub(&fa.census[census_slot], 1);
-    }
-}
-
-// Workgroups per CU.  The register budget admits 8 / NW workgroups per CU, and the dispatcher fills a CU before it moves on only as
-// far as resources allow -- so a batch that needs fewer workgroups per CU than fit would crowd some CUs (two waves per SIMD) and leave
-// others empty.  The launch therefore asks for just enough extra (unused) dynamic LDS that ceil(B / n_cu) workgroups fit per CU and
-// no more: the batch spreads over the whole chip, one wave per SIMD as long as B * NW <= 4 n_cu.
-static unsigned shaping_lds_bytes(int B, int n_cu, int nw, size_t static_lds) {
-    const int kmax = 8 / nw;                                     // two waves per SIMD: 8 waves per CU
-    int k = (B + n_cu - 1) / (n_cu > 0 ? n_cu : 256);
-    if (k < 1) k = 1;
-    if (k >= kmax) return 0;
-    const size_t lds_cu = 160 * 1024;
-    size_t want = lds_cu / (size_t)(k + 1) + 512;                // k + 1 workgroups of this size do not fit ...
-    if (want > lds_cu / (size_t)k) want = lds_cu / (size_t)k;   // ... k do
-    return want > static_lds ? (unsigned)(want - static_lds) : 0u;
+    if (leader) gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
 }
 
 template <int NW, bool GW>
@@ -1535,15 +1522,8 @@ static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {
     const bool wtv = fa.sw.pb.W_tv != 0;
     const bool stg = fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST;
 #define BLOCK_LAUNCH(M, C, W, S) do { \
-        auto kfn = solve_block_kernel<M, C, W, NW, GW, S>; \
-        static size_t static_lds = (size_t)-1; \
-        if (static_lds == (size_t)-1) { \
-            hipFuncAttributes at; \
-            static_lds = (hipFuncGetAttributes(&at, (const void *)kfn) == hipSuccess) ? at.sharedSizeBytes : 48 * 1024; \
-            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)static_lds); \
-        } \
-        const unsigned dyn = fa.census ? shaping_lds_bytes(fa.sw.st.B, fa.n_cu, NW, static_lds) : 0u; \
-        hipLaunchKernelGGL(kfn, grid, block, dyn, s, fa); } while (0)
+        if (NW == 2 && fa.census) hipLaunchKernelGGL((solve_block_kernel<M, C, W, NW, GW, S, NW == 2>), grid, dim3(256), 0, s, fa); \
+        else hipLaunchKernelGGL((solve_block_kernel<M, C, W, NW, GW, S, false>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.model == 1) {
         if (stg) {
             if (fa.sw.pb.cost_tv) { if (wtv) BLOCK_LAUNCH(1, true, true, true); else BLOCK_LAUNCH(1, true, false, true); }
