@@ -169,6 +169,20 @@ rat_rc rat_dp_policy_eval(rat_handle h, const double *q, const double *qv, const
                           const double *L, const double *dl, double theta, double mu, int32_t *status,
                           double *s, double *sv, double *S, double *g, double *G, double *H);
 
+/* Batched forms of the two sweeps on CALLER-SUPPLIED tiles -- the batch path of problems whose f, c, h are arbitrary host closures
+ * (optimal_control_problems.jl:67-73; ileqg.jl:265-273, :302-311): the host rolls out and linearises every sample, the device runs the
+ * B Riccati sweeps of one CE batch in one launch (one wavefront per sample, the solver's own kernels).  Every array holds B consecutive
+ * ApproximationResults / gain histories in the single-sample layouts above (sample slowest); theta[B], mu[B], delta[B] per sample.
+ *   rat_dp_gain_sweep_batch  : solve_approximate_dp! per sample (mu restarts inside): in/out mu, delta; out L, dl, status[b]
+ *   rat_dp_policy_eval_batch : solve_approximate_dp with dl = nothing per sample (initialize!, line-search candidates): out value[b] =
+ *                              s_array[1] (+Inf and status RAT_ST_M_NOT_PD_GAIN where the reference's @assert fires) */
+rat_rc rat_dp_gain_sweep_batch(rat_handle h, int64_t B, const double *q, const double *qv, const double *Q, const double *r,
+                               const double *R, const double *P, const double *A, const double *Bm, const double *theta,
+                               double *mu, double *delta, double *L, double *dl, int32_t *status);
+rat_rc rat_dp_policy_eval_batch(rat_handle h, int64_t B, const double *q, const double *qv, const double *Q, const double *r,
+                                const double *R, const double *P, const double *A, const double *Bm, const double *L,
+                                const double *theta, const double *mu, double *value, int32_t *status);
+
 /* ---- Cross-Entropy loop over theta (RAT iLQR) -------------------------------------------------- */
 
 /* Replaces CrossEntropyBilevelOptimizationSolver (cross_entropy_bilevel_optimization.jl:70-127).

@@ -327,6 +327,34 @@ function solve_approximate_dp(s::ILEQGSolver, ap::ApproximationResult, L_array::
     dp_result(b)
 end
 
+# ---- batched sweeps on host-built tiles: the CE batch path of problems the host linearises itself (closures + ForwardDiff) ----------
+stack_ap(aps::Vector{ApproximationResult}) = (reduce(vcat, [a.q_array for a in aps]), cat([flat(a.q_vec_array) for a in aps]...; dims=3),
+    cat([flat(a.Q_array) for a in aps]...; dims=4), cat([flat(a.r_array) for a in aps]...; dims=3), cat([flat(a.R_array) for a in aps]...; dims=4),
+    cat([flat(a.P_array) for a in aps]...; dims=4), cat([flat(a.A_array) for a in aps]...; dims=4), cat([flat(a.B_array) for a in aps]...; dims=4))
+
+"solve_approximate_dp! for B samples in one launch (tiles from `approximate_model` of each sample): returns (L_arrays, dl_arrays, μ, Δ, status)"
+function solve_approximate_dp_batch!(s::ILEQGSolver, aps::Vector{ApproximationResult}, θ::Vector{Float64}, μ::Vector{Float64}, Δ::Vector{Float64})
+    B = length(aps); n, m = size(aps[1].B_array[1]); N = length(aps[1].B_array)
+    t = stack_ap(aps); mu = copy(μ); de = copy(Δ)
+    L = Array{Float64}(undef, m, n, N, B); dl = Array{Float64}(undef, m, N, B); st = Vector{Int32}(undef, B)
+    check(ccall((:rat_dp_gain_sweep_batch, LIB), Int32,
+                (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                s.h.ptr, B, t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], θ, mu, de, L, dl, st))
+    [unflat_mat(L[:, :, :, b]) for b in 1:B], [unflat_vec(dl[:, :, b]) for b in 1:B], mu, de, st
+end
+"solve_approximate_dp (dl = nothing) for B samples in one launch: returns (s_array[1] per sample, Inf where M is not PD; status)"
+function solve_approximate_dp_batch(s::ILEQGSolver, aps::Vector{ApproximationResult}, L_arrays::Vector{Vector{Matrix{Float64}}},
+                                    θ::Vector{Float64}, μ::Vector{Float64})
+    B = length(aps); t = stack_ap(aps)
+    L = cat([flat(Lb) for Lb in L_arrays]...; dims=4); value = Vector{Float64}(undef, B); st = Vector{Int32}(undef, B)
+    check(ccall((:rat_dp_policy_eval_batch, LIB), Int32,
+                (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                s.h.ptr, B, t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], L, θ, μ, value, st))
+    value, st
+end
+
 "increase_μ_and_Δ! -- ileqg.jl:471-474"
 function increase_μ_and_Δ!(s::ILEQGSolver)
     s.Δ = max(s.Δ_0, s.Δ * s.Δ_0)
@@ -748,7 +776,7 @@ end
 export OptimalControlProblem, LQRiskSensitiveProblem, PowerLawRiskSensitiveProblem, LQGenerativeProblem,
        simulate_dynamics, simulate_dynamics_noisy, integrate_cost, ILEQGSolver, initialize!, ApproximationResult, approximate_model,
        DynamicProgrammingResult, solve_approximate_dp!, solve_approximate_dp, increase_μ_and_Δ!, decrease_μ_and_Δ!, line_search!, step!, solve!,
-       solve_batch, CrossEntropyBilevelOptimizationSolver, compute_value_worker, compute_cost, compute_cost_serial, get_positive_samples,
+       solve_batch, solve_approximate_dp_batch!, solve_approximate_dp_batch, CrossEntropyBilevelOptimizationSolver, compute_value_worker, compute_cost, compute_cost_serial, get_positive_samples,
        set_initial!, compute_cost_dev!, NelderMeadBilevelOptimizationSolver, compute_cost_worker, CrossEntropyDirectOptimizationSolver,
        shard_bounds
 end

@@ -456,3 +456,121 @@ class PetsSolver:
         rc = lib().orc_pets_step(C.byref(self.c), C.byref(G.c), _p(np.ascontiguousarray(x0, float)), C.c_int(int(use_true_model)),
                                  _p(zc), _p(zn), _p(zu) if zu is not None else None, _p(ctrl), _p(cost))
         return rc, ctrl, cost
+
+
+# ---- generic closures: the reference's own solve! loop over host closures, sweeps by the C oracle ----------------
+class ClosureProblem:
+    """FiniteHorizonRiskSensitiveOptimalControlProblem(f, c, h, W, N) with arbitrary Python closures (optimal_control_problems.jl:67-73).
+    jac(x, u) -> (A, B), cost_derivs(k, x, u) -> (q_vec, Q, r_vec, R, P), term_derivs(x) -> (q_vec, Q) stand for the ForwardDiff closures
+    of ileqg.jl:265-273 (exact derivatives supplied by the test)."""
+
+    def __init__(self, f, c, h, W, N, n, m, jac, cost_derivs, term_derivs):
+        self.f, self.c, self.h, self.W, self.N, self.n, self.m = f, c, h, W, int(N), int(n), int(m)
+        self.jac, self.cost_derivs, self.term_derivs = jac, cost_derivs, term_derivs
+
+
+def approx_from_arrays(shape, q, qv, Q, r, R, P, A, B, W) -> Approx:
+    """An orc_approx filled from ApproximationResult arrays of natural (time, row, col) shapes; `shape` has n, m, N."""
+    ap = Approx(shape)
+    a = ap.ptr.contents
+    for dst, src in ((a.q, np.ascontiguousarray(q, float)), (a.qv, np.ascontiguousarray(qv, float).ravel()), (a.Q, _cm3(Q)),
+                     (a.r, np.ascontiguousarray(r, float).ravel()), (a.R, _cm3(R)), (a.P, _cm3(P)), (a.A, _cm3(A)), (a.B, _cm3(B)),
+                     (a.W, _cm3(W))):
+        C.memmove(dst, src.ctypes.data, src.nbytes)
+    return ap
+
+
+def closure_approximate_model(cp: ClosureProblem, u, x) -> Approx:                      # approximate_model  ileqg.jl:258-322
+    n, m, N = cp.n, cp.m, cp.N
+    q, qv, Q = np.zeros(N + 1), np.zeros((N + 1, n)), np.zeros((N + 1, n, n))
+    r, R, P = np.zeros((N, m)), np.zeros((N, m, m)), np.zeros((N, m, n))
+    A, B, W = np.zeros((N, n, n)), np.zeros((N, n, m)), np.zeros((N, n, n))
+    for k in range(N):                                                                   # k is the reference's 0-based time (:284-313)
+        q[k] = cp.c(k, x[k], u[k])
+        qv[k], Q[k], r[k], R[k], P[k] = cp.cost_derivs(k, x[k], u[k])
+        A[k], B[k] = cp.jac(x[k], u[k])
+        W[k] = cp.W(k)
+    q[N] = cp.h(x[N])
+    qv[N], Q[N] = cp.term_derivs(x[N])
+    return approx_from_arrays(cp, q, qv, Q, r, R, P, A, B, W)
+
+
+def closure_solve(cp: ClosureProblem, x0, u0, theta, mu_min=1e-6, delta_0=2.0, lam=0.5, d=1e-2, iter_max=100, eps_init=1.0, eps_min=1e-6,
+                  adaptive_eps_init=False):
+    """solve!(ileqg, problem, x_0, u_array; theta) (ileqg.jl:635-659) statement by statement over host closures:
+    initialize! (:214-236), step! (:598-613), line_search! (:494-592); the sweeps are orc_dp_gain / orc_dp_eval.
+    Returns dict(status, value, x, l, L, iters, ls_evals, eps_history)."""
+    n, m, N = cp.n, cp.m, cp.N
+    sqrt_eps = 1.4901161193847656e-8
+
+    def rollout_open(x0, u):
+        x = np.zeros((N + 1, n)); x[0] = x0
+        for t in range(N):
+            x[t + 1] = cp.f(x[t], u[t])
+        return x
+
+    def rollout_fb(xbar, l, L):
+        xn, un = np.zeros((N + 1, n)), np.zeros((N, m)); xn[0] = xbar[0]
+        for t in range(N):
+            un[t] = l[t] + L[t] @ (xn[t] - xbar[t])
+            xn[t + 1] = cp.f(xn[t], un[t])
+        return xn, un
+
+    def isapprox(a, b):
+        if a == b:
+            return True
+        if not (np.isfinite(a) and np.isfinite(b)):
+            return False
+        return abs(a - b) <= sqrt_eps * max(abs(a), abs(b))
+
+    out = dict(status=0, value=np.inf, iters=0, ls_evals=0, eps_history=[])
+    mu, delta, d_cur, eps_i = 0.0, delta_0, np.inf, eps_init                              # :216-219
+    x = rollout_open(np.asarray(x0, float), np.asarray(u0, float))                        # :225
+    l, L = np.array(u0, float), np.zeros((N, m, n))                                       # :228-232
+    rc, dp = dp_eval(cp, closure_approximate_model(cp, l, x), L, None, theta, mu)         # :233-234
+    if rc:
+        out["status"] = 1
+        return out
+    value = dp["s"][0]
+    it = 0
+    while True:
+        it += 1                                                                           # step!  :599
+        rc, L, dl, _, mu, delta = dp_gain(cp, closure_approximate_model(cp, l, x), theta, mu, delta, mu_min, delta_0)   # :604-611
+        if rc:
+            out.update(status=2 if rc == 2 else 5, iters=it)
+            return out
+        eps, count = eps_i, 0                                                             # line_search!  :502
+        while True:
+            count += 1
+            out["ls_evals"] += 1
+            if count > 4000:
+                out.update(status=7, iters=it)
+                return out
+            xn, un = rollout_fb(x, l + eps * dl, L)                                       # :509-519
+            rc, dpn = dp_eval(cp, closure_approximate_model(cp, un, xn), L, None, theta, mu)   # :520-528
+            if rc:
+                eps *= lam                                                                # :529-535
+                continue
+            new = dpn["s"][0]
+            out["eps_history"].append((eps, new - value))                                 # :537
+            if not (isapprox(new, value) or new < value):                                 # :538
+                eps *= lam                                                                # :557
+                if not eps < eps_min:
+                    continue
+            d_cur = float(np.max(np.linalg.norm(l - un, axis=1)))                         # :539 / :559
+            value, x, l = new, xn, un
+            break
+        if adaptive_eps_init:                                                             # :582-591
+            if count == 1:
+                eps_i = min(eps_init, eps / lam)
+            else:
+                while eps < eps_min:
+                    eps = eps / lam
+                eps_i = eps
+        if d > d_cur and mu <= mu_min:                                                    # :642
+            break
+        if it == iter_max:                                                                # :648
+            out["status"] = 3
+            break
+    out.update(value=value, x=x, l=l, L=L, iters=it)
+    return out

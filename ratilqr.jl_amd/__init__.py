@@ -32,7 +32,7 @@ from .ileqg import (  # noqa: F401,E402
 )
 from .ileqg import initialize_ as initialize_ileqg_  # noqa: F401,E402
 from . import ileqg, cross_entropy  # noqa: F401,E402
-from .generic import GenericRiskSensitiveProblem, GenericContext  # noqa: F401,E402
+from .generic import GenericRiskSensitiveProblem, GenericContext, solve_closure_batch  # noqa: F401,E402
 from .cross_entropy import (  # noqa: F401,E402
     CrossEntropyBilevelOptimizationSolver,
     compute_cost,

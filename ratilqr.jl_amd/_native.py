@@ -80,6 +80,7 @@ EXPORTS = [
     "rat_nm_compute_cost", "rat_nm_step", "rat_nm_solve", "rat_pets_problem_set", "rat_pets_initialize",
     "rat_pets_compute_cost", "rat_pets_sample_controls", "rat_pets_update", "rat_pets_step", "rat_pets_solve", "rat_profile_enable", "rat_profile_reset", "rat_profile_get",
     "rat_stream", "rat_layout_info",
+    "rat_dp_gain_sweep_batch", "rat_dp_policy_eval_batch",
     "rat_shard_bounds", "rat_create_multi", "rat_multi_destroy", "rat_multi_n_devices", "rat_multi_handle", "rat_multi_uses_rccl",
     "rat_multi_allgathers", "rat_multi_problem_set", "rat_multi_set_initial", "rat_multi_ce_compute_cost", "rat_multi_ce_step",
     "rat_multi_ce_solve",

@@ -109,6 +109,10 @@ def compute_value_worker(ce_solver, problem, x, u_array, theta):             # c
 
 def compute_cost(ce_solver, problem, x, u_array, theta_array, kl_bound):     # compute_cost  :173-195
     theta = nv.f64(theta_array)
+    if getattr(problem, "model", 0) == 0:            # closure problem: host rollouts / linearisation, the batch's sweeps in single launches
+        from .generic import solve_closure_batch
+        value, _, _, _ = solve_closure_batch(problem, x, u_array, theta, opts=ce_solver.ileqg_opts)
+        return value + kl_bound / theta
     ctx = ce_solver.context(problem)
     if theta.size > ctx.max_batch:
         ce_solver._ctx = ctx = Context(problem, ce_solver.ileqg_opts, max_batch=theta.size, spec_eps=ce_solver.spec_eps,

@@ -1080,6 +1080,102 @@ extern "C" rat_rc rat_dp_policy_eval(rat_handle h, const double *q, const double
     return unpack_dump(h, s, sv, S, g, G, H);
 }
 
+// ---- batched sweeps on caller-supplied tiles (generic closures: the host linearises, the device sweeps) -------------------------
+// B ApproximationResults, sample slowest (q[B][N+1], qv[B][n(N+1)], ...): packed into the tile bundles of samples 0..B-1 and swept by
+// the SAME kernels the solver uses (sweep_kernel<gain> / sweep_kernel<eval>), one wavefront per sample.
+static rat_rc upload_tiles_batch(rat_handle h, StateDev &st, int64_t B, bool candidate, const double *q, const double *qv, const double *Q,
+                                 const double *r, const double *R, const double *P, const double *A, const double *Bm) {
+    const int n = h->n, m = h->m, N = h->N;
+    const size_t ts = (size_t)st.tile_stride;
+    std::vector<double> host((size_t)B * ts), tp;
+    for (int64_t b = 0; b < B; ++b) {
+        pack_tiles(h, q + b * (N + 1), qv + b * (size_t)n * (N + 1), Q + b * (size_t)n * n * (N + 1), r + b * (size_t)m * N,
+                   R + b * (size_t)m * m * N, P + b * (size_t)m * n * N, A + b * (size_t)n * n * N, Bm + b * (size_t)n * m * N, tp);
+        memcpy(&host[(size_t)b * ts], tp.data(), ts * 8);
+    }
+    if (st.tile_alias) {                                  // one bundle per sample, contiguous
+        HIPCHK(hipMemcpyAsync(st.tiles, host.data(), host.size() * 8, hipMemcpyHostToDevice, h->stream));
+    } else {                                              // bundle of slot (nominal 0 | candidate 0) of every sample
+        for (int64_t b = 0; b < B; ++b) {
+            const long slot = candidate ? cand_slot((int)b, 0, 0, st.E) : (long)b * (st.E + 1);
+            HIPCHK(hipMemcpyAsync(st.tiles + (size_t)slot * ts, &host[(size_t)b * ts], ts * 8, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));              // (host staging buffer goes out of scope)
+    return RAT_OK;
+}
+
+static rat_rc batch_state(rat_handle h, int64_t B, const double *theta, const double *mu, const double *delta, StateDev *out) {
+    if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
+    if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");
+    HIPCHK(hipSetDevice(h->device));
+    StateDev st = h->st; st.B = (int)B;
+    HIPCHK(hipMemcpyAsync(h->d_theta, theta, B * 8, hipMemcpyHostToDevice, h->stream));
+    launch_init_state(st, h->opd, h->d_theta, h->stream);            // status RUNNING, slot_nom 0, lsel 0, ls_active 0
+    HIPCHK(hipMemcpyAsync(st.mu, mu, B * 8, hipMemcpyHostToDevice, h->stream));
+    if (delta) HIPCHK(hipMemcpyAsync(st.delta, delta, B * 8, hipMemcpyHostToDevice, h->stream));
+    *out = st;
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_dp_gain_sweep_batch(rat_handle h, int64_t B, const double *q, const double *qv, const double *Q, const double *r,
+                                          const double *R, const double *P, const double *A, const double *Bm, const double *theta,
+                                          double *mu, double *delta, double *L, double *dl, int32_t *status) {
+    if (!h || !q || !qv || !Q || !r || !R || !P || !A || !Bm || !theta || !mu || !delta) return fail(RAT_ERR_ARG, "null");
+    StateDev st;
+    rat_rc rc = batch_state(h, B, theta, mu, delta, &st);
+    if (rc) return rc;
+    if ((rc = upload_tiles_batch(h, st, B, false, q, qv, Q, r, R, P, A, Bm))) return rc;
+    launch_sweep(sweep_args(h, st, 0), (int)B, true, false, h->stream);                  // solve_approximate_dp! per sample, mu restarts inside
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> sth((size_t)B);
+    HIPCHK(hipMemcpy(mu, st.mu, B * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(delta, st.delta, B * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sth.data(), st.status, B * 4, hipMemcpyDeviceToHost));
+    const int n = h->n, m = h->m, N = h->N;
+    std::vector<double> Lp((size_t)B * N * LSTR), dlp((size_t)B * N * USTR), Lone((size_t)N * LSTR), dlone((size_t)N * USTR);
+    HIPCHK(hipMemcpy(Lp.data(), st.L, Lp.size() * 8, hipMemcpyDeviceToHost));             // half 0 (lsel = 0 after init)
+    HIPCHK(hipMemcpy(dlp.data(), st.dl, dlp.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t b = 0; b < B; ++b) {
+        if (status) status[b] = (sth[(size_t)b] == ST_RUNNING) ? 0 : sth[(size_t)b];
+        if (L) { Lone.assign(Lp.begin() + (size_t)b * N * LSTR, Lp.begin() + (size_t)(b + 1) * N * LSTR); unpad_L(h, Lone, L + (size_t)b * m * n * N); }
+        if (dl) { dlone.assign(dlp.begin() + (size_t)b * N * USTR, dlp.begin() + (size_t)(b + 1) * N * USTR); unpad_u(h, dlone, dl + (size_t)b * m * N); }
+    }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_dp_policy_eval_batch(rat_handle h, int64_t B, const double *q, const double *qv, const double *Q, const double *r,
+                                           const double *R, const double *P, const double *A, const double *Bm, const double *L,
+                                           const double *theta, const double *mu, double *value, int32_t *status) {
+    if (!h || !q || !qv || !Q || !r || !R || !P || !A || !Bm || !L || !theta || !mu || !value) return fail(RAT_ERR_ARG, "null");
+    StateDev st;
+    rat_rc rc = batch_state(h, B, theta, mu, nullptr, &st);
+    if (rc) return rc;
+    st.E = 1;                                             // one candidate per sample (candidate 0), whatever the handle speculates
+    if (h->st.E != 1 && !st.tile_alias) return fail(RAT_ERR_UNSUPPORTED, "batched tile sweeps need a handle created with spec_eps = 1");
+    if ((rc = upload_tiles_batch(h, st, B, true, q, qv, Q, r, R, P, A, Bm))) return rc;
+    const int n = h->n, m = h->m, N = h->N;
+    std::vector<double> Lp((size_t)B * N * LSTR, 0.0), Lone;
+    for (int64_t b = 0; b < B; ++b) {
+        pad_L(h, L + (size_t)b * m * n * N, Lone);
+        memcpy(&Lp[(size_t)b * N * LSTR], Lone.data(), Lone.size() * 8);
+    }
+    HIPCHK(hipMemcpyAsync(st.L, Lp.data(), Lp.size() * 8, hipMemcpyHostToDevice, h->stream));
+    std::vector<int> ones((size_t)B, 1);
+    HIPCHK(hipMemcpyAsync(st.ls_active, ones.data(), B * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(st.flag_c, 0, B * 4, h->stream));
+    launch_sweep(sweep_args(h, st, 1), (int)B, false, false, h->stream);                 // solve_approximate_dp (dl = nothing) per sample
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> fl((size_t)B);
+    HIPCHK(hipMemcpy(value, st.value_c, B * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fl.data(), st.flag_c, B * 4, hipMemcpyDeviceToHost));
+    for (int64_t b = 0; b < B; ++b) {
+        if (status) status[b] = fl[(size_t)b] ? RAT_ST_M_NOT_PD_GAIN : 0;
+        if (fl[(size_t)b]) value[b] = INFINITY;
+    }
+    return RAT_OK;
+}
+
 // ---- Cross-Entropy loop -----------------------------------------------------------------------------------
 extern "C" void rat_ce_default(rat_ce_solver *c) {                       // :100-127
     memset(c, 0, sizeof(*c));

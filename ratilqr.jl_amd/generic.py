@@ -87,8 +87,9 @@ class GenericContext(il.Context):
         n, m, N = problem.n, problem.m, problem.N
         carrier = LQRiskSensitiveProblem(np.zeros((n, n)), np.zeros((n, m)), Q=np.zeros((n, n)), R=np.eye(m), N=N,
                                          W=problem.Wtab if problem.W_tv else problem.Wtab[0])
-        super().__init__(carrier, opts, max_batch=1, spec_eps=1, device=device)
+        super().__init__(carrier, opts, max_batch=max(1, int(max_batch)), spec_eps=1, device=device)
         self.generic = problem
+        self._opts = opts
 
     def rollout_open(self, x0, u):                                   # simulate_dynamics  ileqg.jl:18-38
         p = self.generic
@@ -130,6 +131,47 @@ class GenericContext(il.Context):
     def solve(self, x0, u, theta, hist_cap=4096):
         raise NotImplementedError("generic closures are solved by ileqg.solve_ (host-driven initialize!/step! loop)")
 
+    # ---- batched sweeps on host-built tiles (rat_dp_*_batch): the CE batch path of closure problems --------------------------------
+    @staticmethod
+    def _stack(aps):
+        from . import _native as nv
+        cat = np.concatenate
+        return [cat([nv.f64(a.q_array) for a in aps]), cat([nv.f64(a.q_vec_array).ravel() for a in aps]), cat([nv.cm3(a.Q_array) for a in aps]),
+                cat([nv.f64(a.r_array).ravel() for a in aps]), cat([nv.cm3(a.R_array) for a in aps]), cat([nv.cm3(a.P_array) for a in aps]),
+                cat([nv.cm3(a.A_array) for a in aps]), cat([nv.cm3(a.B_array) for a in aps])]
+
+    def _ensure_batch(self, B):
+        """The carrier handle is created for one sample; a batch needs device buffers for B of them."""
+        if B > self.max_batch:
+            il.Context.__init__(self, self.problem, self._opts, max_batch=B, spec_eps=1, device=self.device)
+
+    def dp_gain_sweep_batch(self, aps, theta, mu, delta):
+        """solve_approximate_dp! (ileqg.jl:341-406) of B samples in ONE launch.  Returns status (B,), L (B, N, m, n), dl (B, N, m), mu, delta."""
+        import ctypes as C
+        from . import _native as nv
+        B, n, m, N = len(aps), self.n, self.m, self.N
+        self._ensure_batch(B)
+        bufs = self._stack(aps)
+        th, mu_c, de_c = nv.f64(theta).copy(), nv.f64(mu).copy(), nv.f64(delta).copy()
+        Lb, dl, st = np.zeros(B * m * n * N), np.zeros((B, N, m)), np.zeros(B, np.int32)
+        nv.check(nv.lib().rat_dp_gain_sweep_batch(self.h, C.c_int64(B), *[nv.P(b) for b in bufs], nv.P(th), nv.P(mu_c), nv.P(de_c), nv.P(Lb),
+                                                  nv.P(dl), nv.PI(st)))
+        L = np.stack([nv.from_cm3(Lb[b * m * n * N:(b + 1) * m * n * N], N, m, n) for b in range(B)])
+        return st, L, dl, mu_c, de_c
+
+    def dp_policy_eval_batch(self, aps, Ls, theta, mu):
+        """solve_approximate_dp with dl = nothing (ileqg.jl:412-465) of B samples in ONE launch: value (Inf where M is not PD), status."""
+        import ctypes as C
+        from . import _native as nv
+        B = len(aps)
+        self._ensure_batch(B)
+        bufs = self._stack(aps)
+        Lc = np.concatenate([nv.cm3(L) for L in Ls])
+        val, st = np.zeros(B), np.zeros(B, np.int32)
+        nv.check(nv.lib().rat_dp_policy_eval_batch(self.h, C.c_int64(B), *[nv.P(b) for b in bufs], nv.P(Lc), nv.P(nv.f64(theta)), nv.P(nv.f64(mu)),
+                                                   nv.P(val), nv.PI(st)))
+        return val, st
+
     # The remaining device-family entry points of Context would run on the CARRIER (A = 0, B = 0, R = I), not on the user's f, c, h:
     # they fail loudly instead.
     def _carrier_only(self, name):
@@ -153,3 +195,88 @@ class GenericContext(il.Context):
 
     def set_initial(self, *a, **k):
         self._carrier_only("set_initial")
+
+
+def solve_closure_batch(problem: GenericRiskSensitiveProblem, x_0, u_array, theta_array, opts=None, ctx: GenericContext | None = None, **kw):
+    """B complete solve!s (ileqg.jl:635-659) of a closure problem, one per theta -- what compute_cost fans out over workers
+    (cross_entropy_bilevel_optimization.jl:144-192) -- with every Riccati sweep of the batch in ONE device launch.
+
+    Per sample this is the reference's own sequence (initialize!, then step! = approximate_model -> solve_approximate_dp! -> line_search!
+    until convergence); the samples advance in lockstep rounds only so that their sweeps can share launches: the host evaluates the
+    closures (rollouts, linearisation) of every live sample, the device sweeps all of them at once.  Results equal B separate
+    ileqg.solve_ calls.  Returns value (Inf where the reference would throw), status, iters, ls_evals."""
+    from . import _native as nv
+    th = nv.f64(theta_array)
+    B, N, n, m = th.size, problem.N, problem.n, problem.m
+    o = opts if opts is not None else il.make_opts(**kw)
+    ctx = ctx or GenericContext(problem, o, max_batch=B)
+    x0 = np.asarray(x_0, float)
+    status, value = np.full(B, -1, np.int32), np.full(B, np.inf)
+    iters, ls_evals = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    mu, delta, d_cur, eps_i = np.zeros(B), np.full(B, o.delta_0), np.full(B, np.inf), np.full(B, o.eps_init)
+    # initialize!: one rollout / linearisation serves every sample (theta only enters the sweep)
+    xs0 = ctx.rollout_open(x0, u_array)
+    ap0 = ctx.approximate_model(np.asarray(u_array, float), xs0)
+    x = [xs0.copy() for _ in range(B)]
+    l = [np.array(u_array, float) for _ in range(B)]
+    L = [np.zeros((N, m, n)) for _ in range(B)]
+    v, st = ctx.dp_policy_eval_batch([ap0] * B, L, th, mu)
+    status[st != 0] = nv.ST_M_NOT_PD_INIT
+    value = np.where(st == 0, v, np.inf)
+    dl = [None] * B
+    eps, count, in_ls = eps_i.copy(), np.zeros(B, int), np.zeros(B, bool)
+    while True:
+        live = np.flatnonzero(status == -1)
+        if live.size == 0:
+            break
+        need = [b for b in live if not in_ls[b]]
+        if need:                                                                  # step!: approximate_model + solve_approximate_dp!
+            iters[need] += 1
+            aps = [ctx.approximate_model(l[b], x[b]) for b in need]
+            stg, Lg, dlg, mug, deg = ctx.dp_gain_sweep_batch(aps, th[need], mu[need], delta[need])
+            for i, b in enumerate(need):
+                mu[b], delta[b] = mug[i], deg[i]
+                if stg[i] != 0:
+                    status[b], value[b] = stg[i], np.inf
+                    continue
+                L[b], dl[b] = Lg[i], dlg[i]
+                eps[b], count[b], in_ls[b] = eps_i[b], 0, True
+        cand = [b for b in np.flatnonzero(status == -1) if in_ls[b]]
+        if not cand:
+            continue
+        trial = {}
+        for b in cand:                                                            # line_search! candidate (ileqg.jl:504-521)
+            count[b] += 1
+            ls_evals[b] += 1
+            xn, un = ctx.rollout_feedback(x[b], l[b] + eps[b] * dl[b], L[b])
+            trial[b] = (xn, un, ctx.approximate_model(un, xn))
+        vn, stn = ctx.dp_policy_eval_batch([trial[b][2] for b in cand], [L[b] for b in cand], th[cand], mu[cand])
+        for i, b in enumerate(cand):
+            if count[b] > 4000:
+                status[b], value[b], in_ls[b] = nv.ST_LS_DIVERGED, np.inf, False
+                continue
+            if stn[i] != 0:
+                eps[b] *= o.lam                                                   # :529-535 (no eps_min test, no history entry)
+                continue
+            new, cur = vn[i], value[b]
+            if not (il._isapprox(new, cur) or new < cur):                         # :538
+                eps[b] *= o.lam                                                   # :557
+                if not eps[b] < o.eps_min:
+                    continue
+            xn, un, _ = trial[b]
+            d_cur[b] = float(np.max(np.linalg.norm(l[b] - un, axis=1)))           # :539 / :559
+            value[b], x[b], l[b], in_ls[b] = new, xn, un, False
+            if o.adaptive_eps_init:                                               # :582-591
+                if count[b] == 1:
+                    eps_i[b] = min(o.eps_init, eps[b] / o.lam)
+                else:
+                    e = eps[b]
+                    while e < o.eps_min:
+                        e = e / o.lam
+                    eps_i[b] = e
+            if o.d > d_cur[b] and mu[b] <= o.mu_min:                              # :642
+                status[b] = nv.ST_OK
+            elif iters[b] == o.iter_max:                                          # :648
+                status[b] = nv.ST_ITER_MAX
+    value = np.where((status == nv.ST_OK) | (status == nv.ST_ITER_MAX), value, np.inf)
+    return value, status, iters, ls_evals

@@ -106,3 +106,82 @@ def test_generic_nonlinear_closure_outside_the_families():
     assert v < v_init and s.iter_current >= 2 and all(e[1] < 0 or abs(e[1]) < 1e-6 * abs(v) for e in hist[:1])
     xn, un = rat.simulate_dynamics(gen, x, l, L)
     assert rel(xn, x) < 1e-12 and rel(un, l) < 1e-12          # the nominal trajectory is a fixed point of its own policy
+
+
+# ---- against the ORACLE's closure path (not HIP against HIP), and the batch entry points ---------------------------
+from oracle import oracle as orc  # noqa: E402
+
+
+def pendulum():
+    n, m, N, dt = 2, 1, 25, 0.1
+
+    def f(x, u, f_returns_jacobian=False):
+        xn = np.array([x[0] + dt * x[1], x[1] + dt * (-np.sin(x[0]) - 0.1 * x[1] + u[0])])
+        if not f_returns_jacobian:
+            return xn
+        return xn, np.array([[1.0, dt], [-dt * np.cos(x[0]), 1.0 - 0.1 * dt]]), np.array([[0.0], [dt]])
+
+    c = lambda k, x, u: 0.5 * (x @ x) + 0.05 * (u @ u) + 0.01 * k * x[0]                      # (time-dependent cost: exercises the k argument)
+    cd = lambda k, x, u: (x + np.array([0.01 * k, 0.0]), np.eye(2), 0.1 * u, 0.1 * np.eye(1), np.zeros((1, 2)))
+    h = lambda x: 2.0 * (x @ x)
+    hd = lambda x: (4.0 * x, 4.0 * np.eye(2))
+    W = lambda k: (1e-3 + 1e-4 * k) * np.eye(2)                                              # time-varying noise
+    gen = rat.GenericRiskSensitiveProblem(f, c, h, W, N, n, m, f_returns_jacobian=True, c_derivatives=cd, h_derivatives=hd)
+    cp = orc.ClosureProblem(lambda x, u: f(x, u), c, h, W, N, n, m, lambda x, u: f(x, u, True)[1:], cd, hd)
+    return gen, cp, np.array([1.0, 0.0]), np.zeros((N, m))
+
+
+def check_against_oracle(r, s, x, l, L, v, hist, vt=1e-9):
+    assert r["status"] == 0 and r["iters"] == s.iter_current and r["ls_evals"] == len(hist)
+    assert [e[0] for e in hist] == [e[0] for e in r["eps_history"]]                          # identical accepted / rejected step sizes
+    assert abs(v - r["value"]) <= vt * abs(r["value"])
+    assert rel(x, r["x"]) < 1e-9 and rel(l, r["l"]) < 1e-9 and rel(L, r["L"]) < 1e-9
+
+
+@pytest.mark.parametrize("theta", [0.0, 0.5, 3.0])
+def test_pendulum_closure_solve_against_the_oracle_closure_path(theta):
+    gen, cp, x0, u0 = pendulum()
+    s = rat.ILEQGSolver(gen, f_returns_jacobian=True)
+    x, l, L, v, hist = rat.solve_(s, gen, x0, u0, theta=theta)
+    check_against_oracle(orc.closure_solve(cp, x0, u0, theta), s, x, l, L, v, hist)
+
+
+def test_f_returns_jacobian_problem_against_the_oracle_closure_path():
+    """The family written as closures whose f returns its Jacobians (ileqg.jl:302-311), solved through the generic path and checked
+    against the oracle's closure path AND the oracle's family path."""
+    prob, x0, u = small_lq()
+    f, c, cd, h, hd = lq_closures(prob)
+    gen = rat.GenericRiskSensitiveProblem(f, c, h, prob.W, prob.N, prob.n, prob.m, f_returns_jacobian=True, c_derivatives=cd, h_derivatives=hd)
+    cp = orc.ClosureProblem(lambda x, uu: f(x, uu), c, h, prob.W, prob.N, prob.n, prob.m, lambda x, uu: f(x, uu, True)[1:], cd, hd)
+    for theta in (0.0, 1.5, 6.0):
+        s = rat.ILEQGSolver(gen, f_returns_jacobian=True, adaptive_eps_init=True)
+        x, l, L, v, hist = rat.solve_(s, gen, x0, u, theta=theta)
+        check_against_oracle(orc.closure_solve(cp, x0, u, theta, adaptive_eps_init=True), s, x, l, L, v, hist)
+        so = orc.ILEQGSolver(orc.Problem(prob), adaptive_eps_init=1)
+        assert so.solve(x0, u, theta) == 0 and abs(v - so.s.value_current) <= 1e-9 * abs(v) and so.s.iter_current == s.iter_current
+
+
+def test_closure_batch_solve_equals_per_sample_solves_and_the_oracle():
+    """rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch: a CE batch of a closure problem with every sweep of the batch in one launch."""
+    gen, cp, x0, u0 = pendulum()
+    theta = np.array([0.0, 0.2, 0.5, 1.0, 3.0, 8.0, 1e4])
+    val, st, it, ls = rat.solve_closure_batch(gen, x0, u0, theta)
+    assert st[-1] == 1 and np.isposinf(val[-1]) and np.all(st[:-1] == 0)
+    for i, th in enumerate(theta[:-1]):
+        r = orc.closure_solve(cp, x0, u0, th)
+        assert r["status"] == st[i] and r["iters"] == it[i] and r["ls_evals"] == ls[i]
+        assert abs(val[i] - r["value"]) <= 1e-9 * abs(r["value"])
+        s = rat.ILEQGSolver(gen, f_returns_jacobian=True)
+        v1 = rat.solve_(s, gen, x0, u0, theta=th)[3]
+        assert abs(val[i] - v1) <= 1e-12 * abs(v1) and s.iter_current == it[i]
+    assert orc.closure_solve(cp, x0, u0, 1e4)["status"] == 1
+    # a CE compute_cost over a closure problem goes through the same batch path and equals the device family's costs
+    prob, lx0, lu = small_lq()
+    f, c, cd, h, hd = lq_closures(prob)
+    lgen = rat.GenericRiskSensitiveProblem(f, c, h, prob.W, prob.N, prob.n, prob.m, f_returns_jacobian=True, c_derivatives=cd, h_derivatives=hd)
+    solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=6)
+    th = np.array([0.1, 0.5, 1.0, 2.0, 5.0, 1e5])
+    cg = rat.compute_cost(solver, lgen, lx0, lu, th, 0.3)
+    cf = rat.compute_cost(rat.CrossEntropyBilevelOptimizationSolver(num_samples=6), prob, lx0, lu, th, 0.3)
+    assert np.array_equal(np.isinf(cg), np.isinf(cf)) and np.isinf(cg[-1])
+    assert np.all(np.abs(cg[:-1] - cf[:-1]) <= 1e-9 * np.abs(cf[:-1]))

@@ -235,3 +235,33 @@ def test_noisy_rollouts_of_the_oracle(base):                  # simulate_dynamic
             assert np.allclose(xf[k, t + 1], xf[k, t] + uf[k, t] + Lc @ z[k, t], rtol=1e-13, atol=1e-13)
         rc, ck = orc.integrate_cost(P2, xf[k], uf[k])
         assert ck == cf[k]
+
+
+def test_closure_path_of_the_oracle_equals_its_family_path():
+    """oracle.closure_solve (the reference's solve! loop over Python closures, sweeps by orc_dp_gain / orc_dp_eval: the checker of the
+    generic-closure GPU path) reproduces the C oracle's own solve on a family problem written as closures -- bit for bit."""
+    rng = np.random.default_rng(2)
+    n, m, N = 4, 2, 12
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    prob = rat.LQRiskSensitiveProblem(0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), Q=np.eye(n), R=0.3 * np.eye(m),
+                                      P=0.05 * rng.standard_normal((m, n)), qv=0.1 * rng.standard_normal(n), rv=0.1 * rng.standard_normal(m),
+                                      q0=0.2, N=N, W=1e-3 * np.eye(n), Qf=np.eye(n), kappa=0.02)
+    x0, u = 0.5 * rng.standard_normal(n), np.zeros((N, m))
+    A, B, kap, Q, R, P, qv, rv, q0, Qf = prob.A, prob.B, prob.kappa, prob.Q, prob.R, prob.P, prob.qv, prob.rv, float(prob.q0), prob.Qf
+    cp = orc.ClosureProblem(lambda x, uu: A @ x + B @ uu + kap * x ** 3,
+                            lambda k, x, uu: 0.5 * x @ Q @ x + 0.5 * uu @ R @ uu + uu @ P @ x + qv @ x + rv @ uu + q0, lambda x: 0.5 * x @ Qf @ x,
+                            prob.W, N, n, m, lambda x, uu: (A + np.diag(3 * kap * x ** 2), B),
+                            lambda k, x, uu: (Q @ x + P.T @ uu + qv, Q, R @ uu + P @ x + rv, R, P), lambda x: (Qf @ x, Qf))
+    P_ = orc.Problem(prob)
+    for theta in (0.0, 1.5, 8.0, 400.0):
+        r = orc.closure_solve(cp, x0, u, theta)
+        s = orc.ILEQGSolver(P_)
+        rc = s.solve(x0, u, theta)
+        assert r["status"] == rc
+        if rc == 0:
+            assert r["iters"] == s.s.iter_current and r["ls_evals"] == s.s.n_ls_evals
+            assert abs(r["value"] - s.s.value_current) <= 1e-12 * abs(r["value"])
+            assert np.abs(r["L"] - s.L_array).max() <= 1e-12 and np.abs(r["x"] - s.x_array).max() <= 1e-12
+            assert np.array_equal(np.array(r["eps_history"])[:, 0], s.eps_history[:, 0])
+        else:
+            assert np.isinf(r["value"])
