@@ -138,12 +138,18 @@ def check_against_oracle(r, s, x, l, L, v, hist, vt=1e-9):
     assert rel(x, r["x"]) < 1e-9 and rel(l, r["l"]) < 1e-9 and rel(L, r["L"]) < 1e-9
 
 
-@pytest.mark.parametrize("theta", [0.0, 0.5, 3.0])
+@pytest.mark.parametrize("theta", [0.0, 0.5, 1.5])
 def test_pendulum_closure_solve_against_the_oracle_closure_path(theta):
     gen, cp, x0, u0 = pendulum()
     s = rat.ILEQGSolver(gen, f_returns_jacobian=True)
     x, l, L, v, hist = rat.solve_(s, gen, x0, u0, theta=theta)
-    check_against_oracle(orc.closure_solve(cp, x0, u0, theta), s, x, l, L, v, hist)
+    r = orc.closure_solve(cp, x0, u0, theta)
+    check_against_oracle(r, s, x, l, L, v, hist)
+    assert theta == 0.0 or r["ls_evals"] > r["iters"]                      # the line search backtracks on this problem (theta > 0)
+    # above the breakdown both refuse in initialize! (the reference's uncaught @assert, ileqg.jl:234 -> :440)
+    assert orc.closure_solve(cp, x0, u0, 3.0)["status"] == 1
+    with pytest.raises(AssertionError):
+        rat.solve_(rat.ILEQGSolver(gen, f_returns_jacobian=True), gen, x0, u0, theta=3.0)
 
 
 def test_f_returns_jacobian_problem_against_the_oracle_closure_path():
@@ -164,17 +170,20 @@ def test_f_returns_jacobian_problem_against_the_oracle_closure_path():
 def test_closure_batch_solve_equals_per_sample_solves_and_the_oracle():
     """rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch: a CE batch of a closure problem with every sweep of the batch in one launch."""
     gen, cp, x0, u0 = pendulum()
-    theta = np.array([0.0, 0.2, 0.5, 1.0, 3.0, 8.0, 1e4])
+    theta = np.array([0.0, 0.2, 0.5, 1.0, 1.5, 1.7, 1e4])
     val, st, it, ls = rat.solve_closure_batch(gen, x0, u0, theta)
-    assert st[-1] == 1 and np.isposinf(val[-1]) and np.all(st[:-1] == 0)
-    for i, th in enumerate(theta[:-1]):
+    assert st[-1] == 1 and np.isposinf(val[-1]) and np.all(st[:5] == 0)
+    for i, th in enumerate(theta):
         r = orc.closure_solve(cp, x0, u0, th)
-        assert r["status"] == st[i] and r["iters"] == it[i] and r["ls_evals"] == ls[i]
+        assert r["status"] == st[i], (th, r["status"], st[i])
+        if st[i] != 0:
+            assert np.isposinf(val[i])
+            continue
+        assert r["iters"] == it[i] and r["ls_evals"] == ls[i]
         assert abs(val[i] - r["value"]) <= 1e-9 * abs(r["value"])
         s = rat.ILEQGSolver(gen, f_returns_jacobian=True)
         v1 = rat.solve_(s, gen, x0, u0, theta=th)[3]
         assert abs(val[i] - v1) <= 1e-12 * abs(v1) and s.iter_current == it[i]
-    assert orc.closure_solve(cp, x0, u0, 1e4)["status"] == 1
     # a CE compute_cost over a closure problem goes through the same batch path and equals the device family's costs
     prob, lx0, lu = small_lq()
     f, c, cd, h, hd = lq_closures(prob)
