@@ -75,7 +75,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_SO)
+        _lib = C.CDLL(os.environ.get("RATILQR_ORACLE_SO", _SO))          # override: the ASan / UBSan build of tools/sanitize_host.sh
         _lib.orc_solver_new.restype = C.POINTER(_Solver)
         _lib.orc_approx_alloc.restype = C.POINTER(_Approx)
         _lib.orc_dp_alloc.restype = C.POINTER(_Dp)

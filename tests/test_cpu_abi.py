@@ -153,3 +153,32 @@ def test_create_multi_without_devices_fails_loudly():
     m = C.c_void_p()
     rc = nv.lib().rat_create_multi(None, 64, 1, 2, None, C.byref(m))
     assert rc != 0 and not m.value
+
+
+def test_pets_host_bookkeeping_replays_the_oracle():
+    """rat_pets_sample_controls / rat_pets_update (device-free host code of the .so, pets.jl:159-191, 206-216) against the oracle's
+    update on the same costs: elites, smoothed means, diagonal variances."""
+    from ratilqr.jl_amd import pets
+    L = nv.lib()
+    rng = np.random.default_rng(8)
+    Nh, m, S = 6, 3, 20
+    mu0 = rng.standard_normal((Nh, m))
+    Sig0 = np.stack([np.diag(rng.uniform(0.5, 2.0, m)) + 0.1 * np.ones((m, m)) for _ in range(Nh)])
+    ds = pets.CrossEntropyDirectOptimizationSolver(mu0, Sig0, num_control_samples=S, num_trajectory_samples=4, num_elite=5, smoothing_factor=0.3)
+    zc = rng.standard_normal((S, Nh, m))
+    ctrl = np.zeros((S, Nh, m))
+    nv.check(L.rat_pets_sample_controls(C.byref(ds.c), nv.P(nv.f64(zc)), nv.P(ctrl)))
+    want = mu0[None] + np.einsum("tab,stb->sta", np.linalg.cholesky(Sig0), zc)            # rand(rng, MvNormal(mu_t, Sigma_t))
+    assert np.allclose(ctrl, want, rtol=0, atol=1e-13)
+    cost = rng.standard_normal(S)
+    cost[3] = np.nan                                                                        # sorts last (isless)
+    idx = np.zeros(5, np.int64)
+    nv.check(L.rat_pets_update(C.byref(ds.c), nv.P(ctrl), nv.P(cost), idx.ctypes.data_as(C.POINTER(C.c_int64))))
+    op = orc.PetsSolver(mu0, Sig0, num_control_samples=S, num_trajectory_samples=4, num_elite=5, smoothing_factor=0.3)
+    idx_o = op.update(ctrl, cost)
+    assert np.array_equal(idx, idx_o) and 3 not in idx
+    assert np.allclose(ds.mu_array, op.mu_array, rtol=1e-15, atol=0) and np.allclose(ds.Sigma_array, op.Sigma_array, rtol=1e-14, atol=1e-16)
+    bad = Sig0.copy()
+    bad[2] = -np.eye(m)                                                                     # MvNormal would throw
+    ds2 = pets.CrossEntropyDirectOptimizationSolver(mu0, bad, num_control_samples=S)
+    assert L.rat_pets_sample_controls(C.byref(ds2.c), nv.P(nv.f64(zc)), nv.P(ctrl)) == 1
