@@ -13,7 +13,7 @@ for b in re.split(r"remark: Function Name: ", txt)[1:]:
     if not any(f in name for f in filt):
         continue
     try:
-        name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip() or name
+        name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
     except Exception:
         pass
     g = lambda k: re.search(re.escape(k) + r": (\d+)", b).group(1)
