@@ -42,7 +42,7 @@ for seed in range(NS):
         if badi.size and badi[0] > 0:
             lo_, hi_ = grid[badi[0] - 1], grid[badi[0]]
             theta = np.concatenate([[0.0], np.linspace(lo_, hi_, 23)])
-    E = int(rng.choice([1, 1, 1, 2, 3, 8, 11]))
+    E = int(rng.choice([1, 1, 2, 3, 4, 8, 11]))       # 1, 2, 4, 8: solve_block_kernel (default path for small batches); 3, 11: round-based path
     kw = {}
     if rng.integers(0, 2):
         kw = dict(lam=float(rng.uniform(0.3, 0.7)), iter_max=int(rng.integers(3, 40)), adaptive_eps_init=int(rng.integers(0, 2)))
