@@ -443,10 +443,13 @@ def rank_main(args):
     # conditioning (untimed, before the W warm-up steps): a batch is < 0.5 ms, so W = 3 steps after an idle period are over before the
     # chip has left its idle clocks -- `steady_state` below (>= 1 s of batches) showed the first ~10 ms running 5 % slow.  0.3 s of the
     # same batches first; the timed region is still EXACTLY `steps` batches.
-    t_c = time.perf_counter()
-    while time.perf_counter() - t_c < args.condition_seconds:
-        for _ in range(16):
-            w.step()
+    # (every rank must issue the SAME number of collectives: the number of conditioning blocks is fixed from one block timed on all
+    #  ranks and max-reduced, never from a rank-local clock)
+    if args.condition_seconds > 0:
+        t_blk = D.timed(w.step, 16, 0)
+        for _ in range(max(0, min(2000, int(math.ceil(args.condition_seconds / max(t_blk, 1e-6))) - 1))):
+            for _ in range(16):
+                w.step()
         D.sync()
     for _ in range(W):
         w.step()
@@ -487,7 +490,7 @@ def rank_main(args):
             K8 = max(3, K // 3)
             e8 = D.timed(w8.step, K8, max(2, W))
             strong8 = {"value": G * K8 / e8, "unit": "solves/s", "ms_per_step": e8 / K8 * 1e3, "steps": K8, "global_batch": G,
-                       "spec_eps": 8, "costs_identical_to_primary": bool(torch.equal(w8.cost, w.cost))}
+                       "spec_eps": 8, "costs_identical_to_primary": bool(torch.equal(w8.cost[: w8.nloc], w.cost[: w.nloc]))}
             del w8
 
     # ---- single-GPU secondaries ---------------------------------------------------------------------------------------------------
