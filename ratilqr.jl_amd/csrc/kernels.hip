@@ -944,6 +944,226 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
     BODY_MARK(a.dump, 12 + 4 * MODE + 3);
 }
 
+// =====================================================================================================
+// rollin split over TWO wavefronts of a workgroup (solve_block_kernel, LQ family, N <= ROLLIN_NST): the recursion and the
+// linearisation of rollin_body on different SIMDs.
+//   rollrec_body (candidate wave): x_{t+1} = [A|B][x_t; u_t], u_t = l_t + eps dl_t + L_t (x_t - xbar_t) -- 7 MFMAs per step (4 open
+//                loop) and nothing else: no tile, no store to HBM.  Operands come from LDS (staged once), [x_t; u_t] goes to an LDS
+//                trajectory buffer (16 doubles per step) followed by a progress word.
+//   rolllin_body (the gain wave, idle during rollouts otherwise): waits for step t, reads [x_t; u_t] from LDS and does everything
+//                else rollin_body does per step -- f_x | f_u, C [x;u] (4 MFMAs), c, the six record stores, the x / u history.
+// Same expressions as rollin_body (the paths are tested bit for bit).  A rollout then takes ~50 x 560 cycles (both halves are bound
+// by their MFMAs: 7 x 64 and 4 x 64 + stores) instead of 62 k (open loop) / 85 k (closed loop): -127 k of the 760 k-cycle critical
+// path of a 2-iteration solve at one wave per SIMD.
+// Hand-off: LDS operations of one CU execute in arrival order, and a wave's own LDS instructions are issued in program order, so
+// "data written, then progress word written" by the producer and "progress word read, then data read" by the consumer need no fence
+// beyond the compiler's (wavefront scope).  The progress word counts up over the whole solve (epoch + t + 1): no reset, no ABA.
+// =====================================================================================================
+#define XU_DOUBLES ((ROLLIN_NST + 1) * 16 + 64)     /* [x_t; u_t] packed, t = 0..N, + dump slots of the idle lanes */
+
+// true when this sample takes part in the rollout phase MODE (both waves evaluate the same words: they agree)
+template <int MODE>
+__device__ __forceinline__ bool rollout_active(const StateDev &st, const int b, int &nom, int &lsel, double &eps_in) {
+    const int v_stat = st.status[b], v_act = st.ls_active[b], v_nom = st.slot_nom[b], v_lsel = st.lsel[b];
+    const int s_stat = wave_uniform(v_stat), s_act = wave_uniform(v_act);
+    nom = wave_uniform(v_nom); lsel = wave_uniform(v_lsel);
+    eps_in = st.ls_eps[b];
+    return (MODE == 0) ? (s_stat == ST_RUNNING) : (s_act != 0);
+}
+
+template <int MODE>
+__device__ __forceinline__ void rollrec_body(const RolloutArgs &a, const int b, double *const stg, double *const xu, int *const prog, const int epoch) {
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));
+    const int l = lane_, j = l & 15, g = l >> 4;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    const int N = st.N;
+    int nom, lsel;
+    double eps_in;
+    if (!rollout_active<MODE>(st, b, nom, lsel, eps_in)) return;
+    const int slot_n = b * (st.E + 1) + nom;
+    const double *__restrict__ xbar = st.xs + (long)slot_n * st.x_stride;
+    const double *__restrict__ lnom = (MODE == 0) ? a.u0 : st.us + (long)slot_n * st.u_stride;
+    const double *__restrict__ Lb = st.L + (long)lsel * st.l_half + (long)b * N * LSTR;
+    const double *__restrict__ dlb = st.dl + (long)lsel * st.dl_half + (long)b * N * USTR;
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    const double eps = (MODE == 1) ? eps_in : 0.0;                  // candidate 0: eps_k = eps lambda^0
+    const double mq = (j < 12) ? 1.0 : 0.0;
+    const int jx = (j < 12) ? j : 11, j3 = j & 3;
+    double zA[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) zA[s] = pb.Zt[jx * 16 + 4 * s + g] * mq;
+    const double pm[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
+    const int xoff = (j < 4) ? 4 * j + g : (ROLLIN_NST + 1) * 16 + l;     // packed [x; u]: lane (g, s), s < 4, holds component 4 s + g; idle lanes: dump
+    const int xstep = (j < 4) ? 16 : 0;
+    double xb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) xb[s] = (MODE == 0) ? a.x0[4 * s + g] : xbar[4 * s + g];
+    // operands of the whole trajectory into LDS (rollin_body's STAGE layout; open loop: the controls only)
+    constexpr int cL = STG_CL, cX = STG_CX, cU = STG_CU;
+    double *const sL = stg, *const sX = stg + cL * 64, *const sl = sX + cX * 64, *const sdl = sl + cU * 64;
+    {
+        double tl[cU];
+#pragma unroll
+        for (int q = 0; q < cU; ++q) { const int e = 64 * q + l; tl[q] = lnom[(e < N * USTR) ? e : 0]; }
+        if (MODE == 1) {
+            double tL[cL], tX[cX], tdl[cU];
+#pragma unroll
+            for (int q = 0; q < cL; ++q) { const int e = 64 * q + l; tL[q] = Lb[(e < N * LSTR) ? e : 0]; }
+#pragma unroll
+            for (int q = 0; q < cX; ++q) { const int e = 64 * q + l; tX[q] = xbar[(e < (N + 1) * XSTR) ? e : 0]; }
+#pragma unroll
+            for (int q = 0; q < cU; ++q) { const int e = 64 * q + l; tdl[q] = dlb[(e < N * USTR) ? e : 0]; }
+#pragma unroll
+            for (int q = 0; q < cL; ++q) sL[64 * q + l] = tL[q];
+#pragma unroll
+            for (int q = 0; q < cX; ++q) sX[64 * q + l] = tX[q];
+#pragma unroll
+            for (int q = 0; q < cU; ++q) sdl[64 * q + l] = tdl[q];
+        }
+#pragma unroll
+        for (int q = 0; q < cU; ++q) sl[64 * q + l] = tl[q];
+        WAVE_SYNC();
+    }
+    double dmax = -INFINITY;
+    bool dnan = false;
+    for (int t = 0; t < N; ++t) {
+        const double c_l = sl[t * USTR + g];
+        d4 xa = zero4;
+        xa = MFMA(zA[0], xb[0], xa);
+        xa = MFMA(zA[1], xb[1], xa);
+        xa = MFMA(zA[2], xb[2], xa);
+        double u = c_l;
+        if (MODE == 1) {
+            const double c_dl = sdl[t * USTR + g];
+            double c_xb[3], c_La[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) { c_xb[s] = sX[t * XSTR + 4 * s + g]; c_La[s] = sL[t * LSTR + j3 * 12 + 4 * s + g]; }
+            d4 fb = MFMA(c_La[0], xb[0] - c_xb[0], zero4);          // L_t (x_t - xbar_t)   (:82)
+            fb = MFMA(c_La[1], xb[1] - c_xb[1], fb);
+            fb = MFMA(c_La[2], xb[2] - c_xb[2], fb);
+            const double lnew = c_l + eps * c_dl;                   // l + eps dl           (:509)
+            u = lnew + fb[0];
+            const double du = c_l - u, dsq = du * du;               // d = maximum(norm(l_t - u_t))  (:517-519), as rollin_body
+            const double dn2 = ((readlane_f64(dsq, 0) + readlane_f64(dsq, 16)) + readlane_f64(dsq, 32)) + readlane_f64(dsq, 48);
+            dnan |= (dn2 != dn2);
+            dmax = (dn2 > dmax) ? dn2 : dmax;
+        }
+        xa = MFMA(zA[3], u, xa);
+        const double pk = ((xb[0] * pm[0] + xb[1] * pm[1]) + xb[2] * pm[2]) + u * pm[3];
+        xu[t * xstep + xoff] = pk;
+        WAVE_SYNC();
+        __hip_atomic_store(prog, epoch + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xb[r] = xa[r] + pb.kappa * (xb[r] * xb[r] * xb[r]);
+    }
+    xu[N * xstep + xoff] = (xb[0] * pm[0] + xb[1] * pm[1]) + xb[2] * pm[2];          // x_N (lanes j == 3: 0)
+    WAVE_SYNC();
+    __hip_atomic_store(prog, epoch + N + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (MODE == 1 && l == 0) {
+        st.d_c[b * st.E] = dnan ? NAN : sqrt(dmax);
+        st.flag_c[b * st.E] = 0;
+    }
+}
+
+template <int MODE, bool CTV>
+__device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, double *const shxu, const double *const xu, int *const prog, const int epoch) {
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));
+    const int l = lane_, j = l & 15, g = l >> 4;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    const int N = st.N;
+    int nom, lsel;
+    double eps_in;
+    if (!rollout_active<MODE>(st, b, nom, lsel, eps_in)) return;
+    const int slot_n = b * (st.E + 1) + nom;
+    const int slot_o = (MODE == 0) ? slot_n : cand_slot(b, 0, nom, st.E);
+    double *__restrict__ xo = st.xs + (long)slot_o * st.x_stride;
+    double *__restrict__ uo = st.us + (long)slot_o * st.u_stride;
+    double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot_o) * st.tile_stride;
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    double cf[4] = {0, 0, 0, 0};
+    double es[4];
+    double cq0 = 0, cq1 = 0, cq2 = 0, cpr = 0, clin = 0, cq00 = 0;
+    const double mq = (j < 12) ? 1.0 : 0.0;
+    const int jx = (j < 12) ? j : 11, j3 = j & 3;
+    const int pkc = 4 * j3 + g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) es[s] = (j == 4 * s + g) ? 1.0 : 0.0;
+    const double dgz[3] = {es[0], es[1], es[2]};
+    const double zt0 = pb.Zt[l], zt1 = pb.Zt[64 + l], zt2 = pb.Zt[128 + l];
+    if (!CTV) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cf[s] = pb.Ctab[64 * s + l];
+        cq0 = cf[0] * mq; cq1 = cf[1] * mq; cq2 = cf[2] * mq; cpr = cf[3];
+        clin = pb.lin[pkc];
+        cq00 = pb.q0[0];
+    }
+    double *const pxu = (j < 3) ? xo + 4 * j + g : (j == 3 ? uo + g : tile0 + TS_PAD);
+    const long sxu = (j < 3) ? XSTR : (j == 3 ? USTR : TSTRIDE);
+    const int qoff = (j < 4) ? TS_QR + 4 * j + g : (l == 4 ? TS_q : TS_PAD);
+    const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);
+    const double pm[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
+    const double m_j4 = (j < 4) ? 1.0 : 0.0, m_l4 = (l == 4) ? 1.0 : 0.0;
+    const int pkoff = (j < 4) ? 4 * j + g : 0;
+    auto wait_for = [&](const int want) {
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - want < 0) __builtin_amdgcn_s_sleep(1);
+        WAVE_SYNC();
+    };
+    for (int t = 0; t < N; ++t) {
+        wait_for(epoch + t + 1);
+        const double *xt = xu + t * 16;
+        const double xb[3] = {xt[g], xt[4 + g], xt[8 + g]};
+        const double u = xt[12 + g];
+        const double pk = xt[pkoff] * m_j4;
+        double *__restrict__ tp = tile0 + (long)t * TSTRIDE;
+        if (CTV) {
+            const double *__restrict__ C = pb.Ctab + (long)t * 256;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) cf[s] = C[64 * s + l];
+            cq0 = cf[0] * mq; cq1 = cf[1] * mq; cq2 = cf[2] * mq; cpr = cf[3];
+            clin = pb.lin[(long)t * 16 + pkc];
+            cq00 = pb.q0[t];
+        }
+        pxu[(long)t * sxu] = pk;
+        const double z0 = zt0 + dgz[0] * (3.0 * pb.kappa * (xb[0] * xb[0]));
+        const double z1 = zt1 + dgz[1] * (3.0 * pb.kappa * (xb[1] * xb[1]));
+        const double z2 = zt2 + dgz[2] * (3.0 * pb.kappa * (xb[2] * xb[2]));
+        double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
+        t2[l] = make_double2(z0, z1);
+        t2[64 + l] = make_double2(z2, cpr);
+        *reinterpret_cast<double2 *>(tp + c34) = make_double2(cq0, cq1);
+        tp[r5] = cq2;
+        d4 cx = MFMA(cf[0], xb[0], zero4);                      // C [x;u] in B-form
+        cx = MFMA(cf[1], xb[1], cx);
+        cx = MFMA(cf[2], xb[2], cx);
+        cx = MFMA(cf[3], u, cx);
+        const double acc = ((cx[0] * pm[0] + cx[1] * pm[1]) + cx[2] * pm[2]) + cx[3] * pm[3];
+        const double w = row_sum16(pk * (0.5 * acc + clin));
+        const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
+        tp[qoff] = fma(m_l4, part + cq00, m_j4 * (acc + clin));
+    }
+    // x_N and the terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316), as rollin_body
+    wait_for(epoch + N + 1);
+    {
+        const double x = (l < 12) ? xu[N * 16 + l] : 0.0;
+        if (l < 12) { xo[(long)N * XSTR + l] = x; shxu[l] = x; }
+        WAVE_SYNC();
+        double *__restrict__ tp = tile0 + (long)N * TSTRIDE;
+        for (int e = l; e < 144; e += 64) tp[TT_Q + e] = pb.Qf[e];
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) acc += pb.Qf[jx * 12 + q] * shxu[q];
+        const double qvf = pb.qvf[jx];
+        if (l < 12) tp[TT_QV + l] = acc + qvf;
+        const double part = row_sum16((j < 12) ? shxu[jx] * (0.5 * acc + qvf) : 0.0);
+        if (l == 0) tp[TT_q] = part + pb.q0f;
+        WAVE_SYNC();
+    }
+}
+
 template <int MODEL, int MODE, bool CTV, bool SEP>
 __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     __shared__ double shxu[16];
@@ -1433,12 +1653,18 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     constexpr int E = GW ? NW - 1 : NW;          // candidate waves
     constexpr int WG = GW ? NW - 1 : 0;          // the wave that runs gain sweeps
     constexpr int HWAVES = PAD4 ? 4 : NW;
+    // two waves, LQ family, staged operands: the rollouts are split over both waves (rollrec_body / rolllin_body)
+    constexpr bool SPLIT = (NW == 2) && GW && STG && (MODEL == 1);
     const int b = blockIdx.x;
     const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const StateDev &st = fa.sw.st;
     __shared__ double wls_all[HWAVES][WLS_SWEEP];
     __shared__ double shxu_all[HWAVES][16];
     __shared__ double stg[STG ? STG_DOUBLES : 1];
+    __shared__ double xu[SPLIT ? XU_DOUBLES : 1];
+    __shared__ int prog;
+    int epoch = 0;
+    if (threadIdx.x == 0) prog = 0;
     double *const wls = wls_all[hwave], *const shxu = shxu_all[hwave];
     int wave = hwave;                            // role: 0 .. E-1 candidates, WG gain sweeps
     if (PAD4) {
@@ -1460,13 +1686,30 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         if (wave < 0) return;                    // (an ended wave no longer takes part in the workgroup's barriers)
     }
     const bool leader = (wave == 0) && ((threadIdx.x & 63) == 0);
+#ifdef RAT_DIAG_PHASES
+    const unsigned long long dg_t0 = __builtin_readcyclecounter();
+    int dg_pi = 0;
+#define BLK_MARK() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8 && fa.sw.dump && dg_pi < 40 && wave < 2) \
+        fa.sw.dump[1024 + blockIdx.x * 80 + wave * 40 + dg_pi] = (double)(__builtin_readcyclecounter() - dg_t0); ++dg_pi; } while (0)
+#else
+#define BLK_MARK() do {} while (0)
+#endif
     if (leader) init_state_body(st, fa.sw.op, fa.theta_in, b);
+    BLK_MARK();
     __syncthreads();
-    if (wave == 0) {                             // initialize!: open-loop rollout + linearise   (ileqg.jl:214-233)
+    BLK_MARK();
+    if (SPLIT) {                                 // initialize!: open-loop rollout (wave 0) + linearise (gain wave)   (ileqg.jl:214-233)
+        RolloutArgs ra = fa.ro; ra.mode = 0;
+        if (wave == 0) rollrec_body<0>(ra, b, stg, xu, &prog, epoch);
+        else rolllin_body<0, CTV>(ra, b, shxu, xu, &prog, epoch);
+        epoch += st.N + 2;
+    } else if (wave == 0) {
         RolloutArgs ra = fa.ro; ra.mode = 0;
         rollin_body<MODEL, 0, CTV>(ra, b, shxu);
     }
+    BLK_MARK();
     __syncthreads();
+    BLK_MARK();
     if (wave == 0) {                             // open-loop policy evaluation (:234) ...
         SweepArgs sa = fa.sw; sa.mode = 2;
         sweep_body<false, false, WTV, false>(sa, b, wls);
@@ -1474,10 +1717,14 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         SweepArgs sa = fa.sw; sa.mode = 5;
         sweep_body<true, false, WTV, false>(sa, b, wls);
     }
+    BLK_MARK();
     __syncthreads();
+    BLK_MARK();
     if (GW) {
         if (leader) commit_init_body(st, b);
-        __syncthreads();
+        BLK_MARK();
+    __syncthreads();
+    BLK_MARK();
     }
     for (int guard = 0; guard < fa.max_rounds; ++guard) {
         const int v_stat = __atomic_load_n(&st.status[b], __ATOMIC_RELAXED), v_act = __atomic_load_n(&st.ls_active[b], __ATOMIC_RELAXED);
@@ -1487,14 +1734,23 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
                 SweepArgs sa = fa.sw; sa.mode = 0;
                 sweep_body<true, false, WTV, false>(sa, b, wls);
             }
-            __syncthreads();
+            BLK_MARK();
+    __syncthreads();
+    BLK_MARK();
             continue;
         }
-        if (wave < E) {                                       // candidates of this line-search round  (ileqg.jl:504-521)
+        if (SPLIT) {                                          // the candidate of this line-search round  (ileqg.jl:504-521), split over both waves
+            RolloutArgs ra = fa.ro; ra.mode = 1;
+            if (wave == 0) rollrec_body<1>(ra, b, stg, xu, &prog, epoch);
+            else rolllin_body<1, CTV>(ra, b, shxu, xu, &prog, epoch);
+            epoch += st.N + 2;
+        } else if (wave < E) {                                // candidates of this line-search round  (ileqg.jl:504-521)
             RolloutArgs ra = fa.ro; ra.mode = 1;
             rollin_body<MODEL, 1, CTV, STG, false>(ra, b * E + wave, shxu, stg);
         }
-        __syncthreads();
+        BLK_MARK();
+    __syncthreads();
+    BLK_MARK();
         if (wave < E) {                                       // their policy evaluations  (:522-536)
             SweepArgs sa = fa.sw; sa.mode = 1;
             sweep_body<false, false, WTV, true>(sa, b * E + wave, wls);
@@ -1508,14 +1764,21 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
                 sweep_body<true, false, WTV, false>(sa, b, wls);
             }
         }
-        __syncthreads();
-        if (leader) ls_select_body(st, fa.sw.op, b, nullptr);
-        __syncthreads();
-    }
+        BLK_MARK();
     __syncthreads();
+    BLK_MARK();
+        if (leader) ls_select_body(st, fa.sw.op, b, nullptr);
+        BLK_MARK();
+    __syncthreads();
+    BLK_MARK();
+    }
+    BLK_MARK();
+    __syncthreads();
+    BLK_MARK();
     if (leader) gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
 }
 
+#undef BLK_MARK
 template <int NW, bool GW>
 static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {
     const dim3 grid(fa.sw.st.B), block(64 * NW);
