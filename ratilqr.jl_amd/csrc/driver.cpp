@@ -48,6 +48,7 @@ struct rat_handle_s {
     int n_cu = 256;                  // compute units of the device
     int *d_census = nullptr;         // solve_block_kernel's per-CU workgroup tickets (two-wave geometry: which SIMD pair a workgroup keeps)
     bool block_shape = true;         // RATILQR_BLOCK_SHAPE=0: plain two-wave workgroups, placement left to the dispatcher
+    bool block_helpers = true;       // RATILQR_BLOCK_HELPERS=0: no spare linearise waves at one workgroup per CU
     rat_ileqg_opts opts;
     OptsDev opd;
     int Bmax = 0, E = 1;
@@ -140,6 +141,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_BLOCK")) h->block_mode = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
     if (const char *e = getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = atoi(e);
     if (const char *e = getenv("RATILQR_BLOCK_SHAPE")) h->block_shape = (e[0] != '0');
+    if (const char *e = getenv("RATILQR_BLOCK_HELPERS")) h->block_helpers = (e[0] != '0');
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     CREATECHK(hipMalloc((void **)&h->d_census, sizeof(int) * CENSUS_SLOTS));
     CREATECHK(hipMemset(h->d_census, 0, sizeof(int) * CENSUS_SLOTS));
@@ -549,6 +551,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         // register slots of the two waves that exit at once stay charged to the workgroup until it ends, so a third padded workgroup
         // per CU would have to wait for a whole solve (measured: 768 samples 0.515 ms padded, 0.420 ms plain)
         fa.census = (h->block_shape && h->E == 1 && B <= 2 * h->n_cu) ? h->d_census : nullptr;
+        fa.helpers = (fa.census && B <= h->n_cu && h->block_helpers) ? 1 : 0;
         prof_begin(h, path == PATH_BLOCK ? RAT_K_SOLVE_BLOCK : RAT_K_SOLVE_FUSED, B);
         if (path == PATH_BLOCK) launch_solve_block(fa, h->stream); else launch_solve_fused(fa, h->stream);
         prof_end(h);

@@ -41,6 +41,7 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     double *out_cost; double kl_bound; // [B] cost = value + kl_bound / theta  (cross_entropy_bilevel_optimization.jl:193) or null
     // solve_block_kernel only:
     int *census;                       // [CENSUS_SLOTS] per-CU workgroup tickets of the two-wave geometry, or null: see solve_block_kernel
+    int helpers;                       // 1: one workgroup per CU (B <= n_cu): the two spare waves of a padded workgroup help linearising
 };
 #define CENSUS_SLOTS 4096              /* (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID / HW_REG_XCC_ID: 4 + 3 + 1 + 4 bits */
 

@@ -959,7 +959,8 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
 // "data written, then progress word written" by the producer and "progress word read, then data read" by the consumer need no fence
 // beyond the compiler's (wavefront scope).  The progress word counts up over the whole solve (epoch + t + 1): no reset, no ABA.
 // =====================================================================================================
-#define XU_DOUBLES ((ROLLIN_NST + 1) * 16 + 64)     /* [x_t; u_t] packed, t = 0..N, + dump slots of the idle lanes */
+#define XU_REC 20                                   /* doubles per step: [x_t; u_t] packed (16) + (l_t - u_t)^2 per control (4) */
+#define XU_DOUBLES ((ROLLIN_NST + 1) * XU_REC + 64) /* t = 0..N, + dump slots of the idle lanes */
 
 // true when this sample takes part in the rollout phase MODE (both waves evaluate the same words: they agree)
 template <int MODE>
@@ -971,8 +972,11 @@ __device__ __forceinline__ bool rollout_active(const StateDev &st, const int b, 
     return (MODE == 0) ? (s_stat == ST_RUNNING) : (s_act != 0);
 }
 
-template <int MODE>
-__device__ __forceinline__ void rollrec_body(const RolloutArgs &a, const int b, double *const stg, double *const xu, int *const prog, const int epoch) {
+// HELP (the workgroup has spare linearise waves: one sample per CU): the squared control steps go to the trajectory buffer and the
+// linearise waves take their maximum (d_acc), so that the recursion wave's step is nothing but its MFMA chain.
+template <int MODE, bool HELP>
+__device__ __forceinline__ void rollrec_body(const RolloutArgs &a, const int b, double *const stg, double *const xu, int *const prog, const int epoch,
+                                             unsigned long long *const d_acc) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));
     const int l = lane_, j = l & 15, g = l >> 4;
@@ -995,8 +999,11 @@ __device__ __forceinline__ void rollrec_body(const RolloutArgs &a, const int b, 
 #pragma unroll
     for (int s = 0; s < 4; ++s) zA[s] = pb.Zt[jx * 16 + 4 * s + g] * mq;
     const double pm[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
-    const int xoff = (j < 4) ? 4 * j + g : (ROLLIN_NST + 1) * 16 + l;     // packed [x; u]: lane (g, s), s < 4, holds component 4 s + g; idle lanes: dump
-    const int xstep = (j < 4) ? 16 : 0;
+    // packed [x; u]: lane (g, s), s < 4, holds component 4 s + g; lane (g, 4): (l_g - u_g)^2 (HELP); idle lanes: dump
+    const int xoff = (j < 4) ? 4 * j + g : ((HELP && j == 4) ? 16 + g : (ROLLIN_NST + 1) * XU_REC + l);
+    const int xstep = (j < 4 || (HELP && j == 4)) ? XU_REC : 0;
+    const double m_4 = (j == 4) ? 1.0 : 0.0;
+    if (HELP && MODE == 1 && l == 0) { d_acc[0] = 0ull; d_acc[1] = 0ull; }     // max of the squared step norms (bits of a double >= +0), NaN flag
     double xb[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) xb[s] = (MODE == 0) ? a.x0[4 * s + g] : xbar[4 * s + g];
@@ -1028,47 +1035,63 @@ __device__ __forceinline__ void rollrec_body(const RolloutArgs &a, const int b, 
     }
     double dmax = -INFINITY;
     bool dnan = false;
+    // operands of step t + 1 are read from LDS during step t (the fence before the progress word would otherwise pin them to their step)
+    double n_l = sl[g], n_dl = 0.0, n_xb[3] = {0, 0, 0}, n_La[3] = {0, 0, 0};
+    if (MODE == 1) {
+        n_dl = sdl[g];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { n_xb[s] = sX[4 * s + g]; n_La[s] = sL[j3 * 12 + 4 * s + g]; }
+    }
     for (int t = 0; t < N; ++t) {
-        const double c_l = sl[t * USTR + g];
+        const double c_l = n_l;
+        const int tn = (t + 1 < N) ? t + 1 : t;
+        n_l = sl[tn * USTR + g];
         d4 xa = zero4;
         xa = MFMA(zA[0], xb[0], xa);
         xa = MFMA(zA[1], xb[1], xa);
         xa = MFMA(zA[2], xb[2], xa);
         double u = c_l;
+        double dsq = 0.0;
         if (MODE == 1) {
-            const double c_dl = sdl[t * USTR + g];
-            double c_xb[3], c_La[3];
+            const double c_dl = n_dl;
+            const double c_xb[3] = {n_xb[0], n_xb[1], n_xb[2]}, c_La[3] = {n_La[0], n_La[1], n_La[2]};
+            n_dl = sdl[tn * USTR + g];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) { c_xb[s] = sX[t * XSTR + 4 * s + g]; c_La[s] = sL[t * LSTR + j3 * 12 + 4 * s + g]; }
+            for (int s = 0; s < 3; ++s) { n_xb[s] = sX[tn * XSTR + 4 * s + g]; n_La[s] = sL[tn * LSTR + j3 * 12 + 4 * s + g]; }
             d4 fb = MFMA(c_La[0], xb[0] - c_xb[0], zero4);          // L_t (x_t - xbar_t)   (:82)
             fb = MFMA(c_La[1], xb[1] - c_xb[1], fb);
             fb = MFMA(c_La[2], xb[2] - c_xb[2], fb);
             const double lnew = c_l + eps * c_dl;                   // l + eps dl           (:509)
             u = lnew + fb[0];
-            const double du = c_l - u, dsq = du * du;               // d = maximum(norm(l_t - u_t))  (:517-519), as rollin_body
-            const double dn2 = ((readlane_f64(dsq, 0) + readlane_f64(dsq, 16)) + readlane_f64(dsq, 32)) + readlane_f64(dsq, 48);
-            dnan |= (dn2 != dn2);
-            dmax = (dn2 > dmax) ? dn2 : dmax;
+            const double du = c_l - u;                              // d = maximum(norm(l_t - u_t))  (:517-519), as rollin_body
+            dsq = du * du;
+            if (!HELP) {
+                const double dn2 = ((readlane_f64(dsq, 0) + readlane_f64(dsq, 16)) + readlane_f64(dsq, 32)) + readlane_f64(dsq, 48);
+                dnan |= (dn2 != dn2);
+                dmax = (dn2 > dmax) ? dn2 : dmax;
+            }
         }
         xa = MFMA(zA[3], u, xa);
         const double pk = ((xb[0] * pm[0] + xb[1] * pm[1]) + xb[2] * pm[2]) + u * pm[3];
-        xu[t * xstep + xoff] = pk;
+        xu[t * xstep + xoff] = (HELP && m_4 != 0.0) ? dsq : pk;
         WAVE_SYNC();
         __hip_atomic_store(prog, epoch + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int r = 0; r < 3; ++r) xb[r] = xa[r] + pb.kappa * (xb[r] * xb[r] * xb[r]);
     }
-    xu[N * xstep + xoff] = (xb[0] * pm[0] + xb[1] * pm[1]) + xb[2] * pm[2];          // x_N (lanes j == 3: 0)
+    xu[N * xstep + xoff] = (xb[0] * pm[0] + xb[1] * pm[1]) + xb[2] * pm[2];          // x_N (lanes j >= 3: 0)
     WAVE_SYNC();
     __hip_atomic_store(prog, epoch + N + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (MODE == 1 && l == 0) {
+    if (!HELP && MODE == 1 && l == 0) {
         st.d_c[b * st.E] = dnan ? NAN : sqrt(dmax);
         st.flag_c[b * st.E] = 0;
     }
 }
 
-template <int MODE, bool CTV>
-__device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, double *const shxu, const double *const xu, int *const prog, const int epoch) {
+// the steps first, first + stride, ... of the trajectory (and, first == 0, the terminal tile)
+template <int MODE, bool CTV, bool HELP>
+__device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, double *const shxu, const double *const xu, int *const prog, const int epoch,
+                                             const int first, const int stride, unsigned long long *const d_acc) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));
     const int l = lane_, j = l & 15, g = l >> 4;
@@ -1112,9 +1135,16 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
         while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - want < 0) __builtin_amdgcn_s_sleep(1);
         WAVE_SYNC();
     };
-    for (int t = 0; t < N; ++t) {
+    double dmax = 0.0;
+    bool dnan = false;
+    for (int t = first; t < N; t += stride) {
         wait_for(epoch + t + 1);
-        const double *xt = xu + t * 16;
+        const double *xt = xu + t * XU_REC;
+        if (HELP && MODE == 1) {                                    // d = maximum(norm(l_t - u_t))  (:517-519): same sum as rollin_body
+            const double dn2 = ((xt[16] + xt[17]) + xt[18]) + xt[19];
+            dnan |= (dn2 != dn2);
+            dmax = (dn2 > dmax) ? dn2 : dmax;
+        }
         const double xb[3] = {xt[g], xt[4 + g], xt[8 + g]};
         const double u = xt[12 + g];
         const double pk = xt[pkoff] * m_j4;
@@ -1145,10 +1175,15 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
         const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
         tp[qoff] = fma(m_l4, part + cq00, m_j4 * (acc + clin));
     }
+    if (HELP && MODE == 1 && l == 0) {
+        atomicMax(&d_acc[0], (unsigned long long)__double_as_longlong(dmax));     // doubles >= +0 order like their bit patterns
+        if (dnan) atomicOr(&d_acc[1], 1ull);
+    }
+    if (first != 0) return;
     // x_N and the terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316), as rollin_body
     wait_for(epoch + N + 1);
     {
-        const double x = (l < 12) ? xu[N * 16 + l] : 0.0;
+        const double x = (l < 12) ? xu[N * XU_REC + l] : 0.0;
         if (l < 12) { xo[(long)N * XSTR + l] = x; shxu[l] = x; }
         WAVE_SYNC();
         double *__restrict__ tp = tile0 + (long)N * TSTRIDE;
@@ -1663,6 +1698,8 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     __shared__ double stg[STG ? STG_DOUBLES : 1];
     __shared__ double xu[SPLIT ? XU_DOUBLES : 1];
     __shared__ int prog;
+    __shared__ unsigned long long d_acc[2];
+    constexpr bool HELP = SPLIT && PAD4;         // fa.helpers: the two waves a padded workgroup does not need stay as linearise helpers
     int epoch = 0;
     if (threadIdx.x == 0) prog = 0;
     double *const wls = wls_all[hwave], *const shxu = shxu_all[hwave];
@@ -1679,6 +1716,10 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
                 const bool in_pair = odd ? (sid == 1 || sid == 3) : (sid == 0 || sid == 2);
                 const bool first = odd ? (sid == 1) : (sid == 0);
                 s_role[w] = in_pair ? ((first != (flip != 0)) ? 0 : 1) : -1;
+            }
+            if (HELP && fa.helpers) {            // one workgroup per CU: all four SIMDs are this sample's
+                int next = 2;
+                for (int w = 0; w < 4; ++w) if (s_role[w] < 0) s_role[w] = next++;
             }
         }
         __syncthreads();
@@ -1698,10 +1739,17 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     BLK_MARK();
     __syncthreads();
     BLK_MARK();
-    if (SPLIT) {                                 // initialize!: open-loop rollout (wave 0) + linearise (gain wave)   (ileqg.jl:214-233)
+    const bool helpers = HELP && fa.helpers;
+    const int nlin = helpers ? 3 : 1;            // linearise waves: the gain wave (+ the two spare waves)
+    if (SPLIT) {                                 // initialize!: open-loop rollout (wave 0) + linearise (the other waves)   (ileqg.jl:214-233)
         RolloutArgs ra = fa.ro; ra.mode = 0;
-        if (wave == 0) rollrec_body<0>(ra, b, stg, xu, &prog, epoch);
-        else rolllin_body<0, CTV>(ra, b, shxu, xu, &prog, epoch);
+        if (helpers) {
+            if (wave == 0) rollrec_body<0, HELP>(ra, b, stg, xu, &prog, epoch, d_acc);
+            else rolllin_body<0, CTV, HELP>(ra, b, shxu, xu, &prog, epoch, wave - 1, nlin, d_acc);
+        } else {
+            if (wave == 0) rollrec_body<0, false>(ra, b, stg, xu, &prog, epoch, d_acc);
+            else rolllin_body<0, CTV, false>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc);
+        }
         epoch += st.N + 2;
     } else if (wave == 0) {
         RolloutArgs ra = fa.ro; ra.mode = 0;
@@ -1741,8 +1789,13 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         }
         if (SPLIT) {                                          // the candidate of this line-search round  (ileqg.jl:504-521), split over both waves
             RolloutArgs ra = fa.ro; ra.mode = 1;
-            if (wave == 0) rollrec_body<1>(ra, b, stg, xu, &prog, epoch);
-            else rolllin_body<1, CTV>(ra, b, shxu, xu, &prog, epoch);
+            if (helpers) {
+                if (wave == 0) rollrec_body<1, HELP>(ra, b, stg, xu, &prog, epoch, d_acc);
+                else rolllin_body<1, CTV, HELP>(ra, b, shxu, xu, &prog, epoch, wave - 1, nlin, d_acc);
+            } else {
+                if (wave == 0) rollrec_body<1, false>(ra, b, stg, xu, &prog, epoch, d_acc);
+                else rolllin_body<1, CTV, false>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc);
+            }
             epoch += st.N + 2;
         } else if (wave < E) {                                // candidates of this line-search round  (ileqg.jl:504-521)
             RolloutArgs ra = fa.ro; ra.mode = 1;
@@ -1754,7 +1807,12 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         if (wave < E) {                                       // their policy evaluations  (:522-536)
             SweepArgs sa = fa.sw; sa.mode = 1;
             sweep_body<false, false, WTV, true>(sa, b * E + wave, wls);
-        } else {                                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
+        } else if (wave == WG) {                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
+            if (helpers && (threadIdx.x & 63) == 0) {         // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
+                st.d_c[b * E] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
+                st.flag_c[b * E] = 0;
+            }
+            if (helpers) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             const double v_dc = *(const volatile double *)&st.d_c[b * E], v_mu = *(const volatile double *)&st.mu[b];   // it ends solve! (:642-653)
             const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
             const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);

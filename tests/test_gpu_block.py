@@ -72,6 +72,33 @@ def test_block_kernel_against_the_oracle_on_a_backtracking_workload(E, monkeypat
     assert np.abs(r["L"] - s.L_array).max() < 1e-9 and np.abs(r["x"] - s.x_array).max() < 1e-9
 
 
+def test_block_geometries_are_bit_identical(monkeypatch):
+    """E = 1 geometries of the block kernel: four-wave workgroups with ticketed SIMD pairs and linearise helper waves (one sample per CU),
+    without the helpers, plain two-wave workgroups -- and rollouts split over the waves or not (N > 52: unsplit)."""
+    prob, x0, u = rat.synthetic_lq_problem(kappa=0.04)
+    theta = np.concatenate([[0.0], np.linspace(0.05, 9.0, 60), [40.0]])
+    long_p, lx0, lu = rat.synthetic_lq_problem(N=60, seed=3, kappa=0.02)
+    th_l = np.array([0.0, 0.5, 2.0])
+
+    def run():
+        out = list(rat.Context(prob, max_batch=theta.size).solve_batch(x0, u, theta))
+        out += list(rat.Context(long_p, max_batch=3).solve_batch(lx0, lu, th_l))
+        r = rat.Context(prob).solve(x0, u, 3.0)
+        return out + [r["x"], r["l"], r["L"], np.array([r["value"]]), np.asarray(r["eps_history"], dtype=float)]
+
+    monkeypatch.setenv("RATILQR_BLOCK", "1")
+    ref = run()                                                # padded workgroups + helpers
+    for env in ({"RATILQR_BLOCK_HELPERS": "0"}, {"RATILQR_BLOCK_SHAPE": "0"}, {"RATILQR_BLOCK": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for k in env:
+            monkeypatch.delenv(k) if k != "RATILQR_BLOCK" else monkeypatch.setenv("RATILQR_BLOCK", "1")
+        assert all(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True) for a, b in zip(ref, got)), env
+    P = orc.Problem(prob)
+    check_batch(rat.Context(prob, max_batch=theta.size), P, x0, u, theta)
+
+
 def test_block_kernel_default_policy_and_several_generations(monkeypatch):
     """E = 1: batches up to 512 samples run on the block kernel (two SIMDs per sample), larger ones on the fused kernel; forced, a batch
     larger than the chip runs its workgroups in several generations with unchanged results."""
