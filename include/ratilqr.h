@@ -349,6 +349,12 @@ rat_rc  rat_multi_ce_step(rat_multi m, rat_ce_solver *c, const double *x0, const
 rat_rc  rat_multi_ce_solve(rat_multi m, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
                            double *theta_opt, double *x, double *l, double *L, double *value,
                            double *theta_min, double *theta_max);
+/* PETS on all devices (pets.jl:100-126, the `remotecall_fetch(compute_cost_worker, ...)` fan-out :108-124): the S control samples in
+ * contiguous blocks, all K stochastic rollouts of a sample on one device, costs straight to the host; arguments as rat_pets_compute_cost.
+ * Costs do not depend on n_devices (injected noise is addressed by global sample index, the device generator by global trajectory). */
+rat_rc  rat_multi_pets_problem_set(rat_multi m, const rat_gen_problem_desc *desc);
+rat_rc  rat_multi_pets_compute_cost(rat_multi m, const double *x0, const double *controls, int64_t S, int64_t K,
+                                    int32_t use_true_model, const double *zn, const double *zu, uint64_t seed, double *cost);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 #define RAT_K_ROLLOUT   0

@@ -661,41 +661,66 @@ mutable struct CrossEntropyDirectOptimizationSolver
     N::Int64; iter_current::Int64
     device::Int
     h::Union{Nothing,Handle}
+    devices::Vector{Int32}                 # more than one: compute_cost shards the control samples over these GPUs (rat_multi_pets_*)
+    mh::Union{Nothing,MultiHandle}
 end
 function CrossEntropyDirectOptimizationSolver(μ_init_array::Vector{Vector{Float64}}, Σ_init_array::Vector{Matrix{Float64}};
-        num_control_samples=10, num_trajectory_samples=10, num_elite=3, iter_max=5, smoothing_factor=0.1, device=0)
+        num_control_samples=10, num_trajectory_samples=10, num_elite=3, iter_max=5, smoothing_factor=0.1, device=0, devices=[device])
     @assert length(μ_init_array) == length(Σ_init_array)
     CrossEntropyDirectOptimizationSolver(num_control_samples, num_trajectory_samples, num_elite, iter_max, smoothing_factor,
-                                         μ_init_array, Σ_init_array, copy(μ_init_array), copy(Σ_init_array), length(μ_init_array), 0, device, nothing)
+                                         μ_init_array, Σ_init_array, copy(μ_init_array), copy(Σ_init_array), length(μ_init_array), 0, Int(devices[1]), nothing,
+                                         collect(Int32, devices), nothing)
 end
 "initialize!(direct_solver) -- pets.jl:70-74"
 function initialize!(s::CrossEntropyDirectOptimizationSolver)
     s.iter_current = 0
     s.μ_array = copy(s.μ_init_array); s.Σ_array = copy(s.Σ_init_array)
 end
+function with_gen_desc(f::Function, problem::LQGenerativeProblem)
+    p = problem.lq; n, m, N = dims(p)
+    GC.@preserve problem begin
+        lq = ProblemDesc(1, n, m, N, ndims(p.Q) == 3, 0, pointer(p.A), pointer(p.B), pointer(p.Q), pointer(p.R), pointer(p.P), pointer(p.qv),
+                         pointer(p.rv), pointer(p.q0), pointer(p.Qf), pointer(p.qvf), p.q0f, p.kappa, 0, 0, 0, 0, 0, 0, 0, Ptr{Float64}(C_NULL))
+        f(GenProblemDesc(lq, problem.l1u, problem.noise_kind, pointer(problem.nmean), pointer(problem.nchol), problem.nlo, problem.nhi,
+                         problem.tw2, pointer(problem.tmean2), pointer(problem.tchol2)))
+    end
+end
 function handle!(s::CrossEntropyDirectOptimizationSolver, problem::LQGenerativeProblem)
     if s.h === nothing || s.h.problem !== problem
         s.h === nothing && (s.h = Handle(IleqgOpts(1e-6, 2.0, 0.5, 1e-2, 100, 1.0, 1e-6, 0), 1, 1, s.device))
-        p = problem.lq; n, m, N = dims(p)
-        GC.@preserve problem begin
-            lq = ProblemDesc(1, n, m, N, ndims(p.Q) == 3, 0, pointer(p.A), pointer(p.B), pointer(p.Q), pointer(p.R), pointer(p.P), pointer(p.qv),
-                             pointer(p.rv), pointer(p.q0), pointer(p.Qf), pointer(p.qvf), p.q0f, p.kappa, 0, 0, 0, 0, 0, 0, 0, Ptr{Float64}(C_NULL))
-            d = GenProblemDesc(lq, problem.l1u, problem.noise_kind, pointer(problem.nmean), pointer(problem.nchol), problem.nlo, problem.nhi,
-                               problem.tw2, pointer(problem.tmean2), pointer(problem.tchol2))
+        with_gen_desc(problem) do d
             check(ccall((:rat_pets_problem_set, LIB), Int32, (Ptr{Cvoid}, Ref{GenProblemDesc}), s.h.ptr, d))
         end
         s.h.problem = problem
     end
     s.h
 end
+function multi_handle!(s::CrossEntropyDirectOptimizationSolver, problem::LQGenerativeProblem)
+    if s.mh === nothing || s.mh.problem !== problem
+        s.mh === nothing && (s.mh = MultiHandle(IleqgOpts(1e-6, 2.0, 0.5, 1e-2, 100, 1.0, 1e-6, 0), 1, 1, s.devices))
+        with_gen_desc(problem) do d
+            check(ccall((:rat_multi_pets_problem_set, LIB), Int32, (Ptr{Cvoid}, Ref{GenProblemDesc}), s.mh.ptr, d))
+        end
+        s.mh.problem = problem
+    end
+    s.mh
+end
 
 """compute_cost(direct_solver, problem, x, control_sequence_array, rng, use_true_model) -- pets.jl:100-126 (all S × K stochastic rollouts in
 one launch; noise from the device generator keyed by a seed drawn from `rng`)"""
 function compute_cost(s::CrossEntropyDirectOptimizationSolver, problem::LQGenerativeProblem, x::Vector{Float64},
                       control_sequence_array::Vector{Vector{Vector{Float64}}}, rng::AbstractRNG, use_true_model=false)
-    h = handle!(s, problem); S = length(control_sequence_array)
+    S = length(control_sequence_array)
     ctrl = cat([flat(c) for c in control_sequence_array]...; dims=3)           # m × N × S
     cost = Vector{Float64}(undef, S)
+    if length(s.devices) > 1                                                   # control samples sharded over the GPUs (pets.jl:108-124)
+        mh = multi_handle!(s, problem)
+        check(ccall((:rat_multi_pets_compute_cost, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int32, Ptr{Float64}, Ptr{Float64}, UInt64, Ptr{Float64}),
+                    mh.ptr, x, ctrl, S, s.num_trajectory_samples, use_true_model, C_NULL, C_NULL, rand(rng, UInt64), cost))
+        return cost
+    end
+    h = handle!(s, problem)
     check(ccall((:rat_pets_compute_cost, LIB), Int32,
                 (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int32, Ptr{Float64}, Ptr{Float64}, UInt64, Ptr{Float64}),
                 h.ptr, x, ctrl, S, s.num_trajectory_samples, use_true_model, C_NULL, C_NULL, rand(rng, UInt64), cost))

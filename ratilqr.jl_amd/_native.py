@@ -83,7 +83,7 @@ EXPORTS = [
     "rat_dp_gain_sweep_batch", "rat_dp_policy_eval_batch",
     "rat_shard_bounds", "rat_create_multi", "rat_multi_destroy", "rat_multi_n_devices", "rat_multi_handle", "rat_multi_uses_rccl",
     "rat_multi_allgathers", "rat_multi_problem_set", "rat_multi_set_initial", "rat_multi_ce_compute_cost", "rat_multi_ce_step",
-    "rat_multi_ce_solve",
+    "rat_multi_ce_solve", "rat_multi_pets_problem_set", "rat_multi_pets_compute_cost",
 ]
 
 _lib = None

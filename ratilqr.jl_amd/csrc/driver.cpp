@@ -82,6 +82,7 @@ struct rat_handle_s {
     std::vector<void *> gen_allocs;
     double *d_px0 = nullptr, *d_pctrl = nullptr, *d_pzn = nullptr, *d_pzu = nullptr, *d_ptraj = nullptr, *d_pcost = nullptr;
     size_t cap_ctrl = 0, cap_zn = 0, cap_zu = 0, cap_traj = 0, cap_cost = 0;
+    double *h_pstage = nullptr; size_t cap_pstage = 0;      // pinned staging of x0 | padded controls (asynchronous uploads)
     // CE randomness
     const double *z = nullptr;
     int64_t nz = 0, zpos = 0;
@@ -172,6 +173,7 @@ extern "C" void rat_destroy(rat_handle h) {
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->d_hist) (void)hipFree(h->d_hist);
+    if (h->h_pstage) (void)hipHostFree(h->h_pstage);
     if (h->d_census) (void)hipFree(h->d_census);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -1567,8 +1569,22 @@ static rat_rc grow(double **p, size_t *cap, size_t need) {
     return RAT_OK;
 }
 
+// enqueue form (multi.cpp drives several devices from one thread): everything up to and including the copy of the costs into
+// `cost` -- which should be pinned memory for the copy to be asynchronous -- is ordered on the handle's stream; no host wait.
+// sample0 = global index of controls[0] among the whole batch's control samples.
+rat_rc rat_pets_enqueue(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K, int32_t use_true_model, const double *zn,
+                        const double *zu, uint64_t seed, int64_t sample0, double *cost);
+
 extern "C" rat_rc rat_pets_compute_cost(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K,
                                         int32_t use_true_model, const double *zn, const double *zu, uint64_t seed, double *cost) {   // pets.jl:128-157
+    rat_rc rc = rat_pets_enqueue(h, x0, controls, S, K, use_true_model, zn, zu, seed, 0, cost);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RAT_OK;
+}
+
+rat_rc rat_pets_enqueue(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K, int32_t use_true_model, const double *zn,
+                        const double *zu, uint64_t seed, int64_t sample0, double *cost) {
     if (!h || !x0 || !controls || !cost) return fail(RAT_ERR_ARG, "null");
     if (!h->have_gen) return fail(RAT_ERR_NO_PROBLEM, "rat_pets_problem_set was not called");
     if (S < 1 || K < 1) return fail(RAT_ERR_ARG, "S, K must be positive");
@@ -1580,15 +1596,27 @@ extern "C" rat_rc rat_pets_compute_cost(rat_handle h, const double *x0, const do
     if ((rc = grow(&h->d_pctrl, &h->cap_ctrl, (size_t)S * N * USTR))) return rc;
     if ((rc = grow(&h->d_ptraj, &h->cap_traj, ntraj))) return rc;
     if ((rc = grow(&h->d_pcost, &h->cap_cost, (size_t)S))) return rc;
-    std::vector<double> xp(XSTR, 0.0), cp((size_t)S * N * USTR, 0.0);
+    // padded x0 and controls in a pinned staging area owned by the handle: the uploads are asynchronous and must outlive this call
+    const size_t nstage = XSTR + (size_t)S * N * USTR;
+    if (nstage > h->cap_pstage) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->h_pstage) (void)hipHostFree(h->h_pstage);
+        h->h_pstage = nullptr; h->cap_pstage = 0;
+        HIPCHK(hipHostMalloc((void **)&h->h_pstage, nstage * sizeof(double), hipHostMallocDefault));
+        h->cap_pstage = nstage;
+    } else {
+        HIPCHK(hipStreamSynchronize(h->stream));          // (a previous enqueue may still be reading the staging area)
+    }
+    double *xp = h->h_pstage, *cp = h->h_pstage + XSTR;
+    memset(xp, 0, nstage * sizeof(double));
     for (int i = 0; i < n; ++i) xp[i] = x0[i];
     for (int64_t ii = 0; ii < S; ++ii) for (int t = 0; t < N; ++t) for (int a = 0; a < m; ++a)
         cp[((size_t)ii * N + t) * USTR + a] = controls[((size_t)ii * N + t) * m + a];
-    HIPCHK(hipMemcpyAsync(h->d_px0, xp.data(), xp.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pctrl, cp.data(), cp.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_px0, xp, XSTR * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pctrl, cp, (size_t)S * N * USTR * 8, hipMemcpyHostToDevice, h->stream));
     PetsArgs a;
     a.g = h->gen; a.x0 = h->d_px0; a.controls = h->d_pctrl; a.S = S; a.K = K; a.use_true = use_true_model ? 1 : 0;
-    a.zn = nullptr; a.zu = nullptr; a.seed = seed; a.traj_cost = h->d_ptraj; a.cost = h->d_pcost;
+    a.zn = nullptr; a.zu = nullptr; a.seed = seed; a.traj0 = (long)(sample0 * K); a.traj_cost = h->d_ptraj; a.cost = h->d_pcost;
     if (zn) {
         if ((rc = grow(&h->d_pzn, &h->cap_zn, ntraj * N * n))) return rc;
         HIPCHK(hipMemcpyAsync(h->d_pzn, zn, ntraj * N * n * 8, hipMemcpyHostToDevice, h->stream));
@@ -1601,7 +1629,6 @@ extern "C" rat_rc rat_pets_compute_cost(rat_handle h, const double *x0, const do
     }
     launch_pets(a, h->stream);
     HIPCHK(hipMemcpyAsync(cost, h->d_pcost, (size_t)S * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
     return RAT_OK;
 }
 

@@ -65,6 +65,7 @@ struct PetsArgs {
     int use_true;
     const double *zn, *zu;      // injected draws or null (device Philox)
     unsigned long long seed;
+    long traj0;                 // global index of this launch's first trajectory (device generator counter)
     double *traj_cost;          // [S*K]
     double *cost;               // [S]
 };

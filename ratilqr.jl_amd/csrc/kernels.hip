@@ -1925,6 +1925,8 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
     const long ntraj = a.S * a.K;
     const long tj = (long)blockIdx.x * 4 + row;
     const bool live = tj < ntraj;
+    const long tjg = tj + a.traj0;         // global trajectory index: keys the device generator, so that a shard of the control samples draws
+                                           // the noise it would draw as part of the whole batch (results do not depend on the sharding)
     const long ii = live ? tj / a.K : 0;
     __shared__ double shxu[4][16];
     __shared__ double shz[4][16];
@@ -1960,7 +1962,7 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
             // one Philox block and one Box-Muller transform serve two consecutive steps (both outputs of the transform are used)
             if ((t & 1) == 0) {
                 unsigned r[4];
-                philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)(t >> 1), (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+                philox4x32_10((unsigned)tjg, (unsigned)(tjg >> 32), (unsigned)(t >> 1), (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
                 const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
                 if (g.noise_kind == 1 && !need_sel) { z = u1; znext = u2; }
                 else {
@@ -1972,7 +1974,7 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
             } else z = znext;
             if (need_sel) {
                 unsigned rs[4];
-                philox4x32_10((unsigned)tj, (unsigned)(tj >> 32), (unsigned)t, 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);
+                philox4x32_10((unsigned)tjg, (unsigned)(tjg >> 32), (unsigned)t, 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);
                 zsel = u01(rs[0], rs[1]);
             }
         }

@@ -71,6 +71,8 @@ struct rat_multi_s {
     std::vector<ncclComm_t> comm;                   // empty: no RCCL (one device)
     std::vector<double *> d_theta, d_cost, d_all;   // per device: theta shard [chunk_max], cost shard [chunk_max], gathered [G * chunk_max]
     double *h_stage = nullptr;                      // pinned: theta (Bmax) | gathered costs (G * chunk_max)
+    double *h_pets = nullptr; size_t pets_cap = 0;  // pinned: PETS per-sample costs
+    int pets_n = 0, pets_m = 0, pets_N = 0;
     int64_t n_allgathers = 0;
 };
 
@@ -92,6 +94,7 @@ extern "C" void rat_multi_destroy(rat_multi m) {
         if (m->h[g]) rat_destroy(m->h[g]);
     }
     if (m->h_stage) (void)hipHostFree(m->h_stage);
+    if (m->h_pets) (void)hipHostFree(m->h_pets);
     delete m;
 }
 
@@ -198,6 +201,48 @@ extern "C" rat_rc rat_multi_ce_compute_cost(rat_multi m, const double *x0, const
         MRC(rat_shard_bounds(B, G, g, &lo, &hi));
         memcpy(cost + lo, p_all + (size_t)g * chunk, sizeof(double) * (hi - lo));
     }
+    return RAT_OK;
+}
+
+// PETS (pets.jl:100-126): the S control samples of compute_cost split in contiguous blocks over the devices, all K stochastic rollouts of a
+// sample on one device (their mean is the sample's cost, :150); every device evaluates its block concurrently and copies its costs straight
+// to the host (the elite selection needs them there: no collective).  Injected noise is addressed by global sample index and the device
+// generator is keyed by the global trajectory index, so the costs do not depend on the number of devices.
+rat_rc rat_pets_enqueue(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K, int32_t use_true_model, const double *zn,
+                        const double *zu, uint64_t seed, int64_t sample0, double *cost);
+
+extern "C" rat_rc rat_multi_pets_problem_set(rat_multi m, const rat_gen_problem_desc *d) {
+    if (!m || !d) return mfail(RAT_ERR_ARG, "null");
+    for (int g = 0; g < m->G; ++g) MRC(rat_pets_problem_set(m->h[g], d));
+    m->pets_n = d->lq.n; m->pets_m = d->lq.m; m->pets_N = d->lq.N;
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_multi_pets_compute_cost(rat_multi m, const double *x0, const double *controls, int64_t S, int64_t K, int32_t use_true_model,
+                                              const double *zn, const double *zu, uint64_t seed, double *cost) {
+    if (!m || !x0 || !controls || !cost) return mfail(RAT_ERR_ARG, "null");
+    if (m->pets_N <= 0) return mfail(RAT_ERR_NO_PROBLEM, "rat_multi_pets_problem_set was not called");
+    if (S < 1 || K < 1) return mfail(RAT_ERR_ARG, "S, K must be positive");
+    const int G = m->G;
+    const int64_t n = m->pets_n, mm = m->pets_m, N = m->pets_N;
+    if ((size_t)S > m->pets_cap) {                              // pinned landing zone of the per-sample costs
+        if (m->h_pets) (void)hipHostFree(m->h_pets);
+        m->h_pets = nullptr; m->pets_cap = 0;
+        MHIP(hipHostMalloc((void **)&m->h_pets, sizeof(double) * (size_t)S, hipHostMallocDefault));
+        m->pets_cap = (size_t)S;
+    }
+    for (int g = 0; g < G; ++g) {
+        int64_t lo, hi;
+        MRC(rat_shard_bounds(S, G, g, &lo, &hi));
+        if (hi == lo) continue;
+        MRC(rat_pets_enqueue(m->h[g], x0, controls + (size_t)lo * N * mm, hi - lo, K, use_true_model, zn ? zn + (size_t)lo * K * N * n : nullptr,
+                             (zn && zu) ? zu + (size_t)lo * K * N : nullptr, seed, lo, m->h_pets + lo));
+    }
+    for (int g = 0; g < G; ++g) {
+        MHIP(hipSetDevice(m->dev[g]));
+        MHIP(hipStreamSynchronize((hipStream_t)rat_stream(m->h[g])));
+    }
+    memcpy(cost, m->h_pets, sizeof(double) * (size_t)S);
     return RAT_OK;
 }
 

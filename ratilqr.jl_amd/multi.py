@@ -69,3 +69,32 @@ class MultiContext:
         nv.check(nv.lib().rat_multi_ce_solve(self.m_, C.byref(c), nv.P(nv.f64(x0)), nv.P(nv.f64(u)), C.c_double(kl_bound), C.byref(th), nv.P(x),
                                              nv.P(l), nv.P(Lb), C.byref(val), C.byref(tmin), C.byref(tmax)))
         return th.value, x, l, nv.from_cm3(Lb, N, m, n), val.value, tmin.value, tmax.value
+
+
+class MultiPetsContext:
+    """PETS cost evaluation (pets.jl:100-126) over several GPUs behind one object: rat_multi_pets_*."""
+
+    def __init__(self, problem, devices=(0,)):
+        L = nv.lib()
+        self.problem = problem
+        self.devices = [int(d) for d in devices]
+        dev = (C.c_int32 * len(self.devices))(*self.devices)
+        self.m_ = C.c_void_p()
+        nv.check(L.rat_create_multi(None, 1, 1, len(self.devices), dev, C.byref(self.m_)))
+        import weakref
+        self._fin = weakref.finalize(self, L.rat_multi_destroy, self.m_)
+        from .pets import make_gen_desc
+        desc, self._keep = make_gen_desc(problem)
+        nv.check(L.rat_multi_pets_problem_set(self.m_, C.byref(desc)))
+
+    def compute_cost(self, x, control_sequence_array, K, use_true_model=False, streams=None, seed=0):
+        ctrl = nv.f64(control_sequence_array)
+        S = ctrl.shape[0]
+        cost = np.zeros(S)
+        zn = zu = None
+        if streams is not None:
+            zn = nv.f64(streams[0])
+            zu = None if streams[1] is None else nv.f64(streams[1])
+        nv.check(nv.lib().rat_multi_pets_compute_cost(self.m_, nv.P(nv.f64(x)), nv.P(ctrl), C.c_int64(S), C.c_int64(int(K)), int(bool(use_true_model)),
+                                                      nv.P(zn), nv.P(zu), C.c_uint64(int(seed)), nv.P(cost)))
+        return cost

@@ -70,16 +70,22 @@ class CrossEntropyDirectOptimizationSolver:                       # a.k.a. "PETS
     def context(self, problem):
         if self._ctx is None or self._ctx[0] is not problem:
             ctx = Context(problem.lq, device=self.device)
-            t = problem.gen_tables()
-            desc, keep = nv.make_desc(problem.lq)
-            g = nv.GenProblemDesc()
-            g.lq = desc
-            arrs = {k: nv.f64(t[k]) for k in ("nmean", "nchol", "tmean2", "tchol2")}
-            g.l1u, g.noise_kind, g.nlo, g.nhi, g.tw2 = t["l1u"], t["noise_kind"], t["nlo"], t["nhi"], t["tw2"]
-            g.nmean, g.nchol, g.tmean2, g.tchol2 = (nv.P(arrs[k]) for k in ("nmean", "nchol", "tmean2", "tchol2"))
+            g, keep = make_gen_desc(problem)
             nv.check(nv.lib().rat_pets_problem_set(ctx.h, C.byref(g)))
-            self._ctx = (problem, ctx, keep, arrs)
+            self._ctx = (problem, ctx, keep)
         return self._ctx[1]
+
+
+def make_gen_desc(problem):
+    """rat_gen_problem_desc of an LQGenerativeProblem (+ the arrays it points into, to be kept alive)."""
+    t = problem.gen_tables()
+    desc, keep = nv.make_desc(problem.lq)
+    g = nv.GenProblemDesc()
+    g.lq = desc
+    arrs = {k: nv.f64(t[k]) for k in ("nmean", "nchol", "tmean2", "tchol2")}
+    g.l1u, g.noise_kind, g.nlo, g.nhi, g.tw2 = t["l1u"], t["noise_kind"], t["nlo"], t["nhi"], t["tw2"]
+    g.nmean, g.nchol, g.tmean2, g.tchol2 = (nv.P(arrs[k]) for k in ("nmean", "nchol", "tmean2", "tchol2"))
+    return g, (keep, arrs)
 
 
 def initialize_(direct_solver):                                   # initialize!  pets.jl:70-74

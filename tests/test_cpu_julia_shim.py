@@ -226,7 +226,7 @@ def test_solvers_rebind_their_handle_to_the_problem_argument():
     """every entry point that takes a problem goes through bind!/handle! (no stale device tables)."""
     for m in re.finditer(r"\nfunction (\w+!?)\((s::\w+), problem(::\w+)?[^\n]*\n(.*?)\nend", JL, flags=re.S):
         name, body = m.group(1), m.group(4)
-        if "reference_module()" in body or name == "handle!" or (name in ("initialize!", "line_search!", "step!") and "ILEQGSolver" in m.group(2)):
+        if "reference_module()" in body or name in ("handle!", "multi_handle!") or (name in ("initialize!", "line_search!", "step!") and "ILEQGSolver" in m.group(2)):
             continue                                                 # forwarded to the reference / composed from operators that bind
         if "ccall" in body:
             assert "bind!(" in body or "handle!(" in body, f"{name}({m.group(2)}, problem, ...) calls the library without binding the problem"

@@ -50,3 +50,24 @@ def test_multi_rejects_more_devices_than_visible():
         rat.MultiContext(prob, max_batch=8, devices=tuple(range(torch.cuda.device_count() + 1)))
     with pytest.raises(rat.RatError):
         rat.MultiContext(prob, max_batch=8, devices=(0, 0))
+
+
+def test_multi_pets_cost_equals_the_single_handle_cost():
+    """rat_multi_pets_compute_cost (control samples sharded over devices, here one) == rat_pets_compute_cost, with injected noise and with
+    the device generator -- which is keyed by the GLOBAL trajectory index: a block evaluated alone with sample0 > 0 through the Python
+    sharding layer draws what it draws as part of the whole batch."""
+    from ratilqr.jl_amd import pets, multi
+    rng = np.random.default_rng(5)
+    Nh, n, m, S, K = 30, 12, 4, 40, 25
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    prob = rat.LQGenerativeProblem(0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), Nh, ("gaussian", np.zeros(n), 0.05 * np.eye(n)),
+                                   Q=np.eye(n), R=0.1 * np.eye(m), Qf=np.eye(n))
+    ds = rat.CrossEntropyDirectOptimizationSolver(np.zeros((Nh, m)), np.stack([np.eye(m)] * Nh), num_control_samples=S, num_trajectory_samples=K)
+    ctrl, x0 = 0.3 * rng.standard_normal((S, Nh, m)), rng.standard_normal(n)
+    zn, zu = pets.draw_noise(prob, rng, S, K)
+    mp = multi.MultiPetsContext(prob, devices=(0,))
+    ref = pets.compute_cost_serial(ds, prob, x0, ctrl, None, streams=(zn, zu))
+    assert np.array_equal(mp.compute_cost(x0, ctrl, K, streams=(zn, zu)), ref)
+    dev = mp.compute_cost(x0, ctrl, K, seed=7)
+    assert np.array_equal(dev, pets.compute_cost_serial(ds, prob, x0, ctrl, None, seed=7)) and np.all(np.isfinite(dev))
+    assert np.array_equal(dev, mp.compute_cost(x0, ctrl, K, seed=7)) and not np.array_equal(dev, mp.compute_cost(x0, ctrl, K, seed=8))
