@@ -30,13 +30,13 @@
 extern "C" {
 #endif
 
-#define RAT_VERSION 200
+#define RAT_VERSION 201
 
 /* ---- return codes (API level) ---------------------------------------------------------------- */
 typedef int32_t rat_rc;
 #define RAT_OK               0
 #define RAT_ERR_ARG          1   /* bad argument / option out of the reference's @assert ranges */
-#define RAT_ERR_UNSUPPORTED  2   /* problem size or model outside the compiled kernels (n<=12, m<=4) */
+#define RAT_ERR_UNSUPPORTED  2   /* problem size or model outside the compiled kernels (solves: n, m <= 32; operators: n<=12, m<=4) */
 #define RAT_ERR_HIP          3   /* HIP runtime error (see rat_last_error) */
 #define RAT_ERR_NO_PROBLEM   4   /* rat_problem_set was not called */
 #define RAT_ERR_STREAM_DRY   5   /* injected N(0,1) stream exhausted */
@@ -366,7 +366,8 @@ rat_rc  rat_multi_pets_compute_cost(rat_multi m, const double *x0, const double 
 #define RAT_K_SWEEP_DUAL 6   /* fused wavefront: policy evaluation + the next step!'s gain sweep over one pass of the tiles */
 #define RAT_K_SOLVE_FUSED 7  /* one persistent wavefront per sample runs the whole solve! (E = 1): every phase above in one launch */
 #define RAT_K_SOLVE_BLOCK 8  /* one workgroup per sample runs the whole solve!: a wavefront per line-search candidate + a gain-sweep wavefront */
-#define RAT_K_COUNT     9
+#define RAT_K_SOLVE_WIDE  9  /* general-size solve kernel (n <= 32, m <= 32 beyond the 12 + 4 tile): a workgroup per sample, whole solve! */
+#define RAT_K_COUNT     10
 /* When enabled, kernel launches are bracketed by HIP events on the handle's stream.
  * on = 0: off; on = 1: every kernel kind; otherwise on = (mask << 1) | 1 with bit k of mask selecting kind RAT_K_k.
  * Launches of a surplus round (no live sample left) are not counted. */

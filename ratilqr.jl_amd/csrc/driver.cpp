@@ -19,6 +19,7 @@
 #include "../../include/ratilqr.h"
 #include "kernels.h"
 #include "layout.h"
+#include "wide.h"
 
 static thread_local std::string g_err;
 static rat_rc fail(rat_rc rc, const std::string &msg) { g_err = msg; return rc; }
@@ -55,6 +56,11 @@ struct rat_handle_s {
     bool have_problem = false;
     int n = 0, m = 0, N = 0;
     ProblemDev pb;
+    // problems beyond the 12 + 4 tile of the MFMA kernels (wide.hip: n <= 32, m <= 32, LQ family; solve / CE / Nelder-Mead entry points)
+    bool wide = false;
+    WideProblemDev wpb;
+    double *w_xs = nullptr, *w_us = nullptr, *w_L = nullptr, *w_dl = nullptr;
+    int *w_nom = nullptr, *w_hn = nullptr;
     std::vector<void *> pb_allocs, st_allocs;
     std::vector<double> hW;          // host copy of W (col-major, N entries) for rat_approximate_model
     int W_tv = 0;
@@ -239,6 +245,7 @@ static bool host_inv(int n, const double *A, double *Ainv) {
 static rat_rc alloc_state(rat_handle h) {
     free_list(h->st_allocs);
     StateDev &st = h->st;
+    h->wide = false;
     const int N = h->N, E = h->E, B = h->Bmax;
     st.B = B; st.E = E; st.N = N;
     st.tile_stride = (long)N * TSTRIDE + TTERM;
@@ -277,13 +284,96 @@ static rat_rc alloc_state(rat_handle h) {
     return RAT_OK;
 }
 
+// ---- problems beyond n <= 12, m <= 4: tables at their own size for wide.hip ---------------------------
+static rat_rc alloc_state_wide(rat_handle h) {
+    free_list(h->st_allocs);
+    memset(&h->st, 0, sizeof(h->st));
+    const int N = h->N, n = h->n, m = h->m, B = h->Bmax;
+    h->st.B = B; h->st.E = h->E; h->st.N = N;
+    h->st.x_stride = (long)(N + 1) * n; h->st.u_stride = (long)N * m; h->st.tile_stride = 0;
+    rat_rc rc;
+#define AL(ptr, cnt) if ((rc = dev_alloc(h->st_allocs, &(ptr), (cnt)))) return rc
+    AL(h->w_xs, (size_t)B * 2 * (N + 1) * n); AL(h->w_us, (size_t)B * 2 * N * m);
+    AL(h->w_L, (size_t)B * N * n * m); AL(h->w_dl, (size_t)B * N * m); AL(h->w_nom, B); AL(h->w_hn, 1);
+    AL(h->d_x0, n); AL(h->d_u0, (size_t)N * m); AL(h->d_theta, B); AL(h->d_val, B);
+    AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);
+    AL(h->d_opout, 2); AL(h->d_dump, 1); AL(h->d_dlin, 1);
+#undef AL
+    h->wide = true;
+    return RAT_OK;
+}
+
+// log|det W| by LU with partial pivoting (logdet(W M) = logdet W + logdet M, ileqg.jl:387)
+static bool host_logabsdet(int n, const double *A, double *out) {
+    std::vector<double> a(A, A + n * n);
+    double acc = 0.0;
+    for (int k = 0; k < n; ++k) {
+        int p = k; double best = std::fabs(a[k + n * k]);
+        for (int i = k + 1; i < n; ++i) if (std::fabs(a[i + n * k]) > best) { best = std::fabs(a[i + n * k]); p = i; }
+        if (best == 0.0 || best != best) return false;
+        if (p != k) for (int j = 0; j < n; ++j) std::swap(a[k + n * j], a[p + n * j]);
+        acc += std::log(std::fabs(a[k + n * k]));
+        for (int i = k + 1; i < n; ++i) {
+            const double f = a[i + n * k] / a[k + n * k];
+            for (int j = k + 1; j < n; ++j) a[i + n * j] -= f * a[k + n * j];
+        }
+    }
+    *out = acc;
+    return true;
+}
+
+static rat_rc problem_set_wide(rat_handle h, const rat_problem_desc *d) {
+    const int n = d->n, m = d->m, N = d->N;
+    if (!d->A || !d->B || !d->Q || !d->R || !d->P || !d->qv || !d->rv || !d->q0 || !d->Qf || !d->qvf)
+        return fail(RAT_ERR_ARG, "LQ family: a table pointer is null");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_list(h->pb_allocs);
+    WideProblemDev wp;
+    memset(&wp, 0, sizeof(wp));
+    wp.n = n; wp.m = m; wp.N = N; wp.cost_tv = d->cost_tv ? 1 : 0; wp.W_tv = d->W_tv ? 1 : 0;
+    wp.kappa = d->kappa; wp.q0f = d->q0f;
+    const int Nc = wp.cost_tv ? N : 1, Nw = wp.W_tv ? N : 1;
+    const size_t n2 = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+    auto sym_upper = [](int k, const double *src, double *dst) {                        // Symmetric(X): the upper triangle rules
+        for (int j = 0; j < k; ++j) for (int i = 0; i < k; ++i) dst[i + k * j] = (i <= j) ? src[i + k * j] : src[j + k * i];
+    };
+    std::vector<double> A(d->A, d->A + n2), B(d->B, d->B + nm), Q(Nc * n2), R(Nc * mm), P(d->P, d->P + Nc * nm);
+    std::vector<double> qv(d->qv, d->qv + (size_t)Nc * n), rv(d->rv, d->rv + (size_t)Nc * m), q0(d->q0, d->q0 + Nc), Qf(n2), qvf(d->qvf, d->qvf + n);
+    for (int k = 0; k < Nc; ++k) { sym_upper(n, d->Q + k * n2, &Q[k * n2]); sym_upper(m, d->R + k * mm, &R[k * mm]); }
+    sym_upper(n, d->Qf, Qf.data());
+    std::vector<double> W(d->W, d->W + Nw * n2), Winv(Nw * n2), ldW(Nw), wi(n2);
+    for (int k = 0; k < Nw; ++k) {
+        if (!host_inv(n, d->W + k * n2, wi.data()) || !host_logabsdet(n, d->W + k * n2, &ldW[k]))
+            return fail(RAT_ERR_ARG, "rat_problem_set: W(k) is singular (inv(W) would throw, ileqg.jl:365)");
+        sym_upper(n, wi.data(), &Winv[k * n2]);
+    }
+    h->hW = W; h->W_tv = wp.W_tv;
+    rat_rc rc;
+#define UP(field, vec) if ((rc = dev_upload(h, h->pb_allocs, &wp.field, vec))) return rc
+    UP(A, A); UP(B, B); UP(Q, Q); UP(R, R); UP(P, P); UP(qv, qv); UP(rv, rv); UP(q0, q0); UP(Qf, Qf); UP(qvf, qvf);
+    UP(W, W); UP(Winv, Winv); UP(ldW, ldW);
+#undef UP
+    const bool realloc_state = !h->have_problem || !h->wide || h->N != N || h->n != n || h->m != m;
+    memset(&h->pb, 0, sizeof(h->pb));
+    h->pb.model = d->model; h->pb.n = n; h->pb.m = m; h->pb.N = N;
+    h->wpb = wp; h->n = n; h->m = m; h->N = N;
+    h->have_problem = true; h->have_initial = false;
+    if (realloc_state && (rc = alloc_state_wide(h))) return rc;
+    return RAT_OK;
+}
+
 extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
     if (!h || !d) return fail(RAT_ERR_ARG, "null");
     HIPCHK(hipSetDevice(h->device));
     const int n = d->n, m = d->m, N = d->N;
     if (n < 1 || m < 1 || N < 1) return fail(RAT_ERR_ARG, "rat_problem_set: n, m, N must be positive");
-    if (n > RAT_NP || m > RAT_MP)
-        return fail(RAT_ERR_UNSUPPORTED, "rat_problem_set: kernels are compiled for n <= 12, m <= 4");
+    if (n > RAT_NP || m > RAT_MP) {          // beyond the MFMA tile: the general-size solve kernel (wide.hip)
+        if (n > WIDE_MAX_N || m > WIDE_MAX_M) return fail(RAT_ERR_UNSUPPORTED, "rat_problem_set: kernels are compiled for n <= 32, m <= 32");
+        if (d->model != RAT_MODEL_LQ)
+            return fail(RAT_ERR_UNSUPPORTED, "rat_problem_set: beyond n <= 12, m <= 4 only the LQ family is compiled");
+        if (!d->W) return fail(RAT_ERR_ARG, "W missing");
+        return problem_set_wide(h, d);
+    }
     if (d->model != RAT_MODEL_LQ && d->model != RAT_MODEL_POWERLAW) return fail(RAT_ERR_UNSUPPORTED, "unknown model family");
     if (d->model == RAT_MODEL_POWERLAW && n != m) return fail(RAT_ERR_ARG, "power-law family needs n == m");
     if (!d->W) return fail(RAT_ERR_ARG, "W missing");
@@ -362,7 +452,7 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
     // same N but smaller n or m would find the previous problem's values there, so the pools are rebuilt (and re-zeroed by
     // alloc_state) whenever ANY dimension changes; a problem of the same shape (a receding-horizon caller re-setting its tables every
     // control step) keeps its buffers: every live lane is rewritten by the next solve.
-    const bool realloc_state = !h->have_problem || h->N != N || h->n != n || h->m != m;
+    const bool realloc_state = !h->have_problem || h->wide || h->N != N || h->n != n || h->m != m;
     h->pb = pb; h->n = n; h->m = m; h->N = N;
     h->have_problem = true; h->have_initial = false;
     if (realloc_state && (rc = alloc_state(h))) return rc;
@@ -508,8 +598,10 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
 //   PATH_ROUNDS  one launch per phase, host-polled rounds                                                              (any E, operators)
 // E = 1: the chip has 1024 SIMDs.  Up to 512 samples the block kernel gives every sample two SIMDs (its evaluation and gain
 // recursions run side by side); from there on the in-wave pairing of the fused kernel is the better use of a SIMD (measured).
-enum Path { PATH_ROUNDS, PATH_FUSED, PATH_BLOCK };
+//   PATH_WIDE    wide_solve_kernel: problems beyond n <= 12, m <= 4, one workgroup per sample, whole solve! in one launch       (wide.hip)
+enum Path { PATH_ROUNDS, PATH_FUSED, PATH_BLOCK, PATH_WIDE };
 static Path pick_path(const rat_handle h, int B) {
+    if (h->wide) return PATH_WIDE;
     const bool block_ok = solve_block_supported(h->E) && h->block_mode != 0 && (h->E > 1 || h->fused) && !h->speculate &&
                           (h->E == 1 || getenv("RATILQR_DUAL") == nullptr);
     if (h->E == 1) {
@@ -536,6 +628,19 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
     StateDev st = h->st;
     st.B = B;
     const Path path = pick_path(h, B);
+    if (path == PATH_WIDE) {
+        WideArgs wa;
+        wa.pb = h->wpb; wa.op = h->opd; wa.B = B;
+        wa.x0 = h->d_x0; wa.u0 = h->d_u0; wa.theta = theta_dev;
+        wa.xs = h->w_xs; wa.us = h->w_us; wa.L = h->w_L; wa.dl = h->w_dl; wa.nom = h->w_nom;
+        wa.out_value = out.value; wa.out_status = out.status; wa.out_iters = out.iters; wa.out_ls = out.ls;
+        wa.out_cost = out.cost; wa.kl_bound = out.kl_bound;
+        wa.hist = h->st.hist; wa.hist_cap = h->st.hist_cap; wa.hist_n = h->w_hn;
+        prof_begin(h, RAT_K_SOLVE_WIDE, B);
+        HIPCHK(launch_wide_solve(wa, h->stream));
+        prof_end(h);
+        return RAT_OK;
+    }
     if (path == PATH_ROUNDS) launch_init_state(st, h->opd, theta_dev, h->stream);     // (the single-launch solves initialise each sample themselves)
     // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation; the first gain
     // sweep (step! number 1 re-linearises the same trajectory, App. B.1) runs speculatively beside it.
@@ -610,8 +715,12 @@ extern "C" rat_rc rat_set_initial(rat_handle h, const double *x0, const double *
     if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
     HIPCHK(hipSetDevice(h->device));
     std::vector<double> xp(XSTR, 0.0), up((size_t)h->N * USTR, 0.0);
-    for (int i = 0; i < h->n; ++i) xp[i] = x0[i];
-    for (int t = 0; t < h->N; ++t) for (int g = 0; g < h->m; ++g) up[(size_t)t * USTR + g] = u0[(size_t)t * h->m + g];
+    if (h->wide) {                       // (own-size tables: the caller's layout as it is)
+        xp.assign(x0, x0 + h->n); up.assign(u0, u0 + (size_t)h->N * h->m);
+    } else {
+        for (int i = 0; i < h->n; ++i) xp[i] = x0[i];
+        for (int t = 0; t < h->N; ++t) for (int g = 0; g < h->m; ++g) up[(size_t)t * USTR + g] = u0[(size_t)t * h->m + g];
+    }
     // (the bilevel drivers pass the same x_0 / u_array for every batch of a solve: upload only what changed)
     if (h->have_initial && xp == h->x0_host && up == h->u0_host) return RAT_OK;
     HIPCHK(hipMemcpyAsync(h->d_x0, xp.data(), xp.size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -727,8 +836,10 @@ static rat_rc fetch_slot(rat_handle h, int slot, std::vector<double> *xp, std::v
 }
 
 // one-sample state for the operator forms: status RUNNING, slot_nom 0, given theta/mu/delta
+#define WIDE_OP_MSG "the operator entry points are compiled for n <= 12, m <= 4 (larger problems: rat_ileqg_solve*, rat_ce_*, rat_nm_*)"
 static rat_rc op_prepare(rat_handle h, double theta, double mu, double delta, StateDev *out) {
     if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
+    if (h->wide) return fail(RAT_ERR_UNSUPPORTED, WIDE_OP_MSG);
     HIPCHK(hipSetDevice(h->device));
     StateDev st = h->st; st.B = 1;
     HIPCHK(hipMemcpyAsync(h->d_theta, &theta, 8, hipMemcpyHostToDevice, h->stream));
@@ -760,6 +871,30 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     }
     const bool want_hist = eps_hist && cap > 0;
     h->st.hist = want_hist ? h->d_hist : nullptr; h->st.hist_cap = want_hist ? cap : 0;
+    if (h->wide) {                       // the sample's own kernel writes its outputs; x_array / l_array / L_array at their own size
+        BatchOut wo; wo.value = h->d_val; wo.status = h->d_ist; wo.iters = h->d_iit;
+        rc = run_batch(h, h->d_theta, 1, wo);
+        h->st.hist = nullptr; h->st.hist_cap = 0;
+        if (rc) return rc;
+        int32_t *p_j = reinterpret_cast<int32_t *>(h->h_io);
+        HIPCHK(hipMemcpyAsync(p_d + 1, h->d_val, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(p_i + 0, h->d_ist, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(p_i + 1, h->d_iit, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(p_i + 2, h->w_nom, 4, hipMemcpyDeviceToHost, h->stream));
+        if (want_hist) HIPCHK(hipMemcpyAsync(p_j, h->w_hn, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const int nom = p_i[2], hn = want_hist ? p_j[0] : 0;
+        if (status) *status = p_i[0];
+        if (iters) *iters = p_i[1];
+        if (value) *value = p_d[1];
+        if (hist_n) *hist_n = hn;
+        const size_t xs = (size_t)(h->N + 1) * h->n, us = (size_t)h->N * h->m;
+        if (want_hist && hn > 0) HIPCHK(hipMemcpy(eps_hist, h->d_hist, (size_t)std::min(hn, cap) * 16, hipMemcpyDeviceToHost));
+        if (x) HIPCHK(hipMemcpy(x, h->w_xs + (size_t)nom * xs, xs * 8, hipMemcpyDeviceToHost));
+        if (l) HIPCHK(hipMemcpy(l, h->w_us + (size_t)nom * us, us * 8, hipMemcpyDeviceToHost));
+        if (L) HIPCHK(hipMemcpy(L, h->w_L, us * h->n * 8, hipMemcpyDeviceToHost));
+        return RAT_OK;
+    }
     rc = run_batch(h, h->d_theta, 1);
     h->st.hist = nullptr; h->st.hist_cap = 0;
     if (rc) return rc;
@@ -850,6 +985,7 @@ extern "C" rat_rc rat_rollout_noisy(rat_handle h, const double *x_nom, const dou
                                     int32_t *domain_fail) {
     if (!h || !x_nom || !l) return fail(RAT_ERR_ARG, "null");
     if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
+    if (h->wide) return fail(RAT_ERR_UNSUPPORTED, WIDE_OP_MSG);
     if (K < 1) return fail(RAT_ERR_ARG, "K must be positive");
     HIPCHK(hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, Nw = h->W_tv ? N : 1;
@@ -1112,6 +1248,7 @@ static rat_rc upload_tiles_batch(rat_handle h, StateDev &st, int64_t B, bool can
 
 static rat_rc batch_state(rat_handle h, int64_t B, const double *theta, const double *mu, const double *delta, StateDev *out) {
     if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
+    if (h->wide) return fail(RAT_ERR_UNSUPPORTED, WIDE_OP_MSG);
     if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");
     HIPCHK(hipSetDevice(h->device));
     StateDev st = h->st; st.B = (int)B;

@@ -1,0 +1,420 @@
+// wide.hip -- the complete solve! of one theta-sample for problems beyond the 12 + 4 tile of kernels.hip (n <= 32, m <= 32, LQ family).
+//
+// The MFMA kernels of kernels.hip are specialised for n <= 12, m <= 4 (every BASELINE configuration): there [A|B] is one 12 x 16 operand
+// and the value function one accumulator tile.  The reference itself takes its dimensions from the arrays (ileqg.jl:229); this kernel
+// covers what lies beyond the tile with ONE WORKGROUP (one wavefront) PER SAMPLE and every matrix of a backward step in LDS at its own
+// size (column-major, 6 n^2 + 4 n m + 2 m^2 doubles: 101 KB at n = m = 32 of the CU's 160 KB).  The whole solve! runs inside the
+// launch -- initialize! (ileqg.jl:214-236), then step! / line_search! until the convergence or iter_max test (:598-613, :494-592,
+// :635-659) -- with the per-sample control flow wave-uniform in registers.  Nothing is linearised into HBM: an LQ-family step's
+// derivatives are its tables plus a diagonal (f_x = A + 3 kappa diag(x^2)), so the sweep forms them from (x_t, u_t) as it goes.
+//
+// One backward step (ileqg.jl:361-391 / :435-460), with M = inv(W) - theta S = U'U (Cholesky; isposdef(M) <=> every pivot > 0):
+//     [Z | z] = U^-T [S | s_vec]             one forward substitution, a lane per column
+//     D S = S + theta Z'Z,  D s_vec = s_vec + theta Z'z,  s_vec' M^-1 s_vec = z'z,  logdet(W M) = logdet W + 2 sum log U_kk
+//     g = r + B' D s_vec,  G = P + B'(D S) A,  H = R + B'(D S) B + mu I;  gain sweep: H = Uh'Uh (isposdef(H), else mu, Delta are
+//     raised and the sweep restarts, :372-378), [L | dl] = -H^-1 [G | g]
+//     s, s_vec, S as in :383-391.
+// The arithmetic is plain FP64 vector code: this is the general-size path, not the measured one.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "wide.h"
+
+namespace {
+
+struct Ws {
+    double *S, *U, *Z, *DS, *T, *At, *Bm, *F, *G, *Lt, *H, *Hc;
+    double *sv, *z, *dsv, *qv, *sv0, *xt, *xb, *g, *dlv, *rv, *ut, *hv;
+};
+
+__device__ inline double wsum(double v) {          // butterfly: every lane ends with the same bits
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// in-place upper Cholesky factor of the symmetric k x k matrix in LDS (only its upper triangle is read); false <=> not positive
+// definite (a pivot <= 0 or NaN: what LAPACK potrf reports and isposdef tests); sumlog += sum log U_ii
+__device__ bool chol_upper(double *U, const int k, const int lane, double &sumlog) {
+    for (int p = 0; p < k; ++p) {
+        const double d = U[p + k * p];
+        if (!(d > 0.0)) return false;
+        const double r = sqrt(d);
+        __syncthreads();
+        for (int j = p + lane; j < k; j += 64) U[p + k * j] = (j == p) ? r : U[p + k * j] / r;
+        __syncthreads();
+        const int w = k - p - 1;
+        for (int e = lane; e < w * w; e += 64) {
+            const int i = p + 1 + e % w, j = p + 1 + e / w;
+            if (i <= j) U[i + k * j] -= U[p + k * i] * U[p + k * j];
+        }
+        __syncthreads();
+        sumlog += log(r);
+    }
+    return true;
+}
+// U'y = c and U y = c for one column held by one lane (in place)
+__device__ inline void fwd_sub(const double *U, const int k, double *c) {
+    for (int i = 0; i < k; ++i) {
+        double acc = c[i];
+        for (int q = 0; q < i; ++q) acc -= U[q + k * i] * c[q];
+        c[i] = acc / U[i + k * i];
+    }
+}
+__device__ inline void back_sub(const double *U, const int k, double *c) {
+    for (int i = k - 1; i >= 0; --i) {
+        double acc = c[i];
+        for (int q = i + 1; q < k; ++q) acc -= U[i + k * q] * c[q];
+        c[i] = acc / U[i + k * i];
+    }
+}
+
+// solve_approximate_dp (gain = false, :412-465; dl = nothing) / one pass of solve_approximate_dp! (gain = true, :341-406) over the
+// trajectory (x, u).  Returns 0, 2 (M not positive definite) or -1 (H not positive definite: the caller raises mu and restarts).
+__device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u, const double theta, const double mu,
+                     const bool gain, const bool zeroL, double *Lg, double *dlg, double &value) {
+    const WideProblemDev &pb = a.pb;
+    const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x;
+    // terminal condition (:352-354 / :429-431)
+    if (lane < n) w.xt[lane] = x[(size_t)N * n + lane];
+    __syncthreads();
+    for (int e = lane; e < n2; e += 64) w.S[e] = pb.Qf[e];
+    double part = 0.0;
+    if (lane < n) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += pb.Qf[lane + n * j] * w.xt[j];
+        w.sv[lane] = acc + pb.qvf[lane];
+        part = w.xt[lane] * (0.5 * acc + pb.qvf[lane]);
+    }
+    double s1 = wsum(part) + pb.q0f;
+    __syncthreads();
+    for (int t = N - 1; t >= 0; --t) {
+        const int kc = pb.cost_tv ? t : 0, kw = pb.W_tv ? t : 0;
+        const double *Qk = pb.Q + (size_t)kc * n2, *Rk = pb.R + (size_t)kc * mm, *Pk = pb.P + (size_t)kc * nm;
+        const double *qvk = pb.qv + (size_t)kc * n, *rvk = pb.rv + (size_t)kc * m;
+        const double *Wk = pb.W + (size_t)kw * n2, *Wik = pb.Winv + (size_t)kw * n2;
+        if (lane < n) w.xt[lane] = x[(size_t)t * n + lane];
+        if (lane >= 32 && lane - 32 < m) w.ut[lane - 32] = u[(size_t)t * m + lane - 32];
+        __syncthreads();
+        // approximate_model at (x_t, u_t)  (:294-313): f_x, c_x, c_u, c;  M = inv(W) - theta S  (:365)
+        for (int e = lane; e < n2; e += 64) {
+            const int i = e % n, j = e / n;
+            w.At[e] = pb.A[e] + ((i == j) ? 3.0 * pb.kappa * (w.xt[i] * w.xt[i]) : 0.0);
+            w.U[e] = Wik[e] - theta * w.S[e];
+        }
+        if (!gain) {
+            for (int e = lane; e < nm; e += 64) w.Lt[e] = zeroL ? 0.0 : Lg[(size_t)t * nm + e];
+            if (lane < m) w.dlv[lane] = 0.0;
+        }
+        part = 0.0;
+        if (lane < n) {
+            double qx = 0.0, pu = 0.0;
+            for (int j = 0; j < n; ++j) qx += Qk[lane + n * j] * w.xt[j];
+            for (int g = 0; g < m; ++g) pu += Pk[g + m * lane] * w.ut[g];
+            w.qv[lane] = qx + pu + qvk[lane];
+            part = w.xt[lane] * (0.5 * qx + qvk[lane]);
+        } else if (lane >= 32 && lane - 32 < m) {
+            const int g = lane - 32;
+            double ru = 0.0, px = 0.0;
+            for (int g2 = 0; g2 < m; ++g2) ru += Rk[g + m * g2] * w.ut[g2];
+            for (int j = 0; j < n; ++j) px += Pk[g + m * j] * w.xt[j];
+            w.rv[g] = ru + px + rvk[g];
+            part = w.ut[g] * (0.5 * ru + px + rvk[g]);
+        }
+        const double q = wsum(part) + pb.q0[kc];
+        __syncthreads();
+        double sumlog = 0.0;
+        if (!chol_upper(w.U, n, lane, sumlog)) return 2;                                  // @assert isposdef(M)  :366 / :440
+        // [Z | z] = U^-T [S | s_vec]   (theta = 0: D = I exactly, whatever the size of S -- the products below must not see Z'Z)
+        if (theta == 0.0) {
+            for (int e = lane; e < n2; e += 64) w.Z[e] = 0.0;
+            if (lane < n) w.z[lane] = 0.0;
+        } else if (lane <= n) {
+            double *c = (lane < n) ? w.Z + (size_t)n * lane : w.z;
+            for (int i = 0; i < n; ++i) c[i] = (lane < n) ? w.S[i + n * lane] : w.sv[i];
+            fwd_sub(w.U, n, c);
+        }
+        __syncthreads();
+        for (int e = lane; e < n2; e += 64) {                                              // D S  (:367 with S: symmetric)
+            const int i = e % n, j = e / n;
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += w.Z[k + n * i] * w.Z[k + n * j];
+            w.DS[e] = w.S[e] + theta * acc;
+        }
+        part = 0.0;
+        if (lane < n) {
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += w.Z[k + n * lane] * w.z[k];
+            w.dsv[lane] = w.sv[lane] + theta * acc;                                        // D s_vec
+            part = w.z[lane] * w.z[lane];
+        }
+        const double zz = wsum(part);                                                      // s_vec' M^-1 s_vec
+        __syncthreads();
+        for (int e = lane; e < n2 + nm; e += 64) {                                         // T = (D S) A,  F = (D S) B
+            const int i = e % n, j = e / n;
+            const double *col = (j < n) ? w.At + (size_t)n * j : w.Bm + (size_t)n * (j - n);
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += w.DS[i + n * k] * col[k];
+            if (j < n) w.T[e] = acc; else w.F[e - n2] = acc;
+        }
+        __syncthreads();
+        for (int e = lane; e < nm; e += 64) {                                              // G = P + B'(D S) A  (:369)
+            const int g = e % m, j = e / m;
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += w.Bm[k + n * g] * w.T[k + n * j];
+            w.G[e] = Pk[e] + acc;
+        }
+        for (int e = lane; e < mm; e += 64) {                                              // H = Symmetric(R + B'(D S) B + mu I)  (:370-371)
+            const int g = e % m, g2 = e / m;
+            if (g <= g2) {
+                double acc = 0.0;
+                for (int k = 0; k < n; ++k) acc += w.Bm[k + n * g] * w.F[k + n * g2];
+                const double v = Rk[e] + acc + ((g == g2) ? mu : 0.0);
+                w.H[g + m * g2] = v; w.H[g2 + m * g] = v;
+                w.Hc[g + m * g2] = v;
+            }
+        }
+        if (lane < m) {                                                                    // g = r + B' D s_vec  (:368)
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += w.Bm[k + n * lane] * w.dsv[k];
+            w.g[lane] = w.rv[lane] + acc;
+        }
+        __syncthreads();
+        if (gain) {
+            double dummy = 0.0;
+            if (!chol_upper(w.Hc, m, lane, dummy)) return -1;                              // !isposdef(H)  :372
+            if (lane <= n) {                                                               // [L | dl] = -H \ [G | g]  (:379-381)
+                double *c = (lane < n) ? w.Lt + (size_t)m * lane : w.dlv;
+                for (int i = 0; i < m; ++i) c[i] = -((lane < n) ? w.G[i + m * lane] : w.g[i]);
+                fwd_sub(w.Hc, m, c);
+                back_sub(w.Hc, m, c);
+            }
+            __syncthreads();
+            for (int e = lane; e < nm; e += 64) Lg[(size_t)t * nm + e] = w.Lt[e];
+            if (lane < m) dlg[(size_t)t * m + lane] = w.dlv[lane];
+        }
+        part = 0.0;
+        if (lane < m) {
+            double hd = 0.0;
+            for (int g2 = 0; g2 < m; ++g2) hd += w.H[lane + m * g2] * w.dlv[g2];
+            w.hv[lane] = hd + w.g[lane];
+            part = w.dlv[lane] * (0.5 * hd + w.g[lane]);                                   // 0.5 dl'H dl + dl'g  (:383)
+        }
+        double s0 = q + s1 + wsum(part);
+        if (theta == 0.0) {                                                                // :384-385
+            part = 0.0;
+            for (int e = lane; e < n2; e += 64) part += Wk[e] * w.S[(e / n) + n * (e % n)];
+            s0 += 0.5 * wsum(part);
+        } else {                                                                           // :387
+            s0 += 0.5 * theta * zz - (pb.ldW[kw] + 2.0 * sumlog) / (2.0 * theta);
+        }
+        __syncthreads();
+        if (lane < n) {                                                                    // s_vec  (:389)
+            double acc = w.qv[lane];
+            for (int k = 0; k < n; ++k) acc += w.At[k + n * lane] * w.dsv[k];
+            for (int g = 0; g < m; ++g) acc += w.Lt[g + m * lane] * w.hv[g] + w.G[g + m * lane] * w.dlv[g];
+            w.sv0[lane] = acc;
+        }
+        for (int e = lane; e < nm; e += 64) {                                              // H L + G  (into F, dead by now)
+            const int g = e % m, j = e / m;
+            double acc = w.G[e];
+            for (int g2 = 0; g2 < m; ++g2) acc += w.H[g + m * g2] * w.Lt[g2 + m * j];
+            w.F[e] = acc;
+        }
+        __syncthreads();
+        for (int e = lane; e < n2; e += 64) {                                              // S = Symmetric(Q + A'(D S)A + L'HL + L'G + G'L)  (:390-391)
+            const int i = e % n, j = e / n;
+            if (i <= j) {
+                double acc = Qk[e];
+                for (int k = 0; k < n; ++k) acc += w.At[k + n * i] * w.T[k + n * j];
+                for (int g = 0; g < m; ++g) acc += w.Lt[g + m * i] * w.F[g + m * j] + w.G[g + m * i] * w.Lt[g + m * j];
+                w.U[i + n * j] = acc; w.U[j + n * i] = acc;
+            }
+        }
+        if (lane < n) w.sv[lane] = w.sv0[lane];
+        __syncthreads();
+        double *tmp = w.S; w.S = w.U; w.U = tmp;
+        s1 = s0;
+    }
+    value = s1;
+    return 0;
+}
+
+// simulate_dynamics(problem, x_0, u_array)  (ileqg.jl:18-38) into (xo, uo)
+__device__ void rollout_open(const WideArgs &a, Ws &w, double *xo, double *uo) {
+    const WideProblemDev &pb = a.pb;
+    const int n = pb.n, m = pb.m, N = pb.N, lane = threadIdx.x;
+    for (int e = lane; e < n * n; e += 64) w.At[e] = pb.A[e];
+    if (lane < n) { w.xt[lane] = a.x0[lane]; xo[lane] = a.x0[lane]; }
+    __syncthreads();
+    for (int t = 0; t < N; ++t) {
+        if (lane < m) { const double v = a.u0[(size_t)t * m + lane]; w.ut[lane] = v; uo[(size_t)t * m + lane] = v; }
+        __syncthreads();
+        double xn = 0.0;
+        if (lane < n) {
+            double acc = 0.0, accb = 0.0;
+            for (int j = 0; j < n; ++j) acc += w.At[lane + n * j] * w.xt[j];
+            for (int g = 0; g < m; ++g) accb += w.Bm[lane + n * g] * w.ut[g];
+            const double xi = w.xt[lane];
+            xn = acc + accb + pb.kappa * (xi * xi * xi);
+        }
+        __syncthreads();
+        if (lane < n) { w.xt[lane] = xn; xo[(size_t)(t + 1) * n + lane] = xn; }
+    }
+    __syncthreads();
+}
+
+// simulate_dynamics(problem, x_array, l_array + eps dl, L_array)  (ileqg.jl:62-87, :509-517); returns maximum(norm.(l .- u_new))  (:539)
+__device__ double rollout_closed(const WideArgs &a, Ws &w, const double *xbar, const double *l, const double *dl, const double *L,
+                                 const double eps, double *xo, double *uo) {
+    const WideProblemDev &pb = a.pb;
+    const int n = pb.n, m = pb.m, N = pb.N, nm = n * m, lane = threadIdx.x;
+    for (int e = lane; e < n * n; e += 64) w.At[e] = pb.A[e];
+    if (lane < n) { w.xt[lane] = xbar[lane]; xo[lane] = xbar[lane]; }
+    double best = -INFINITY;
+    bool nan_seen = false;
+    __syncthreads();
+    for (int t = 0; t < N; ++t) {
+        if (lane < n) w.xb[lane] = w.xt[lane] - xbar[(size_t)t * n + lane];
+        __syncthreads();
+        double diff2 = 0.0;
+        if (lane < m) {
+            const double *Lt = L + (size_t)t * nm;
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) acc += Lt[lane + m * j] * w.xb[j];
+            const double lt = l[(size_t)t * m + lane];
+            const double un = (lt + eps * dl[(size_t)t * m + lane]) + acc;
+            w.ut[lane] = un; uo[(size_t)t * m + lane] = un;
+            const double df = lt - un;
+            diff2 = df * df;
+        }
+        const double v = sqrt(wsum(diff2));
+        if (!nan_seen) {
+            if (v > best || v != v) best = v;          // Julia's maximum propagates NaN
+            if (v != v) nan_seen = true;
+        }
+        __syncthreads();
+        double xn = 0.0;
+        if (lane < n) {
+            double acc = 0.0, accb = 0.0;
+            for (int j = 0; j < n; ++j) acc += w.At[lane + n * j] * w.xt[j];
+            for (int g = 0; g < m; ++g) accb += w.Bm[lane + n * g] * w.ut[g];
+            const double xi = w.xt[lane];
+            xn = acc + accb + pb.kappa * (xi * xi * xi);
+        }
+        __syncthreads();
+        if (lane < n) { w.xt[lane] = xn; xo[(size_t)(t + 1) * n + lane] = xn; }
+    }
+    __syncthreads();
+    return best;
+}
+
+__device__ inline bool isapprox_default(double x, double y) {       // isapprox with rtol = sqrt(eps)  (:538)
+    if (x == y) return true;
+    if (!isfinite(x) || !isfinite(y)) return false;
+    return fabs(x - y) <= 1.4901161193847656e-8 * fmax(fabs(x), fabs(y));
+}
+
+__global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
+    extern __shared__ double lds[];
+    const WideProblemDev &pb = a.pb;
+    const OptsDev &op = a.op;
+    const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x, b = blockIdx.x;
+    Ws w;
+    {
+        double *p = lds;
+        w.S = p; p += n2; w.U = p; p += n2; w.Z = p; p += n2; w.DS = p; p += n2; w.T = p; p += n2; w.At = p; p += n2;
+        w.Bm = p; p += nm; w.F = p; p += nm; w.G = p; p += nm; w.Lt = p; p += nm; w.H = p; p += mm; w.Hc = p; p += mm;
+        w.sv = p; p += n; w.z = p; p += n; w.dsv = p; p += n; w.qv = p; p += n; w.sv0 = p; p += n; w.xt = p; p += n; w.xb = p; p += n;
+        w.g = p; p += m; w.dlv = p; p += m; w.rv = p; p += m; w.ut = p; p += m; w.hv = p; p += m;
+    }
+    for (int e = lane; e < nm; e += 64) w.Bm[e] = pb.B[e];
+    const size_t xstr = (size_t)(N + 1) * n, ustr = (size_t)N * m;
+    double *const xs = a.xs + (size_t)b * 2 * xstr, *const us = a.us + (size_t)b * 2 * ustr;
+    double *const Lg = a.L + (size_t)b * N * nm, *const dlg = a.dl + (size_t)b * N * m;
+    const double theta = a.theta[b];
+    const bool hist_on = a.hist && b == 0;
+    // ---- initialize!  (ileqg.jl:214-236)
+    double mu = 0.0, delta = op.delta_0, d_cur = INFINITY, value_cur = INFINITY, eps_init = op.eps_init;
+    int iter = 0, n_ls = 0, hn = 0, nom = 0, status = ST_RUNNING;
+    for (size_t e = lane; e < (size_t)N * nm; e += 64) Lg[e] = 0.0;                         // :230-232
+    rollout_open(a, w, xs, us);                                                             // :225, :228
+    {
+        const int rc = sweep(a, w, xs, us, theta, mu, false, true, Lg, dlg, value_cur);     // :233-235
+        if (rc) status = 1;
+    }
+    // ---- while true: step!  (:640-654)
+    while (status == ST_RUNNING) {
+        iter++;                                                                             // :599
+        double *xn = xs + (size_t)nom * xstr, *un = us + (size_t)nom * ustr;                // x_array, l_array
+        double *xc = xs + (size_t)(nom ^ 1) * xstr, *uc = us + (size_t)(nom ^ 1) * ustr;    // the candidate's
+        int restarts = 0;
+        for (;;) {                                                                          // solve_approximate_dp!  (:359-403)
+            double dummy;
+            const int rc = sweep(a, w, xn, un, theta, mu, true, false, Lg, dlg, dummy);
+            if (rc == 0) break;
+            if (rc == 2) { status = 2; break; }
+            delta = fmax(op.delta_0, delta * op.delta_0);                                   // increase_mu_and_delta!  (:471-474)
+            mu = fmax(op.mu_min, mu * delta);
+            if (++restarts > 400 || !isfinite(mu)) { status = 5; break; }                   // (the reference would spin)
+        }
+        if (status != ST_RUNNING) break;
+        // line_search!  (:494-592)
+        const double cur = value_cur;
+        double eps = eps_init;
+        int count = 0;
+        for (;;) {
+            count++;                                                                        // :505
+            if (count > 4000) { status = 7; break; }                                        // (App. B.5)
+            n_ls++;
+            const double d_new = rollout_closed(a, w, xn, un, dlg, Lg, eps, xc, uc);        // :509-517
+            double newv;
+            const int rc = sweep(a, w, xc, uc, theta, mu, false, false, Lg, dlg, newv);     // :520-528
+            if (rc) { eps *= op.lambda; continue; }                                         // :529-535
+            if (hist_on) {                                                                  // :537
+                if (hn < a.hist_cap && lane == 0) { a.hist[2 * (size_t)hn] = eps; a.hist[2 * (size_t)hn + 1] = newv - cur; }
+                hn++;
+            }
+            if (!(isapprox_default(newv, cur) || newv < cur)) {                             // :538
+                eps *= op.lambda;                                                           // :557
+                if (!(eps < op.eps_min)) continue;                                          // :558
+            }
+            d_cur = d_new; value_cur = newv; nom ^= 1;                                      // :539-555 / :559-575
+            break;
+        }
+        if (status != ST_RUNNING) break;
+        if (op.adaptive) {                                                                  // :582-591
+            if (count == 1) eps_init = fmin(op.eps_init, eps / op.lambda);
+            else { while (eps < op.eps_min) eps = eps / op.lambda; eps_init = eps; }
+        }
+        if (op.d > d_cur && mu <= op.mu_min) status = 0;                                    // :642
+        else if (iter == op.iter_max) status = 3;                                           // :648
+    }
+    if (lane == 0) {
+        const bool ok = status == 0 || status == 3;
+        const double val = ok ? value_cur : INFINITY;                                       // catch -> Inf  (cross_entropy...jl:163)
+        a.nom[b] = nom;
+        if (a.out_value) a.out_value[b] = val;
+        if (a.out_status) a.out_status[b] = status;
+        if (a.out_iters) a.out_iters[b] = iter;
+        if (a.out_ls) a.out_ls[b] = n_ls;
+        if (a.out_cost) a.out_cost[b] = ok ? val + a.kl_bound / theta : INFINITY;           // :193
+        if (hist_on && a.hist_n) a.hist_n[0] = hn;
+    }
+}
+
+}  // namespace
+
+size_t wide_lds_bytes(int n, int m) {
+    return sizeof(double) * ((size_t)6 * n * n + (size_t)4 * n * m + (size_t)2 * m * m + (size_t)7 * n + (size_t)5 * m);
+}
+
+hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s) {
+    const size_t lds = wide_lds_bytes(a.pb.n, a.pb.m);
+    if (lds > 64 * 1024) {               // (per device: set on every launch that needs it, the call is cheap)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(wide_solve_kernel, dim3(a.B), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
