@@ -3,7 +3,7 @@
 // The MFMA kernels of kernels.hip are specialised for n <= 12, m <= 4 (every BASELINE configuration): there [A|B] is one 12 x 16 operand
 // and the value function one accumulator tile.  The reference itself takes its dimensions from the arrays (ileqg.jl:229); this kernel
 // covers what lies beyond the tile with ONE WORKGROUP (one wavefront) PER SAMPLE and every matrix of a backward step in LDS at its own
-// size (column-major, 6 n^2 + 4 n m + 2 m^2 doubles: 101 KB at n = m = 32 of the CU's 160 KB).  The whole solve! runs inside the
+// size (column-major with odd leading dimensions, 6 n^2 + 4 n m + 2 m^2 doubles + padding: 104 KB at n = m = 32 of the CU's 160 KB).  The whole solve! runs inside the
 // launch -- initialize! (ileqg.jl:214-236), then step! / line_search! until the convergence or iter_max test (:598-613, :494-592,
 // :635-659) -- with the per-sample control flow wave-uniform in registers.  Nothing is linearised into HBM: an LQ-family step's
 // derivatives are its tables plus a diagonal (f_x = A + 3 kappa diag(x^2)), so the sweep forms them from (x_t, u_t) as it goes.
@@ -35,18 +35,18 @@ __device__ inline double wsum(double v) {          // butterfly: every lane ends
 
 // in-place upper Cholesky factor of the symmetric k x k matrix in LDS (only its upper triangle is read); false <=> not positive
 // definite (a pivot <= 0 or NaN: what LAPACK potrf reports and isposdef tests); sumlog += sum log U_ii
-__device__ bool chol_upper(double *U, const int k, const int lane, double &sumlog) {
+__device__ bool chol_upper(double *U, const int k, const int ld, const int lane, double &sumlog) {
     for (int p = 0; p < k; ++p) {
-        const double d = U[p + k * p];
+        const double d = U[p + ld * p];
         if (!(d > 0.0)) return false;
         const double r = sqrt(d);
         __syncthreads();
-        for (int j = p + lane; j < k; j += 64) U[p + k * j] = (j == p) ? r : U[p + k * j] / r;
+        for (int j = p + lane; j < k; j += 64) U[p + ld * j] = (j == p) ? r : U[p + ld * j] / r;
         __syncthreads();
         const int w = k - p - 1;
         for (int e = lane; e < w * w; e += 64) {
             const int i = p + 1 + e % w, j = p + 1 + e / w;
-            if (i <= j) U[i + k * j] -= U[p + k * i] * U[p + k * j];
+            if (i <= j) U[i + ld * j] -= U[p + ld * i] * U[p + ld * j];
         }
         __syncthreads();
         sumlog += log(r);
@@ -54,18 +54,18 @@ __device__ bool chol_upper(double *U, const int k, const int lane, double &sumlo
     return true;
 }
 // U'y = c and U y = c for one column held by one lane (in place)
-__device__ inline void fwd_sub(const double *U, const int k, double *c) {
+__device__ inline void fwd_sub(const double *U, const int k, const int ld, double *c) {
     for (int i = 0; i < k; ++i) {
         double acc = c[i];
-        for (int q = 0; q < i; ++q) acc -= U[q + k * i] * c[q];
-        c[i] = acc / U[i + k * i];
+        for (int q = 0; q < i; ++q) acc -= U[q + ld * i] * c[q];
+        c[i] = acc / U[i + ld * i];
     }
 }
-__device__ inline void back_sub(const double *U, const int k, double *c) {
+__device__ inline void back_sub(const double *U, const int k, const int ld, double *c) {
     for (int i = k - 1; i >= 0; --i) {
         double acc = c[i];
-        for (int q = i + 1; q < k; ++q) acc -= U[i + k * q] * c[q];
-        c[i] = acc / U[i + k * i];
+        for (int q = i + 1; q < k; ++q) acc -= U[i + ld * q] * c[q];
+        c[i] = acc / U[i + ld * i];
     }
 }
 
@@ -75,10 +75,11 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
                      const bool gain, const bool zeroL, double *Lg, double *dlg, double &value) {
     const WideProblemDev &pb = a.pb;
     const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x;
+    const int ldn = n | 1, ldm = m | 1;          // odd leading dimensions in LDS: a column stride of n doubles puts every lane on one bank
     // terminal condition (:352-354 / :429-431)
     if (lane < n) w.xt[lane] = x[(size_t)N * n + lane];
     __syncthreads();
-    for (int e = lane; e < n2; e += 64) w.S[e] = pb.Qf[e];
+    for (int e = lane; e < n2; e += 64) w.S[e % n + ldn * (e / n)] = pb.Qf[e];
     double part = 0.0;
     if (lane < n) {
         double acc = 0.0;
@@ -99,11 +100,11 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
         // approximate_model at (x_t, u_t)  (:294-313): f_x, c_x, c_u, c;  M = inv(W) - theta S  (:365)
         for (int e = lane; e < n2; e += 64) {
             const int i = e % n, j = e / n;
-            w.At[e] = pb.A[e] + ((i == j) ? 3.0 * pb.kappa * (w.xt[i] * w.xt[i]) : 0.0);
-            w.U[e] = Wik[e] - theta * w.S[e];
+            w.At[i + ldn * j] = pb.A[e] + ((i == j) ? 3.0 * pb.kappa * (w.xt[i] * w.xt[i]) : 0.0);
+            w.U[i + ldn * j] = Wik[e] - theta * w.S[i + ldn * j];
         }
         if (!gain) {
-            for (int e = lane; e < nm; e += 64) w.Lt[e] = zeroL ? 0.0 : Lg[(size_t)t * nm + e];
+            for (int e = lane; e < nm; e += 64) w.Lt[e % m + ldm * (e / m)] = zeroL ? 0.0 : Lg[(size_t)t * nm + e];
             if (lane < m) w.dlv[lane] = 0.0;
         }
         part = 0.0;
@@ -124,27 +125,27 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
         const double q = wsum(part) + pb.q0[kc];
         __syncthreads();
         double sumlog = 0.0;
-        if (!chol_upper(w.U, n, lane, sumlog)) return 2;                                  // @assert isposdef(M)  :366 / :440
+        if (!chol_upper(w.U, n, ldn, lane, sumlog)) return 2;                                  // @assert isposdef(M)  :366 / :440
         // [Z | z] = U^-T [S | s_vec]   (theta = 0: D = I exactly, whatever the size of S -- the products below must not see Z'Z)
         if (theta == 0.0) {
-            for (int e = lane; e < n2; e += 64) w.Z[e] = 0.0;
+            for (int e = lane; e < ldn * n; e += 64) w.Z[e] = 0.0;
             if (lane < n) w.z[lane] = 0.0;
         } else if (lane <= n) {
-            double *c = (lane < n) ? w.Z + (size_t)n * lane : w.z;
-            for (int i = 0; i < n; ++i) c[i] = (lane < n) ? w.S[i + n * lane] : w.sv[i];
-            fwd_sub(w.U, n, c);
+            double *c = (lane < n) ? w.Z + (size_t)ldn * lane : w.z;
+            for (int i = 0; i < n; ++i) c[i] = (lane < n) ? w.S[i + ldn * lane] : w.sv[i];
+            fwd_sub(w.U, n, ldn, c);
         }
         __syncthreads();
         for (int e = lane; e < n2; e += 64) {                                              // D S  (:367 with S: symmetric)
             const int i = e % n, j = e / n;
             double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += w.Z[k + n * i] * w.Z[k + n * j];
-            w.DS[e] = w.S[e] + theta * acc;
+            for (int k = 0; k < n; ++k) acc += w.Z[k + ldn * i] * w.Z[k + ldn * j];
+            w.DS[i + ldn * j] = w.S[i + ldn * j] + theta * acc;
         }
         part = 0.0;
         if (lane < n) {
             double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += w.Z[k + n * lane] * w.z[k];
+            for (int k = 0; k < n; ++k) acc += w.Z[k + ldn * lane] * w.z[k];
             w.dsv[lane] = w.sv[lane] + theta * acc;                                        // D s_vec
             part = w.z[lane] * w.z[lane];
         }
@@ -152,58 +153,58 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
         __syncthreads();
         for (int e = lane; e < n2 + nm; e += 64) {                                         // T = (D S) A,  F = (D S) B
             const int i = e % n, j = e / n;
-            const double *col = (j < n) ? w.At + (size_t)n * j : w.Bm + (size_t)n * (j - n);
+            const double *col = (j < n) ? w.At + (size_t)ldn * j : w.Bm + (size_t)ldn * (j - n);
             double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += w.DS[i + n * k] * col[k];
-            if (j < n) w.T[e] = acc; else w.F[e - n2] = acc;
+            for (int k = 0; k < n; ++k) acc += w.DS[i + ldn * k] * col[k];
+            if (j < n) w.T[i + ldn * j] = acc; else w.F[i + ldn * (j - n)] = acc;
         }
         __syncthreads();
         for (int e = lane; e < nm; e += 64) {                                              // G = P + B'(D S) A  (:369)
             const int g = e % m, j = e / m;
             double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += w.Bm[k + n * g] * w.T[k + n * j];
-            w.G[e] = Pk[e] + acc;
+            for (int k = 0; k < n; ++k) acc += w.Bm[k + ldn * g] * w.T[k + ldn * j];
+            w.G[g + ldm * j] = Pk[e] + acc;
         }
         for (int e = lane; e < mm; e += 64) {                                              // H = Symmetric(R + B'(D S) B + mu I)  (:370-371)
             const int g = e % m, g2 = e / m;
             if (g <= g2) {
                 double acc = 0.0;
-                for (int k = 0; k < n; ++k) acc += w.Bm[k + n * g] * w.F[k + n * g2];
+                for (int k = 0; k < n; ++k) acc += w.Bm[k + ldn * g] * w.F[k + ldn * g2];
                 const double v = Rk[e] + acc + ((g == g2) ? mu : 0.0);
-                w.H[g + m * g2] = v; w.H[g2 + m * g] = v;
-                w.Hc[g + m * g2] = v;
+                w.H[g + ldm * g2] = v; w.H[g2 + ldm * g] = v;
+                w.Hc[g + ldm * g2] = v;
             }
         }
         if (lane < m) {                                                                    // g = r + B' D s_vec  (:368)
             double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += w.Bm[k + n * lane] * w.dsv[k];
+            for (int k = 0; k < n; ++k) acc += w.Bm[k + ldn * lane] * w.dsv[k];
             w.g[lane] = w.rv[lane] + acc;
         }
         __syncthreads();
         if (gain) {
             double dummy = 0.0;
-            if (!chol_upper(w.Hc, m, lane, dummy)) return -1;                              // !isposdef(H)  :372
+            if (!chol_upper(w.Hc, m, ldm, lane, dummy)) return -1;                              // !isposdef(H)  :372
             if (lane <= n) {                                                               // [L | dl] = -H \ [G | g]  (:379-381)
-                double *c = (lane < n) ? w.Lt + (size_t)m * lane : w.dlv;
-                for (int i = 0; i < m; ++i) c[i] = -((lane < n) ? w.G[i + m * lane] : w.g[i]);
-                fwd_sub(w.Hc, m, c);
-                back_sub(w.Hc, m, c);
+                double *c = (lane < n) ? w.Lt + (size_t)ldm * lane : w.dlv;
+                for (int i = 0; i < m; ++i) c[i] = -((lane < n) ? w.G[i + ldm * lane] : w.g[i]);
+                fwd_sub(w.Hc, m, ldm, c);
+                back_sub(w.Hc, m, ldm, c);
             }
             __syncthreads();
-            for (int e = lane; e < nm; e += 64) Lg[(size_t)t * nm + e] = w.Lt[e];
+            for (int e = lane; e < nm; e += 64) Lg[(size_t)t * nm + e] = w.Lt[e % m + ldm * (e / m)];
             if (lane < m) dlg[(size_t)t * m + lane] = w.dlv[lane];
         }
         part = 0.0;
         if (lane < m) {
             double hd = 0.0;
-            for (int g2 = 0; g2 < m; ++g2) hd += w.H[lane + m * g2] * w.dlv[g2];
+            for (int g2 = 0; g2 < m; ++g2) hd += w.H[lane + ldm * g2] * w.dlv[g2];
             w.hv[lane] = hd + w.g[lane];
             part = w.dlv[lane] * (0.5 * hd + w.g[lane]);                                   // 0.5 dl'H dl + dl'g  (:383)
         }
         double s0 = q + s1 + wsum(part);
         if (theta == 0.0) {                                                                // :384-385
             part = 0.0;
-            for (int e = lane; e < n2; e += 64) part += Wk[e] * w.S[(e / n) + n * (e % n)];
+            for (int e = lane; e < n2; e += 64) part += Wk[e] * w.S[(e / n) + ldn * (e % n)];
             s0 += 0.5 * wsum(part);
         } else {                                                                           // :387
             s0 += 0.5 * theta * zz - (pb.ldW[kw] + 2.0 * sumlog) / (2.0 * theta);
@@ -211,24 +212,24 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
         __syncthreads();
         if (lane < n) {                                                                    // s_vec  (:389)
             double acc = w.qv[lane];
-            for (int k = 0; k < n; ++k) acc += w.At[k + n * lane] * w.dsv[k];
-            for (int g = 0; g < m; ++g) acc += w.Lt[g + m * lane] * w.hv[g] + w.G[g + m * lane] * w.dlv[g];
+            for (int k = 0; k < n; ++k) acc += w.At[k + ldn * lane] * w.dsv[k];
+            for (int g = 0; g < m; ++g) acc += w.Lt[g + ldm * lane] * w.hv[g] + w.G[g + ldm * lane] * w.dlv[g];
             w.sv0[lane] = acc;
         }
         for (int e = lane; e < nm; e += 64) {                                              // H L + G  (into F, dead by now)
             const int g = e % m, j = e / m;
-            double acc = w.G[e];
-            for (int g2 = 0; g2 < m; ++g2) acc += w.H[g + m * g2] * w.Lt[g2 + m * j];
-            w.F[e] = acc;
+            double acc = w.G[g + ldm * j];
+            for (int g2 = 0; g2 < m; ++g2) acc += w.H[g + ldm * g2] * w.Lt[g2 + ldm * j];
+            w.F[g + ldm * j] = acc;
         }
         __syncthreads();
         for (int e = lane; e < n2; e += 64) {                                              // S = Symmetric(Q + A'(D S)A + L'HL + L'G + G'L)  (:390-391)
             const int i = e % n, j = e / n;
             if (i <= j) {
                 double acc = Qk[e];
-                for (int k = 0; k < n; ++k) acc += w.At[k + n * i] * w.T[k + n * j];
-                for (int g = 0; g < m; ++g) acc += w.Lt[g + m * i] * w.F[g + m * j] + w.G[g + m * i] * w.Lt[g + m * j];
-                w.U[i + n * j] = acc; w.U[j + n * i] = acc;
+                for (int k = 0; k < n; ++k) acc += w.At[k + ldn * i] * w.T[k + ldn * j];
+                for (int g = 0; g < m; ++g) acc += w.Lt[g + ldm * i] * w.F[g + ldm * j] + w.G[g + ldm * i] * w.Lt[g + ldm * j];
+                w.U[i + ldn * j] = acc; w.U[j + ldn * i] = acc;
             }
         }
         if (lane < n) w.sv[lane] = w.sv0[lane];
@@ -244,7 +245,8 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
 __device__ void rollout_open(const WideArgs &a, Ws &w, double *xo, double *uo) {
     const WideProblemDev &pb = a.pb;
     const int n = pb.n, m = pb.m, N = pb.N, lane = threadIdx.x;
-    for (int e = lane; e < n * n; e += 64) w.At[e] = pb.A[e];
+    const int ldn = n | 1;
+    for (int e = lane; e < n * n; e += 64) w.At[e % n + ldn * (e / n)] = pb.A[e];
     if (lane < n) { w.xt[lane] = a.x0[lane]; xo[lane] = a.x0[lane]; }
     __syncthreads();
     for (int t = 0; t < N; ++t) {
@@ -253,8 +255,8 @@ __device__ void rollout_open(const WideArgs &a, Ws &w, double *xo, double *uo) {
         double xn = 0.0;
         if (lane < n) {
             double acc = 0.0, accb = 0.0;
-            for (int j = 0; j < n; ++j) acc += w.At[lane + n * j] * w.xt[j];
-            for (int g = 0; g < m; ++g) accb += w.Bm[lane + n * g] * w.ut[g];
+            for (int j = 0; j < n; ++j) acc += w.At[lane + ldn * j] * w.xt[j];
+            for (int g = 0; g < m; ++g) accb += w.Bm[lane + ldn * g] * w.ut[g];
             const double xi = w.xt[lane];
             xn = acc + accb + pb.kappa * (xi * xi * xi);
         }
@@ -269,7 +271,8 @@ __device__ double rollout_closed(const WideArgs &a, Ws &w, const double *xbar, c
                                  const double eps, double *xo, double *uo) {
     const WideProblemDev &pb = a.pb;
     const int n = pb.n, m = pb.m, N = pb.N, nm = n * m, lane = threadIdx.x;
-    for (int e = lane; e < n * n; e += 64) w.At[e] = pb.A[e];
+    const int ldn = n | 1;
+    for (int e = lane; e < n * n; e += 64) w.At[e % n + ldn * (e / n)] = pb.A[e];
     if (lane < n) { w.xt[lane] = xbar[lane]; xo[lane] = xbar[lane]; }
     double best = -INFINITY;
     bool nan_seen = false;
@@ -297,8 +300,8 @@ __device__ double rollout_closed(const WideArgs &a, Ws &w, const double *xbar, c
         double xn = 0.0;
         if (lane < n) {
             double acc = 0.0, accb = 0.0;
-            for (int j = 0; j < n; ++j) acc += w.At[lane + n * j] * w.xt[j];
-            for (int g = 0; g < m; ++g) accb += w.Bm[lane + n * g] * w.ut[g];
+            for (int j = 0; j < n; ++j) acc += w.At[lane + ldn * j] * w.xt[j];
+            for (int g = 0; g < m; ++g) accb += w.Bm[lane + ldn * g] * w.ut[g];
             const double xi = w.xt[lane];
             xn = acc + accb + pb.kappa * (xi * xi * xi);
         }
@@ -319,16 +322,17 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     extern __shared__ double lds[];
     const WideProblemDev &pb = a.pb;
     const OptsDev &op = a.op;
-    const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x, b = blockIdx.x;
+    const int n = pb.n, m = pb.m, N = pb.N, nm = n * m, lane = threadIdx.x, b = blockIdx.x;
     Ws w;
     {
+        const int ldn = n | 1, ldm = m | 1, sn = ldn * n, sb = ldn * m, sg = ldm * n, sf = sb > sg ? sb : sg, sh = ldm * m;
         double *p = lds;
-        w.S = p; p += n2; w.U = p; p += n2; w.Z = p; p += n2; w.DS = p; p += n2; w.T = p; p += n2; w.At = p; p += n2;
-        w.Bm = p; p += nm; w.F = p; p += nm; w.G = p; p += nm; w.Lt = p; p += nm; w.H = p; p += mm; w.Hc = p; p += mm;
+        w.S = p; p += sn; w.U = p; p += sn; w.Z = p; p += sn; w.DS = p; p += sn; w.T = p; p += sn; w.At = p; p += sn;
+        w.Bm = p; p += sb; w.F = p; p += sf; w.G = p; p += sg; w.Lt = p; p += sg; w.H = p; p += sh; w.Hc = p; p += sh;
         w.sv = p; p += n; w.z = p; p += n; w.dsv = p; p += n; w.qv = p; p += n; w.sv0 = p; p += n; w.xt = p; p += n; w.xb = p; p += n;
         w.g = p; p += m; w.dlv = p; p += m; w.rv = p; p += m; w.ut = p; p += m; w.hv = p; p += m;
     }
-    for (int e = lane; e < nm; e += 64) w.Bm[e] = pb.B[e];
+    for (int e = lane; e < nm; e += 64) w.Bm[e % n + (n | 1) * (e / n)] = pb.B[e];
     const size_t xstr = (size_t)(N + 1) * n, ustr = (size_t)N * m;
     double *const xs = a.xs + (size_t)b * 2 * xstr, *const us = a.us + (size_t)b * 2 * ustr;
     double *const Lg = a.L + (size_t)b * N * nm, *const dlg = a.dl + (size_t)b * N * m;
@@ -406,7 +410,8 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
 }  // namespace
 
 size_t wide_lds_bytes(int n, int m) {
-    return sizeof(double) * ((size_t)6 * n * n + (size_t)4 * n * m + (size_t)2 * m * m + (size_t)7 * n + (size_t)5 * m);
+    const size_t ldn = n | 1, ldm = m | 1, sb = ldn * m, sg = ldm * n;
+    return sizeof(double) * (6 * ldn * n + sb + (sb > sg ? sb : sg) + 2 * sg + 2 * ldm * m + (size_t)7 * n + (size_t)5 * m);
 }
 
 hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s) {

@@ -6,6 +6,7 @@ import pytest
 
 import ratilqr.jl_amd as rat
 from ratilqr.jl_amd import cross_entropy as ce
+from ratilqr.jl_amd import nelder_mead as nm
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -175,3 +176,30 @@ def test_value_against_the_first_principles_gaussian_integral():
         assert r["status"] == 0
         exact, feasible = ex.exact_value(prob, x0, r["l"], None, r["L"], r["x"], theta)
         assert feasible and abs(r["value"] - exact) <= 1e-9 * abs(exact), (theta, r["value"], exact)
+
+
+def test_nelder_mead_matches_the_sequential_oracle():
+    """RAT iLQR++ on a 16-state problem; theta_high_init beyond the breakdown is halved until feasible (nm.jl:283-293)"""
+    prob, x0, u = wide_problem(16, 6, 15, 51)
+    P = orc.Problem(prob)
+    hi = theta_grid(P, x0, u, 2)[-2] / 1.05
+    kw = dict(theta_high_init=6.0 * hi, theta_low_init=1e-8, iter_max=12, eps=1e-4)
+    so, sg = orc.NelderMeadBilevelOptimizationSolver(**kw), rat.NelderMeadBilevelOptimizationSolver(**kw)
+    rc, th_o, x_o, l_o, L_o, v_o = so.solve(P, x0, u, 0.2)
+    th_g, x_g, l_g, L_g, v_g = nm.solve_(sg, prob, x0, u, kl_bound=0.2)
+    assert rc == 0 and so.c.iter_current == sg.c.iter_current and so.c.n_solves == sg.c.n_solves
+    assert abs(th_g - th_o) <= 1e-9 * abs(th_o) and abs(v_g - v_o) <= 1e-9 * abs(v_o)
+    assert sg.c.theta_high_init == so.c.theta_high_init < 6.0 * hi
+    assert np.abs(x_g - x_o).max() < 1e-8 * (1 + np.abs(x_o).max()) and np.abs(L_g - L_o).max() < 1e-8 * (1 + np.abs(L_o).max())
+
+
+def test_multi_device_object_takes_wide_problems(monkeypatch):
+    monkeypatch.setenv("RATILQR_MULTI_FORCE_RCCL", "1")
+    prob, x0, u = wide_problem(20, 6, 12, 71)
+    theta = theta_grid(orc.Problem(prob), x0, u, 20)
+    mc = rat.MultiContext(prob, max_batch=theta.size, devices=(0,))
+    cost = mc.compute_cost(x0, u, theta, 0.1)
+    v, st, _, _ = rat.Context(prob, max_batch=theta.size).solve_batch(x0, u, theta)
+    with np.errstate(divide="ignore"):
+        want = np.where(np.isfinite(v), v + 0.1 / theta, np.inf)
+    assert np.array_equal(cost, want) and mc.allgathers == 1
