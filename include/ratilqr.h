@@ -36,7 +36,7 @@ extern "C" {
 typedef int32_t rat_rc;
 #define RAT_OK               0
 #define RAT_ERR_ARG          1   /* bad argument / option out of the reference's @assert ranges */
-#define RAT_ERR_UNSUPPORTED  2   /* problem size or model outside the compiled kernels (solves: n, m <= 32; operators: n<=12, m<=4) */
+#define RAT_ERR_UNSUPPORTED  2   /* problem size or model outside the compiled kernels (n, m <= 32; power-law family n = m <= 4) */
 #define RAT_ERR_HIP          3   /* HIP runtime error (see rat_last_error) */
 #define RAT_ERR_NO_PROBLEM   4   /* rat_problem_set was not called */
 #define RAT_ERR_STREAM_DRY   5   /* injected N(0,1) stream exhausted */
@@ -103,7 +103,10 @@ rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int32_t spec_ep
 void   rat_destroy(rat_handle h);
 rat_rc rat_set_ileqg_opts(rat_handle h, const rat_ileqg_opts *opts);
 
-/* Upload a problem (tables are copied).  Replaces passing `problem` to every call. */
+/* Upload a problem (tables are copied).  Replaces passing `problem` to every call.
+ * Sizes: n <= 12, m <= 4 run on the MFMA kernels.  LQ-family problems up to n <= 32, m <= 32 are accepted too (the reference takes its
+ * dimensions from the arrays, ileqg.jl:229) and run every entry point in general-size kernels; the power-law family beyond n = m = 4
+ * and any larger problem return RAT_ERR_UNSUPPORTED. */
 rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *desc);
 
 /* ---- the hot path ----------------------------------------------------------------------------- */

@@ -836,7 +836,7 @@ static rat_rc fetch_slot(rat_handle h, int slot, std::vector<double> *xp, std::v
 }
 
 // one-sample state for the operator forms: status RUNNING, slot_nom 0, given theta/mu/delta
-#define WIDE_OP_MSG "the operator entry points are compiled for n <= 12, m <= 4 (larger problems: rat_ileqg_solve*, rat_ce_*, rat_nm_*)"
+#define WIDE_OP_MSG "this entry point is compiled for n <= 12, m <= 4"
 static rat_rc op_prepare(rat_handle h, double theta, double mu, double delta, StateDev *out) {
     if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
     if (h->wide) return fail(RAT_ERR_UNSUPPORTED, WIDE_OP_MSG);
@@ -925,9 +925,125 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     return RAT_OK;
 }
 
+// ---- operator forms at general size (wide.hip): the C ABI's dense column-major arrays ARE the kernel's layout ---------------------
+struct WideTmp {                         // device temporaries of one operator call (operators are not a hot path)
+    std::vector<void *> v;
+    ~WideTmp() { for (void *p : v) (void)hipFree(p); }
+    template <class T> T *out(size_t cnt) {
+        void *q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(cnt, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        v.push_back(q);
+        return (T *)q;
+    }
+    template <class T> T *in(const T *host, size_t cnt) {
+        T *q = out<T>(cnt);
+        if (q && hipMemcpy(q, host, cnt * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return q;
+    }
+};
+#define WIDE_NEED(ptr) do { if (!(ptr)) return fail(RAT_ERR_HIP, "device allocation / upload failed in a general-size operator"); } while (0)
+static WideOpArgs wide_op_args(rat_handle h, int opcode, long count) {
+    WideOpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pb = h->wpb; a.op = h->opd; a.opcode = opcode; a.count = count;
+    return a;
+}
+static rat_rc wide_run(rat_handle h, const WideOpArgs &a) {
+    HIPCHK(launch_wide_op(a, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RAT_OK;
+}
+#define WIDE_BACK(host, dev, cnt) do { if (host) HIPCHK(hipMemcpy((host), (dev), (size_t)(cnt) * sizeof(*(host)), hipMemcpyDeviceToHost)); } while (0)
+
+static rat_rc wide_rollout_open(rat_handle h, const double *x0, const double *u, double *x) {
+    const size_t n = h->n, m = h->m, N = h->N;
+    WideTmp t;
+    WideOpArgs a = wide_op_args(h, WOP_ROLL_OPEN, 1);
+    WIDE_NEED(a.x0 = t.in(x0, n)); WIDE_NEED(a.u = t.in(u, N * m)); WIDE_NEED(a.x_out = t.out<double>((N + 1) * n));
+    rat_rc rc = wide_run(h, a);
+    if (rc) return rc;
+    WIDE_BACK(x, a.x_out, (N + 1) * n);
+    return RAT_OK;
+}
+static rat_rc wide_rollout_feedback(rat_handle h, const double *xbar, const double *l, const double *L, double *x_new, double *u_new) {
+    const size_t n = h->n, m = h->m, N = h->N;
+    WideTmp t;
+    WideOpArgs a = wide_op_args(h, WOP_ROLL_FEEDBACK, 1);
+    WIDE_NEED(a.xbar = t.in(xbar, (N + 1) * n)); WIDE_NEED(a.l = t.in(l, N * m)); WIDE_NEED(a.L = t.in(L, N * m * n));
+    WIDE_NEED(a.x_out = t.out<double>((N + 1) * n)); WIDE_NEED(a.u_out = t.out<double>(N * m));
+    rat_rc rc = wide_run(h, a);
+    if (rc) return rc;
+    WIDE_BACK(x_new, a.x_out, (N + 1) * n); WIDE_BACK(u_new, a.u_out, N * m);
+    return RAT_OK;
+}
+static rat_rc wide_integrate_cost(rat_handle h, const double *x, const double *u, double *cost) {
+    const size_t n = h->n, m = h->m, N = h->N;
+    WideTmp t;
+    WideOpArgs a = wide_op_args(h, WOP_COST, 1);
+    WIDE_NEED(a.xbar = t.in(x, (N + 1) * n)); WIDE_NEED(a.u = t.in(u, N * m)); WIDE_NEED(a.cost_out = t.out<double>(1));
+    rat_rc rc = wide_run(h, a);
+    if (rc) return rc;
+    WIDE_BACK(cost, a.cost_out, 1);
+    return RAT_OK;
+}
+static rat_rc wide_approximate_model(rat_handle h, const double *u, const double *x, double *q, double *qv, double *Q, double *r, double *R,
+                                     double *P, double *A, double *B, double *W) {
+    const size_t n = h->n, m = h->m, N = h->N;
+    WideTmp t;
+    WideOpArgs a = wide_op_args(h, WOP_APPROX, 1);
+    WIDE_NEED(a.xbar = t.in(x, (N + 1) * n)); WIDE_NEED(a.u = t.in(u, N * m));
+    WIDE_NEED(a.q = t.out<double>(N + 1)); WIDE_NEED(a.qv = t.out<double>((N + 1) * n)); WIDE_NEED(a.Q = t.out<double>((N + 1) * n * n));
+    WIDE_NEED(a.r = t.out<double>(N * m)); WIDE_NEED(a.R = t.out<double>(N * m * m)); WIDE_NEED(a.P = t.out<double>(N * m * n));
+    WIDE_NEED(a.A = t.out<double>(N * n * n)); WIDE_NEED(a.B = t.out<double>(N * n * m)); WIDE_NEED(a.W = t.out<double>(N * n * n));
+    rat_rc rc = wide_run(h, a);
+    if (rc) return rc;
+    WIDE_BACK(q, a.q, N + 1); WIDE_BACK(qv, a.qv, (N + 1) * n); WIDE_BACK(Q, a.Q, (N + 1) * n * n);
+    WIDE_BACK(r, a.r, N * m); WIDE_BACK(R, a.R, N * m * m); WIDE_BACK(P, a.P, N * m * n);
+    WIDE_BACK(A, a.A, N * n * n); WIDE_BACK(B, a.B, N * n * m); WIDE_BACK(W, a.W, N * n * n);
+    return RAT_OK;
+}
+// the two sweeps on caller-built tiles, B samples (B = 1: the single-sample operator forms, with the DynamicProgrammingResult dumps)
+static rat_rc wide_dp(rat_handle h, bool gain, int64_t B, const double *q, const double *qv, const double *Q, const double *r, const double *R,
+                      const double *P, const double *A, const double *Bm, const double *theta, double *mu, double *delta, const double *mu_in,
+                      const double *Lin, const double *dlin, double *Lout, double *dlout, double *value, int32_t *status,
+                      double *s, double *sv, double *S, double *g, double *G, double *H) {
+    if (B < 1) return fail(RAT_ERR_ARG, "batch size must be positive");
+    const size_t n = h->n, m = h->m, N = h->N, b = (size_t)B;
+    WideTmp t;
+    WideOpArgs a = wide_op_args(h, gain ? WOP_DP_GAIN : WOP_DP_EVAL, (long)B);
+    WIDE_NEED(a.q = t.in(q, b * (N + 1))); WIDE_NEED(a.qv = t.in(qv, b * (N + 1) * n)); WIDE_NEED(a.Q = t.in(Q, b * (N + 1) * n * n));
+    WIDE_NEED(a.r = t.in(r, b * N * m)); WIDE_NEED(a.R = t.in(R, b * N * m * m)); WIDE_NEED(a.P = t.in(P, b * N * m * n));
+    WIDE_NEED(a.A = t.in(A, b * N * n * n)); WIDE_NEED(a.B = t.in(Bm, b * N * n * m));
+    WIDE_NEED(a.theta = t.in(theta, b));
+    WIDE_NEED(a.value = t.out<double>(b)); WIDE_NEED(a.status = t.out<int>(b));
+    if (gain) {
+        WIDE_NEED(a.mu = t.in(mu, b)); WIDE_NEED(a.delta = t.in(delta, b));
+        WIDE_NEED(a.Lio = t.out<double>(b * N * m * n)); WIDE_NEED(a.dl_out = t.out<double>(b * N * m));
+    } else {
+        WIDE_NEED(a.mu_in = t.in(mu_in, b));
+        WIDE_NEED(a.Lio = t.in(Lin, b * N * m * n));
+        if (dlin) WIDE_NEED(a.dlin = t.in(dlin, b * N * m));
+    }
+    if (s) WIDE_NEED(a.ds = t.out<double>(N + 1));
+    if (sv) WIDE_NEED(a.dsv = t.out<double>((N + 1) * n));
+    if (S) WIDE_NEED(a.dS = t.out<double>((N + 1) * n * n));
+    if (g) WIDE_NEED(a.dg = t.out<double>(N * m));
+    if (G) WIDE_NEED(a.dG = t.out<double>(N * m * n));
+    if (H) WIDE_NEED(a.dH = t.out<double>(N * m * m));
+    rat_rc rc = wide_run(h, a);
+    if (rc) return rc;
+    if (gain) { WIDE_BACK(mu, a.mu, b); WIDE_BACK(delta, a.delta, b); WIDE_BACK(Lout, a.Lio, b * N * m * n); WIDE_BACK(dlout, a.dl_out, b * N * m); }
+    WIDE_BACK(value, a.value, b);
+    if (status) { std::vector<int> st(b); HIPCHK(hipMemcpy(st.data(), a.status, b * 4, hipMemcpyDeviceToHost)); for (size_t i = 0; i < b; ++i) status[i] = st[i]; }
+    WIDE_BACK(s, a.ds, N + 1); WIDE_BACK(sv, a.dsv, (N + 1) * n); WIDE_BACK(S, a.dS, (N + 1) * n * n);
+    WIDE_BACK(g, a.dg, N * m); WIDE_BACK(G, a.dG, N * m * n); WIDE_BACK(H, a.dH, N * m * m);
+    return RAT_OK;
+}
+
 // ---- operator forms ------------------------------------------------------------------------------------
 extern "C" rat_rc rat_rollout_open(rat_handle h, const double *x0, const double *u, double *x, int32_t *domain_fail) {
     if (!h || !x0 || !u || !x) return fail(RAT_ERR_ARG, "null");
+    if (h->have_problem && h->wide) { if (domain_fail) *domain_fail = 0; return wide_rollout_open(h, x0, u, x); }
     rat_rc rc = rat_set_initial(h, x0, u);
     if (rc) return rc;
     StateDev st;
@@ -954,6 +1070,7 @@ static rat_rc put_slot0(rat_handle h, const double *x, const double *u) {
 extern "C" rat_rc rat_rollout_feedback(rat_handle h, const double *xbar, const double *l, const double *L,
                                        double *x_new, double *u_new, int32_t *domain_fail) {
     if (!h || !xbar || !l || !L) return fail(RAT_ERR_ARG, "null");
+    if (h->have_problem && h->wide) { if (domain_fail) *domain_fail = 0; return wide_rollout_feedback(h, xbar, l, L, x_new, u_new); }
     StateDev st;
     rat_rc rc = op_prepare(h, 0.0, 0.0, h->opts.delta_0, &st);
     if (rc) return rc;
@@ -985,10 +1102,31 @@ extern "C" rat_rc rat_rollout_noisy(rat_handle h, const double *x_nom, const dou
                                     int32_t *domain_fail) {
     if (!h || !x_nom || !l) return fail(RAT_ERR_ARG, "null");
     if (!h->have_problem) return fail(RAT_ERR_NO_PROBLEM, "rat_problem_set was not called");
-    if (h->wide) return fail(RAT_ERR_UNSUPPORTED, WIDE_OP_MSG);
     if (K < 1) return fail(RAT_ERR_ARG, "K must be positive");
     HIPCHK(hipSetDevice(h->device));
     const int n = h->n, m = h->m, N = h->N, Nw = h->W_tv ? N : 1;
+    if (h->wide) {                       // general size: dense column-major in and out, one workgroup per rollout
+        std::vector<double> Lw((size_t)Nw * n * n, 0.0);
+        for (int k = 0; k < Nw; ++k)
+            if (!host_chol_lower(n, h->hW.data() + (size_t)k * n * n, Lw.data() + (size_t)k * n * n))
+                return fail(RAT_ERR_ARG, "W(k) is not positive definite (MvNormal would throw)");
+        const size_t sn = n, sm = m, sN = N, sK = (size_t)K;
+        WideTmp t;
+        WideOpArgs a = wide_op_args(h, WOP_NOISY, (long)K);
+        WIDE_NEED(a.xbar = t.in(x_nom, L ? (sN + 1) * sn : sn)); WIDE_NEED(a.l = t.in(l, sN * sm));
+        if (L) WIDE_NEED(a.L = t.in(L, sN * sm * sn));
+        if (z) WIDE_NEED(a.z = t.in(z, sK * sN * sn));
+        a.seed = seed;
+        WIDE_NEED(a.Wchol = t.in(Lw.data(), Lw.size()));
+        if (x_out) WIDE_NEED(a.x_out = t.out<double>(sK * (sN + 1) * sn));
+        if (u_out) WIDE_NEED(a.u_out = t.out<double>(sK * sN * sm));
+        if (cost_out) WIDE_NEED(a.cost_out = t.out<double>(sK));
+        rat_rc rcw = wide_run(h, a);
+        if (rcw) return rcw;
+        WIDE_BACK(x_out, a.x_out, sK * (sN + 1) * sn); WIDE_BACK(u_out, a.u_out, sK * sN * sm); WIDE_BACK(cost_out, a.cost_out, sK);
+        if (domain_fail) *domain_fail = 0;
+        return RAT_OK;
+    }
     // lower Cholesky factors of W(k) (MvNormal sampling unwhitens with them), padded to 12 x 16 row-major
     std::vector<double> Lc((size_t)n * n), Wc((size_t)Nw * 192, 0.0);
     for (int k = 0; k < Nw; ++k) {
@@ -1071,6 +1209,7 @@ static rat_rc linearize_slot0(rat_handle h, const double *u, const double *x, st
 
 extern "C" rat_rc rat_integrate_cost(rat_handle h, const double *x, const double *u, double *cost) {
     if (!h || !x || !u || !cost) return fail(RAT_ERR_ARG, "null");
+    if (h->have_problem && h->wide) return wide_integrate_cost(h, x, u, cost);
     std::vector<double> tp;
     int32_t dom = 0;
     rat_rc rc = linearize_slot0(h, u, x, &tp, &dom);
@@ -1085,6 +1224,7 @@ extern "C" rat_rc rat_integrate_cost(rat_handle h, const double *x, const double
 extern "C" rat_rc rat_approximate_model(rat_handle h, const double *u, const double *x, double *q, double *qv, double *Q,
                                         double *r, double *R, double *P, double *A, double *B, double *W, int32_t *domain_fail) {
     if (!h || !x || !u) return fail(RAT_ERR_ARG, "null");
+    if (h->have_problem && h->wide) { if (domain_fail) *domain_fail = 0; return wide_approximate_model(h, u, x, q, qv, Q, r, R, P, A, B, W); }
     std::vector<double> tp;
     rat_rc rc = linearize_slot0(h, u, x, &tp, domain_fail);
     if (rc) return rc;
@@ -1174,6 +1314,8 @@ extern "C" rat_rc rat_dp_gain_sweep(rat_handle h, const double *q, const double 
                                     double *mu, double *delta, double *L, double *dl, int32_t *status,
                                     double *s, double *sv, double *S, double *g, double *G, double *H) {
     if (!h || !q || !qv || !Q || !r || !R || !P || !A || !B || !mu || !delta) return fail(RAT_ERR_ARG, "null");
+    if (h->have_problem && h->wide)
+        return wide_dp(h, true, 1, q, qv, Q, r, R, P, A, B, &theta, mu, delta, nullptr, nullptr, nullptr, L, dl, nullptr, status, s, sv, S, g, G, H);
     StateDev st;
     rat_rc rc = op_prepare(h, theta, *mu, *delta, &st);
     if (rc) return rc;
@@ -1202,6 +1344,8 @@ extern "C" rat_rc rat_dp_policy_eval(rat_handle h, const double *q, const double
                                      const double *dl, double theta, double mu, int32_t *status,
                                      double *s, double *sv, double *S, double *g, double *G, double *H) {
     if (!h || !q || !qv || !Q || !r || !R || !P || !A || !B || !L) return fail(RAT_ERR_ARG, "null");
+    if (h->have_problem && h->wide)
+        return wide_dp(h, false, 1, q, qv, Q, r, R, P, A, B, &theta, nullptr, nullptr, &mu, L, dl, nullptr, nullptr, nullptr, status, s, sv, S, g, G, H);
     StateDev st;
     rat_rc rc = op_prepare(h, theta, mu, h->opts.delta_0, &st);
     if (rc) return rc;
@@ -1264,6 +1408,9 @@ extern "C" rat_rc rat_dp_gain_sweep_batch(rat_handle h, int64_t B, const double 
                                           const double *R, const double *P, const double *A, const double *Bm, const double *theta,
                                           double *mu, double *delta, double *L, double *dl, int32_t *status) {
     if (!h || !q || !qv || !Q || !r || !R || !P || !A || !Bm || !theta || !mu || !delta) return fail(RAT_ERR_ARG, "null");
+    if (h->have_problem && h->wide)
+        return wide_dp(h, true, B, q, qv, Q, r, R, P, A, Bm, theta, mu, delta, nullptr, nullptr, nullptr, L, dl, nullptr, status,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     StateDev st;
     rat_rc rc = batch_state(h, B, theta, mu, delta, &st);
     if (rc) return rc;
@@ -1290,6 +1437,9 @@ extern "C" rat_rc rat_dp_policy_eval_batch(rat_handle h, int64_t B, const double
                                            const double *R, const double *P, const double *A, const double *Bm, const double *L,
                                            const double *theta, const double *mu, double *value, int32_t *status) {
     if (!h || !q || !qv || !Q || !r || !R || !P || !A || !Bm || !L || !theta || !mu || !value) return fail(RAT_ERR_ARG, "null");
+    if (h->have_problem && h->wide)
+        return wide_dp(h, false, B, q, qv, Q, r, R, P, A, Bm, theta, nullptr, nullptr, mu, L, nullptr, nullptr, nullptr, value, status,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     StateDev st;
     rat_rc rc = batch_state(h, B, theta, mu, nullptr, &st);
     if (rc) return rc;

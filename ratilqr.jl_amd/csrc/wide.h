@@ -34,5 +34,29 @@ struct WideArgs {
     double *hist; int hist_cap; int *hist_n;     // sample 0's line-search history (eps, value difference) or null
 };
 
+// Operator forms at general size (the reference's building blocks as individual calls; unit parity with test/ileqg_test.jl).  All arrays
+// are device pointers in the C ABI layout (column-major, time slowest); `count` workgroups each handle one rollout / one sample.
+enum WideOp { WOP_ROLL_OPEN = 1, WOP_ROLL_FEEDBACK, WOP_COST, WOP_NOISY, WOP_APPROX, WOP_DP_GAIN, WOP_DP_EVAL };
+struct WideOpArgs {
+    WideProblemDev pb;
+    OptsDev op;
+    int opcode;
+    long count;                           // rollouts (WOP_NOISY) or samples (WOP_DP_*), else 1
+    // trajectories
+    const double *x0, *u;                 // open loop: x0 [n], u [N*m];  WOP_COST / WOP_APPROX: x = xbar [(N+1)*n], u [N*m]
+    const double *xbar, *l, *L;           // feedback / noisy: nominal states, l [N*m], L [N*m*n] (noisy: null = open loop)
+    double *x_out, *u_out, *cost_out;     // rollouts / noisy: per workgroup [(N+1)*n], [N*m], [1]; any may be null
+    const double *z; unsigned long long seed; const double *Wchol;   // noisy: injected N(0,1) [count][N][n] or null (Philox); chol_lower(W(k)) [Nw][n*n]
+    // ApproximationResult: outputs of WOP_APPROX, inputs of WOP_DP_* (per sample, sample slowest)
+    double *q, *qv, *Q, *r, *R, *P, *A, *B, *W;
+    // sweeps
+    const double *theta, *mu_in, *dlin;   // [count]; dlin: [N*m] per sample or null (WOP_DP_EVAL)
+    double *mu, *delta;                   // [count] in/out (WOP_DP_GAIN)
+    double *Lio, *dl_out;                 // L: [N*m*n] per sample, in (eval) / out (gain); dl out (gain)
+    double *value; int *status;           // [count]
+    double *ds, *dsv, *dS, *dg, *dG, *dH; // DynamicProgrammingResult dumps of sample 0, any may be null
+};
+
 size_t wide_lds_bytes(int n, int m);
+hipError_t launch_wide_op(const WideOpArgs &a, hipStream_t s);
 hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s);

@@ -71,29 +71,69 @@ __device__ inline void back_sub(const double *U, const int k, const int ld, doub
 
 // solve_approximate_dp (gain = false, :412-465; dl = nothing) / one pass of solve_approximate_dp! (gain = true, :341-406) over the
 // trajectory (x, u).  Returns 0, 2 (M not positive definite) or -1 (H not positive definite: the caller raises mu and restarts).
-__device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u, const double theta, const double mu,
-                     const bool gain, const bool zeroL, double *Lg, double *dlg, double &value) {
-    const WideProblemDev &pb = a.pb;
+// Where a step's quadratic model comes from: the solver forms it on the fly from the trajectory (x, u) and the problem tables; the
+// operator forms (rat_dp_*) read caller-built ApproximationResult arrays in the C ABI layout (A != nullptr).
+struct Tiles {
+    const double *x, *u;
+    const double *q, *qv, *Q, *r, *R, *P, *A, *B;
+};
+struct Dump { double *s, *sv, *S, *g, *G, *H; };        // DynamicProgrammingResult arrays of the operator forms (any may be null)
+
+__device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const double theta, const double mu,
+                     const bool gain, const bool zeroL, double *Lg, double *dlg, const double *dlin, const Dump *dump, double &value) {
     const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x;
     const int ldn = n | 1, ldm = m | 1;          // odd leading dimensions in LDS: a column stride of n doubles puts every lane on one bank
+    const bool arr = tl.A != nullptr;
+    const double *const x = tl.x, *const u = tl.u;
     // terminal condition (:352-354 / :429-431)
-    if (lane < n) w.xt[lane] = x[(size_t)N * n + lane];
-    __syncthreads();
-    for (int e = lane; e < n2; e += 64) w.S[e % n + ldn * (e / n)] = pb.Qf[e];
-    double part = 0.0;
-    if (lane < n) {
-        double acc = 0.0;
-        for (int j = 0; j < n; ++j) acc += pb.Qf[lane + n * j] * w.xt[j];
-        w.sv[lane] = acc + pb.qvf[lane];
-        part = w.xt[lane] * (0.5 * acc + pb.qvf[lane]);
+    double s1;
+    if (arr) {
+        const double *Qn = tl.Q + (size_t)N * n2;
+        for (int e = lane; e < n2; e += 64) { const int i = e % n, j = e / n; w.S[i + ldn * j] = (i <= j) ? Qn[e] : Qn[j + n * i]; }
+        if (lane < n) w.sv[lane] = tl.qv[(size_t)N * n + lane];
+        s1 = tl.q[N];
+    } else {
+        if (lane < n) w.xt[lane] = x[(size_t)N * n + lane];
+        __syncthreads();
+        for (int e = lane; e < n2; e += 64) w.S[e % n + ldn * (e / n)] = pb.Qf[e];
+        double part0 = 0.0;
+        if (lane < n) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) acc += pb.Qf[lane + n * j] * w.xt[j];
+            w.sv[lane] = acc + pb.qvf[lane];
+            part0 = w.xt[lane] * (0.5 * acc + pb.qvf[lane]);
+        }
+        s1 = wsum(part0) + pb.q0f;
     }
-    double s1 = wsum(part) + pb.q0f;
+    double part = 0.0;
     __syncthreads();
+    if (dump) {
+        if (dump->s && lane == 0) dump->s[N] = s1;
+        if (dump->sv && lane < n) dump->sv[(size_t)N * n + lane] = w.sv[lane];
+        if (dump->S) for (int e = lane; e < n2; e += 64) dump->S[(size_t)N * n2 + e] = w.S[e % n + ldn * (e / n)];
+    }
     for (int t = N - 1; t >= 0; --t) {
         const int kc = pb.cost_tv ? t : 0, kw = pb.W_tv ? t : 0;
-        const double *Qk = pb.Q + (size_t)kc * n2, *Rk = pb.R + (size_t)kc * mm, *Pk = pb.P + (size_t)kc * nm;
-        const double *qvk = pb.qv + (size_t)kc * n, *rvk = pb.rv + (size_t)kc * m;
+        const double *Qk = arr ? tl.Q + (size_t)t * n2 : pb.Q + (size_t)kc * n2, *Rk = arr ? tl.R + (size_t)t * mm : pb.R + (size_t)kc * mm;
+        const double *Pk = arr ? tl.P + (size_t)t * nm : pb.P + (size_t)kc * nm;
         const double *Wk = pb.W + (size_t)kw * n2, *Wik = pb.Winv + (size_t)kw * n2;
+        if (!gain) {
+            for (int e = lane; e < nm; e += 64) w.Lt[e % m + ldm * (e / m)] = zeroL ? 0.0 : Lg[(size_t)t * nm + e];
+            if (lane < m) w.dlv[lane] = dlin ? dlin[(size_t)t * m + lane] : 0.0;
+        }
+        double q;
+        if (arr) {                                                                         // caller-built tiles of step t
+            for (int e = lane; e < n2; e += 64) {
+                const int i = e % n, j = e / n;
+                w.At[i + ldn * j] = tl.A[(size_t)t * n2 + e];
+                w.U[i + ldn * j] = Wik[e] - theta * w.S[i + ldn * j];
+            }
+            for (int e = lane; e < nm; e += 64) w.Bm[e % n + ldn * (e / n)] = tl.B[(size_t)t * nm + e];
+            if (lane < n) w.qv[lane] = tl.qv[(size_t)t * n + lane];
+            if (lane < m) w.rv[lane] = tl.r[(size_t)t * m + lane];
+            q = tl.q[t];
+        } else {
+        const double *qvk = pb.qv + (size_t)kc * n, *rvk = pb.rv + (size_t)kc * m;
         if (lane < n) w.xt[lane] = x[(size_t)t * n + lane];
         if (lane >= 32 && lane - 32 < m) w.ut[lane - 32] = u[(size_t)t * m + lane - 32];
         __syncthreads();
@@ -102,10 +142,6 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
             const int i = e % n, j = e / n;
             w.At[i + ldn * j] = pb.A[e] + ((i == j) ? 3.0 * pb.kappa * (w.xt[i] * w.xt[i]) : 0.0);
             w.U[i + ldn * j] = Wik[e] - theta * w.S[i + ldn * j];
-        }
-        if (!gain) {
-            for (int e = lane; e < nm; e += 64) w.Lt[e % m + ldm * (e / m)] = zeroL ? 0.0 : Lg[(size_t)t * nm + e];
-            if (lane < m) w.dlv[lane] = 0.0;
         }
         part = 0.0;
         if (lane < n) {
@@ -122,7 +158,8 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
             w.rv[g] = ru + px + rvk[g];
             part = w.ut[g] * (0.5 * ru + px + rvk[g]);
         }
-        const double q = wsum(part) + pb.q0[kc];
+        q = wsum(part) + pb.q0[kc];
+        }
         __syncthreads();
         double sumlog = 0.0;
         if (!chol_upper(w.U, n, ldn, lane, sumlog)) return 2;                                  // @assert isposdef(M)  :366 / :440
@@ -181,6 +218,11 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
             w.g[lane] = w.rv[lane] + acc;
         }
         __syncthreads();
+        if (dump) {
+            if (dump->g && lane < m) dump->g[(size_t)t * m + lane] = w.g[lane];
+            if (dump->G) for (int e = lane; e < nm; e += 64) dump->G[(size_t)t * nm + e] = w.G[e % m + ldm * (e / m)];
+            if (dump->H) for (int e = lane; e < mm; e += 64) dump->H[(size_t)t * mm + e] = w.H[e % m + ldm * (e / m)];
+        }
         if (gain) {
             double dummy = 0.0;
             if (!chol_upper(w.Hc, m, ldm, lane, dummy)) return -1;                              // !isposdef(H)  :372
@@ -236,21 +278,25 @@ __device__ int sweep(const WideArgs &a, Ws &w, const double *x, const double *u,
         __syncthreads();
         double *tmp = w.S; w.S = w.U; w.U = tmp;
         s1 = s0;
+        if (dump) {
+            if (dump->s && lane == 0) dump->s[t] = s1;
+            if (dump->sv && lane < n) dump->sv[(size_t)t * n + lane] = w.sv[lane];
+            if (dump->S) for (int e = lane; e < n2; e += 64) dump->S[(size_t)t * n2 + e] = w.S[e % n + ldn * (e / n)];
+        }
     }
     value = s1;
     return 0;
 }
 
 // simulate_dynamics(problem, x_0, u_array)  (ileqg.jl:18-38) into (xo, uo)
-__device__ void rollout_open(const WideArgs &a, Ws &w, double *xo, double *uo) {
-    const WideProblemDev &pb = a.pb;
+__device__ void rollout_open(const WideProblemDev &pb, Ws &w, const double *x0, const double *u0, double *xo, double *uo) {
     const int n = pb.n, m = pb.m, N = pb.N, lane = threadIdx.x;
     const int ldn = n | 1;
     for (int e = lane; e < n * n; e += 64) w.At[e % n + ldn * (e / n)] = pb.A[e];
-    if (lane < n) { w.xt[lane] = a.x0[lane]; xo[lane] = a.x0[lane]; }
+    if (lane < n) { w.xt[lane] = x0[lane]; xo[lane] = x0[lane]; }
     __syncthreads();
     for (int t = 0; t < N; ++t) {
-        if (lane < m) { const double v = a.u0[(size_t)t * m + lane]; w.ut[lane] = v; uo[(size_t)t * m + lane] = v; }
+        if (lane < m) { const double v = u0[(size_t)t * m + lane]; w.ut[lane] = v; if (uo) uo[(size_t)t * m + lane] = v; }
         __syncthreads();
         double xn = 0.0;
         if (lane < n) {
@@ -267,9 +313,8 @@ __device__ void rollout_open(const WideArgs &a, Ws &w, double *xo, double *uo) {
 }
 
 // simulate_dynamics(problem, x_array, l_array + eps dl, L_array)  (ileqg.jl:62-87, :509-517); returns maximum(norm.(l .- u_new))  (:539)
-__device__ double rollout_closed(const WideArgs &a, Ws &w, const double *xbar, const double *l, const double *dl, const double *L,
+__device__ double rollout_closed(const WideProblemDev &pb, Ws &w, const double *xbar, const double *l, const double *dl, const double *L,
                                  const double eps, double *xo, double *uo) {
-    const WideProblemDev &pb = a.pb;
     const int n = pb.n, m = pb.m, N = pb.N, nm = n * m, lane = threadIdx.x;
     const int ldn = n | 1;
     for (int e = lane; e < n * n; e += 64) w.At[e % n + ldn * (e / n)] = pb.A[e];
@@ -286,7 +331,7 @@ __device__ double rollout_closed(const WideArgs &a, Ws &w, const double *xbar, c
             double acc = 0.0;
             for (int j = 0; j < n; ++j) acc += Lt[lane + m * j] * w.xb[j];
             const double lt = l[(size_t)t * m + lane];
-            const double un = (lt + eps * dl[(size_t)t * m + lane]) + acc;
+            const double un = (dl ? lt + eps * dl[(size_t)t * m + lane] : lt) + acc;
             w.ut[lane] = un; uo[(size_t)t * m + lane] = un;
             const double df = lt - un;
             diff2 = df * df;
@@ -312,6 +357,14 @@ __device__ double rollout_closed(const WideArgs &a, Ws &w, const double *xbar, c
     return best;
 }
 
+__device__ inline void carve(Ws &w, double *p, const int n, const int m) {                  // the workgroup's LDS area -> named matrices
+    const int ldn = n | 1, ldm = m | 1, sn = ldn * n, sb = ldn * m, sg = ldm * n, sf = sb > sg ? sb : sg, sh = ldm * m;
+    w.S = p; p += sn; w.U = p; p += sn; w.Z = p; p += sn; w.DS = p; p += sn; w.T = p; p += sn; w.At = p; p += sn;
+    w.Bm = p; p += sb; w.F = p; p += sf; w.G = p; p += sg; w.Lt = p; p += sg; w.H = p; p += sh; w.Hc = p; p += sh;
+    w.sv = p; p += n; w.z = p; p += n; w.dsv = p; p += n; w.qv = p; p += n; w.sv0 = p; p += n; w.xt = p; p += n; w.xb = p; p += n;
+    w.g = p; p += m; w.dlv = p; p += m; w.rv = p; p += m; w.ut = p; p += m; w.hv = p; p += m;
+}
+
 __device__ inline bool isapprox_default(double x, double y) {       // isapprox with rtol = sqrt(eps)  (:538)
     if (x == y) return true;
     if (!isfinite(x) || !isfinite(y)) return false;
@@ -324,14 +377,7 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     const OptsDev &op = a.op;
     const int n = pb.n, m = pb.m, N = pb.N, nm = n * m, lane = threadIdx.x, b = blockIdx.x;
     Ws w;
-    {
-        const int ldn = n | 1, ldm = m | 1, sn = ldn * n, sb = ldn * m, sg = ldm * n, sf = sb > sg ? sb : sg, sh = ldm * m;
-        double *p = lds;
-        w.S = p; p += sn; w.U = p; p += sn; w.Z = p; p += sn; w.DS = p; p += sn; w.T = p; p += sn; w.At = p; p += sn;
-        w.Bm = p; p += sb; w.F = p; p += sf; w.G = p; p += sg; w.Lt = p; p += sg; w.H = p; p += sh; w.Hc = p; p += sh;
-        w.sv = p; p += n; w.z = p; p += n; w.dsv = p; p += n; w.qv = p; p += n; w.sv0 = p; p += n; w.xt = p; p += n; w.xb = p; p += n;
-        w.g = p; p += m; w.dlv = p; p += m; w.rv = p; p += m; w.ut = p; p += m; w.hv = p; p += m;
-    }
+    carve(w, lds, n, m);
     for (int e = lane; e < nm; e += 64) w.Bm[e % n + (n | 1) * (e / n)] = pb.B[e];
     const size_t xstr = (size_t)(N + 1) * n, ustr = (size_t)N * m;
     double *const xs = a.xs + (size_t)b * 2 * xstr, *const us = a.us + (size_t)b * 2 * ustr;
@@ -342,9 +388,11 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     double mu = 0.0, delta = op.delta_0, d_cur = INFINITY, value_cur = INFINITY, eps_init = op.eps_init;
     int iter = 0, n_ls = 0, hn = 0, nom = 0, status = ST_RUNNING;
     for (size_t e = lane; e < (size_t)N * nm; e += 64) Lg[e] = 0.0;                         // :230-232
-    rollout_open(a, w, xs, us);                                                             // :225, :228
+    rollout_open(pb, w, a.x0, a.u0, xs, us);                                                // :225, :228
+    Tiles tl = {};
     {
-        const int rc = sweep(a, w, xs, us, theta, mu, false, true, Lg, dlg, value_cur);     // :233-235
+        tl.x = xs; tl.u = us;
+        const int rc = sweep(pb, w, tl, theta, mu, false, true, Lg, dlg, nullptr, nullptr, value_cur);     // :233-235
         if (rc) status = 1;
     }
     // ---- while true: step!  (:640-654)
@@ -355,7 +403,8 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
         int restarts = 0;
         for (;;) {                                                                          // solve_approximate_dp!  (:359-403)
             double dummy;
-            const int rc = sweep(a, w, xn, un, theta, mu, true, false, Lg, dlg, dummy);
+            tl.x = xn; tl.u = un;
+            const int rc = sweep(pb, w, tl, theta, mu, true, false, Lg, dlg, nullptr, nullptr, dummy);
             if (rc == 0) break;
             if (rc == 2) { status = 2; break; }
             delta = fmax(op.delta_0, delta * op.delta_0);                                   // increase_mu_and_delta!  (:471-474)
@@ -371,9 +420,10 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
             count++;                                                                        // :505
             if (count > 4000) { status = 7; break; }                                        // (App. B.5)
             n_ls++;
-            const double d_new = rollout_closed(a, w, xn, un, dlg, Lg, eps, xc, uc);        // :509-517
+            const double d_new = rollout_closed(pb, w, xn, un, dlg, Lg, eps, xc, uc);       // :509-517
             double newv;
-            const int rc = sweep(a, w, xc, uc, theta, mu, false, false, Lg, dlg, newv);     // :520-528
+            tl.x = xc; tl.u = uc;
+            const int rc = sweep(pb, w, tl, theta, mu, false, false, Lg, dlg, nullptr, nullptr, newv);     // :520-528
             if (rc) { eps *= op.lambda; continue; }                                         // :529-535
             if (hist_on) {                                                                  // :537
                 if (hn < a.hist_cap && lane == 0) { a.hist[2 * (size_t)hn] = eps; a.hist[2 * (size_t)hn + 1] = newv - cur; }
@@ -407,6 +457,188 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     }
 }
 
+
+// ---- operator forms ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u01(unsigned hi, unsigned lo) {       // 53-bit uniform in [0, 1)
+    return (double)((((unsigned long long)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// c(k, x_t, u_t) of the LQ family with the gradients left in w.qv / w.rv  (x_t in w.xt, u_t in w.ut)
+__device__ double stage_cost(const WideProblemDev &pb, Ws &w, const int t) {
+    const int n = pb.n, m = pb.m, lane = threadIdx.x, kc = pb.cost_tv ? t : 0;
+    const double *Qk = pb.Q + (size_t)kc * n * n, *Rk = pb.R + (size_t)kc * m * m, *Pk = pb.P + (size_t)kc * n * m;
+    const double *qvk = pb.qv + (size_t)kc * n, *rvk = pb.rv + (size_t)kc * m;
+    double part = 0.0;
+    if (lane < n) {
+        double qx = 0.0, pu = 0.0;
+        for (int j = 0; j < n; ++j) qx += Qk[lane + n * j] * w.xt[j];
+        for (int g = 0; g < m; ++g) pu += Pk[g + m * lane] * w.ut[g];
+        w.qv[lane] = qx + pu + qvk[lane];
+        part = w.xt[lane] * (0.5 * qx + qvk[lane]);
+    } else if (lane >= 32 && lane - 32 < m) {
+        const int g = lane - 32;
+        double ru = 0.0, px = 0.0;
+        for (int g2 = 0; g2 < m; ++g2) ru += Rk[g + m * g2] * w.ut[g2];
+        for (int j = 0; j < n; ++j) px += Pk[g + m * j] * w.xt[j];
+        w.rv[g] = ru + px + rvk[g];
+        part = w.ut[g] * (0.5 * ru + px + rvk[g]);
+    }
+    return wsum(part) + pb.q0[kc];
+}
+// h(x_N) with its gradient left in w.qv  (x_N in w.xt)
+__device__ double terminal_cost(const WideProblemDev &pb, Ws &w) {
+    const int n = pb.n, lane = threadIdx.x;
+    double part = 0.0;
+    if (lane < n) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += pb.Qf[lane + n * j] * w.xt[j];
+        w.qv[lane] = acc + pb.qvf[lane];
+        part = w.xt[lane] * (0.5 * acc + pb.qvf[lane]);
+    }
+    return wsum(part) + pb.q0f;
+}
+
+__global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
+    extern __shared__ double lds[];
+    const WideProblemDev &pb = a.pb;
+    const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x, ldn = n | 1;
+    const long b = blockIdx.x;
+    Ws w;
+    carve(w, lds, n, m);
+    for (int e = lane; e < nm; e += 64) w.Bm[e % n + ldn * (e / n)] = pb.B[e];
+    __syncthreads();
+    if (a.opcode == WOP_ROLL_OPEN) {                                  // simulate_dynamics(problem, x_0, u_array)  ileqg.jl:18-38
+        rollout_open(pb, w, a.x0, a.u, a.x_out, nullptr);
+    } else if (a.opcode == WOP_ROLL_FEEDBACK) {                       // simulate_dynamics(problem, x_array, l_array, L_array)  :62-87
+        rollout_closed(pb, w, a.xbar, a.l, nullptr, a.L, 0.0, a.x_out, a.u_out);
+    } else if (a.opcode == WOP_COST || a.opcode == WOP_APPROX) {      // integrate_cost :115-124 / approximate_model :258-322
+        double total = 0.0;
+        for (int t = 0; t <= N; ++t) {
+            if (lane < n) w.xt[lane] = a.xbar[(size_t)t * n + lane];
+            if (t < N && lane < m) w.ut[lane] = a.u[(size_t)t * m + lane];
+            __syncthreads();
+            const double c = (t < N) ? stage_cost(pb, w, t) : terminal_cost(pb, w);
+            total += c;
+            __syncthreads();
+            if (a.opcode == WOP_APPROX) {
+                const int kc = pb.cost_tv ? t : 0, kw = pb.W_tv ? t : 0;
+                if (lane == 0) a.q[t] = c;
+                if (lane < n) a.qv[(size_t)t * n + lane] = w.qv[lane];
+                const double *Qs = (t < N) ? pb.Q + (size_t)kc * n2 : pb.Qf;
+                for (int e = lane; e < n2; e += 64) a.Q[(size_t)t * n2 + e] = Qs[e];
+                if (t < N) {
+                    if (lane < m) a.r[(size_t)t * m + lane] = w.rv[lane];
+                    for (int e = lane; e < mm; e += 64) a.R[(size_t)t * mm + e] = pb.R[(size_t)kc * mm + e];
+                    for (int e = lane; e < nm; e += 64) { a.P[(size_t)t * nm + e] = pb.P[(size_t)kc * nm + e]; a.B[(size_t)t * nm + e] = pb.B[e]; }
+                    for (int e = lane; e < n2; e += 64) {
+                        const int i = e % n, j = e / n;
+                        a.A[(size_t)t * n2 + e] = pb.A[e] + ((i == j) ? 3.0 * pb.kappa * (w.xt[i] * w.xt[i]) : 0.0);
+                        a.W[(size_t)t * n2 + e] = pb.W[(size_t)kw * n2 + e];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (a.opcode == WOP_COST && lane == 0) a.cost_out[0] = total;
+    } else if (a.opcode == WOP_NOISY) {                               // simulate_dynamics(..., rng)  :44-55 / :94-109 + integrate_cost
+        double *xo = a.x_out ? a.x_out + (size_t)b * (N + 1) * n : nullptr, *uo = a.u_out ? a.u_out + (size_t)b * N * m : nullptr;
+        for (int e = lane; e < n2; e += 64) w.At[e % n + ldn * (e / n)] = pb.A[e];
+        if (lane < n) w.xt[lane] = a.xbar[lane];
+        double total = 0.0, znext = 0.0;
+        __syncthreads();
+        for (int t = 0; t < N; ++t) {
+            const int kw = pb.W_tv ? t : 0;
+            if (xo && lane < n) xo[(size_t)t * n + lane] = w.xt[lane];
+            if (a.L && lane < n) w.xb[lane] = w.xt[lane] - a.xbar[(size_t)t * n + lane];
+            double zt = 0.0;
+            if (lane < n) {
+                if (a.z) zt = a.z[((size_t)b * N + t) * n + lane];
+                else if ((t & 1) == 0) {                              // both outputs of one Box-Muller transform: steps t and t + 1
+                    unsigned r[4];
+                    philox4x32_10((unsigned)b, (unsigned)((unsigned long long)b >> 32), (unsigned)(t >> 1), (unsigned)lane, (unsigned)a.seed,
+                                  (unsigned)(a.seed >> 32), r);
+                    const double rad = sqrt(-2.0 * log(1.0 - u01(r[0], r[1])));
+                    double sn, cs;
+                    sincos(6.283185307179586476925286766559 * u01(r[2], r[3]), &sn, &cs);
+                    zt = rad * cs; znext = rad * sn;
+                } else zt = znext;
+                w.z[lane] = zt;
+            }
+            __syncthreads();
+            if (lane < m) {
+                double un = a.l[(size_t)t * m + lane];
+                if (a.L) {
+                    const double *Lt = a.L + (size_t)t * nm;
+                    double acc = 0.0;
+                    for (int j = 0; j < n; ++j) acc += Lt[lane + m * j] * w.xb[j];
+                    un += acc;
+                }
+                w.ut[lane] = un;
+                if (uo) uo[(size_t)t * m + lane] = un;
+            }
+            __syncthreads();
+            total += stage_cost(pb, w, t);
+            double xn = 0.0;
+            if (lane < n) {
+                double acc = 0.0, accb = 0.0, wn = 0.0;
+                for (int j = 0; j < n; ++j) acc += w.At[lane + ldn * j] * w.xt[j];
+                for (int g = 0; g < m; ++g) accb += w.Bm[lane + ldn * g] * w.ut[g];
+                const double *Lw = a.Wchol + (size_t)kw * n2;
+                for (int j = 0; j <= lane; ++j) wn += Lw[lane + n * j] * w.z[j];          // chol_lower(W(k)) z
+                const double xi = w.xt[lane];
+                xn = (acc + accb + pb.kappa * (xi * xi * xi)) + wn;
+            }
+            __syncthreads();
+            if (lane < n) w.xt[lane] = xn;
+            __syncthreads();
+        }
+        if (xo && lane < n) xo[(size_t)N * n + lane] = w.xt[lane];
+        total += terminal_cost(pb, w);
+        if (a.cost_out && lane == 0) a.cost_out[b] = total;
+    } else if (a.opcode == WOP_DP_GAIN || a.opcode == WOP_DP_EVAL) {  // solve_approximate_dp! :341-406 / solve_approximate_dp :412-465
+        Tiles tl = {};
+        tl.q = a.q + (size_t)b * (N + 1); tl.qv = a.qv + (size_t)b * (N + 1) * n; tl.Q = a.Q + (size_t)b * (N + 1) * n2;
+        tl.r = a.r + (size_t)b * N * m; tl.R = a.R + (size_t)b * N * mm; tl.P = a.P + (size_t)b * N * nm;
+        tl.A = a.A + (size_t)b * N * n2; tl.B = a.B + (size_t)b * N * nm;
+        Dump dp = {a.ds, a.dsv, a.dS, a.dg, a.dG, a.dH};
+        const Dump *dump = (b == 0 && (a.ds || a.dsv || a.dS || a.dg || a.dG || a.dH)) ? &dp : nullptr;
+        double *Lg = a.Lio + (size_t)b * N * nm;
+        const double theta = a.theta[b];
+        double value = INFINITY;
+        int status = 0;
+        if (a.opcode == WOP_DP_GAIN) {
+            double mu = a.mu[b], delta = a.delta[b];
+            int restarts = 0;
+            for (;;) {
+                const int rc = sweep(pb, w, tl, theta, mu, true, false, Lg, a.dl_out + (size_t)b * N * m, nullptr, dump, value);
+                if (rc == 0) break;
+                if (rc == 2) { status = 2; break; }
+                delta = fmax(a.op.delta_0, delta * a.op.delta_0);                           // increase_mu_and_delta!  (:471-474)
+                mu = fmax(a.op.mu_min, mu * delta);
+                if (++restarts > 400 || !isfinite(mu)) { status = 5; break; }
+            }
+            if (lane == 0) { a.mu[b] = mu; a.delta[b] = delta; }
+        } else {
+            const int rc = sweep(pb, w, tl, theta, a.mu_in[b], false, false, Lg, nullptr, a.dlin ? a.dlin + (size_t)b * N * m : nullptr, dump, value);
+            if (rc) status = 2;
+        }
+        if (lane == 0) {
+            if (a.status) a.status[b] = status;
+            if (a.value) a.value[b] = status ? INFINITY : value;
+        }
+    }
+}
+
 }  // namespace
 
 size_t wide_lds_bytes(int n, int m) {
@@ -421,5 +653,15 @@ hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(wide_solve_kernel, dim3(a.B), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_wide_op(const WideOpArgs &a, hipStream_t s) {
+    const size_t lds = wide_lds_bytes(a.pb.n, a.pb.m);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_op_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(wide_op_kernel, dim3((unsigned)a.count), dim3(64), lds, s, a);
     return hipGetLastError();
 }

@@ -137,13 +137,121 @@ def test_handle_switches_between_tile_sized_and_wide_problems():
     assert np.array_equal(check_batch(ctx, orc.Problem(small), sx0, su, th)[0], a)
 
 
-def test_operators_fail_loudly_beyond_the_tile():
-    prob, x0, u = wide_problem(13, 2, 8, 41)
-    ctx = rat.Context(prob)
-    with pytest.raises(rat.native.RatError, match="n <= 12"):
-        ctx.rollout_open(x0, u)
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def test_sizes_beyond_the_general_kernel_fail_loudly():
     with pytest.raises(rat.native.RatError, match="n <= 32"):
         rat.Context(rat.LQRiskSensitiveProblem(np.eye(40), np.ones((40, 2)), Q=np.eye(40), R=np.eye(2), N=5, W=np.eye(40)))
+    with pytest.raises(rat.native.RatError, match="LQ family"):
+        rat.Context(rat.PowerLawRiskSensitiveProblem(13, 5, 0.01 * np.eye(13)))
+
+
+@pytest.mark.parametrize("n,m,N,seed,kappa,tv", [(14, 5, 12, 81, 0.03, True), (32, 9, 6, 82, 0.0, False), (7, 7, 9, 83, 0.01, True)])
+def test_operator_forms_match_the_oracle(n, m, N, seed, kappa, tv):
+    """simulate_dynamics (three forms), integrate_cost, approximate_model, solve_approximate_dp(!) as individual calls at general size"""
+    prob, x0, u = wide_problem(n, m, N, seed, kappa, tv)
+    P = orc.Problem(prob)
+    ctx = rat.Context(prob)
+    _, xo = orc.simulate_open(P, x0, u)
+    xg = ctx.rollout_open(x0, u)
+    assert rel(xg, xo) < 1e-12
+    assert abs(ctx.integrate_cost(xo, u) - orc.integrate_cost(P, xo, u)[1]) <= 1e-12 * abs(orc.integrate_cost(P, xo, u)[1])
+    ap = ctx.approximate_model(u, xo)
+    _, ap_o = orc.approximate_model(P, u, xo)
+    a = ap_o.arrays()
+    for kk, name in (("q", "q_array"), ("qv", "q_vec_array"), ("Q", "Q_array"), ("r", "r_array"), ("R", "R_array"),
+                     ("P", "P_array"), ("A", "A_array"), ("B", "B_array"), ("W", "W_array")):
+        assert rel(getattr(ap, name), a[kk]) < 1e-12, kk
+    th_hi = theta_grid(P, x0, u, 2)[2]
+    for theta in (0.0, 0.6 * th_hi):
+        st, L, dl, dp, mu1, de1 = ctx.dp_gain_sweep(ap, theta, 0.0, 2.0)
+        _, Lo, dlo, dpo, mu_o, de_o = orc.dp_gain(P, ap_o, theta)
+        assert st == 0 and mu1 == mu_o and de1 == de_o
+        for got, ref in ((L, Lo), (dl, dlo), (dp.s_array, dpo["s"]), (dp.S_array, dpo["S"]), (dp.s_vec_array, dpo["sv"]),
+                         (dp.g_array, dpo["g"]), (dp.G_array, dpo["G"]), (dp.H_array, dpo["H"])):
+            assert rel(got, ref) < 1e-9
+        # the policy just computed: closed-loop rollout, then its evaluation with and without dl
+        _, xn_o, un_o = orc.simulate_feedback(P, xo, u + dlo, Lo)
+        xn, un = ctx.rollout_feedback(xo, u + dlo, Lo)
+        assert rel(xn, xn_o) < 1e-12 and rel(un, un_o) < 1e-12
+        for dl_in in (None, dlo):
+            st2, dp2 = ctx.dp_policy_eval(ap, Lo, dl_in, theta, 0.0)
+            _, dpo2 = orc.dp_eval(P, ap_o, Lo, dl_in, theta, 0.0)
+            assert st2 == 0 and rel(dp2.s_array, dpo2["s"]) < 1e-9 and rel(dp2.S_array, dpo2["S"]) < 1e-9 and rel(dp2.s_vec_array, dpo2["sv"]) < 1e-9
+        assert abs(dp2.s_array[0] - dp.s_array[0]) <= 1e-9 * abs(dp.s_array[0])       # K8: evaluating (L, dl) returns the gain sweep's value
+    big = 1e3 * th_hi
+    assert ctx.dp_gain_sweep(ap, big, 0.0, 2.0)[0] == orc.dp_gain(P, ap_o, big)[0] == 2   # @assert isposdef(M)
+    # Monte-Carlo rollouts under process noise, injected draws: open loop and under the affine policy
+    z = np.random.default_rng(5).standard_normal((6, N, n))
+    for Lpol in (None, Lo):
+        xnom = x0 if Lpol is None else xo
+        _, xz_o, uz_o, cz_o = orc.simulate_noisy(P, xnom, u, Lpol, z)
+        xz, uz, cz, dom = ctx.rollout_noisy(xnom, u, Lpol, z=z)
+        assert not dom and rel(xz, xz_o) < 1e-12 and rel(uz, uz_o) < 1e-12 and rel(cz, cz_o) < 1e-12
+    _, _, c1, _ = ctx.rollout_noisy(x0, u, None, K=2000, seed=9, want_x=False, want_u=False)   # device generator: reproducible, sane moments
+    _, _, c2, _ = ctx.rollout_noisy(x0, u, None, K=2000, seed=9, want_x=False, want_u=False)
+    assert np.array_equal(c1, c2) and np.all(np.isfinite(c1))
+    if kappa == 0.0:                                                                    # (linear dynamics: the quadratic model is exact)
+        assert abs(c1.mean() - ctx.dp_policy_eval(ap, np.zeros((N, m, n)), None, 0.0, 0.0)[1].s_array[0]) < 6 * c1.std() / np.sqrt(2000)
+
+
+def test_regularisation_restarts_inside_the_gain_sweep():
+    """an indefinite c_uu makes H lose positive definiteness: mu, Delta are raised and the sweep restarts (ileqg.jl:372-378)"""
+    prob, x0, u = wide_problem(14, 5, 10, 91)
+    prob.R = prob.R - 0.9 * np.eye(5) * np.linalg.eigvalsh(prob.R).max()
+    P = orc.Problem(prob)
+    ctx = rat.Context(prob, max_batch=3)
+    _, xo = orc.simulate_open(P, x0, u)
+    ap, (_, ap_o) = ctx.approximate_model(u, xo), orc.approximate_model(P, u, xo)
+    st, L, dl, dp, mu1, de1 = ctx.dp_gain_sweep(ap, 0.1, 0.0, 2.0)
+    rc, Lo, dlo, dpo, mu_o, de_o = orc.dp_gain(P, ap_o, 0.1)
+    assert st == rc == 0 and mu1 == mu_o > 0 and de1 == de_o and rel(L, Lo) < 1e-9
+    check_batch(ctx, P, x0, u, np.array([0.0, 0.1, 0.3]))
+
+
+def test_stepwise_composition_equals_the_single_launch_solve():
+    """initialize! / step! composed through the operator ABI == the solve kernel (same statements, different entry points)"""
+    prob, x0, u = rat.synthetic_lq_problem(n=14, m=6, N=30, seed=0, kappa=0.05)
+    for theta in (0.0, 3.0):
+        s1, s2 = rat.ILEQGSolver(prob), rat.ILEQGSolver(prob)
+        x1, l1, L1, v1, h1 = rat.solve_(s1, prob, x0, u, theta=theta)
+        x2, l2, L2, v2, h2 = rat.solve_stepwise_(s2, prob, x0, u, theta)
+        assert s1.iter_current == s2.iter_current and [a[0] for a in h1] == [a[0] for a in h2]
+        assert abs(v1 - v2) <= 1e-11 * abs(v2) and rel(x1, x2) < 1e-11 and rel(L1, L2) < 1e-10
+
+
+def test_closure_problems_at_general_size():
+    """the LQ family written as host closures whose f returns its Jacobians (ileqg.jl:302-311), n = 14: host rollouts + linearisation,
+    device sweeps through rat_dp_* and their batch forms, against the oracle's closure path and the device family"""
+    rng = np.random.default_rng(3)
+    n, m, N = 14, 5, 10
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    prob = rat.LQRiskSensitiveProblem(0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), Q=np.eye(n), R=0.3 * np.eye(m),
+                                      P=0.05 * rng.standard_normal((m, n)), qv=0.1 * rng.standard_normal(n), rv=0.1 * rng.standard_normal(m),
+                                      q0=0.2, N=N, W=1e-3 * np.eye(n), Qf=np.eye(n), kappa=0.02)
+    x0, u = 0.5 * rng.standard_normal(n), np.zeros((N, m))
+    A, B, kap, Q, R, Pm, qv, rv, q0, Qf = prob.A, prob.B, prob.kappa, prob.Q, prob.R, prob.P, prob.qv, prob.rv, float(prob.q0), prob.Qf
+
+    def f(x, uu, f_returns_jacobian=False):
+        xn = A @ x + B @ uu + kap * x ** 3
+        return (xn, A + np.diag(3 * kap * x ** 2), B) if f_returns_jacobian else xn
+    c = lambda k, x, uu: 0.5 * x @ Q @ x + 0.5 * uu @ R @ uu + uu @ Pm @ x + qv @ x + rv @ uu + q0       # noqa: E731
+    cd = lambda k, x, uu: (Q @ x + Pm.T @ uu + qv, Q, R @ uu + Pm @ x + rv, R, Pm)                      # noqa: E731
+    h = lambda x: 0.5 * x @ Qf @ x                                                                      # noqa: E731
+    hd = lambda x: (Qf @ x, Qf)                                                                         # noqa: E731
+    gen = rat.GenericRiskSensitiveProblem(f, c, h, prob.W, N, n, m, f_returns_jacobian=True, c_derivatives=cd, h_derivatives=hd)
+    cp = orc.ClosureProblem(lambda x, uu: f(x, uu), c, h, prob.W, N, n, m, lambda x, uu: f(x, uu, True)[1:], cd, hd)
+    theta = np.array([0.0, 1.0, 4.0, 1e5])
+    val, st, it, ls = rat.solve_closure_batch(gen, x0, u, theta)
+    vf, sf, itf, lsf = rat.Context(prob, max_batch=4).solve_batch(x0, u, theta)
+    assert np.array_equal(st, sf) and np.array_equal(it, itf) and np.array_equal(ls, lsf) and st[-1] == 1
+    assert np.all(np.abs(val[:3] - vf[:3]) <= 1e-9 * np.abs(vf[:3]))
+    for i in range(3):
+        r = orc.closure_solve(cp, x0, u, theta[i])
+        assert r["status"] == 0 and r["iters"] == it[i] and abs(val[i] - r["value"]) <= 1e-9 * abs(r["value"])
 
 
 def test_ce_solve_matches_the_oracle_on_an_injected_stream():
