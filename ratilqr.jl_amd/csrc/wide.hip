@@ -19,6 +19,7 @@
 #include <math.h>
 
 #include "wide.h"
+#include "device_utils.h"
 
 namespace {
 
@@ -27,50 +28,94 @@ struct Ws {
     double *sv, *z, *dsv, *qv, *sv0, *xt, *xb, *g, *dlv, *rv, *ut, *hv;
 };
 
-__device__ inline double wsum(double v) {          // butterfly: every lane ends with the same bits
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// sum over the wavefront, the same bits on every lane: DPP rotations inside the 16-lane rows, then the four row sums through scalar
+// registers (a butterfly of __shfl_xor goes through the LDS crossbar six times: ~5x the latency, and this sits on every row of the
+// lockstep factorisation below)
+__device__ __forceinline__ double wsum(double v) {
+    const double r = row_sum16(v);
+    return (readlane_f64(r, 0) + readlane_f64(r, 16)) + (readlane_f64(r, 32) + readlane_f64(r, 48));
 }
 
-// in-place upper Cholesky factor of the symmetric k x k matrix in LDS (only its upper triangle is read); false <=> not positive
-// definite (a pivot <= 0 or NaN: what LAPACK potrf reports and isposdef tests); sumlog += sum log U_ii
-__device__ bool chol_upper(double *U, const int k, const int ld, const int lane, double &sumlog) {
-    for (int p = 0; p < k; ++p) {
-        const double d = U[p + ld * p];
-        if (!(d > 0.0)) return false;
-        const double r = sqrt(d);
-        __syncthreads();
-        for (int j = p + lane; j < k; j += 64) U[p + ld * j] = (j == p) ? r : U[p + ld * j] / r;
-        __syncthreads();
-        const int w = k - p - 1;
-        for (int e = lane; e < w * w; e += 64) {
-            const int i = p + 1 + e % w, j = p + 1 + e / w;
-            if (i <= j) U[i + ld * j] -= U[p + ld * i] * U[p + ld * j];
+// ---- small dense linear algebra on matrices in LDS, one wavefront ------------------------------------------------------------------
+// Lanes are an 8 x 8 grid (li, lj) over matrix entries: no integer division anywhere, and products are register-blocked 2 x 2
+// (entries (i, j), (i + 8, j), (i, j + 8), (i + 8, j + 8): four LDS reads per four FMAs).
+template <class F> __device__ __forceinline__ void each(const int rows, const int cols, F f) {
+    const int li = threadIdx.x & 7, lj = threadIdx.x >> 3;
+    for (int j = lj; j < cols; j += 8)
+        for (int i = li; i < rows; i += 8) f(i, j);
+}
+// C(i, j) = sum_k A(i, k) B(k, j), A(i, k) = pa(i)[k * sa], B(k, j) = pb(j)[k * sb]; store(i, j, c) for every entry
+template <class PA, class PB, class ST>
+__device__ __forceinline__ void prod(const int rows, const int cols, const int K, PA pa, const int sa, PB pb, const int sb, ST store) {
+    const int li = threadIdx.x & 7, lj = threadIdx.x >> 3;
+    for (int j0 = lj; j0 < cols; j0 += 16) {
+        const int j1 = j0 + 8;
+        const bool vj = j1 < cols;
+        const double *b0 = pb(j0), *b1 = pb(vj ? j1 : j0);
+        for (int i0 = li; i0 < rows; i0 += 16) {
+            const int i1 = i0 + 8;
+            const bool vi = i1 < rows;
+            const double *a0 = pa(i0), *a1 = pa(vi ? i1 : i0);
+            double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+            #pragma unroll 8
+            for (int k = 0; k < K; ++k) {
+                const double x0 = a0[k * sa], x1 = a1[k * sa], y0 = b0[k * sb], y1 = b1[k * sb];
+                c00 += x0 * y0; c01 += x0 * y1; c10 += x1 * y0; c11 += x1 * y1;
+            }
+            store(i0, j0, c00);
+            if (vj) store(i0, j1, c01);
+            if (vi) store(i1, j0, c10);
+            if (vi && vj) store(i1, j1, c11);
         }
-        __syncthreads();
-        sumlog += log(r);
     }
+}
+
+// Cholesky factorisation X = U'U in place (upper triangle of the k x k matrix Um, k <= 32) FUSED with the forward substitutions
+// U'Y = R for nrhs <= 32 right-hand-side columns (Rm, in place) and one more right-hand side `vec`, in lockstep over the rows: lane c < k
+// owns column c of the matrix, lane 32 + c column c of R (every lane runs the same dot-product loop against column i of U, which is
+// final by the time row i is reached), and the extra right-hand side is reduced across the lanes (lane q holds y_q).  Left-looking, so
+// each entry is M_ij - sum_k U_ki U_kj in ascending k like the textbook loop.  false <=> a pivot <= 0 or NaN: what LAPACK potrf reports
+// and isposdef tests.  yv: lane i < k ends with y_i of the extra right-hand side; sumlog = sum_i log U_ii.
+__device__ bool chol_fwd(double *Um, const int k, const int ld, double *Rm, const int nrhs, const int ldr, const double *vec, double *idle,
+                         double &yv, double &sumlog) {
+    const int lane = threadIdx.x;
+    const bool isM = lane < k, isR = lane >= 32 && lane - 32 < nrhs;
+    double *col = isM ? Um + (size_t)ld * lane : (isR ? Rm + (size_t)ldr * (lane - 32) : idle);
+    double myr = 1.0;
+    yv = 0.0;
+    for (int i = 0; i < k; ++i) {
+        const double *ui = Um + (size_t)ld * i;
+        double acc = col[i];
+        #pragma unroll 8
+        for (int q = 0; q < i; ++q) acc -= ui[q] * col[q];
+        const double dot = wsum((lane < i) ? ui[lane] * yv : 0.0);
+        const double d = readlane_f64(acc, i);
+        if (!(d > 0.0)) return false;
+        const double r = sqrt(d), ri = fast_rcp(r);
+        col[i] = (isM && lane == i) ? r : acc * ri;
+        if (lane == i) { yv = (vec[i] - dot) * ri; myr = r; }
+        __syncthreads();
+    }
+    sumlog = wsum(isM ? log(myr) : 0.0);
     return true;
 }
-// U'y = c and U y = c for one column held by one lane (in place)
-__device__ inline void fwd_sub(const double *U, const int k, const int ld, double *c) {
-    for (int i = 0; i < k; ++i) {
-        double acc = c[i];
-        for (int q = 0; q < i; ++q) acc -= U[q + ld * i] * c[q];
-        c[i] = acc / U[i + ld * i];
-    }
-}
-__device__ inline void back_sub(const double *U, const int k, const int ld, double *c) {
+// back substitutions U X = Y for the nrhs columns of Rm (in place) and the extra right-hand side held in yv (lane i: y_i -> x_i)
+__device__ void back_all(const double *Um, const int k, const int ld, double *Rm, const int nrhs, const int ldr, double *idle, double &yv) {
+    const int lane = threadIdx.x;
+    const bool isR = lane >= 32 && lane - 32 < nrhs;
+    double *col = isR ? Rm + (size_t)ldr * (lane - 32) : idle;
     for (int i = k - 1; i >= 0; --i) {
-        double acc = c[i];
-        for (int q = i + 1; q < k; ++q) acc -= U[i + ld * q] * c[q];
-        c[i] = acc / U[i + ld * i];
+        double acc = col[i];
+        #pragma unroll 8
+        for (int q = i + 1; q < k; ++q) acc -= Um[i + (size_t)ld * q] * col[q];
+        const double dot = wsum((lane > i && lane < k) ? Um[i + (size_t)ld * lane] * yv : 0.0);
+        const double ri = fast_rcp(Um[i + (size_t)ld * i]);
+        col[i] = acc * ri;
+        if (lane == i) yv = (yv - dot) * ri;
+        __syncthreads();
     }
 }
 
-// solve_approximate_dp (gain = false, :412-465; dl = nothing) / one pass of solve_approximate_dp! (gain = true, :341-406) over the
-// trajectory (x, u).  Returns 0, 2 (M not positive definite) or -1 (H not positive definite: the caller raises mu and restarts).
 // Where a step's quadratic model comes from: the solver forms it on the fly from the trajectory (x, u) and the problem tables; the
 // operator forms (rat_dp_*) read caller-built ApproximationResult arrays in the C ABI layout (A != nullptr).
 struct Tiles {
@@ -79,6 +124,8 @@ struct Tiles {
 };
 struct Dump { double *s, *sv, *S, *g, *G, *H; };        // DynamicProgrammingResult arrays of the operator forms (any may be null)
 
+// solve_approximate_dp (gain = false, :412-465) / one pass of solve_approximate_dp! (gain = true, :341-406) over the trajectory.
+// Returns 0, 2 (M not positive definite) or -1 (H not positive definite: the caller raises mu and restarts).
 __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const double theta, const double mu,
                      const bool gain, const bool zeroL, double *Lg, double *dlg, const double *dlin, const Dump *dump, double &value) {
     const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x;
@@ -89,16 +136,17 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
     double s1;
     if (arr) {
         const double *Qn = tl.Q + (size_t)N * n2;
-        for (int e = lane; e < n2; e += 64) { const int i = e % n, j = e / n; w.S[i + ldn * j] = (i <= j) ? Qn[e] : Qn[j + n * i]; }
+        each(n, n, [&](int i, int j) { w.S[i + ldn * j] = (i <= j) ? Qn[i + n * j] : Qn[j + n * i]; });
         if (lane < n) w.sv[lane] = tl.qv[(size_t)N * n + lane];
         s1 = tl.q[N];
     } else {
         if (lane < n) w.xt[lane] = x[(size_t)N * n + lane];
         __syncthreads();
-        for (int e = lane; e < n2; e += 64) w.S[e % n + ldn * (e / n)] = pb.Qf[e];
+        each(n, n, [&](int i, int j) { w.S[i + ldn * j] = pb.Qf[i + n * j]; });
         double part0 = 0.0;
         if (lane < n) {
             double acc = 0.0;
+            #pragma unroll 8
             for (int j = 0; j < n; ++j) acc += pb.Qf[lane + n * j] * w.xt[j];
             w.sv[lane] = acc + pb.qvf[lane];
             part0 = w.xt[lane] * (0.5 * acc + pb.qvf[lane]);
@@ -110,7 +158,7 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
     if (dump) {
         if (dump->s && lane == 0) dump->s[N] = s1;
         if (dump->sv && lane < n) dump->sv[(size_t)N * n + lane] = w.sv[lane];
-        if (dump->S) for (int e = lane; e < n2; e += 64) dump->S[(size_t)N * n2 + e] = w.S[e % n + ldn * (e / n)];
+        if (dump->S) each(n, n, [&](int i, int j) { dump->S[(size_t)N * n2 + i + n * j] = w.S[i + ldn * j]; });
     }
     for (int t = N - 1; t >= 0; --t) {
         const int kc = pb.cost_tv ? t : 0, kw = pb.W_tv ? t : 0;
@@ -118,127 +166,109 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
         const double *Pk = arr ? tl.P + (size_t)t * nm : pb.P + (size_t)kc * nm;
         const double *Wk = pb.W + (size_t)kw * n2, *Wik = pb.Winv + (size_t)kw * n2;
         if (!gain) {
-            for (int e = lane; e < nm; e += 64) w.Lt[e % m + ldm * (e / m)] = zeroL ? 0.0 : Lg[(size_t)t * nm + e];
+            const double *Lt_g = Lg + (size_t)t * nm;
+            each(m, n, [&](int g, int j) { w.Lt[g + ldm * j] = zeroL ? 0.0 : Lt_g[g + m * j]; });
             if (lane < m) w.dlv[lane] = dlin ? dlin[(size_t)t * m + lane] : 0.0;
         }
         double q;
         if (arr) {                                                                         // caller-built tiles of step t
-            for (int e = lane; e < n2; e += 64) {
-                const int i = e % n, j = e / n;
-                w.At[i + ldn * j] = tl.A[(size_t)t * n2 + e];
-                w.U[i + ldn * j] = Wik[e] - theta * w.S[i + ldn * j];
-            }
-            for (int e = lane; e < nm; e += 64) w.Bm[e % n + ldn * (e / n)] = tl.B[(size_t)t * nm + e];
+            const double *At_g = tl.A + (size_t)t * n2, *Bt_g = tl.B + (size_t)t * nm;
+            each(n, n, [&](int i, int j) { w.At[i + ldn * j] = At_g[i + n * j]; });
+            each(n, m, [&](int i, int g) { w.Bm[i + ldn * g] = Bt_g[i + n * g]; });
             if (lane < n) w.qv[lane] = tl.qv[(size_t)t * n + lane];
             if (lane < m) w.rv[lane] = tl.r[(size_t)t * m + lane];
             q = tl.q[t];
-        } else {
-        const double *qvk = pb.qv + (size_t)kc * n, *rvk = pb.rv + (size_t)kc * m;
-        if (lane < n) w.xt[lane] = x[(size_t)t * n + lane];
-        if (lane >= 32 && lane - 32 < m) w.ut[lane - 32] = u[(size_t)t * m + lane - 32];
+        } else {                                                                           // approximate_model at (x_t, u_t)  (:294-313)
+            const double *qvk = pb.qv + (size_t)kc * n, *rvk = pb.rv + (size_t)kc * m;
+            if (lane < n) w.xt[lane] = x[(size_t)t * n + lane];
+            if (lane >= 32 && lane - 32 < m) w.ut[lane - 32] = u[(size_t)t * m + lane - 32];
+            __syncthreads();
+            each(n, n, [&](int i, int j) { w.At[i + ldn * j] = pb.A[i + n * j] + ((i == j) ? 3.0 * pb.kappa * (w.xt[i] * w.xt[i]) : 0.0); });
+            part = 0.0;
+            if (lane < n) {
+                double qx = 0.0, pu = 0.0;
+                #pragma unroll 8
+                for (int j = 0; j < n; ++j) qx += Qk[lane + n * j] * w.xt[j];
+                #pragma unroll 8
+                for (int g = 0; g < m; ++g) pu += Pk[g + m * lane] * w.ut[g];
+                w.qv[lane] = qx + pu + qvk[lane];
+                part = w.xt[lane] * (0.5 * qx + qvk[lane]);
+            } else if (lane >= 32 && lane - 32 < m) {
+                const int g = lane - 32;
+                double ru = 0.0, px = 0.0;
+                #pragma unroll 8
+                for (int g2 = 0; g2 < m; ++g2) ru += Rk[g + m * g2] * w.ut[g2];
+                #pragma unroll 8
+                for (int j = 0; j < n; ++j) px += Pk[g + m * j] * w.xt[j];
+                w.rv[g] = ru + px + rvk[g];
+                part = w.ut[g] * (0.5 * ru + px + rvk[g]);
+            }
+            q = wsum(part) + pb.q0[kc];
+        }
+        // M = inv(W) - theta S  (:365) into U;  Z <- S (right-hand sides of the forward substitution)
+        each(n, n, [&](int i, int j) { const double sij = w.S[i + ldn * j]; w.U[i + ldn * j] = Wik[i + n * j] - theta * sij; w.Z[i + ldn * j] = sij; });
         __syncthreads();
-        // approximate_model at (x_t, u_t)  (:294-313): f_x, c_x, c_u, c;  M = inv(W) - theta S  (:365)
-        for (int e = lane; e < n2; e += 64) {
-            const int i = e % n, j = e / n;
-            w.At[i + ldn * j] = pb.A[e] + ((i == j) ? 3.0 * pb.kappa * (w.xt[i] * w.xt[i]) : 0.0);
-            w.U[i + ldn * j] = Wik[e] - theta * w.S[i + ldn * j];
+        double sumlog = 0.0, zreg = 0.0;
+        if (!chol_fwd(w.U, n, ldn, w.Z, n, ldn, w.sv, w.T, zreg, sumlog)) return 2;       // @assert isposdef(M)  :366 / :440;  [Z | z] = U^-T [S | s_vec]
+        if (theta == 0.0) {                          // D = I exactly, whatever the size of S: the products below must not see Z'Z
+            each(n, n, [&](int i, int j) { w.Z[i + ldn * j] = 0.0; });
+            zreg = 0.0;
         }
-        part = 0.0;
-        if (lane < n) {
-            double qx = 0.0, pu = 0.0;
-            for (int j = 0; j < n; ++j) qx += Qk[lane + n * j] * w.xt[j];
-            for (int g = 0; g < m; ++g) pu += Pk[g + m * lane] * w.ut[g];
-            w.qv[lane] = qx + pu + qvk[lane];
-            part = w.xt[lane] * (0.5 * qx + qvk[lane]);
-        } else if (lane >= 32 && lane - 32 < m) {
-            const int g = lane - 32;
-            double ru = 0.0, px = 0.0;
-            for (int g2 = 0; g2 < m; ++g2) ru += Rk[g + m * g2] * w.ut[g2];
-            for (int j = 0; j < n; ++j) px += Pk[g + m * j] * w.xt[j];
-            w.rv[g] = ru + px + rvk[g];
-            part = w.ut[g] * (0.5 * ru + px + rvk[g]);
-        }
-        q = wsum(part) + pb.q0[kc];
-        }
+        if (lane < n) w.z[lane] = zreg;
         __syncthreads();
-        double sumlog = 0.0;
-        if (!chol_upper(w.U, n, ldn, lane, sumlog)) return 2;                                  // @assert isposdef(M)  :366 / :440
-        // [Z | z] = U^-T [S | s_vec]   (theta = 0: D = I exactly, whatever the size of S -- the products below must not see Z'Z)
-        if (theta == 0.0) {
-            for (int e = lane; e < ldn * n; e += 64) w.Z[e] = 0.0;
-            if (lane < n) w.z[lane] = 0.0;
-        } else if (lane <= n) {
-            double *c = (lane < n) ? w.Z + (size_t)ldn * lane : w.z;
-            for (int i = 0; i < n; ++i) c[i] = (lane < n) ? w.S[i + ldn * lane] : w.sv[i];
-            fwd_sub(w.U, n, ldn, c);
-        }
-        __syncthreads();
-        for (int e = lane; e < n2; e += 64) {                                              // D S  (:367 with S: symmetric)
-            const int i = e % n, j = e / n;
-            double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += w.Z[k + ldn * i] * w.Z[k + ldn * j];
-            w.DS[i + ldn * j] = w.S[i + ldn * j] + theta * acc;
-        }
+        prod(n, n, n, [&](int i) { return w.Z + (size_t)ldn * i; }, 1, [&](int j) { return w.Z + (size_t)ldn * j; }, 1,
+             [&](int i, int j, double c) { w.DS[i + ldn * j] = w.S[i + ldn * j] + theta * c; });          // D S  (:367; S symmetric)
         part = 0.0;
         if (lane < n) {
             double acc = 0.0;
+            #pragma unroll 8
             for (int k = 0; k < n; ++k) acc += w.Z[k + ldn * lane] * w.z[k];
             w.dsv[lane] = w.sv[lane] + theta * acc;                                        // D s_vec
-            part = w.z[lane] * w.z[lane];
+            part = zreg * zreg;
         }
         const double zz = wsum(part);                                                      // s_vec' M^-1 s_vec
         __syncthreads();
-        for (int e = lane; e < n2 + nm; e += 64) {                                         // T = (D S) A,  F = (D S) B
-            const int i = e % n, j = e / n;
-            const double *col = (j < n) ? w.At + (size_t)ldn * j : w.Bm + (size_t)ldn * (j - n);
-            double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += w.DS[i + ldn * k] * col[k];
-            if (j < n) w.T[i + ldn * j] = acc; else w.F[i + ldn * (j - n)] = acc;
-        }
+        prod(n, n + m, n, [&](int i) { return w.DS + i; }, ldn,
+             [&](int j) { return (j < n) ? w.At + (size_t)ldn * j : w.Bm + (size_t)ldn * (j - n); }, 1,
+             [&](int i, int j, double c) { if (j < n) w.T[i + ldn * j] = c; else w.F[i + ldn * (j - n)] = c; });   // T = (D S) A,  F = (D S) B
         __syncthreads();
-        for (int e = lane; e < nm; e += 64) {                                              // G = P + B'(D S) A  (:369)
-            const int g = e % m, j = e / m;
-            double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += w.Bm[k + ldn * g] * w.T[k + ldn * j];
-            w.G[g + ldm * j] = Pk[e] + acc;
-        }
-        for (int e = lane; e < mm; e += 64) {                                              // H = Symmetric(R + B'(D S) B + mu I)  (:370-371)
-            const int g = e % m, g2 = e / m;
-            if (g <= g2) {
-                double acc = 0.0;
-                for (int k = 0; k < n; ++k) acc += w.Bm[k + ldn * g] * w.F[k + ldn * g2];
-                const double v = Rk[e] + acc + ((g == g2) ? mu : 0.0);
-                w.H[g + ldm * g2] = v; w.H[g2 + ldm * g] = v;
-                w.Hc[g + ldm * g2] = v;
-            }
-        }
+        prod(m, n, n, [&](int g) { return w.Bm + (size_t)ldn * g; }, 1, [&](int j) { return w.T + (size_t)ldn * j; }, 1,
+             [&](int g, int j, double c) { w.G[g + ldm * j] = Pk[g + m * j] + c; });                              // G = P + B'(D S) A  (:369)
+        prod(m, m, n, [&](int g) { return w.Bm + (size_t)ldn * g; }, 1, [&](int g2) { return w.F + (size_t)ldn * g2; }, 1,
+             [&](int g, int g2, double c) {                                                                       // H = Symmetric(R + B'(D S) B + mu I)  (:370-371)
+                 if (g <= g2) {
+                     const double v = Rk[g + m * g2] + c + ((g == g2) ? mu : 0.0);
+                     w.H[g + ldm * g2] = v; w.H[g2 + ldm * g] = v; w.Hc[g + ldm * g2] = v;
+                 }
+             });
         if (lane < m) {                                                                    // g = r + B' D s_vec  (:368)
             double acc = 0.0;
+            #pragma unroll 8
             for (int k = 0; k < n; ++k) acc += w.Bm[k + ldn * lane] * w.dsv[k];
             w.g[lane] = w.rv[lane] + acc;
         }
         __syncthreads();
         if (dump) {
             if (dump->g && lane < m) dump->g[(size_t)t * m + lane] = w.g[lane];
-            if (dump->G) for (int e = lane; e < nm; e += 64) dump->G[(size_t)t * nm + e] = w.G[e % m + ldm * (e / m)];
-            if (dump->H) for (int e = lane; e < mm; e += 64) dump->H[(size_t)t * mm + e] = w.H[e % m + ldm * (e / m)];
+            if (dump->G) each(m, n, [&](int g, int j) { dump->G[(size_t)t * nm + g + m * j] = w.G[g + ldm * j]; });
+            if (dump->H) each(m, m, [&](int g, int g2) { dump->H[(size_t)t * mm + g + m * g2] = w.H[g + ldm * g2]; });
         }
-        if (gain) {
-            double dummy = 0.0;
-            if (!chol_upper(w.Hc, m, ldm, lane, dummy)) return -1;                              // !isposdef(H)  :372
-            if (lane <= n) {                                                               // [L | dl] = -H \ [G | g]  (:379-381)
-                double *c = (lane < n) ? w.Lt + (size_t)ldm * lane : w.dlv;
-                for (int i = 0; i < m; ++i) c[i] = -((lane < n) ? w.G[i + ldm * lane] : w.g[i]);
-                fwd_sub(w.Hc, m, ldm, c);
-                back_sub(w.Hc, m, ldm, c);
-            }
+        if (gain) {                                                                        // [L | dl] = -H \ [G | g]  (:379-381)
+            each(m, n, [&](int g, int j) { w.Lt[g + ldm * j] = -w.G[g + ldm * j]; });
+            if (lane < m) w.hv[lane] = -w.g[lane];
             __syncthreads();
-            for (int e = lane; e < nm; e += 64) Lg[(size_t)t * nm + e] = w.Lt[e % m + ldm * (e / m)];
-            if (lane < m) dlg[(size_t)t * m + lane] = w.dlv[lane];
+            double dreg = 0.0, dummy = 0.0;
+            if (!chol_fwd(w.Hc, m, ldm, w.Lt, n, ldm, w.hv, w.DS, dreg, dummy)) return -1; // !isposdef(H)  :372   (D S is dead: idle lanes' scratch)
+            back_all(w.Hc, m, ldm, w.Lt, n, ldm, w.DS, dreg);
+            if (lane < m) { w.dlv[lane] = dreg; dlg[(size_t)t * m + lane] = dreg; }
+            double *Lt_g = Lg + (size_t)t * nm;
+            each(m, n, [&](int g, int j) { Lt_g[g + m * j] = w.Lt[g + ldm * j]; });
+            __syncthreads();
         }
         part = 0.0;
         if (lane < m) {
             double hd = 0.0;
+            #pragma unroll 8
             for (int g2 = 0; g2 < m; ++g2) hd += w.H[lane + ldm * g2] * w.dlv[g2];
             w.hv[lane] = hd + w.g[lane];
             part = w.dlv[lane] * (0.5 * hd + w.g[lane]);                                   // 0.5 dl'H dl + dl'g  (:383)
@@ -246,7 +276,7 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
         double s0 = q + s1 + wsum(part);
         if (theta == 0.0) {                                                                // :384-385
             part = 0.0;
-            for (int e = lane; e < n2; e += 64) part += Wk[e] * w.S[(e / n) + ldn * (e % n)];
+            each(n, n, [&](int i, int j) { part += Wk[i + n * j] * w.S[j + ldn * i]; });
             s0 += 0.5 * wsum(part);
         } else {                                                                           // :387
             s0 += 0.5 * theta * zz - (pb.ldW[kw] + 2.0 * sumlog) / (2.0 * theta);
@@ -254,26 +284,22 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
         __syncthreads();
         if (lane < n) {                                                                    // s_vec  (:389)
             double acc = w.qv[lane];
+            #pragma unroll 8
             for (int k = 0; k < n; ++k) acc += w.At[k + ldn * lane] * w.dsv[k];
+            #pragma unroll 8
             for (int g = 0; g < m; ++g) acc += w.Lt[g + ldm * lane] * w.hv[g] + w.G[g + ldm * lane] * w.dlv[g];
             w.sv0[lane] = acc;
         }
-        for (int e = lane; e < nm; e += 64) {                                              // H L + G  (into F, dead by now)
-            const int g = e % m, j = e / m;
-            double acc = w.G[g + ldm * j];
-            for (int g2 = 0; g2 < m; ++g2) acc += w.H[g + ldm * g2] * w.Lt[g2 + ldm * j];
-            w.F[g + ldm * j] = acc;
-        }
+        prod(m, n, m, [&](int g) { return w.H + g; }, ldm, [&](int j) { return w.Lt + (size_t)ldm * j; }, 1,
+             [&](int g, int j, double c) { w.F[g + ldm * j] = w.G[g + ldm * j] + c; });                           // H L + G  (into F, dead by now)
         __syncthreads();
-        for (int e = lane; e < n2; e += 64) {                                              // S = Symmetric(Q + A'(D S)A + L'HL + L'G + G'L)  (:390-391)
-            const int i = e % n, j = e / n;
-            if (i <= j) {
-                double acc = Qk[e];
-                for (int k = 0; k < n; ++k) acc += w.At[k + ldn * i] * w.T[k + ldn * j];
-                for (int g = 0; g < m; ++g) acc += w.Lt[g + ldm * i] * w.F[g + ldm * j] + w.G[g + ldm * i] * w.Lt[g + ldm * j];
-                w.U[i + ldn * j] = acc; w.U[j + ldn * i] = acc;
-            }
-        }
+        // S = Symmetric(Q + A'(D S)A + L'(HL + G) + G'L)  (:390-391): the upper triangle rules
+        prod(n, n, n, [&](int i) { return w.At + (size_t)ldn * i; }, 1, [&](int j) { return w.T + (size_t)ldn * j; }, 1,
+             [&](int i, int j, double c) { if (i <= j) w.U[i + ldn * j] = Qk[i + n * j] + c; });
+        prod(n, n, m, [&](int i) { return w.Lt + (size_t)ldm * i; }, 1, [&](int j) { return w.F + (size_t)ldm * j; }, 1,
+             [&](int i, int j, double c) { if (i <= j) w.U[i + ldn * j] += c; });
+        prod(n, n, m, [&](int i) { return w.G + (size_t)ldm * i; }, 1, [&](int j) { return w.Lt + (size_t)ldm * j; }, 1,
+             [&](int i, int j, double c) { if (i <= j) { const double v = w.U[i + ldn * j] + c; w.U[i + ldn * j] = v; w.U[j + ldn * i] = v; } });
         if (lane < n) w.sv[lane] = w.sv0[lane];
         __syncthreads();
         double *tmp = w.S; w.S = w.U; w.U = tmp;
@@ -281,7 +307,7 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
         if (dump) {
             if (dump->s && lane == 0) dump->s[t] = s1;
             if (dump->sv && lane < n) dump->sv[(size_t)t * n + lane] = w.sv[lane];
-            if (dump->S) for (int e = lane; e < n2; e += 64) dump->S[(size_t)t * n2 + e] = w.S[e % n + ldn * (e / n)];
+            if (dump->S) each(n, n, [&](int i, int j) { dump->S[(size_t)t * n2 + i + n * j] = w.S[i + ldn * j]; });
         }
     }
     value = s1;
@@ -301,7 +327,9 @@ __device__ void rollout_open(const WideProblemDev &pb, Ws &w, const double *x0, 
         double xn = 0.0;
         if (lane < n) {
             double acc = 0.0, accb = 0.0;
+            #pragma unroll 8
             for (int j = 0; j < n; ++j) acc += w.At[lane + ldn * j] * w.xt[j];
+            #pragma unroll 8
             for (int g = 0; g < m; ++g) accb += w.Bm[lane + ldn * g] * w.ut[g];
             const double xi = w.xt[lane];
             xn = acc + accb + pb.kappa * (xi * xi * xi);
@@ -329,6 +357,7 @@ __device__ double rollout_closed(const WideProblemDev &pb, Ws &w, const double *
         if (lane < m) {
             const double *Lt = L + (size_t)t * nm;
             double acc = 0.0;
+            #pragma unroll 8
             for (int j = 0; j < n; ++j) acc += Lt[lane + m * j] * w.xb[j];
             const double lt = l[(size_t)t * m + lane];
             const double un = (dl ? lt + eps * dl[(size_t)t * m + lane] : lt) + acc;
@@ -345,7 +374,9 @@ __device__ double rollout_closed(const WideProblemDev &pb, Ws &w, const double *
         double xn = 0.0;
         if (lane < n) {
             double acc = 0.0, accb = 0.0;
+            #pragma unroll 8
             for (int j = 0; j < n; ++j) acc += w.At[lane + ldn * j] * w.xt[j];
+            #pragma unroll 8
             for (int g = 0; g < m; ++g) accb += w.Bm[lane + ldn * g] * w.ut[g];
             const double xi = w.xt[lane];
             xn = acc + accb + pb.kappa * (xi * xi * xi);
@@ -365,11 +396,6 @@ __device__ inline void carve(Ws &w, double *p, const int n, const int m) {      
     w.g = p; p += m; w.dlv = p; p += m; w.rv = p; p += m; w.ut = p; p += m; w.hv = p; p += m;
 }
 
-__device__ inline bool isapprox_default(double x, double y) {       // isapprox with rtol = sqrt(eps)  (:538)
-    if (x == y) return true;
-    if (!isfinite(x) || !isfinite(y)) return false;
-    return fabs(x - y) <= 1.4901161193847656e-8 * fmax(fabs(x), fabs(y));
-}
 
 __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     extern __shared__ double lds[];
@@ -481,14 +507,18 @@ __device__ double stage_cost(const WideProblemDev &pb, Ws &w, const int t) {
     double part = 0.0;
     if (lane < n) {
         double qx = 0.0, pu = 0.0;
+        #pragma unroll 8
         for (int j = 0; j < n; ++j) qx += Qk[lane + n * j] * w.xt[j];
+        #pragma unroll 8
         for (int g = 0; g < m; ++g) pu += Pk[g + m * lane] * w.ut[g];
         w.qv[lane] = qx + pu + qvk[lane];
         part = w.xt[lane] * (0.5 * qx + qvk[lane]);
     } else if (lane >= 32 && lane - 32 < m) {
         const int g = lane - 32;
         double ru = 0.0, px = 0.0;
+        #pragma unroll 8
         for (int g2 = 0; g2 < m; ++g2) ru += Rk[g + m * g2] * w.ut[g2];
+        #pragma unroll 8
         for (int j = 0; j < n; ++j) px += Pk[g + m * j] * w.xt[j];
         w.rv[g] = ru + px + rvk[g];
         part = w.ut[g] * (0.5 * ru + px + rvk[g]);
@@ -501,6 +531,7 @@ __device__ double terminal_cost(const WideProblemDev &pb, Ws &w) {
     double part = 0.0;
     if (lane < n) {
         double acc = 0.0;
+        #pragma unroll 8
         for (int j = 0; j < n; ++j) acc += pb.Qf[lane + n * j] * w.xt[j];
         w.qv[lane] = acc + pb.qvf[lane];
         part = w.xt[lane] * (0.5 * acc + pb.qvf[lane]);
@@ -580,6 +611,7 @@ __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
                 if (a.L) {
                     const double *Lt = a.L + (size_t)t * nm;
                     double acc = 0.0;
+                    #pragma unroll 8
                     for (int j = 0; j < n; ++j) acc += Lt[lane + m * j] * w.xb[j];
                     un += acc;
                 }
@@ -591,7 +623,9 @@ __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
             double xn = 0.0;
             if (lane < n) {
                 double acc = 0.0, accb = 0.0, wn = 0.0;
+                #pragma unroll 8
                 for (int j = 0; j < n; ++j) acc += w.At[lane + ldn * j] * w.xt[j];
+                #pragma unroll 8
                 for (int g = 0; g < m; ++g) accb += w.Bm[lane + ldn * g] * w.ut[g];
                 const double *Lw = a.Wchol + (size_t)kw * n2;
                 for (int j = 0; j <= lane; ++j) wn += Lw[lane + n * j] * w.z[j];          // chol_lower(W(k)) z
