@@ -35,6 +35,19 @@ def test_gpus_2_self_launches_two_ranks_without_torchrun():
     assert d["steps"] == 4 and d["value"] > 0 and abs(d["value"] - 1024 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
 
 
+def test_the_drivers_own_eight_rank_command_line():
+    """exactly how the round-end scaling bench is launched: torch.distributed.run with one rank per GPU (here: gloo + the stand-in solver)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK") and not k.startswith("RATILQR_BENCH")}
+    env.update({"RATILQR_BENCH_DRY": "1", "RATILQR_BENCH_BACKEND": "gloo", "OMP_NUM_THREADS": "1"})
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29613", BENCH, "--gpus", "8", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    d = _json(out)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["self_launched"] is False
+    assert d["scaling"] == "strong" and d["config"]["shard_sizes"] == [128] * 8 and d["steps"] == 3
+    assert len([ln for ln in out.stdout.splitlines() if ln.startswith("{")]) == 1          # rank 0 prints ONE line
+
+
 def test_ragged_global_batch_over_three_ranks():
     d = _json(_run(["--gpus", "3", "--steps", "2", "--warmup", "0", "--batch", "1000"], {"RATILQR_BENCH_DRY": "1", "RATILQR_BENCH_BACKEND": "gloo"}))
     assert d["rccl_ranks"] == 3 and d["config"]["shard_sizes"] == [334, 333, 333]
