@@ -43,6 +43,7 @@ struct rat_handle_s {
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
     bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
     std::vector<double> x0_host, u0_host;   // padded copies of what d_x0 / d_u0 hold (rat_set_initial skips identical uploads)
+    int fused_occ2 = 0;              // RATILQR_FUSED_OCC2=B0: batches of at least B0 samples run the 256-register one-recursion-per-pass variant, two samples per SIMD
     bool fused_dual = true;          // ... with policy evaluation + following gain sweep paired in one pass (RATILQR_FUSED_DUAL=0: separate)
     int block_mode = -1;             // workgroup-per-sample solve kernel (solve_block_kernel): -1 auto, 0 never, 1 whenever it is supported (RATILQR_BLOCK)
     int block_max_b = 512;           // auto, E = 1: used for batches up to this size (RATILQR_BLOCK_MAX_B)
@@ -150,6 +151,10 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_BLOCK_SHAPE")) h->block_shape = (e[0] != '0');
     if (const char *e = getenv("RATILQR_BLOCK_HELPERS")) h->block_helpers = (e[0] != '0');
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
+    // E = 1 batches beyond one sample per SIMD: two samples per SIMD in 256 registers each beat two generations of the 342-register
+    // paired kernel (measured +6..10 %); RATILQR_FUSED_OCC2=0 disables, =B0 moves the threshold
+    h->fused_occ2 = 4 * h->n_cu + 1;
+    if (const char *e = getenv("RATILQR_FUSED_OCC2")) h->fused_occ2 = atoi(e);
     CREATECHK(hipMalloc((void **)&h->d_census, sizeof(int) * CENSUS_SLOTS));
     CREATECHK(hipMemset(h->d_census, 0, sizeof(int) * CENSUS_SLOTS));
     if (const char *e = getenv("RATILQR_FUSED")) { if (e[0] == '0') h->block_mode = 0; }     // "round-based path": no single-launch solve at all
@@ -651,6 +656,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.ro = ra;
         fa.max_rounds = (int)std::min<int64_t>(((int64_t)h->opd.iter_max + 1) * 4002, 2000000000);
         fa.dual = h->fused_dual ? 1 : 0;
+        fa.occ2 = (path == PATH_FUSED && h->fused_dual && h->fused_occ2 > 0 && B >= h->fused_occ2) ? 1 : 0;
         fa.theta_in = theta_dev;
         fa.out_value = out.value; fa.out_status = out.status; fa.out_iters = out.iters; fa.out_ls = out.ls;
         fa.out_cost = out.cost; fa.kl_bound = out.kl_bound;

@@ -37,6 +37,9 @@
 #include "device_utils.h"
 #include "sweep_dual.h"
 
+#ifndef OCC2_PREFETCH
+#define OCC2_PREFETCH 3            /* the same for the two-samples-per-SIMD solve: the other wave covers the latency, registers are scarce */
+#endif
 #ifndef ROLLIN_PREFETCH
 #define ROLLIN_PREFETCH 5          /* rotating operand sets of rollin_body: prefetch distance ROLLIN_PREFETCH - 1 steps */
 #endif
@@ -76,7 +79,9 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
 // sweep_body is the whole sweep of ONE wavefront (trajectory `tid` of the launch); sweep_kernel wraps it one block per
 // trajectory, solve_fused_kernel calls it as one phase of a sample's complete solve.
 // wls: this wavefront's LDS scratch (WLS_SWEEP doubles).
-template <bool GAIN, bool DUMP, bool WTV, bool HASL>
+// SWZ: the elimination's row exchange through the LDS crossbar (ds_swizzle) instead of vector-ALU lane swaps: identical values, fewer
+// vector instructions, longer latency -- for the kernel that runs two samples per SIMD, which is short of issue slots, not of latency.
+template <bool GAIN, bool DUMP, bool WTV, bool HASL, bool SWZ = false>
 __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, double *const wls) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase: keeps the per-lane constants of one phase from being shared with
@@ -236,12 +241,12 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
                 int pdmin = 1;                                               // min over the high words of the leading minors (elim_round)
                 double nsum = 0.0;                                           // NaN/Inf tripwire
                 rprod *= epall;
-                elim_round<0, false>(m, em, pdmin, nsum, rprod);
-                elim_round<1, false>(m, em, pdmin, nsum, rprod);
-                elim_round<2, false>(m, em, pdmin, nsum, rprod);
-                elim_round<3, false>(m, em, pdmin, nsum, rprod);
-                elim_round<4, false>(m, em, pdmin, nsum, rprod);
-                elim_round<5, false>(m, em, pdmin, nsum, rprod);
+                elim_round<0, SWZ>(m, em, pdmin, nsum, rprod);
+                elim_round<1, SWZ>(m, em, pdmin, nsum, rprod);
+                elim_round<2, SWZ>(m, em, pdmin, nsum, rprod);
+                elim_round<3, SWZ>(m, em, pdmin, nsum, rprod);
+                elim_round<4, SWZ>(m, em, pdmin, nsum, rprod);
+                elim_round<5, SWZ>(m, em, pdmin, nsum, rprod);
                 DIAG_STAMP(1, m[0]);
                 if (!(pdmin > 0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
                 // theta M^-1 (the sweep left -M^-1); padded columns cleared
@@ -621,7 +626,7 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // time loop (57 loads in flight at once), so the loop issues no global loads at all and its tile stores never meet a vmcnt wait.
 // SEP (operand loads in the loop only): keep the steps of a group apart in the instruction schedule (see the time loop).
 // shxu: 16 doubles of this wavefront's LDS (terminal tile); stg: STG_DOUBLES of LDS shared by the waves of the workgroup (STAGE), else null
-template <int MODEL, int MODE, bool CTV, bool STAGE = false, bool SEP = true>
+template <int MODEL, int MODE, bool CTV, bool STAGE = false, bool SEP = true, int PF = ROLLIN_PREFETCH>
 __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, double *const shxu, double *const stg = nullptr) {
     int lane_ = threadIdx.x & 63;        // (rollin_stage_kernel runs the E candidates of a sample as the waves of one workgroup)
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
@@ -711,7 +716,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
     // the prologue is followed by as many (pad) stores as a step issues, (3) the loads are unconditional (clamped step index).
     // A register set is refilled at the top of the step AFTER the one that consumed it: its old value is dead by then, so
     // the loop-carried sets need no copies (a copy of a just-loaded register would wait for the load and drain the queue).
-    constexpr int RD = (MODEL == 1) ? ROLLIN_PREFETCH : 2;     // (power-law family: pow() expansions are large -- keep its loop short)
+    constexpr int RD = (MODEL == 1) ? PF : 2;     // (power-law family: pow() expansions are large -- keep its loop short)
     constexpr int kStoresPerStep = 6;
     struct StepIn { double l, dl, xb[3], La[3]; };
     StepIn buf[RD];
@@ -1549,8 +1554,10 @@ __device__ __forceinline__ double uniform_load_f64(const double *p) { return rea
 __device__ __forceinline__ void gather_body(const StateDev &st, const int b, double *value, int *status, int *iters, int *ls_evals,
                                             double *cost, double kl_bound);
 
-template <int MODEL, bool CTV, bool WTV, bool DUALF, bool STG>
-__global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
+// OCC2: the compiler is held to 256 registers so that TWO samples share a SIMD (only offered without DUALF / STG: one recursion per pass,
+// 2 KB of LDS per wave) -- the direct test of "hide a wave's dependency stalls with a second sample" for batches beyond one per SIMD.
+template <int MODEL, bool CTV, bool WTV, bool DUALF, bool STG, bool OCC2 = false>
+__global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs fa) {
     const int b = blockIdx.x;
     const StateDev &st = fa.sw.st;
 #ifdef RAT_DIAG_PHASES
@@ -1565,7 +1572,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
     PHASE_FENCE();
     {
         RolloutArgs ra = fa.ro; ra.mode = 0;
-        rollin_body<MODEL, 0, CTV>(ra, b, shxu);
+        rollin_body<MODEL, 0, CTV, false, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH>(ra, b, shxu);
         PHASE_MARK();
         PHASE_FENCE();
         PHASE_MARK();
@@ -1579,7 +1586,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
             PHASE_MARK();
         } else {
             SweepArgs sa = fa.sw; sa.mode = 2;
-            sweep_body<false, false, WTV, false>(sa, b, wls);
+            sweep_body<false, false, WTV, false, OCC2>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1591,7 +1598,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp!  (ileqg.jl:598-613)
             SweepArgs sa = fa.sw; sa.mode = 0;
-            sweep_body<true, false, WTV, false>(sa, b, wls);
+            sweep_body<true, false, WTV, false, OCC2>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1599,7 +1606,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
         }
         {                                                    // one candidate of line_search!  (ileqg.jl:504-581)
             RolloutArgs ra = fa.ro; ra.mode = 1;
-            rollin_body<MODEL, 1, CTV, STG>(ra, b, shxu, stg);
+            rollin_body<MODEL, 1, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH>(ra, b, shxu, stg);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1616,7 +1623,7 @@ __global__ __launch_bounds__(64) void solve_fused_kernel(FusedArgs fa) {
                 sweep_dual_body<WTV, true>(sa, b, wls);
             } else {
                 SweepArgs sa = fa.sw; sa.mode = 1;
-                sweep_body<false, false, WTV, true>(sa, b, wls);
+                sweep_body<false, false, WTV, true, OCC2>(sa, b, wls);
             }
             PHASE_MARK();
             PHASE_FENCE();
@@ -1637,7 +1644,8 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
     const bool wtv = fa.sw.pb.W_tv != 0;
     const bool stg = fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST;
 #define FUSED_LAUNCH(M, C, W) do { \
-        if (fa.dual && stg && M == 1) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, M == 1>), grid, block, 0, s, fa); \
+        if (fa.occ2) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false, true>), grid, block, 0, s, fa); \
+        else if (fa.dual && stg && M == 1) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, M == 1>), grid, block, 0, s, fa); \
         else if (fa.dual) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, false>), grid, block, 0, s, fa); \
         else hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.model == 1) {

@@ -235,9 +235,9 @@ def test_api_misuse_is_reported():
     ctx = rat.Context(prob, max_batch=4)
     with pytest.raises(rat.RatError):
         ctx.solve_batch(x0, u, np.ones(5))                       # exceeds max_batch
-    big = rat.LQRiskSensitiveProblem(np.eye(13), np.ones((13, 2)), Q=np.eye(13), R=np.eye(2), N=5, W=np.eye(13), Qf=np.eye(13))
+    big = rat.LQRiskSensitiveProblem(np.eye(33), np.ones((33, 2)), Q=np.eye(33), R=np.eye(2), N=5, W=np.eye(33), Qf=np.eye(33))
     with pytest.raises(rat.RatError):
-        rat.Context(big)                                         # n > 12: unsupported, fails loudly
+        rat.Context(big)                                         # n > 32: unsupported, fails loudly (13..32: tests/test_gpu_wide.py)
 
 
 @pytest.mark.parametrize("seed,theta", [(1, 1.0), (2, 1.0), (2, 4.0)])
@@ -363,14 +363,18 @@ def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
     monkeypatch.setenv("RATILQR_FUSED_DUAL", "0")
     fused_plain = run_all()                          # fused, one recursion per pass
     monkeypatch.delenv("RATILQR_FUSED_DUAL")
+    monkeypatch.setenv("RATILQR_FUSED_OCC2", "1")
+    fused_occ2 = run_all()                           # fused, the 256-register variant that puts two samples on a SIMD (default beyond 1024 samples)
+    monkeypatch.delenv("RATILQR_FUSED_OCC2")
     monkeypatch.setenv("RATILQR_FUSED", "0")
     rounds = run_all()                               # one launch per phase
     monkeypatch.delenv("RATILQR_FUSED")
     monkeypatch.delenv("RATILQR_BLOCK")
-    assert len(fused) == len(rounds) == len(fused_plain)
-    for a, b, c in zip(fused, rounds, fused_plain):
+    assert len(fused) == len(rounds) == len(fused_plain) == len(fused_occ2)
+    for a, b, c, d in zip(fused, rounds, fused_plain, fused_occ2):
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
         assert np.array_equal(np.asarray(a), np.asarray(c), equal_nan=True)
+        assert np.array_equal(np.asarray(a), np.asarray(d), equal_nan=True)
 
 
 @pytest.mark.parametrize("Nh", [1, 3, 7, 13, 60])

@@ -20,6 +20,9 @@ ap.add_argument("--kappas", type=float, nargs="*", default=[0.0, 0.06])
 a = ap.parse_args()
 
 PATHS = {"fused": {"RATILQR_BLOCK": "0"}, "block": {"RATILQR_BLOCK": "1"}, "rounds": {"RATILQR_FUSED": "0"}}
+if os.environ.get("SWEEP_OCC2") == "1":      # the 256-register one-recursion-per-pass fused variant (two samples per SIMD) beside the default fused kernel
+    PATHS = {"fused": {"RATILQR_BLOCK": "0", "RATILQR_FUSED_OCC2": "0"}, "occ2": {"RATILQR_BLOCK": "0", "RATILQR_FUSED_OCC2": "1"},
+             "nodual": {"RATILQR_BLOCK": "0", "RATILQR_FUSED_DUAL": "0"}}
 
 
 def theta_for(B, kappa):
@@ -40,7 +43,7 @@ for kappa in a.kappas:
             th = torch.as_tensor(theta_for(B, kappa), dtype=torch.float64, device="cuda")
             row, ref = [], None
             for name, env in PATHS.items():
-                if name == "fused" and E != 1:
+                if name in ("fused", "occ2", "nodual") and E != 1:
                     continue
                 for k, v in env.items():
                     os.environ[k] = v

@@ -3,6 +3,7 @@
 # the same run) and SQ counters of the three single-launch solve configurations:
 #   fused   B = 1024, E = 1  (solve_fused_kernel: the headline)        block512 / block128: B = 512 / 128, E = 1 (solve_block_kernel:
 #   the per-GPU shards of strong scaling over 2 / 8 GPUs)              e8: B = 128, E = 8 (solve_block_kernel, config 3's shard at 8 GPUs)
+#   occ2_4096 / fused_4096: B = 4096, E = 1 with two samples per SIMD (default beyond 1024 samples) / the paired kernel in generations
 # Outputs under gpurun_out/r02/prof/; summarised into profiles/ by tools/profile_r02_report.py.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02/prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -21,5 +22,7 @@ run block512 --batch 512
 run block128 --batch 128
 run e8 --batch 128 --spec-eps 8
 RATILQR_BLOCK=1 run block1024 --batch 1024
+run occ2_4096 --batch 4096
+RATILQR_FUSED_OCC2=0 run fused_4096 --batch 4096
 find $O -name "*.csv" | wc -l
 tail -1 $O/bench_fused_under_rocprof.log | cut -c1-200

@@ -8,7 +8,7 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 O = os.path.join(ROOT, "gpurun_out", "r02", "prof")
 CFG = {"fused": ("solve_fused", 1, 1024), "block512": ("solve_block", 1, 512), "block128": ("solve_block", 1, 128), "e8": ("solve_block", 8, 128),
-       "block1024": ("solve_block", 1, 1024)}
+       "block1024": ("solve_block", 1, 1024), "occ2_4096": ("solve_fused", 1, 4096), "fused_4096": ("solve_fused_paired", 1, 4096)}
 
 
 def counters(d):
