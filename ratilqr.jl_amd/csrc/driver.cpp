@@ -97,6 +97,9 @@ struct rat_handle_s {
     uint64_t rs[4] = {0, 0, 0, 0};
     bool have_spare = false;
     double spare = 0;
+    std::vector<double> zfifo;       // normals of the built-in generator drawn ahead of their use while a batch runs on the device (same sequence)
+    size_t zfifo_pos = 0;
+    int64_t prefill_want = 0;        // set by rat_ce_step around its batch: how many normals to have ready when the batch returns
 };
 
 extern "C" int32_t rat_version(void) { return RAT_VERSION; }
@@ -774,6 +777,7 @@ extern "C" rat_rc rat_ce_compute_cost_enqueue(rat_handle h, const double *theta_
     return run_batch(h, theta_dev, (int)B, out);          // one launch on the handle's stream; no host wait
 }
 
+static void prefill_normals(rat_handle h, int64_t count);
 extern "C" rat_rc rat_ileqg_solve_batch(rat_handle h, const double *x0, const double *u0, const double *theta, int64_t B,
                                         double *value, int32_t *status, int32_t *iters, int32_t *ls_evals) {
     if (!h || !theta || !value) return fail(RAT_ERR_ARG, "null");
@@ -798,6 +802,7 @@ extern "C" rat_rc rat_ileqg_solve_batch(rat_handle h, const double *x0, const do
     if (status) HIPCHK(hipMemcpyAsync(p_st, h->d_ist, B * 4, hipMemcpyDeviceToHost, h->stream));
     if (iters) HIPCHK(hipMemcpyAsync(p_it, h->d_iit, B * 4, hipMemcpyDeviceToHost, h->stream));
     if (ls_evals) HIPCHK(hipMemcpyAsync(p_ls, h->d_ils, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (h->prefill_want > 0 && pick_path(h, (int)B) != PATH_ROUNDS) prefill_normals(h, h->prefill_want);   // host work under the batch
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy(value, p_val, B * 8);
     if (status) memcpy(status, p_st, B * 4);
@@ -1500,6 +1505,7 @@ extern "C" rat_rc rat_ce_seed(rat_handle h, uint64_t seed) {
     uint64_t x = seed;
     for (int i = 0; i < 4; ++i) h->rs[i] = splitmix64(x);
     h->internal_rng = true; h->have_spare = false; h->z = nullptr; h->nz = 0; h->zpos = 0;
+    h->zfifo.clear(); h->zfifo_pos = 0;
     return RAT_OK;
 }
 extern "C" int64_t rat_ce_stream_pos(rat_handle h) { return h ? h->zpos : -1; }
@@ -1511,6 +1517,13 @@ static double next_uniform(rat_handle h) {                              // xoshi
     s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
     return ((double)(result >> 11) + 1.0) * (1.0 / 9007199254740992.0);
 }
+static double raw_normal(rat_handle h) {                                // Box-Muller on the built-in generator (both outputs are used)
+    if (h->have_spare) { h->have_spare = false; return h->spare; }
+    const double u1 = next_uniform(h), u2 = next_uniform(h);
+    const double rr = std::sqrt(-2.0 * std::log(u1)), ang = 6.283185307179586476925286766559 * u2;
+    h->spare = rr * std::sin(ang); h->have_spare = true;
+    return rr * std::cos(ang);
+}
 static bool next_normal(rat_handle h, double *z) {
     if (!h->internal_rng) {
         if (!h->z || h->zpos >= h->nz) return false;
@@ -1518,12 +1531,16 @@ static bool next_normal(rat_handle h, double *z) {
         return true;
     }
     h->zpos++;
-    if (h->have_spare) { h->have_spare = false; *z = h->spare; return true; }
-    const double u1 = next_uniform(h), u2 = next_uniform(h);           // Box-Muller
-    const double rr = std::sqrt(-2.0 * std::log(u1)), ang = 6.283185307179586476925286766559 * u2;
-    h->spare = rr * std::sin(ang); h->have_spare = true;
-    *z = rr * std::cos(ang);
+    if (h->zfifo_pos < h->zfifo.size()) { *z = h->zfifo[h->zfifo_pos++]; return true; }   // drawn ahead (prefill_normals): same sequence
+    *z = raw_normal(h);
     return true;
+}
+// Draw normals of the built-in generator ahead of their use (called while a batch runs on the device): the sequence next_normal hands
+// out is unchanged, only when the Box-Muller arithmetic happens.
+static void prefill_normals(rat_handle h, int64_t count) {
+    if (!h->internal_rng || count <= 0) return;
+    if (h->zfifo_pos > 0) { h->zfifo.erase(h->zfifo.begin(), h->zfifo.begin() + (std::ptrdiff_t)h->zfifo_pos); h->zfifo_pos = 0; }
+    while ((int64_t)h->zfifo.size() < count) h->zfifo.push_back(raw_normal(h));
 }
 
 extern "C" rat_rc rat_ce_get_positive_samples(rat_handle h, double mu, double sigma, int64_t num, double *theta) {   // :233-246
@@ -1594,11 +1611,15 @@ extern "C" rat_rc rat_ce_update(rat_ce_solver *c, const double *theta, const dou
     }
     std::vector<int64_t> idx(B);
     for (int64_t i = 0; i < B; ++i) idx[i] = i;
-    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {          // sort(by = cost), isless: NaN last
+    // sort(by = cost) is stable and only its first num_elite entries are read (:326-330): a partial sort under the total order
+    // (isless(cost), original index) yields exactly those entries -- NaN last, ties in input order -- without ordering the other 90 %
+    std::partial_sort(idx.begin(), idx.begin() + (std::ptrdiff_t)c->num_elite, idx.end(), [&](int64_t a, int64_t b) {
         const double x = cost[a], y = cost[b];
-        if (x != x) return false;
-        if (y != y) return true;
-        return x < y;
+        const bool xn = x != x, yn = y != y;
+        if (xn || yn) return xn ? (yn && a < b) : true;
+        if (x < y) return true;
+        if (y < x) return false;
+        return a < b;
     });
     double sum = 0;
     for (int64_t i = 0; i < c->num_elite; ++i) sum += theta[idx[i]];
@@ -1619,7 +1640,10 @@ extern "C" rat_rc rat_ce_step(rat_handle h, rat_ce_solver *c, const double *x0, 
         if (redraws > 1000) return fail(RAT_ERR_DIVERGED, "CE redraw loop cut after 1000 redraws (reference would spin, App. B.11)");
         rat_rc rc = rat_ce_draw(h, c, theta.data());
         if (rc) return rc;
-        if ((rc = rat_ce_compute_cost(h, x0, u0, theta.data(), c->num_samples, kl_bound, cost.data()))) return rc;
+        h->prefill_want = c->num_samples + c->num_samples / 8;       // the next draw's normals (with room for rejected theta <= 0), drawn under this batch
+        rc = rat_ce_compute_cost(h, x0, u0, theta.data(), c->num_samples, kl_bound, cost.data());
+        h->prefill_want = 0;
+        if (rc) return rc;
         c->n_solves += c->num_samples;
         if (redraws) c->n_redraws++;
         int32_t redraw = 0;

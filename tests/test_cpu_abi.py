@@ -97,6 +97,37 @@ def test_ce_host_bookkeeping_replays_oracle_step():
             assert c.theta_min == oc.c.theta_min and c.theta_max == oc.c.theta_max and c.iter_current == oc.c.iter_current
 
 
+def test_ce_elite_selection_equals_a_stable_sort_with_ties_inf_and_nan():
+    """rat_ce_update picks the elites by a partial sort under (isless(cost), input index): exactly the first num_elite entries of the
+    reference's stable sort(by = cost) (cross_entropy...jl:326-330), whatever the ties, +Inf and NaN costs."""
+    L = nv.lib()
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        B = int(rng.integers(4, 40))
+        k = int(rng.integers(1, B // 2 + 1))
+        theta = rng.uniform(0.1, 5.0, B)
+        cost = rng.integers(0, 4, B).astype(float)                       # many exact ties
+        cost[rng.random(B) < 0.15] = np.inf
+        if trial % 3 == 0:
+            cost[rng.random(B) < 0.1] = np.nan
+        n_valid = int(np.sum(~np.isinf(cost)))
+        c = nv.CeSolver()
+        L.rat_ce_default(C.byref(c))
+        c.num_samples, c.num_elite, c.iter_current, c.lam = B, k, 2, 0.0      # (iteration 2, lambda 0: accepted whenever num_valid >= num_elite)
+        redraw = C.c_int32()
+        nv.check(L.rat_ce_update(C.byref(c), nv.P(theta), nv.P(cost), C.byref(redraw)))
+        if n_valid < k:
+            assert redraw.value == 1
+            continue
+        assert redraw.value == 0
+        key = np.where(np.isnan(cost), np.inf, cost)                          # isless: NaN after everything, +Inf included
+        order = sorted(range(B), key=lambda i: (np.isnan(cost[i]), key[i]))   # Python's sort is stable
+        el = theta[order[:k]]
+        mu = sum(el.tolist()) / k                                             # (left-to-right, as the library and the reference sum)
+        assert c.mu == mu, (trial, c.mu, mu)
+        assert c.sigma == float(np.sqrt(sum(((t - mu) * (t - mu)) for t in el.tolist()) / k))
+
+
 def test_stream_exhaustion_is_an_error():
     L = nv.lib()
     c = nv.CeSolver()

@@ -165,3 +165,28 @@ def test_final_solve_retry_matches_the_oracle():                              # 
         assert rc == 0 and got[0] == th and solver.c.n_final_retries == oc.c.n_final_retries >= 1
         assert (np.isinf(val) and np.isinf(got[4])) or abs(got[4] - val) <= 1e-9 * abs(val)
         assert np.isinf(got[5]) and got[6] == 0.0 and np.abs(got[1] - x).max() < 1e-9
+
+
+def test_builtin_generator_sequence_is_unchanged_by_drawing_ahead():
+    """rat_ce_step draws the NEXT iteration's normals on the host while its batch runs on the device (same xoshiro / Box-Muller sequence,
+    only earlier); the thetas it hands out must be what plain get_positive_samples calls draw from the same seed, rejections included."""
+    prob, x0, u = rat.synthetic_lq_problem()
+    kw = dict(num_samples=48, num_elite=6, mu_init=0.5, sigma_init=2.0)          # mu_init / sigma_init: a good share of rejected draws
+    a = rat.CrossEntropyBilevelOptimizationSolver(**kw)
+    ce.initialize_(a)
+    got, params = [], []
+    for _ in range(3):
+        params.append((a.c.mu_init, a.c.sigma_init) if a.c.iter_current == 0 else (a.c.mu, a.c.sigma))
+        th, _ = ce.step_(a, prob, x0, u, 0.1, 777)
+        assert a.c.n_redraws == 0
+        got.append(th)
+    b = rat.CrossEntropyBilevelOptimizationSolver(**kw)
+    for (mu, sigma), th in zip(params, got):
+        assert np.array_equal(rat.get_positive_samples(mu, sigma, 48, 777, ce_solver=b, problem=prob), th)
+    pos_a = nv_pos(a, prob)
+    assert pos_a == nv_pos(b, prob) and pos_a > 3 * 48                                # same number of normals consumed, some rejected
+
+
+def nv_pos(solver, prob):
+    from ratilqr.jl_amd import _native as nv
+    return int(nv.lib().rat_ce_stream_pos(solver.context(prob).h))
