@@ -143,10 +143,14 @@ class Context:
         n, m, N = self.n, self.m, self.N
         x, l, Lb = np.zeros((N + 1, n)), np.zeros((N, m)), np.zeros(m * n * N)
         val, st, it, hn = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()
-        hist = np.zeros((hist_cap, 2))
-        nv.check(nv.lib().rat_ileqg_solve(self.h, nv.P(nv.f64(x0)), nv.P(nv.f64(u)), C.c_double(theta), nv.P(x), nv.P(l),
-                                          nv.P(Lb), C.byref(val), C.byref(st), C.byref(it), nv.P(hist),
-                                          C.c_int64(hist_cap), C.byref(hn)))
+        while True:           # eps_history is unbounded in the reference (ileqg.jl:537): when it did not fit, grow and re-run (deterministic)
+            hist = np.zeros((hist_cap, 2))
+            nv.check(nv.lib().rat_ileqg_solve(self.h, nv.P(nv.f64(x0)), nv.P(nv.f64(u)), C.c_double(theta), nv.P(x), nv.P(l),
+                                              nv.P(Lb), C.byref(val), C.byref(st), C.byref(it), nv.P(hist),
+                                              C.c_int64(hist_cap), C.byref(hn)))
+            if hn.value <= hist_cap:
+                break
+            hist_cap = int(hn.value)
         return dict(x=x, l=l, L=nv.from_cm3(Lb, N, m, n), value=val.value, status=st.value, iters=it.value,
                     eps_history=hist[: min(hn.value, hist_cap)].copy(), hist_n=hn.value)
 

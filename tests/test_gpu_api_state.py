@@ -104,3 +104,15 @@ def test_generic_context_refuses_device_family_entry_points():
             call()
     with pytest.raises(NotImplementedError):
         rat.simulate_dynamics_noisy(gp, np.zeros(n), np.zeros((N, m)), K=2)
+
+
+def test_eps_history_is_never_truncated():
+    """the reference's eps_history is unbounded (ileqg.jl:537): a buffer that is too small is grown and the solve repeated"""
+    import numpy as np
+    import ratilqr.jl_amd as rat
+    prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
+    ctx = rat.Context(prob)
+    full = ctx.solve(x0, u, 5.0)
+    assert full["hist_n"] >= 4
+    small = ctx.solve(x0, u, 5.0, hist_cap=2)
+    assert small["hist_n"] == full["hist_n"] and np.array_equal(small["eps_history"], full["eps_history"])
