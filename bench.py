@@ -526,17 +526,21 @@ def rank_main(args):
         ctx8 = rat.Context(prob, max_batch=B, spec_eps=8, device=D.local_rank)
         ctx8.set_initial(x0, u0)
         v8 = torch.empty(B, dtype=torch.float64, device=dev)
-        for _ in range(6):                  # (as many untimed batches as the primary measurement has behind it when its timing starts)
+        t_c = time.perf_counter()
+        while time.perf_counter() - t_c < 0.1:   # conditioning, as for the primary
             ctx8.solve_batch_dev(theta.data_ptr(), B, v8.data_ptr())
-        ctx8.profile(True)
-        ctx8.profile_reset()
         torch.cuda.synchronize()
         t8 = time.perf_counter()
         K8 = max(3, K // 3)
+        for _ in range(K8):                  # timed WITHOUT profiling events: this path is ~20 launches per batch and an event pair
+            ctx8.solve_batch_dev(theta.data_ptr(), B, v8.data_ptr())     # around each of them costs it 10 %
+        torch.cuda.synchronize()
+        e8 = time.perf_counter() - t8
+        ctx8.profile(True)                   # per-kernel breakdown from a separate pass
+        ctx8.profile_reset()
         for _ in range(K8):
             ctx8.solve_batch_dev(theta.data_ptr(), B, v8.data_ptr())
         torch.cuda.synchronize()
-        e8 = time.perf_counter() - t8
         p8all = ctx8.profile_get()
         k8 = next((k for k in ("solve_fused", "solve_block") if p8all[k]["launches"] > 0), "sweep_eval")
         p8 = p8all[k8]
