@@ -71,6 +71,7 @@ struct rat_handle_s {
     int *d_ist = nullptr, *d_iit = nullptr, *d_ils = nullptr;
     int *h_counters = nullptr;       // pinned, [CTR_RING][2]
     double *d_hist = nullptr; int hist_dev_cap = 0;   // eps-history of single solves (rat_ileqg_solve), grown on demand
+    double *h_sol = nullptr; size_t cap_sol = 0;      // pinned staging of rat_ileqg_solve's outputs (all slots of the sample, both gain halves, eps history)
     char *h_io = nullptr;            // pinned staging of the host-pointer batch entry point: theta | value | status | iters | ls_evals, [Bmax] each
     hipEvent_t round_ev[CTR_RING] = {};
     bool have_initial = false;
@@ -188,6 +189,7 @@ extern "C" void rat_destroy(rat_handle h) {
     if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->d_hist) (void)hipFree(h->d_hist);
     if (h->h_pstage) (void)hipHostFree(h->h_pstage);
+    if (h->h_sol) (void)hipHostFree(h->h_sol);
     if (h->d_census) (void)hipFree(h->d_census);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -867,7 +869,7 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     if (!h || !x0 || !u0) return fail(RAT_ERR_ARG, "null");
     rat_rc rc = rat_set_initial(h, x0, u0);
     if (rc) return rc;
-    // pinned staging (h_io, >= 28 bytes): theta in, the sample's scalars back; asynchronous copies, two host waits per solve
+    // pinned staging (h_io, >= 28 bytes): theta in, the sample's scalars back
     double *p_d = reinterpret_cast<double *>(h->h_io);            // [0] theta, then value
     int32_t *p_i = reinterpret_cast<int32_t *>(h->h_io + 16);     // status, iter, slot_nom (+ lsel, hist_n in the theta slot afterwards)
     p_d[0] = theta;
@@ -882,57 +884,65 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     }
     const bool want_hist = eps_hist && cap > 0;
     h->st.hist = want_hist ? h->d_hist : nullptr; h->st.hist_cap = want_hist ? cap : 0;
-    if (h->wide) {                       // the sample's own kernel writes its outputs; x_array / l_array / L_array at their own size
-        BatchOut wo; wo.value = h->d_val; wo.status = h->d_ist; wo.iters = h->d_iit;
-        rc = run_batch(h, h->d_theta, 1, wo);
-        h->st.hist = nullptr; h->st.hist_cap = 0;
-        if (rc) return rc;
-        int32_t *p_j = reinterpret_cast<int32_t *>(h->h_io);
-        HIPCHK(hipMemcpyAsync(p_d + 1, h->d_val, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(p_i + 0, h->d_ist, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(p_i + 1, h->d_iit, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(p_i + 2, h->w_nom, 4, hipMemcpyDeviceToHost, h->stream));
-        if (want_hist) HIPCHK(hipMemcpyAsync(p_j, h->w_hn, 4, hipMemcpyDeviceToHost, h->stream));
+    // Outputs come back through ONE pinned staging area and ONE host wait: which (x, u) slot and which gain half hold the result is
+    // only known when the kernel has finished, so every slot of the sample and both halves are copied (tens of KB) instead of waiting
+    // for the indices first and copying afterwards (two waits and pageable-memory copies before).
+    const bool wide = h->wide;
+    const size_t nslot = wide ? 2 : (size_t)h->E + 1;
+    const size_t xs = wide ? (size_t)(h->N + 1) * h->n : (size_t)h->st.x_stride, us = wide ? (size_t)h->N * h->m : (size_t)h->st.u_stride;
+    const size_t Ls = wide ? us * h->n : (size_t)h->N * LSTR, nL = wide ? 1 : 2;
+    const size_t hist_first = want_hist ? (size_t)std::min(cap, 4096) : 0;
+    const size_t need = nslot * (xs + us) + nL * Ls + 2 * hist_first;
+    if (need > h->cap_sol) {
         HIPCHK(hipStreamSynchronize(h->stream));
-        const int nom = p_i[2], hn = want_hist ? p_j[0] : 0;
-        if (status) *status = p_i[0];
-        if (iters) *iters = p_i[1];
-        if (value) *value = p_d[1];
-        if (hist_n) *hist_n = hn;
-        const size_t xs = (size_t)(h->N + 1) * h->n, us = (size_t)h->N * h->m;
-        if (want_hist && hn > 0) HIPCHK(hipMemcpy(eps_hist, h->d_hist, (size_t)std::min(hn, cap) * 16, hipMemcpyDeviceToHost));
-        if (x) HIPCHK(hipMemcpy(x, h->w_xs + (size_t)nom * xs, xs * 8, hipMemcpyDeviceToHost));
-        if (l) HIPCHK(hipMemcpy(l, h->w_us + (size_t)nom * us, us * 8, hipMemcpyDeviceToHost));
-        if (L) HIPCHK(hipMemcpy(L, h->w_L, us * h->n * 8, hipMemcpyDeviceToHost));
-        return RAT_OK;
+        if (h->h_sol) (void)hipHostFree(h->h_sol);
+        h->h_sol = nullptr; h->cap_sol = 0;
+        HIPCHK(hipHostMalloc((void **)&h->h_sol, need * 8, hipHostMallocDefault));
+        h->cap_sol = need;
     }
-    rc = run_batch(h, h->d_theta, 1);
+    double *const s_x = h->h_sol, *const s_u = s_x + nslot * xs, *const s_L = s_u + nslot * us, *const s_h = s_L + nL * Ls;
+    BatchOut wo;
+    if (wide) { wo.value = h->d_val; wo.status = h->d_ist; wo.iters = h->d_iit; }
+    rc = run_batch(h, h->d_theta, 1, wo);
     h->st.hist = nullptr; h->st.hist_cap = 0;
     if (rc) return rc;
     int32_t *p_j = reinterpret_cast<int32_t *>(h->h_io);          // (the theta slot is free once the batch is enqueued behind its upload)
-    HIPCHK(hipMemcpyAsync(p_d + 1, h->st.value, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(p_i + 0, h->st.status, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(p_i + 1, h->st.iter, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(p_i + 2, h->st.slot_nom, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(p_j + 0, h->st.lsel, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(p_j + 1, h->st.hist_n, 4, hipMemcpyDeviceToHost, h->stream));
+    const StateDev &st = h->st;
+    HIPCHK(hipMemcpyAsync(p_d + 1, wide ? h->d_val : st.value, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 0, wide ? h->d_ist : st.status, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 1, wide ? h->d_iit : st.iter, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 2, wide ? h->w_nom : st.slot_nom, 4, hipMemcpyDeviceToHost, h->stream));
+    if (!wide) HIPCHK(hipMemcpyAsync(p_j + 0, st.lsel, 4, hipMemcpyDeviceToHost, h->stream));
+    if (want_hist || !wide) HIPCHK(hipMemcpyAsync(p_j + 1, wide ? h->w_hn : st.hist_n, 4, hipMemcpyDeviceToHost, h->stream));
+    if (x) HIPCHK(hipMemcpyAsync(s_x, wide ? h->w_xs : st.xs, nslot * xs * 8, hipMemcpyDeviceToHost, h->stream));
+    if (l) HIPCHK(hipMemcpyAsync(s_u, wide ? h->w_us : st.us, nslot * us * 8, hipMemcpyDeviceToHost, h->stream));
+    if (L) {
+        HIPCHK(hipMemcpyAsync(s_L, wide ? h->w_L : st.L, Ls * 8, hipMemcpyDeviceToHost, h->stream));
+        if (!wide) HIPCHK(hipMemcpyAsync(s_L + Ls, st.L + st.l_half, Ls * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (hist_first) HIPCHK(hipMemcpyAsync(s_h, h->d_hist, hist_first * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const int st_h = p_i[0], it_h = p_i[1], nom = p_i[2], lsel = p_j[0], hn = p_j[1];
-    const double val = p_d[1];
+    const int st_h = p_i[0], it_h = p_i[1], nom = p_i[2], lsel = wide ? 0 : p_j[0], hn = (want_hist || !wide) ? p_j[1] : 0;
     if (status) *status = st_h;
     if (iters) *iters = it_h;
-    if (value) *value = (st_h == 0 || st_h == 3) ? val : INFINITY;
+    if (value) *value = (st_h == 0 || st_h == 3) ? p_d[1] : INFINITY;
     if (hist_n) *hist_n = hn;
-    const StateDev &st = h->st;
-    std::vector<double> xp(st.x_stride), up(st.u_stride), Lp((size_t)h->N * LSTR);
-    if (want_hist && hn > 0) HIPCHK(hipMemcpyAsync(eps_hist, h->d_hist, (size_t)std::min(hn, cap) * 16, hipMemcpyDeviceToHost, h->stream));
-    if (x) HIPCHK(hipMemcpyAsync(xp.data(), st.xs + (size_t)nom * st.x_stride, st.x_stride * 8, hipMemcpyDeviceToHost, h->stream));
-    if (l) HIPCHK(hipMemcpyAsync(up.data(), st.us + (size_t)nom * st.u_stride, st.u_stride * 8, hipMemcpyDeviceToHost, h->stream));
-    if (L) HIPCHK(hipMemcpyAsync(Lp.data(), st.L + (size_t)lsel * st.l_half, Lp.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (x) unpad_x(h, xp, x);
-    if (l) unpad_u(h, up, l);
-    if (L) unpad_L(h, Lp, L);
+    if (want_hist && hn > 0) {
+        const size_t got = (size_t)std::min(hn, cap);
+        memcpy(eps_hist, s_h, std::min(got, hist_first) * 16);
+        if (got > hist_first)                                     // (longer histories than the speculative first block: the rest afterwards)
+            HIPCHK(hipMemcpy(eps_hist + 2 * hist_first, h->d_hist + 2 * hist_first, (got - hist_first) * 16, hipMemcpyDeviceToHost));
+    }
+    if (nom < 0 || (size_t)nom >= nslot || lsel < 0 || lsel > 1) return fail(RAT_ERR_HIP, "rat_ileqg_solve: slot index out of range");
+    if (wide) {
+        if (x) memcpy(x, s_x + (size_t)nom * xs, xs * 8);
+        if (l) memcpy(l, s_u + (size_t)nom * us, us * 8);
+        if (L) memcpy(L, s_L, Ls * 8);
+        return RAT_OK;
+    }
+    if (x) { std::vector<double> xp(s_x + (size_t)nom * xs, s_x + (size_t)(nom + 1) * xs); unpad_x(h, xp, x); }
+    if (l) { std::vector<double> up(s_u + (size_t)nom * us, s_u + (size_t)(nom + 1) * us); unpad_u(h, up, l); }
+    if (L) { std::vector<double> Lp(s_L + (size_t)lsel * Ls, s_L + (size_t)(lsel + 1) * Ls); unpad_L(h, Lp, L); }
     return RAT_OK;
 }
 
