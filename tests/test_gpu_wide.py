@@ -311,3 +311,24 @@ def test_multi_device_object_takes_wide_problems(monkeypatch):
     with np.errstate(divide="ignore"):
         want = np.where(np.isfinite(v), v + 0.1 / theta, np.inf)
     assert np.array_equal(cost, want) and mc.allgathers == 1
+
+
+def test_full_size_ce_batch_at_general_size():
+    """1024 theta-samples at n = 20, m = 6, N = 50: the oracle on a sample of the batch, size-independent properties on all of it"""
+    prob, x0, u = rat.synthetic_lq_problem(n=20, m=6, N=50)
+    P = orc.Problem(prob)
+    hi = theta_grid(P, x0, u, 2)[-2] / 1.05
+    rng = np.random.default_rng(5)
+    theta = np.sort(np.concatenate([rng.uniform(0.0, 0.98 * hi, 1000), rng.uniform(1.02 * hi, 3.0 * hi, 24)]))
+    ctx = rat.Context(prob, max_batch=1024)
+    v, st, it, ls = ctx.solve_batch(x0, u, theta)
+    feas = theta < hi
+    assert np.all(st[feas] == 0) and np.all(st[~feas] == 1) and np.all(np.isposinf(v[~feas]))
+    assert np.all(np.diff(v[feas]) > 0)                                   # the value grows with the risk-sensitivity parameter
+    pick = np.concatenate([np.arange(0, 1000, 37), np.arange(1000, 1024, 5)])
+    vo, so, io, lo = orc.compute_value_batch(P, x0, u, theta[pick], nthreads=8)
+    assert np.array_equal(so, st[pick]) and np.array_equal(io, it[pick]) and np.array_equal(lo, ls[pick])
+    f = np.isfinite(vo)
+    assert np.all(np.abs(v[pick][f] - vo[f]) <= VT * np.abs(vo[f]))
+    v2, st2, _, _ = ctx.solve_batch(x0, u, theta[::-1].copy())           # batch composition / order must not matter
+    assert np.array_equal(v2[::-1], v) and np.array_equal(st2[::-1], st)
