@@ -1,0 +1,52 @@
+"""Race hunt for solve_block_kernel (waves of a workgroup hand data to each other through LDS: the trajectory buffer and progress word
+of the split rollouts, the helper waves' d_current reduction, the per-CU placement tickets): random batch sizes, thetas and problems,
+thousands of launches, every output compared bit for bit with solve_fused_kernel (one wave per sample: no intra-sample concurrency).
+  STRESS_S=60 python tools/stress_block.py      (on an MI355X)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ratilqr.jl_amd as rat
+
+
+def ctx_for(prob, B, E, env):
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        return rat.Context(prob, max_batch=B, spec_eps=E)
+    finally:
+        for k in env:
+            del os.environ[k]
+
+
+def main():
+    budget = float(os.environ.get("STRESS_S", "60"))
+    rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "1")))
+    t0, launches, bad = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        kappa = float(rng.choice([0.0, 0.0, 0.03, 0.06]))
+        N = int(rng.choice([50, 50, 50, 7, 23, 52, 53, 60]))
+        n, m = (12, 4) if rng.random() < 0.6 else (int(rng.integers(1, 13)), int(rng.integers(1, 5)))
+        prob, x0, u = rat.synthetic_lq_problem(n=n, m=m, N=N, seed=int(rng.integers(0, 50)), kappa=kappa)
+        Bmax = int(rng.choice([1, 3, 17, 64, 128, 200, 256, 257, 400, 512, 700]))
+        E = int(rng.choice([1, 1, 1, 2, 4, 8]))
+        ref = ctx_for(prob, Bmax, 1, {"RATILQR_BLOCK": "0"})
+        blk = ctx_for(prob, Bmax, E, {"RATILQR_BLOCK": "1"})
+        for _ in range(int(rng.integers(3, 12))):
+            B = int(rng.integers(1, Bmax + 1))
+            theta = np.abs(rng.normal(1.0, 2.0, B)) * float(rng.choice([0.05, 1.0, 1.0, 3.0]))
+            if rng.random() < 0.3:
+                theta[rng.integers(0, B)] = 0.0
+            a = ref.solve_batch(x0, u, theta)
+            b = blk.solve_batch(x0, u, theta)
+            launches += 1
+            if not all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a, b)):
+                bad += 1
+                print("MISMATCH", dict(n=n, m=m, N=N, kappa=kappa, Bmax=Bmax, B=B, E=E), flush=True)
+    print(f"stress done: {launches} block-kernel launches compared with the fused kernel, {bad} mismatches, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
