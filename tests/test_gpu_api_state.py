@@ -116,3 +116,39 @@ def test_eps_history_is_never_truncated():
     assert full["hist_n"] >= 4
     small = ctx.solve(x0, u, 5.0, hist_cap=2)
     assert small["hist_n"] == full["hist_n"] and np.array_equal(small["eps_history"], full["eps_history"])
+
+
+def test_handles_release_their_device_memory():
+    """create / bind / solve / re-bind / destroy in a loop (tile-sized, general-size, speculative, multi-device, PETS handles): the free
+    device memory afterwards is what it was before"""
+    import gc
+    import torch
+    import ratilqr.jl_amd as rat
+
+    def cycle(k):
+        prob, x0, u = rat.synthetic_lq_problem(n=12, m=4, N=50, seed=k)
+        big, bx0, bu = rat.synthetic_lq_problem(n=20, m=6, N=20, seed=k)
+        th = np.array([0.0, 0.5, 1.0])
+        ctx = rat.Context(prob, max_batch=64, spec_eps=(1, 2, 8)[k % 3])
+        ctx.solve_batch(x0, u, th)
+        ctx.solve(x0, u, 0.5)
+        ctx.set_problem(big)                              # tile-sized -> general-size pools on the same handle
+        ctx.solve_batch(bx0, bu, 0.2 * th)
+        ctx.rollout_open(bx0, bu)
+        ctx.set_problem(prob)
+        ctx.solve_batch(x0, u, th)
+        mc = rat.MultiContext(prob, max_batch=16, devices=(0,))
+        mc.compute_cost(x0, u, th + 0.1, 0.1)
+        del ctx, mc
+
+    for k in range(3):                                    # warm-up: allocator pools, code objects, RCCL (if loaded) settle
+        cycle(k)
+    gc.collect()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(30):
+        cycle(k)
+    gc.collect()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 30 create / destroy cycles"
