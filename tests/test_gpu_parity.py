@@ -484,3 +484,21 @@ def test_trajectory_that_overflows_fails_like_the_reference():
         ctx = rat.Context(prob, max_batch=3, spec_eps=E)
         v, st, it, ls = check_batch(ctx, orc.Problem(prob), x0, u, theta)
         assert st.tolist() == [1, 1, 1] and np.all(np.isposinf(v))
+
+
+def test_negative_and_non_finite_theta():
+    """theta < 0 (risk-seeking: M = inv(W) + |theta| S is always positive definite) runs through the same formulas; NaN / +-Inf fail the
+    isposdef(M) assert of initialize! like the reference (NaN pivots).  Tile-sized and general-size kernels, every execution path."""
+    for n, m, N in ((12, 4, 50), (20, 6, 20)):
+        prob, x0, u = rat.synthetic_lq_problem(n=n, m=m, N=N, kappa=0.02)
+        th = np.array([-5.0, -0.5, -0.01, 0.0, 0.3, np.nan, np.inf, -np.inf])
+        vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, th, nthreads=4)
+        assert so.tolist() == [0, 0, 0, 0, 0, 1, 1, 1] and np.all(np.diff(vo[:5]) > 0)
+        for env in ({}, {"RATILQR_BLOCK": "0"}, {"RATILQR_FUSED": "0"}):
+            os.environ.update(env)
+            try:
+                ctx = rat.Context(prob, max_batch=8)
+            finally:
+                for k in env:
+                    del os.environ[k]
+            check_batch(ctx, orc.Problem(prob), x0, u, th)
