@@ -771,6 +771,10 @@ extern "C" rat_rc rat_ce_compute_cost_dev(rat_handle h, const double *theta_dev,
     return RAT_OK;
 }
 
+// (multi.cpp) true when a batch of B samples is ONE asynchronous launch on this handle; false when it runs the round-based path, whose
+// host loop polls the device between rounds
+bool rat_batch_is_single_launch(rat_handle h, int64_t B) { return h && B >= 1 && B <= h->Bmax && pick_path(h, (int)B) != PATH_ROUNDS; }
+
 extern "C" rat_rc rat_ce_compute_cost_enqueue(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev) {
     if (!h || !theta_dev || !cost_dev) return fail(RAT_ERR_ARG, "null");
     if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ratilqr.h"
@@ -38,6 +39,7 @@ struct Rccl {
 static Rccl g_rccl;
 
 void rat_set_error(const char *msg);                // driver.cpp: thread-local message behind rat_last_error()
+bool rat_batch_is_single_launch(rat_handle h, int64_t B);   // driver.cpp
 static rat_rc mfail(rat_rc rc, const std::string &m) { rat_set_error(m.c_str()); return rc; }
 #define MHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mfail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 #define MRC(expr) do { rat_rc r_ = (expr); if (r_ != RAT_OK) return r_; } while (0)
@@ -163,6 +165,7 @@ extern "C" rat_rc rat_multi_ce_compute_cost(rat_multi m, const double *x0, const
     double *p_theta = m->h_stage, *p_all = m->h_stage + m->Bmax;
     memcpy(p_theta, theta, sizeof(double) * B);
     const double nan = std::nan("");
+    bool polled = false;
     // every device: its theta block in, its solves enqueued -- all asynchronous on the device's own stream, no host wait in this loop
     for (int g = 0; g < G; ++g) {
         int64_t lo, hi;
@@ -176,8 +179,29 @@ extern "C" rat_rc rat_multi_ce_compute_cost(rat_multi m, const double *x0, const
         }
         if (hi > lo) {
             MHIP(hipMemcpyAsync(m->d_theta[g], p_theta + lo, sizeof(double) * (hi - lo), hipMemcpyHostToDevice, s));
-            MRC(rat_ce_compute_cost_enqueue(m->h[g], m->d_theta[g], hi - lo, kl_bound, m->d_cost[g]));
+            if (rat_batch_is_single_launch(m->h[g], hi - lo)) MRC(rat_ce_compute_cost_enqueue(m->h[g], m->d_theta[g], hi - lo, kl_bound, m->d_cost[g]));
+            else polled = true;
         }
+    }
+    if (polled) {
+        // Shards on the round-based path (speculative step sizes on a shard too large for one generation of workgroups): its host loop
+        // polls the device between rounds, so one calling thread would process the devices one after the other.  A helper thread per
+        // such device instead, joined before the collective; their error messages come back through rc / msg.
+        std::vector<std::thread> th;
+        std::vector<rat_rc> rcs((size_t)G, RAT_OK);
+        std::vector<std::string> msgs((size_t)G);
+        for (int g = 0; g < G; ++g) {
+            int64_t lo, hi;
+            MRC(rat_shard_bounds(B, G, g, &lo, &hi));
+            if (hi <= lo || rat_batch_is_single_launch(m->h[g], hi - lo)) continue;
+            th.emplace_back([m, g, lo, hi, kl_bound, &rcs, &msgs]() {
+                if (hipSetDevice(m->dev[g]) != hipSuccess) { rcs[(size_t)g] = RAT_ERR_HIP; msgs[(size_t)g] = "hipSetDevice failed in a shard thread"; return; }
+                rcs[(size_t)g] = rat_ce_compute_cost_dev(m->h[g], m->d_theta[g], hi - lo, kl_bound, m->d_cost[g]);
+                if (rcs[(size_t)g] != RAT_OK) msgs[(size_t)g] = rat_last_error();
+            });
+        }
+        for (auto &t : th) t.join();
+        for (int g = 0; g < G; ++g) if (rcs[(size_t)g] != RAT_OK) return mfail(rcs[(size_t)g], msgs[(size_t)g]);
     }
     if (!m->comm.empty()) {
         // ONE collective per batch: every rank contributes `chunk` doubles and receives G * chunk, ordered behind its solves on its stream

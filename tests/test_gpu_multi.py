@@ -71,3 +71,21 @@ def test_multi_pets_cost_equals_the_single_handle_cost():
     dev = mp.compute_cost(x0, ctrl, K, seed=7)
     assert np.array_equal(dev, pets.compute_cost_serial(ds, prob, x0, ctrl, None, seed=7)) and np.all(np.isfinite(dev))
     assert np.array_equal(dev, mp.compute_cost(x0, ctrl, K, seed=7)) and not np.array_equal(dev, mp.compute_cost(x0, ctrl, K, seed=8))
+
+
+def test_multi_shards_on_the_round_based_path_run_on_helper_threads(monkeypatch):
+    """E = 8 with a shard beyond one generation of workgroups (300 > 256 samples) runs the round-based path, whose host loop polls the
+    device: rat_multi hands such shards to a helper thread per device (joined before the collective) -- same costs as the single handle"""
+    monkeypatch.setenv("RATILQR_MULTI_FORCE_RCCL", "1")
+    prob, x0, u = rat.synthetic_lq_problem()
+    B = 300
+    theta = np.abs(1.0 + 2.0 * np.random.default_rng(8).standard_normal(B))
+    theta[-1] = 80.0
+    mc = rat.MultiContext(prob, max_batch=B, spec_eps=8, devices=(0,))
+    cost = mc.compute_cost(x0, u, theta, 0.1)
+    ctx = rat.Context(prob, max_batch=B, spec_eps=8)
+    ctx.profile(True)
+    v, st, _, _ = ctx.solve_batch(x0, u, theta)
+    assert "solve_block" not in [k for k, p in ctx.profile_get().items() if p["launches"]]      # (the round-based path indeed)
+    assert np.array_equal(cost[:-1], (v + 0.1 / theta)[:-1]) and np.isposinf(cost[-1]) and st[-1] == 1 and mc.allgathers == 1
+    assert np.array_equal(mc.compute_cost(x0, u, theta[:100], 0.1), cost[:100])                    # a block-kernel shard right after
