@@ -26,6 +26,7 @@ namespace {
 struct Ws {
     double *S, *U, *Z, *DS, *T, *At, *Bm, *F, *G, *Lt, *H, *Hc;
     double *sv, *z, *dsv, *qv, *sv0, *xt, *xb, *g, *dlv, *rv, *ut, *hv;
+    double *idle;          // [WIDE_MAX]: what lanes without a column of their own work on in the lockstep factorisation
 };
 
 // sum over the wavefront, the same bits on every lane: DPP rotations inside the 16-lane rows, then the four row sums through scalar
@@ -209,7 +210,7 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
         each(n, n, [&](int i, int j) { const double sij = w.S[i + ldn * j]; w.U[i + ldn * j] = Wik[i + n * j] - theta * sij; w.Z[i + ldn * j] = sij; });
         __syncthreads();
         double sumlog = 0.0, zreg = 0.0;
-        if (!chol_fwd(w.U, n, ldn, w.Z, n, ldn, w.sv, w.T, zreg, sumlog)) return 2;       // @assert isposdef(M)  :366 / :440;  [Z | z] = U^-T [S | s_vec]
+        if (!chol_fwd(w.U, n, ldn, w.Z, n, ldn, w.sv, w.idle, zreg, sumlog)) return 2;       // @assert isposdef(M)  :366 / :440;  [Z | z] = U^-T [S | s_vec]
         if (theta == 0.0) {                          // D = I exactly, whatever the size of S: the products below must not see Z'Z
             each(n, n, [&](int i, int j) { w.Z[i + ldn * j] = 0.0; });
             zreg = 0.0;
@@ -258,8 +259,8 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
             if (lane < m) w.hv[lane] = -w.g[lane];
             __syncthreads();
             double dreg = 0.0, dummy = 0.0;
-            if (!chol_fwd(w.Hc, m, ldm, w.Lt, n, ldm, w.hv, w.DS, dreg, dummy)) return -1; // !isposdef(H)  :372   (D S is dead: idle lanes' scratch)
-            back_all(w.Hc, m, ldm, w.Lt, n, ldm, w.DS, dreg);
+            if (!chol_fwd(w.Hc, m, ldm, w.Lt, n, ldm, w.hv, w.idle, dreg, dummy)) return -1; // !isposdef(H)  :372
+            back_all(w.Hc, m, ldm, w.Lt, n, ldm, w.idle, dreg);
             if (lane < m) { w.dlv[lane] = dreg; dlg[(size_t)t * m + lane] = dreg; }
             double *Lt_g = Lg + (size_t)t * nm;
             each(m, n, [&](int g, int j) { Lt_g[g + m * j] = w.Lt[g + ldm * j]; });
@@ -394,6 +395,7 @@ __device__ inline void carve(Ws &w, double *p, const int n, const int m) {      
     w.Bm = p; p += sb; w.F = p; p += sf; w.G = p; p += sg; w.Lt = p; p += sg; w.H = p; p += sh; w.Hc = p; p += sh;
     w.sv = p; p += n; w.z = p; p += n; w.dsv = p; p += n; w.qv = p; p += n; w.sv0 = p; p += n; w.xt = p; p += n; w.xb = p; p += n;
     w.g = p; p += m; w.dlv = p; p += m; w.rv = p; p += m; w.ut = p; p += m; w.hv = p; p += m;
+    w.idle = p;
 }
 
 
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
 
 size_t wide_lds_bytes(int n, int m) {
     const size_t ldn = n | 1, ldm = m | 1, sb = ldn * m, sg = ldm * n;
-    return sizeof(double) * (6 * ldn * n + sb + (sb > sg ? sb : sg) + 2 * sg + 2 * ldm * m + (size_t)7 * n + (size_t)5 * m);
+    return sizeof(double) * (6 * ldn * n + sb + (sb > sg ? sb : sg) + 2 * sg + 2 * ldm * m + (size_t)7 * n + (size_t)5 * m + 64);
 }
 
 hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s) {

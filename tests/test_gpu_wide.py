@@ -71,6 +71,10 @@ def check_batch(ctx, P, x0, u, theta, **opts):
     (32, 8, 12, 5, 0.0, False),        # the largest state dimension
     (24, 24, 10, 6, 0.0, True),        # m = n
     (32, 32, 6, 7, 0.0, False),        # the largest of both (101 KB of LDS per sample)
+    (1, 5, 10, 8, 0.01, False),        # more controls than states: m > n (the scratch of the lockstep factorisation once assumed n >= m)
+    (3, 32, 6, 9, 0.0, True),
+    (1, 32, 1, 10, 0.0, False),        # a single step, a single state
+    (32, 1, 8, 11, 0.01, True),
 ])
 def test_batched_solves_match_the_oracle(n, m, N, seed, kappa, tv):
     prob, x0, u = wide_problem(n, m, N, seed, kappa, tv)

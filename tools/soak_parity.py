@@ -3,7 +3,7 @@ time-varying tables, cubic drift, random solver options and speculation widths, 
 boundary).  Round 1: 3000 problems, 2 mismatches, both on trajectories that overflow to 1e57+ and run into iter_max (chaotic
 line-search paths / an LU singularity in 1e120-scale arithmetic): no mismatch on a well-posed problem.
   SOAK_N=3000 python tools/soak_parity.py   (on an MI355X; ~40 s)
-  SOAK_WIDE=1: shapes 13..32 x 1..12 x 1..30 instead (the general-size kernels of wide.hip)."""
+  SOAK_WIDE=1: shapes beyond the tile instead -- n 13..32 with m 1..32, or n 1..12 with m 5..32; N 1..30 (the general-size kernels of wide.hip)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,6 +17,10 @@ for seed in range(NS):
     n, m, N = int(rng.integers(1, 13)), int(rng.integers(1, 5)), int(rng.integers(1, 61))
     if os.environ.get('SOAK_WIDE') == '1':
         n, m, N = int(rng.integers(13, 33)), int(rng.integers(1, 13)), int(rng.integers(1, 31))
+        if seed % 3 == 1:                      # few states, many controls (only m exceeds the tile); up to the largest m
+            n, m = int(rng.integers(1, 13)), int(rng.integers(5, 33))
+        elif seed % 3 == 2:
+            m = int(rng.integers(1, 33))
     tv = bool(rng.integers(0, 2))
     A = (0.7 + 0.3 * rng.random()) * np.linalg.qr(rng.standard_normal((n, n)))[0]
     B = rng.standard_normal((n, m)) / np.sqrt(n)
