@@ -153,7 +153,8 @@ def test_sizes_beyond_the_general_kernel_fail_loudly():
         rat.Context(rat.PowerLawRiskSensitiveProblem(13, 5, 0.01 * np.eye(13)))
 
 
-@pytest.mark.parametrize("n,m,N,seed,kappa,tv", [(14, 5, 12, 81, 0.03, True), (32, 9, 6, 82, 0.0, False), (7, 7, 9, 83, 0.01, True)])
+@pytest.mark.parametrize("n,m,N,seed,kappa,tv", [(14, 5, 12, 81, 0.03, True), (32, 9, 6, 82, 0.0, False), (7, 7, 9, 83, 0.01, True),
+                                                 (2, 7, 5, 84, 0.0, False), (3, 32, 4, 85, 0.02, True), (32, 32, 3, 86, 0.0, False)])
 def test_operator_forms_match_the_oracle(n, m, N, seed, kappa, tv):
     """simulate_dynamics (three forms), integrate_cost, approximate_model, solve_approximate_dp(!) as individual calls at general size"""
     prob, x0, u = wide_problem(n, m, N, seed, kappa, tv)
