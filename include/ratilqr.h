@@ -346,6 +346,16 @@ rat_rc  rat_multi_set_initial(rat_multi m, const double *x0, const double *u0);
 /* compute_cost (:173-195) on all devices; x0/u0 may be NULL (keep the last rat_multi_set_initial) */
 rat_rc  rat_multi_ce_compute_cost(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B,
                                   double kl_bound, double *cost);
+/* the same with the gathered per-sample status (RAT_ST_*), iLEQG iteration count and line-search evaluation count of every shard
+ * (the all-gather carries cost + status); any of the three may be NULL */
+rat_rc  rat_multi_ce_compute_cost_ex(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B,
+                                     double kl_bound, double *cost, int32_t *status, int32_t *iters, int32_t *ls_evals);
+/* rat_ileqg_solve_batch (compute_value_worker over a batch, :144-167) on all devices: value (+Inf for failures) and the per-sample counters */
+rat_rc  rat_multi_ileqg_solve_batch(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B,
+                                    double *value, int32_t *status, int32_t *iters, int32_t *ls_evals);
+/* 1 when the devices are logical (test hook RATILQR_MULTI_LOGICAL=1: device index d runs on physical device d mod the visible count
+ * and the all-gather is carried out by stream-ordered device copies: the G > 1 code on a one-GPU box) */
+int32_t rat_multi_is_logical(rat_multi m);
 /* step! (:252-335) / solve! (:364-415) with the cost evaluation on all devices; draws come from rat_multi_handle(m, 0) */
 rat_rc  rat_multi_ce_step(rat_multi m, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
                           double *theta_out, double *cost_out);
@@ -358,6 +368,22 @@ rat_rc  rat_multi_ce_solve(rat_multi m, rat_ce_solver *c, const double *x0, cons
 rat_rc  rat_multi_pets_problem_set(rat_multi m, const rat_gen_problem_desc *desc);
 rat_rc  rat_multi_pets_compute_cost(rat_multi m, const double *x0, const double *controls, int64_t S, int64_t K,
                                     int32_t use_true_model, const double *zn, const double *zu, uint64_t seed, double *cost);
+
+/* ---- execution path of the batched solves of a handle ------------------------------------------
+ * Results are identical on every path (tested bit for bit); AUTO picks by batch size, speculation width E and the device's CU count:
+ *   E = 1: BLOCK up to 2 n_cu samples (a sample's evaluation and gain recursions side by side on two SIMDs), FUSED beyond (in-wave
+ *          pairing; from 4 n_cu + 1 samples on, its two-samples-per-SIMD variant);
+ *   E = 2 / 4 / 8: BLOCK while the batch fits one generation of workgroups (n_cu * floor(8 / (E + 1)) samples; E = 8: n_cu), ROUNDS beyond;
+ *   any other E, and the operator entry points: ROUNDS.
+ * rat_set_path fixes the path of the handle (RAT_ERR_UNSUPPORTED when the handle's E has no such kernel); the RATILQR_* environment
+ * variables read at rat_create remain as test overrides of the defaults. */
+#define RAT_PATH_AUTO   0
+#define RAT_PATH_ROUNDS 1   /* one launch per phase, rounds polled by the host */
+#define RAT_PATH_FUSED  2   /* one persistent wavefront per sample: whole solve! in one launch (E = 1) */
+#define RAT_PATH_BLOCK  3   /* one workgroup per sample: whole solve! in one launch (E = 1, 2, 4, 8) */
+rat_rc  rat_set_path(rat_handle h, int32_t path);
+/* the path (RAT_PATH_ROUNDS / _FUSED / _BLOCK; 4 = general-size kernel) a batch of B samples takes on this handle, or -1 */
+int32_t rat_get_path(rat_handle h, int64_t B);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 #define RAT_K_ROLLOUT   0

@@ -143,6 +143,13 @@ n_devices(h::MultiHandle) = ccall((:rat_multi_n_devices, LIB), Int32, (Ptr{Cvoid
 uses_rccl(h::MultiHandle) = ccall((:rat_multi_uses_rccl, LIB), Int32, (Ptr{Cvoid},), h.ptr) != 0
 allgathers(h::MultiHandle) = ccall((:rat_multi_allgathers, LIB), Int64, (Ptr{Cvoid},), h.ptr)
 device_handle(h::MultiHandle, i::Integer) = ccall((:rat_multi_handle, LIB), Ptr{Cvoid}, (Ptr{Cvoid}, Int32), h.ptr, i)
+"true under the test hook RATILQR_MULTI_LOGICAL=1 (several logical devices per GPU, all-gather by device copies)"
+is_logical(h::MultiHandle) = ccall((:rat_multi_is_logical, LIB), Int32, (Ptr{Cvoid},), h.ptr) != 0
+
+# execution path of a handle's batched solves (include/ratilqr.h RAT_PATH_*; results are identical on all of them)
+const PATH_AUTO, PATH_ROUNDS, PATH_FUSED, PATH_BLOCK = Int32(0), Int32(1), Int32(2), Int32(3)
+set_path!(h::Handle, path::Integer) = check(ccall((:rat_set_path, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, path))
+get_path(h::Handle, B::Integer) = ccall((:rat_get_path, LIB), Int32, (Ptr{Cvoid}, Int64), h.ptr, B)
 function shard_bounds(B::Integer, world::Integer, rank::Integer)
     lo = Ref(Int64(0)); hi = Ref(Int64(0))
     check(ccall((:rat_shard_bounds, LIB), Int32, (Int64, Int32, Int32, Ref{Int64}, Ref{Int64}), B, world, rank, lo, hi))
@@ -505,6 +512,41 @@ function compute_cost(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceR
     end
     cost
 end
+"compute_cost with the per-sample solver statistics of every shard: (cost, status, iterations, line-search evaluations).  On several
+devices the four arrays travel in the one all-gather of the batch (rat_multi_ce_compute_cost_ex)."
+function compute_cost_detail(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSensitiveProblem, x::Vector{Float64}, u_array,
+                             θ_array::Vector{Float64}, kl_bound::Float64)
+    B = length(θ_array)
+    h = handle!(s, problem, B); cost = similar(θ_array)
+    st = Vector{Int32}(undef, B); it = Vector{Int32}(undef, B); ls = Vector{Int32}(undef, B)
+    if h isa MultiHandle
+        check(ccall((:rat_multi_ce_compute_cost_ex, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                    h.ptr, x, flat(u_array), θ_array, B, kl_bound, cost, st, it, ls))
+    else
+        check(ccall((:rat_ileqg_solve_batch, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                    h.ptr, x, flat(u_array), θ_array, B, cost, st, it, ls))
+        cost .+= kl_bound ./ θ_array                                                     # :193
+    end
+    cost, st, it, ls
+end
+"Batched solve! over the solver's devices: value (Inf on failure), status, iterations, line-search evaluations (compute_value_worker over a batch, :144-167)"
+function solve_batch(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSensitiveProblem, x_0::Vector{Float64}, u_array, θ_array::Vector{Float64})
+    B = length(θ_array)
+    h = handle!(s, problem, B)
+    value = Vector{Float64}(undef, B); st = Vector{Int32}(undef, B); it = Vector{Int32}(undef, B); ls = Vector{Int32}(undef, B)
+    if h isa MultiHandle
+        check(ccall((:rat_multi_ileqg_solve_batch, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                    h.ptr, x_0, flat(u_array), θ_array, B, value, st, it, ls))
+    else
+        check(ccall((:rat_ileqg_solve_batch, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                    h.ptr, x_0, flat(u_array), θ_array, B, value, st, it, ls))
+    end
+    value, st, it, ls
+end
 "compute_cost_serial -- :198-227: one solve per call, the reference's debugging twin of compute_cost"
 function compute_cost_serial(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSensitiveProblem, x, u_array, θ_array::Vector{Float64}, kl_bound::Float64)
     @assert length(θ_array) == s.c.num_samples                                       # :204
@@ -549,16 +591,80 @@ function compute_cost_dev!(s::CrossEntropyBilevelOptimizationSolver, problem, θ
 end
 hip_stream(s::CrossEntropyBilevelOptimizationSolver) = ccall((:rat_stream, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), single(s.h))
 
-function bind_stream!(s::CrossEntropyBilevelOptimizationSolver, h, rng::AbstractRNG, stream_len::Integer)
-    s.z = randn(rng, stream_len)                         # θ = μ + σ z, consumed in order (get_positive_samples :233-246)
-    check(ccall((:rat_ce_set_stream, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64), single(h), s.z, length(s.z)))
+# The reference's step! / solve! consume `rng` exactly as far as get_positive_samples needs (:233-246): a hand-driven loop of step! with
+# one MersenneTwister, or anything the caller draws from it afterwards, must see the same generator state.  So the draws are made HERE
+# with the caller's rng (the reference's own sequence), the batch goes to the device (compute_cost), and the bookkeeping of :291-334 is
+# the library's host arithmetic (rat_ce_begin_step / rat_ce_update) -- no pre-drawn stream, nothing consumed that the reference leaves.
+function ce_round!(s::CrossEntropyBilevelOptimizationSolver, problem, x::Vector{Float64}, u_array, kl_bound::Float64, rng::AbstractRNG)
+    handle!(s, problem); B = s.c.num_samples
+    check(ccall((:rat_ce_begin_step, LIB), Int32, (Ref{CeState},), s.c))                 # :259
+    redraws = 0
+    while true
+        redraws > 1000 && error("CE redraw loop cut after 1000 redraws (the reference would spin, :266-305)")
+        μ, σ = s.c.iter_current == 1 ? (s.c.mu_init, s.c.sigma_init) : (s.c.mu, s.c.sigma)   # :266-279
+        θ = get_positive_samples(μ, σ, B, rng)
+        cost = compute_cost(s, problem, x, u_array, θ, kl_bound)
+        s.c.n_solves += B
+        redraws > 0 && (s.c.n_redraws += 1)
+        redraw = Ref{Int32}(0)
+        check(ccall((:rat_ce_update, LIB), Int32, (Ref{CeState}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}), s.c, θ, cost, redraw))   # :291-334
+        redraw[] == 0 && return θ, cost
+        redraws += 1
+    end
 end
 
 "step!(ce_solver, problem, x, u_array, kl_bound, rng) -- :252-335.  Returns (θ_array, cost_array) of the accepted batch."
 function step!(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSensitiveProblem, x::Vector{Float64}, u_array, kl_bound::Float64,
-               rng::AbstractRNG, verbose=false, serial=false; stream_len=1 << 18)
+               rng::AbstractRNG, verbose=false, serial=false)
+    ce_round!(s, problem, x, u_array, kl_bound, rng)
+end
+
+"solve!(ce_solver, problem, x_0, u_array, rng; kl_bound) -- :364-415."
+function solve!(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSensitiveProblem, x_0::Vector{Float64},
+                u_array::Vector{Vector{Float64}}, rng::AbstractRNG; kl_bound::Float64, verbose=false, serial=false)
+    @assert kl_bound >= 0 "KL Divergence Bound must be non-negative"
+    h = handle!(s, problem); n, m, N = dims(problem)
+    initialize!(s)                                                                        # :370
+    s.c.n_final_retries = 0
+    θ_opt, θ_min, θ_max = 0.0, 0.0, 0.0
+    if kl_bound > 0.0
+        while s.c.iter_current < s.c.iter_max                                             # :371-373
+            ce_round!(s, problem, x_0, u_array, kl_bound, rng)
+        end
+        θ_min, θ_max = s.c.theta_min, s.c.theta_max
+        θ_opt = s.c.use_theta_max != 0 ? θ_max : s.c.mu                                   # :375-382
+    end
+    x = Matrix{Float64}(undef, n, N + 1); l = Matrix{Float64}(undef, m, N); L = Array{Float64}(undef, m, n, N)
+    val = Ref(0.0); st = Ref{Int32}(0)
+    tries = 0
+    while true                                                                            # :390-414: final solve, retried at max(0, θ_opt - σ)
+        tries > 10000 && error("final-solve retry loop cut (the reference would spin, :410-413)")
+        check(ccall((:rat_ileqg_solve, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Int32},
+                     Ptr{Int32}, Ptr{Float64}, Int64, Ptr{Int64}),
+                    single(h), x_0, flat(u_array), θ_opt, x, l, L, val, st, C_NULL, C_NULL, 0, C_NULL))
+        st[] in (0, 3) && break
+        θ_opt = max(0.0, θ_opt - s.c.sigma)                                               # :412
+        s.c.n_final_retries += 1
+        tries += 1
+    end
+    value = kl_bound > 0.0 ? val[] + kl_bound / θ_opt : val[]                             # :406 / :408
+    return θ_opt, unflat_vec(x), unflat_vec(l), unflat_mat(L), value, θ_min, θ_max
+end
+
+# One-ccall variants on an injected N(0,1) stream `z` (θ = μ + σ z, consumed in order, θ <= 0 rejected: get_positive_samples :233-246): the
+# whole CE step / solve runs behind the C ABI -- draws, batches on the device(s), updates, final solve -- which is the lowest-latency way to
+# run RAT iLQR in a receding-horizon loop (2.8 ms per solve at 1024 samples x 5 iterations on one MI355X).  They do not touch a Julia rng;
+# `stream_pos(ce_solver)` tells how many draws were consumed.
+function set_stream!(s::CrossEntropyBilevelOptimizationSolver, h, z::Vector{Float64})
+    s.z = z                                              # kept alive: the handle reads it in place
+    check(ccall((:rat_ce_set_stream, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64), single(h), s.z, length(s.z)))
+end
+stream_pos(s::CrossEntropyBilevelOptimizationSolver) = ccall((:rat_ce_stream_pos, LIB), Int64, (Ptr{Cvoid},), single(s.h))
+function step_stream!(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSensitiveProblem, x::Vector{Float64}, u_array, kl_bound::Float64,
+                      z::Vector{Float64})
     h = handle!(s, problem); B = s.c.num_samples
-    bind_stream!(s, h, rng, stream_len)
+    z === s.z || set_stream!(s, h, z)                    # the same stream object continues where the last call stopped
     θ = Vector{Float64}(undef, B); cost = Vector{Float64}(undef, B)
     GC.@preserve s begin
         if h isa MultiHandle
@@ -571,13 +677,11 @@ function step!(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSens
     end
     θ, cost
 end
-
-"solve!(ce_solver, problem, x_0, u_array, rng; kl_bound) -- :364-415.  `rng` supplies the N(0,1) stream (randn(rng, k))."
-function solve!(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSensitiveProblem, x_0::Vector{Float64},
-                u_array::Vector{Vector{Float64}}, rng::AbstractRNG; kl_bound::Float64, verbose=false, serial=false, stream_len=1 << 20)
+function solve_stream!(s::CrossEntropyBilevelOptimizationSolver, problem::DeviceRiskSensitiveProblem, x_0::Vector{Float64},
+                       u_array::Vector{Vector{Float64}}, z::Vector{Float64}; kl_bound::Float64)
     @assert kl_bound >= 0 "KL Divergence Bound must be non-negative"
     h = handle!(s, problem); n, m, N = dims(problem)
-    bind_stream!(s, h, rng, stream_len)
+    z === s.z || set_stream!(s, h, z)
     x = Matrix{Float64}(undef, n, N + 1); l = Matrix{Float64}(undef, m, N); L = Array{Float64}(undef, m, n, N)
     θ = Ref(0.0); val = Ref(0.0); θmin = Ref(0.0); θmax = Ref(0.0)
     GC.@preserve s begin
@@ -803,5 +907,5 @@ export OptimalControlProblem, LQRiskSensitiveProblem, PowerLawRiskSensitiveProbl
        DynamicProgrammingResult, solve_approximate_dp!, solve_approximate_dp, increase_μ_and_Δ!, decrease_μ_and_Δ!, line_search!, step!, solve!,
        solve_batch, solve_approximate_dp_batch!, solve_approximate_dp_batch, CrossEntropyBilevelOptimizationSolver, compute_value_worker, compute_cost, compute_cost_serial, get_positive_samples,
        set_initial!, compute_cost_dev!, NelderMeadBilevelOptimizationSolver, compute_cost_worker, CrossEntropyDirectOptimizationSolver,
-       shard_bounds
+       shard_bounds, compute_cost_detail, step_stream!, solve_stream!, stream_pos, set_path!, get_path, is_logical
 end

@@ -84,6 +84,7 @@ EXPORTS = [
     "rat_shard_bounds", "rat_create_multi", "rat_multi_destroy", "rat_multi_n_devices", "rat_multi_handle", "rat_multi_uses_rccl",
     "rat_multi_allgathers", "rat_multi_problem_set", "rat_multi_set_initial", "rat_multi_ce_compute_cost", "rat_multi_ce_step",
     "rat_multi_ce_solve", "rat_multi_pets_problem_set", "rat_multi_pets_compute_cost",
+    "rat_multi_ce_compute_cost_ex", "rat_multi_ileqg_solve_batch", "rat_multi_is_logical", "rat_set_path", "rat_get_path",
 ]
 
 _lib = None
@@ -109,6 +110,9 @@ def lib():
         _lib.rat_multi_handle.restype = C.c_void_p
         _lib.rat_multi_allgathers.argtypes = [C.c_void_p]
         _lib.rat_multi_allgathers.restype = C.c_int64
+        _lib.rat_set_path.argtypes = [C.c_void_p, C.c_int32]
+        _lib.rat_get_path.argtypes = [C.c_void_p, C.c_int64]
+        _lib.rat_get_path.restype = C.c_int32
     return _lib
 
 

@@ -139,6 +139,17 @@ __device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, int &pdmi
     m = MFMA(t, nu, m);
 }
 
+// f_x of the LQ family, one register of the [A | B] image: A_ij, + 3 kappa x_i^2 on the lane that holds a diagonal element (dg = 1 there,
+// 0 elsewhere; x = that lane's own state component).  Formed by the rollout kernels (tile records), the fly sweeps (in registers) and
+// materialize_kernel: one rounding order everywhere, whatever the surrounding code lets the compiler contract.
+__device__ __forceinline__ double fx_diag(double zt, double dg, double kappa, double x) {
+#pragma clang fp contract(off)
+    const double k3 = 3.0 * kappa;
+    const double xx = x * x;
+    const double d = k3 * xx;
+    return __builtin_fma(dg, d, zt);
+}
+
 __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base.isapprox, rtol = sqrt(eps), atol = 0
     if (x == y) return true;
     if (!isfinite(x) || !isfinite(y)) return false;

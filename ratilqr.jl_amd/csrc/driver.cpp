@@ -51,6 +51,9 @@ struct rat_handle_s {
     int *d_census = nullptr;         // solve_block_kernel's per-CU workgroup tickets (two-wave geometry: which SIMD pair a workgroup keeps)
     bool block_shape = true;         // RATILQR_BLOCK_SHAPE=0: plain two-wave workgroups, placement left to the dispatcher
     bool block_helpers = true;       // RATILQR_BLOCK_HELPERS=0: no spare linearise waves at one workgroup per CU
+    int path_fixed = RAT_PATH_AUTO;  // rat_set_path
+    bool fly = true;                 // round-based path, E > 1, LQ family: line-search candidates are evaluated without tile records in HBM
+                                     // (their sweeps form the step's tile from x_t; accepted trajectories are completed on demand); RATILQR_FLY=0
     rat_ileqg_opts opts;
     OptsDev opd;
     int Bmax = 0, E = 1;
@@ -154,6 +157,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = atoi(e);
     if (const char *e = getenv("RATILQR_BLOCK_SHAPE")) h->block_shape = (e[0] != '0');
     if (const char *e = getenv("RATILQR_BLOCK_HELPERS")) h->block_helpers = (e[0] != '0');
+    if (const char *e = getenv("RATILQR_FLY")) h->fly = (e[0] != '0');
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     // E = 1 batches beyond one sample per SIMD: two samples per SIMD in 256 registers each beat two generations of the 342-register
     // paired kernel (measured +6..10 %); RATILQR_FUSED_OCC2=0 disables, =B0 moves the threshold
@@ -543,6 +547,7 @@ extern "C" rat_rc rat_layout_info(rat_handle h, int64_t *tile_bytes, int64_t *L_
 static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     SweepArgs a;
     a.st = st; a.pb = h->pb; a.op = h->opd; a.mode = mode; a.k_first = 0; a.dl_in = nullptr; a.mu_op = 0.0; a.op_out = nullptr; a.dump = nullptr;
+    a.fly = 0;
 #if defined(RAT_DIAG) || defined(RAT_DIAG_PHASES)
     a.dump = h->d_dump;
 #endif
@@ -563,7 +568,11 @@ static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
 static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     const int slot = round % CTR_RING;
     const int64_t nc = (int64_t)st.B * st.E;
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0;
+    // no tile records for line-search candidates (LQ family, E > 1): the evaluation sweeps form each step's tile from x_t themselves, and
+    // only an accepted trajectory that the plain gain sweep of the next step! will read is completed (materialize, after the accept rule)
+    const bool fly = h->fly && !h->speculate && rollin_notile_supported(h->pb, st);
+    ra.notile = fly ? 1 : 0;
     if (h->dual) {
         // fused path (E = 1): the plain gain sweep only serves samples whose fused gain recursion was abandoned (H not PD)
         prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
@@ -573,13 +582,16 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_a, 0));
             SweepArgs se = sweep_args(h, st, 1);
             se.k_first = 1;
+            se.fly = fly;
             const int64_t n1 = (int64_t)st.B * (st.E - 1);
             prof_begin(h, RAT_K_SWEEP_EVAL, n1, h->stream2); launch_sweep(se, (int)n1, false, false, h->stream2); prof_end(h, h->stream2);
             HIPCHK(hipEventRecord(h->ev_b, h->stream2));
         }
-        prof_begin(h, RAT_K_SWEEP_DUAL, st.B); launch_sweep_dual(sweep_args(h, st, 7), st.B, h->stream); prof_end(h);
+        { SweepArgs sd = sweep_args(h, st, 7); sd.fly = fly;
+          prof_begin(h, RAT_K_SWEEP_DUAL, st.B); launch_sweep_dual(sd, st.B, h->stream); prof_end(h); }
         if (st.E > 1) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
         prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
+        if (fly) launch_materialize(st, h->pb, h->stream);
         HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
         return RAT_OK;
@@ -594,9 +606,11 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
         prof_begin(h, RAT_K_SWEEP_GAIN, st.B, h->stream2); launch_sweep(sweep_args(h, st, 4), st.B, true, false, h->stream2); prof_end(h, h->stream2);
         HIPCHK(hipEventRecord(h->ev_b, h->stream2));
     }
-    prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(sweep_args(h, st, 1), (int)nc, false, false, h->stream); prof_end(h);
+    { SweepArgs se = sweep_args(h, st, 1); se.fly = fly;
+      prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(se, (int)nc, false, false, h->stream); prof_end(h); }
     if (h->speculate) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
     prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
+    if (fly) launch_materialize(st, h->pb, h->stream);
     HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
     return RAT_OK;
@@ -612,6 +626,9 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
 enum Path { PATH_ROUNDS, PATH_FUSED, PATH_BLOCK, PATH_WIDE };
 static Path pick_path(const rat_handle h, int B) {
     if (h->wide) return PATH_WIDE;
+    if (h->path_fixed == RAT_PATH_ROUNDS) return PATH_ROUNDS;      // (rat_set_path has checked that the handle's E has the kernel)
+    if (h->path_fixed == RAT_PATH_FUSED) return PATH_FUSED;
+    if (h->path_fixed == RAT_PATH_BLOCK) return PATH_BLOCK;
     const bool block_ok = solve_block_supported(h->E) && h->block_mode != 0 && (h->E > 1 || h->fused) && !h->speculate &&
                           (h->E == 1 || getenv("RATILQR_DUAL") == nullptr);
     if (h->E == 1) {
@@ -625,6 +642,39 @@ static Path pick_path(const rat_handle h, int B) {
     const int nw = h->E == 2 ? 3 : (h->E == 4 ? 5 : 8);
     if (block_ok && (h->block_mode == 1 || B <= h->n_cu * (8 / nw))) return PATH_BLOCK;
     return PATH_ROUNDS;
+}
+
+extern "C" int32_t rat_get_path(rat_handle h, int64_t B) {
+    if (!h || B < 1 || B > h->Bmax) return -1;
+    switch (pick_path(h, (int)B)) {
+        case PATH_ROUNDS: return RAT_PATH_ROUNDS;
+        case PATH_FUSED: return RAT_PATH_FUSED;
+        case PATH_BLOCK: return RAT_PATH_BLOCK;
+        default: return 4;
+    }
+}
+
+// The single-launch E = 1 kernels keep ONE tile bundle per sample (StateDev.tile_alias), the round-based path one per slot: moving a
+// handle between them re-lays its state, so the initial trajectory has to be given again (rat_set_initial; the batch entry points that
+// take x0 / u0 do it themselves).
+static rat_rc alloc_state(rat_handle h);
+extern "C" rat_rc rat_set_path(rat_handle h, int32_t path) {
+    if (!h) return fail(RAT_ERR_ARG, "null");
+    if (path < RAT_PATH_AUTO || path > RAT_PATH_BLOCK) return fail(RAT_ERR_ARG, "rat_set_path: unknown path");
+    if (h->wide && path != RAT_PATH_AUTO) return fail(RAT_ERR_UNSUPPORTED, "rat_set_path: problems beyond n <= 12, m <= 4 run the general-size kernel only");
+    if (path == RAT_PATH_FUSED && h->E != 1) return fail(RAT_ERR_UNSUPPORTED, "rat_set_path: the one-wavefront-per-sample kernel exists for spec_eps = 1 only");
+    if (path == RAT_PATH_BLOCK && !solve_block_supported(h->E)) return fail(RAT_ERR_UNSUPPORTED, "rat_set_path: the workgroup-per-sample kernel exists for spec_eps 1, 2, 4, 8");
+    if ((path == RAT_PATH_FUSED || path == RAT_PATH_BLOCK) && (h->speculate || (h->E == 1 && h->dual)))
+        return fail(RAT_ERR_UNSUPPORTED, "rat_set_path: RATILQR_SPECULATE / RATILQR_DUAL handles run the round-based path only");
+    const bool was_alias = h->st.tile_alias != 0;
+    if (h->E == 1 && !h->speculate && !h->dual) h->fused = (path != RAT_PATH_ROUNDS);
+    h->path_fixed = path;
+    if (h->have_problem && !h->wide && was_alias != h->fused) {
+        rat_rc rc = alloc_state(h);
+        if (rc) return rc;
+        h->have_initial = false; h->x0_host.clear(); h->u0_host.clear();
+    }
+    return RAT_OK;
 }
 
 // outputs of a batch (device pointers, any may be null); cost = value + kl_bound / theta  (cross_entropy...jl:193)
@@ -654,7 +704,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
     if (path == PATH_ROUNDS) launch_init_state(st, h->opd, theta_dev, h->stream);     // (the single-launch solves initialise each sample themselves)
     // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation; the first gain
     // sweep (step! number 1 re-linearises the same trajectory, App. B.1) runs speculatively beside it.
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0;
     if (path != PATH_ROUNDS) {       // the whole state machine below, per sample, inside one launch
         FusedArgs fa;
         fa.sw = sweep_args(h, st, 0);
@@ -774,6 +824,27 @@ extern "C" rat_rc rat_ce_compute_cost_dev(rat_handle h, const double *theta_dev,
 // (multi.cpp) true when a batch of B samples is ONE asynchronous launch on this handle; false when it runs the round-based path, whose
 // host loop polls the device between rounds
 bool rat_batch_is_single_launch(rat_handle h, int64_t B) { return h && B >= 1 && B <= h->Bmax && pick_path(h, (int)B) != PATH_ROUNDS; }
+
+// (multi.cpp) one batch with every per-sample output left on the device: cost = value + kl_bound / theta (as_value: the value itself, what
+// rat_ileqg_solve_batch returns -- not cost at kl_bound = 0, which is NaN at theta = 0), status, iterations, line-search evaluations
+// (any may be null).  Single-launch paths return as soon as the launch is enqueued on the
+// handle's stream unless `wait`; the round-based path, whose host loop polls the device, always returns with the batch complete.
+rat_rc rat_batch_outputs_dev(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, bool as_value, double *cost_dev, int32_t *status_dev,
+                             int32_t *iters_dev, int32_t *ls_dev, bool wait) {
+    if (!h || !theta_dev) return fail(RAT_ERR_ARG, "null");
+    if (B < 1 || B > h->Bmax) return fail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create");
+    BatchOut out; out.kl_bound = kl_bound; out.status = status_dev; out.iters = iters_dev; out.ls = ls_dev;
+    if (as_value) out.value = cost_dev; else out.cost = cost_dev;
+    rat_rc rc = run_batch(h, theta_dev, (int)B, out);
+    if (rc) return rc;
+    const bool rounds = pick_path(h, (int)B) == PATH_ROUNDS;
+    if (rounds) {
+        StateDev st = h->st; st.B = (int)B;
+        launch_gather(st, out.value, status_dev, iters_dev, ls_dev, out.cost, kl_bound, h->stream);
+    }
+    if (rounds || wait) HIPCHK(hipStreamSynchronize(h->stream));
+    return RAT_OK;
+}
 
 extern "C" rat_rc rat_ce_compute_cost_enqueue(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev) {
     if (!h || !theta_dev || !cost_dev) return fail(RAT_ERR_ARG, "null");
@@ -1073,7 +1144,7 @@ extern "C" rat_rc rat_rollout_open(rat_handle h, const double *x0, const double 
     if (rc) return rc;
     StateDev st;
     if ((rc = op_prepare(h, 0.0, 0.0, h->opts.delta_0, &st))) return rc;
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0;
     launch_rollout(ra, h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> xp;
@@ -1106,7 +1177,7 @@ extern "C" rat_rc rat_rollout_feedback(rat_handle h, const double *xbar, const d
     HIPCHK(hipMemset(st.dl, 0, (size_t)h->N * USTR * 8));
     const int one = 1;
     HIPCHK(hipMemcpy(st.ls_active, &one, 4, hipMemcpyHostToDevice));
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0;
     launch_rollout(ra, h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> xp, up;

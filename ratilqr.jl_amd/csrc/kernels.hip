@@ -50,6 +50,7 @@
 struct TileRegs {
     d4 z, c;
     double x, la;          // x: lanes 0..15 = qr, lane 16 = q;  la: this lane's entry L[g][j] of the natural 4 x 16 gain layout
+    double xj;             // FLY: x_t[j] of this lane's column (the lanes holding a diagonal element of f_x need it)
 };
 
 // All loads are unconditional and branch-free (clamped lane offsets): the number of loads in flight is then a
@@ -57,15 +58,25 @@ struct TileRegs {
 // s_waitcnt vmcnt(N).  (A lane-conditional load makes the count path-dependent and degrades the wait to ~vmcnt(0),
 // which exposes a full HBM latency per time step.)  The record is a register image (layout.h): three 16-B/lane loads
 // fetch R0..R5, two 8-B/lane loads R6 and the [qr | q] row; policy evaluation adds one for its gain row.
-template <bool HASL, bool DUMP>
+template <bool HASL, bool DUMP, int FLY = 0>
 __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict__ tp, int l, int lx, int lq,
-                                          const double *__restrict__ Lp, const double *__restrict__ dlp, double mL, int g, int j) {
-    const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
-    const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);            // (loop-invariant per lane; dead lanes: the record's zero pair)
-    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = *reinterpret_cast<const double2 *>(tp + c34);
-    tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
-    tr.c[0] = w2.x; tr.c[1] = w2.y; tr.c[2] = tp[r5];
-    tr.c[3] = w1.y;
+                                          const double *__restrict__ Lp, const double *__restrict__ dlp, double mL, int g, int j,
+                                          const FlyCtx *fc = nullptr, int t = 0) {
+    if (FLY) {
+        tr.xj = fc->xh[(long)t * XSTR + ((j < 12) ? j : 11)];
+        if (FLY == 2) {
+            const double *__restrict__ C = fc->ctab + (long)t * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr.c[r] = C[64 * r + l];
+        }
+    } else {
+        const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
+        const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);            // (loop-invariant per lane; dead lanes: the record's zero pair)
+        const double2 w0 = t2[l], w1 = t2[64 + l], w2 = *reinterpret_cast<const double2 *>(tp + c34);
+        tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
+        tr.c[0] = w2.x; tr.c[1] = w2.y; tr.c[2] = tp[r5];
+        tr.c[3] = w1.y;
+    }
     tr.x = tp[TS_QR + lx];
     tr.la = 0.0;
     if (HASL) {
@@ -81,7 +92,7 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
 // wls: this wavefront's LDS scratch (WLS_SWEEP doubles).
 // SWZ: the elimination's row exchange through the LDS crossbar (ds_swizzle) instead of vector-ALU lane swaps: identical values, fewer
 // vector instructions, longer latency -- for the kernel that runs two samples per SIMD, which is short of issue slots, not of latency.
-template <bool GAIN, bool DUMP, bool WTV, bool HASL, bool SWZ = false>
+template <bool GAIN, bool DUMP, bool WTV, bool HASL, bool SWZ = false, int FLY = 0>
 __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, double *const wls) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase: keeps the per-lane constants of one phase from being shared with
@@ -120,6 +131,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
     double mu = (a.mode == 2) ? 0.0 : (a.mode == 3 ? a.mu_op : mu_in);
     const int N = st.N;
     const double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot) * st.tile_stride;
+    FlyCtx fc;
+    if (FLY) fly_init(fc, pb, st.xs + (long)slot * st.x_stride, l, g, j, FLY == 2);
     const int osel = (a.mode >= 4) ? (sel ^ 1) : sel;      // speculative sweeps fill the other half; committed by select
     const double *__restrict__ Lb = st.L + (long)sel * st.l_half + (long)b * N * LSTR;
     double *__restrict__ Lout = st.L + (long)osel * st.l_half + (long)b * N * LSTR;
@@ -200,8 +213,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
             if (l == 12) dp[DUMP_s] = 0.5 * v[3];
         }
         TileRegs nx;
-        load_tile<HASL, DUMP>(nx, tile0 + (long)(N - 1) * TSTRIDE, l, lx, lq, Lb + (long)(N - 1) * LSTR,
-                        a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, mL, g, j);
+        load_tile<HASL, DUMP, FLY>(nx, tile0 + (long)(N - 1) * TSTRIDE, l, lx, lq, Lb + (long)(N - 1) * LSTR,
+                        a.dl_in ? a.dl_in + (long)(N - 1) * USTR : nullptr, mL, g, j, &fc, N - 1);
         bool h_not_pd = false;
         // one backward step (ileqg.jl:361-391 / :435-460) on the tile registers `cur`; returns 0, 1 (M not PD), 2 (H not PD)
         auto step = [&](const int t, const TileRegs &cur) -> int {
@@ -219,9 +232,19 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
                 const double *ept = pb.epiv + (long)t * 16;
                 epall = ((((ept[0] * ept[2]) * ept[4]) * ept[6]) * ept[8]) * ept[10];
             }
+            // the step's tile: [A | B] and [[Q, 0], [P, R]] from the record, or (FLY) formed from x_t and the problem tables
+            d4 cz, ccs;
+            if (!FLY) { cz = cur.z; ccs = cur.c; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) cz[r] = fx_diag(fc.zt[r], fc.dg[r], fc.kappa, cur.xj);
+                cz[3] = 0.0;
+                if (FLY == 2) { ccs[0] = cur.c[0] * fc.mq; ccs[1] = cur.c[1] * fc.mq; ccs[2] = cur.c[2] * fc.mq; ccs[3] = cur.c[3]; }
+                else ccs = fc.cc;
+            }
             // X = V[:, 0:12] [A|B] (rows 0..11 = S [A|B], row 12 = s_vec'[A|B]).  Issued first: it does not depend on the
             // inverse, so the matrix pipe works through it while the VALU runs the elimination below.
-            const d4 xz = mm3(v, cur.z, (d4){0, 0, 0, 0});
+            const d4 xz = mm3(v, cz, (d4){0, 0, 0, 0});
             if (HASL) lbuf[l] = cur.la;                                     // rows of [L | dl] to every lane (read after the next fence)
             const double qc = readlane_f64(cur.x, 16);                      // c (ileqg.jl:296)
             d4 tm;
@@ -274,7 +297,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
                 tm = xz;
             }
             // F = [A|B]' T + [[Q,P'],[P,R]]  (:369-370 and the Q + A'DSA term of :390)
-            d4 f = mm3(cur.z, tm, cur.c);
+            d4 f = mm3(cz, tm, ccs);
             // H block: rows 12..15 of F live in register 3;  + mu I  (:370)
             const double gh = fma(mu, mH, f[3]);
             const double fv = tm[3] + cur.x;      // lanes g == 0: [q_vec + A' D s_vec | r + B' D s_vec]  (:368, :389)
@@ -363,15 +386,15 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
         for (int t = N - 1; t >= 0; t -= 2) {
             {
                 const int tn = (t > 0) ? t - 1 : 0;
-                load_tile<HASL, DUMP>(rb, tile0 + (long)tn * TSTRIDE, l, lx, lq, Lb + (long)tn * LSTR,
-                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g, j);
+                load_tile<HASL, DUMP, FLY>(rb, tile0 + (long)tn * TSTRIDE, l, lx, lq, Lb + (long)tn * LSTR,
+                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g, j, &fc, tn);
             }
             if (step(t, nx)) break;
             if (t == 0) break;
             {
                 const int tn = (t > 1) ? t - 2 : 0;
-                load_tile<HASL, DUMP>(nx, tile0 + (long)tn * TSTRIDE, l, lx, lq, Lb + (long)tn * LSTR,
-                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g, j);
+                load_tile<HASL, DUMP, FLY>(nx, tile0 + (long)tn * TSTRIDE, l, lx, lq, Lb + (long)tn * LSTR,
+                                a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g, j, &fc, tn);
             }
             if (step(t - 1, rb)) break;
         }
@@ -425,10 +448,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
 #undef SVB
 }
 
-template <bool GAIN, bool DUMP, bool WTV, bool HASL>
+template <bool GAIN, bool DUMP, bool WTV, bool HASL, int FLY = 0>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     __shared__ double wls[WLS_SWEEP];
-    sweep_body<GAIN, DUMP, WTV, HASL>(a, blockIdx.x, wls);
+    sweep_body<GAIN, DUMP, WTV, HASL, false, FLY>(a, blockIdx.x, wls);
 }
 
 template <bool GAIN, bool DUMP, bool HASL>
@@ -445,6 +468,15 @@ void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream
         else launch_sweep_w<true, false, false>(a, grid, s);
     } else if (a.mode == 2) {                      // initialize!: zero gains
         launch_sweep_w<false, false, false>(a, grid, s);
+    } else if (a.fly && a.mode == 1 && !dump) {    // candidates whose records hold only [c_x | c_u | c]: tiles formed in the sweep
+        const bool wtv = a.pb.W_tv != 0;
+        if (a.pb.cost_tv) {
+            if (wtv) hipLaunchKernelGGL((sweep_kernel<false, false, true, true, 2>), grid, dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((sweep_kernel<false, false, false, true, 2>), grid, dim3(64), 0, s, a);
+        } else {
+            if (wtv) hipLaunchKernelGGL((sweep_kernel<false, false, true, true, 1>), grid, dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((sweep_kernel<false, false, false, true, 1>), grid, dim3(64), 0, s, a);
+        }
     } else {
         if (dump) launch_sweep_w<false, true, true>(a, grid, s);
         else launch_sweep_w<false, false, true>(a, grid, s);
@@ -626,7 +658,11 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // time loop (57 loads in flight at once), so the loop issues no global loads at all and its tile stores never meet a vmcnt wait.
 // SEP (operand loads in the loop only): keep the steps of a group apart in the instruction schedule (see the time loop).
 // shxu: 16 doubles of this wavefront's LDS (terminal tile); stg: STG_DOUBLES of LDS shared by the waves of the workgroup (STAGE), else null
-template <int MODEL, int MODE, bool CTV, bool STAGE = false, bool SEP = true, int PF = ROLLIN_PREFETCH>
+// NOTILE (line-search candidates of the speculative path, LQ family): the step record keeps only [c_x | c_u], c and its zero pair; the
+// sweeps that evaluate the candidate form f_x | f_u and the cost Hessian of step t from (x_t, u_t) and the problem tables themselves
+// (load_tile<.., FLY>), and only an ACCEPTED candidate whose tiles a later gain sweep reads gets the rest of its records
+// (materialize_kernel) -- as the reference keeps approximate_model's result only for the trajectory it accepts (ileqg.jl:514-555).
+template <int MODEL, int MODE, bool CTV, bool STAGE = false, bool SEP = true, int PF = ROLLIN_PREFETCH, bool NOTILE = false>
 __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, double *const shxu, double *const stg = nullptr) {
     int lane_ = threadIdx.x & 63;        // (rollin_stage_kernel runs the E candidates of a sample as the waves of one workgroup)
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
@@ -835,14 +871,16 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
         // ---- tile of step t: approximate_model at (x_t, u_t)   (ileqg.jl:294-313) ---------------------
         if (lq) {
             // f_x = A + diag(3 kappa x^2) | f_u = B: the diagonal element of row 4 r + g sits on lane (g, 4 r + g), which holds x_{4r+g}
-            const double z0 = zt0 + dgz[0] * (3.0 * pb.kappa * (xb[0] * xb[0]));
-            const double z1 = zt1 + dgz[1] * (3.0 * pb.kappa * (xb[1] * xb[1]));
-            const double z2 = zt2 + dgz[2] * (3.0 * pb.kappa * (xb[2] * xb[2]));
-            double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
-            t2[l] = make_double2(z0, z1);
-            t2[64 + l] = make_double2(z2, cpr);
-            *reinterpret_cast<double2 *>(tp + c34) = make_double2(cq0, cq1);     // dead lanes: (0, 0) to the zero pair
-            tp[r5] = cq2;
+            if (!NOTILE) {
+                const double z0 = fx_diag(zt0, dgz[0], pb.kappa, xb[0]);
+                const double z1 = fx_diag(zt1, dgz[1], pb.kappa, xb[1]);
+                const double z2 = fx_diag(zt2, dgz[2], pb.kappa, xb[2]);
+                double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
+                t2[l] = make_double2(z0, z1);
+                t2[64 + l] = make_double2(z2, cpr);
+                *reinterpret_cast<double2 *>(tp + c34) = make_double2(cq0, cq1);     // dead lanes: (0, 0) to the zero pair
+                tp[r5] = cq2;
+            }
             d4 cx = MFMA(cf[0], xb[0], zero4);                      // C [x;u] in B-form
             cx = MFMA(cf[1], xb[1], cx);
             cx = MFMA(cf[2], xb[2], cx);
@@ -1163,9 +1201,9 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
             cq00 = pb.q0[t];
         }
         pxu[(long)t * sxu] = pk;
-        const double z0 = zt0 + dgz[0] * (3.0 * pb.kappa * (xb[0] * xb[0]));
-        const double z1 = zt1 + dgz[1] * (3.0 * pb.kappa * (xb[1] * xb[1]));
-        const double z2 = zt2 + dgz[2] * (3.0 * pb.kappa * (xb[2] * xb[2]));
+        const double z0 = fx_diag(zt0, dgz[0], pb.kappa, xb[0]);
+        const double z1 = fx_diag(zt1, dgz[1], pb.kappa, xb[1]);
+        const double z2 = fx_diag(zt2, dgz[2], pb.kappa, xb[2]);
         double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
         t2[l] = make_double2(z0, z1);
         t2[64 + l] = make_double2(z2, cpr);
@@ -1214,23 +1252,63 @@ __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
 // (L, xbar, l, dl), so the staged variant of rollin_body applies -- every wave copies the operands of the whole trajectory into the
 // workgroup's LDS area (identical values: benign overlap, each wave reads back what it wrote itself) and its time loop issues no
 // global load.  The unstaged kernel spends 60 % of its cycles in s_waitcnt on those loads (tools/profile_rollin.sh).
-template <int MODEL, bool CTV>
+template <int MODEL, bool CTV, bool NOTILE>
 __global__ __launch_bounds__(512) void rollin_stage_kernel(RolloutArgs a) {
     const int nb = (a.st.E + 7) >> 3;                           // workgroups per sample: eight candidates each
     const int b = blockIdx.x / nb, k = (blockIdx.x - b * nb) * 8 + (threadIdx.x >> 6);
     if (k >= a.st.E) return;
     __shared__ double shxu[8][16];
     __shared__ double stg[STG_DOUBLES];
-    rollin_body<MODEL, 1, CTV, true, false>(a, b * a.st.E + k, shxu[(threadIdx.x >> 6) & 7], stg);
+    rollin_body<MODEL, 1, CTV, true, false, ROLLIN_PREFETCH, NOTILE>(a, b * a.st.E + k, shxu[(threadIdx.x >> 6) & 7], stg);
 }
 
+// The rest of the step records of a trajectory whose candidate records hold only [c_x | c_u | c] (rollin_body<.., NOTILE>): f_x | f_u and
+// the cost Hessian, in the expressions of rollin_body's own stores.  Runs after the accept rule for the samples whose NEXT step! will read
+// the accepted trajectory's tiles with the plain gain sweep (no valid speculative sweep): approximate_model of step! (ileqg.jl:604) for
+// exactly the trajectories the reference keeps it for.  One wavefront per (sample, step).
+__global__ __launch_bounds__(256) void materialize_kernel(StateDev st, ProblemDev pb) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+    const int N = st.N;
+    const int nchunk = (N + 3) / 4;
+    const int b = blockIdx.x / nchunk;
+    const int t = (blockIdx.x - b * nchunk) * 4 + w;
+    if (t >= N) return;
+    if (st.status[b] != ST_RUNNING || st.ls_active[b] != 0) return;      // finished, or the next step!'s gain sweep is already committed
+    const int slot = b * (st.E + 1) + st.slot_nom[b];
+    const double *__restrict__ xp = st.xs + (long)slot * st.x_stride + (long)t * XSTR;
+    double *__restrict__ tp = st.tiles + tile_slot(st, b, slot) * st.tile_stride + (long)t * TSTRIDE;
+    const double mq = (j < 12) ? 1.0 : 0.0;
+    const double xj = xp[(j < 12) ? j : 11];
+    const double *__restrict__ C = pb.Ctab + (pb.cost_tv ? (long)t * 256 : 0);
+    double z[3], cf[4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) z[r] = fx_diag(pb.Zt[64 * r + l], (j == 4 * r + g) ? 1.0 : 0.0, pb.kappa, xj);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cf[r] = C[64 * r + l];
+    double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
+    t2[l] = make_double2(z[0], z[1]);
+    t2[64 + l] = make_double2(z[2], cf[3]);
+    *reinterpret_cast<double2 *>(tp + TS_REG(3, l)) = make_double2(cf[0] * mq, cf[1] * mq);     // dead lanes: (0, 0) to the zero pair
+    tp[TS_REG(5, l)] = cf[2] * mq;
+}
+void launch_materialize(const StateDev &st, const ProblemDev &pb, hipStream_t s) {
+    if (st.B <= 0) return;
+    hipLaunchKernelGGL(materialize_kernel, dim3(st.B * ((st.N + 3) / 4)), dim3(256), 0, s, st, pb);
+}
+
+bool rollin_notile_supported(const ProblemDev &pb, const StateDev &st) { return pb.model == 1 && st.E > 1 && st.N <= ROLLIN_NST; }
 void launch_rollin(const RolloutArgs &a, hipStream_t s) {
     const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
     if (ncand <= 0) return;
     if (a.mode == 1 && a.pb.model == 1 && a.st.E > 1 && a.st.N <= ROLLIN_NST) {
         const dim3 g2(a.st.B * ((a.st.E + 7) / 8)), b2(64 * (a.st.E < 8 ? a.st.E : 8));
-        if (a.pb.cost_tv) hipLaunchKernelGGL((rollin_stage_kernel<1, true>), g2, b2, 0, s, a);
-        else hipLaunchKernelGGL((rollin_stage_kernel<1, false>), g2, b2, 0, s, a);
+        if (a.notile) {
+            if (a.pb.cost_tv) hipLaunchKernelGGL((rollin_stage_kernel<1, true, true>), g2, b2, 0, s, a);
+            else hipLaunchKernelGGL((rollin_stage_kernel<1, false, true>), g2, b2, 0, s, a);
+        } else {
+            if (a.pb.cost_tv) hipLaunchKernelGGL((rollin_stage_kernel<1, true, false>), g2, b2, 0, s, a);
+            else hipLaunchKernelGGL((rollin_stage_kernel<1, false, false>), g2, b2, 0, s, a);
+        }
         return;
     }
     const dim3 grid(ncand), block(64);
@@ -1719,11 +1797,18 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         if (threadIdx.x == 0) {
             const int ticket = atomicAdd(&fa.census[hw_cu_key()], 1);
             const int odd = ticket & 1, flip = (ticket >> 1) & 1;
+            // The SIMD-derived roles need the four waves on four DISTINCT SIMDs.  The dispatcher gives that to a 256-thread workgroup
+            // on an otherwise empty CU, but not when another kernel is resident on it (a second handle or stream, RCCL, a framework
+            // kernel): two waves may then share a SIMD, and roles read off the SIMD ids would leave the workgroup without a leader or
+            // without a gain wave.  Anything but a permutation of 0..3 falls back to roles by wave index.
+            unsigned seen = 0;
+            for (int w = 0; w < 4; ++w) seen |= 1u << (s_simd[w] & 3);
+            const bool distinct = (seen == 0xFu);
             for (int w = 0; w < 4; ++w) {
                 const int sid = s_simd[w];
                 const bool in_pair = odd ? (sid == 1 || sid == 3) : (sid == 0 || sid == 2);
                 const bool first = odd ? (sid == 1) : (sid == 0);
-                s_role[w] = in_pair ? ((first != (flip != 0)) ? 0 : 1) : -1;
+                s_role[w] = distinct ? (in_pair ? ((first != (flip != 0)) ? 0 : 1) : -1) : (w < 2 ? w : -1);
             }
             if (HELP && fa.helpers) {            // one workgroup per CU: all four SIMDs are this sample's
                 int next = 2;
@@ -1732,7 +1817,10 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         }
         __syncthreads();
         wave = __builtin_amdgcn_readfirstlane(s_role[hwave]);
-        if (wave < 0) return;                    // (an ended wave no longer takes part in the workgroup's barriers)
+        // (an ended wave no longer takes part in the workgroup's barriers: s_barrier on gfx9 / CDNA counts the waves of the workgroup that
+        //  are still alive -- validated on gfx950 (tools/stress_block.py); HIP leaves a barrier not reached by every thread undefined,
+        //  so this early exit must be revisited for any other target)
+        if (wave < 0) return;
     }
     const bool leader = (wave == 0) && ((threadIdx.x & 63) == 0);
 #ifdef RAT_DIAG_PHASES

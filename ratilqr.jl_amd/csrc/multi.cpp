@@ -9,8 +9,14 @@
 //   * ONE ncclAllGather (RCCL over xGMI) of the per-sample costs, ordered on those same streams inside one ncclGroup, leaves cost[B] on
 //     every device -- B/G doubles per rank, latency-bound, nothing else crosses devices -- and device 0's copy goes back to the host;
 //   * elite selection (rat_ce_update) is host arithmetic, the final solve at theta_opt is a single trajectory on device 0.
+//   * the gathered record of a sample is its cost AND its status, iteration count and line-search count: every rank
+//     contributes ONE byte block [cost f64 x chunk | status, iters, ls_evals i32 x chunk], so it is still one collective per batch.
 // RCCL (librccl.so, 570 MB) is loaded with dlopen the first time a rat_multi with more than one device is created: single-GPU users of
 // libratilqr_hip.so never pay for it (RATILQR_MULTI_FORCE_RCCL=1 runs the collective with a one-rank communicator: test hook).
+// RATILQR_MULTI_LOGICAL=1 (test hook for a one-GPU box): the G "devices" are logical -- device index d runs on physical device d mod the
+// number visible, several handles per GPU, each with its own stream -- and the all-gather is carried out by stream-ordered device copies
+// into the very slots d_all[g] + r * block that RCCL would fill (RCCL refuses two ranks on one GPU).  Everything else -- shard bounds,
+// ragged pads, per-device enqueue, offsets of the read-back -- is the code a real G-device node runs.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -26,7 +32,7 @@
 // the handful of RCCL entry points used, resolved at run time (signatures: /opt/rocm/include/rccl/rccl.h)
 typedef struct ncclComm *ncclComm_t;
 typedef int ncclResult_t;
-enum { NCCL_SUCCESS_ = 0, NCCL_FLOAT64_ = 8 };      // ncclSuccess, ncclFloat64 / ncclDouble
+enum { NCCL_SUCCESS_ = 0, NCCL_INT8_ = 0, NCCL_FLOAT64_ = 8 };      // ncclSuccess, ncclInt8 / ncclChar, ncclFloat64 / ncclDouble
 struct Rccl {
     void *so = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
@@ -40,6 +46,8 @@ static Rccl g_rccl;
 
 void rat_set_error(const char *msg);                // driver.cpp: thread-local message behind rat_last_error()
 bool rat_batch_is_single_launch(rat_handle h, int64_t B);   // driver.cpp
+rat_rc rat_batch_outputs_dev(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, bool as_value, double *cost_dev, int32_t *status_dev,
+                             int32_t *iters_dev, int32_t *ls_dev, bool wait);                    // driver.cpp
 static rat_rc mfail(rat_rc rc, const std::string &m) { rat_set_error(m.c_str()); return rc; }
 #define MHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mfail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 #define MRC(expr) do { rat_rc r_ = (expr); if (r_ != RAT_OK) return r_; } while (0)
@@ -71,12 +79,18 @@ struct rat_multi_s {
     std::vector<int> dev;
     std::vector<rat_handle> h;
     std::vector<ncclComm_t> comm;                   // empty: no RCCL (one device)
-    std::vector<double *> d_theta, d_cost, d_all;   // per device: theta shard [chunk_max], cost shard [chunk_max], gathered [G * chunk_max]
-    double *h_stage = nullptr;                      // pinned: theta (Bmax) | gathered costs (G * chunk_max)
+    bool logical = false;                           // RATILQR_MULTI_LOGICAL=1: several handles per GPU, all-gather by device copies
+    std::vector<hipEvent_t> ev;                     // per device: "this device's block is complete" (copy-based gather)
+    std::vector<double *> d_theta;                  // per device: theta shard [chunk_max]
+    std::vector<char *> d_send, d_all;              // per device: its block [block_bytes(chunk_max)], the gathered blocks [G * block_bytes(chunk_max)]
+    char *h_stage = nullptr;                        // pinned: theta (Bmax doubles) | gathered blocks (G * block_bytes(chunk_max))
     double *h_pets = nullptr; size_t pets_cap = 0;  // pinned: PETS per-sample costs
     int pets_n = 0, pets_m = 0, pets_N = 0;
     int64_t n_allgathers = 0;
 };
+
+// one rank's contribution to the all-gather: [cost f64 x chunk | status i32 x chunk | iters i32 x chunk | ls_evals i32 x chunk], 8-B aligned
+static inline size_t block_bytes(int64_t chunk) { return ((size_t)chunk * 20 + 7) & ~(size_t)7; }
 
 extern "C" rat_rc rat_shard_bounds(int64_t B, int32_t world, int32_t rank, int64_t *lo, int64_t *hi) {
     if (B < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return mfail(RAT_ERR_ARG, "rat_shard_bounds: bad arguments");
@@ -92,7 +106,9 @@ extern "C" void rat_multi_destroy(rat_multi m) {
         (void)hipSetDevice(m->dev[g]);
         if (m->h[g]) (void)hipStreamSynchronize((hipStream_t)rat_stream(m->h[g]));
         if (g < (int)m->comm.size() && m->comm[g]) (void)g_rccl.CommDestroy(m->comm[g]);
-        for (auto *v : {&m->d_theta, &m->d_cost, &m->d_all}) if (g < (int)v->size() && (*v)[g]) (void)hipFree((*v)[g]);
+        if (g < (int)m->d_theta.size() && m->d_theta[g]) (void)hipFree(m->d_theta[g]);
+        for (auto *v : {&m->d_send, &m->d_all}) if (g < (int)v->size() && (*v)[g]) (void)hipFree((*v)[g]);
+        if (g < (int)m->ev.size() && m->ev[g]) (void)hipEventDestroy(m->ev[g]);
         if (m->h[g]) rat_destroy(m->h[g]);
     }
     if (m->h_stage) (void)hipHostFree(m->h_stage);
@@ -105,28 +121,34 @@ extern "C" rat_rc rat_create_multi(const rat_ileqg_opts *opts, int32_t max_batch
     if (!out || max_batch < 1 || n_devices < 1) return mfail(RAT_ERR_ARG, "rat_create_multi: bad max_batch / n_devices");
     int ndev = 0;
     MHIP(hipGetDeviceCount(&ndev));
-    if (n_devices > ndev) return mfail(RAT_ERR_ARG, "rat_create_multi: more devices requested than are visible (there is no CPU fallback)");
+    if (ndev < 1) return mfail(RAT_ERR_HIP, "rat_create_multi: no HIP device (this library has no CPU fallback)");
+    const char *lg = getenv("RATILQR_MULTI_LOGICAL");
+    const bool logical = lg && lg[0] == '1';
+    if (n_devices > ndev && !logical) return mfail(RAT_ERR_ARG, "rat_create_multi: more devices requested than are visible (there is no CPU fallback)");
     rat_multi m = new rat_multi_s();
+    m->logical = logical;
     m->G = n_devices; m->Bmax = max_batch; m->chunk_max = (max_batch + n_devices - 1) / n_devices;
     m->h.assign(n_devices, nullptr);
     for (int g = 0; g < n_devices; ++g) {
-        const int d = devices ? devices[g] : g;
-        if (d < 0 || d >= ndev) { rat_multi_destroy(m); return mfail(RAT_ERR_ARG, "rat_create_multi: bad device index"); }
-        for (int q = 0; q < g; ++q) if (m->dev[q] == d) { rat_multi_destroy(m); return mfail(RAT_ERR_ARG, "rat_create_multi: device listed twice"); }
-        m->dev.push_back(d);
+        int d = devices ? devices[g] : g;
+        if (d < 0 || (d >= ndev && !logical)) { rat_multi_destroy(m); return mfail(RAT_ERR_ARG, "rat_create_multi: bad device index"); }
+        if (!logical) for (int q = 0; q < g; ++q) if (m->dev[q] == d) { rat_multi_destroy(m); return mfail(RAT_ERR_ARG, "rat_create_multi: device listed twice"); }
+        m->dev.push_back(logical ? d % ndev : d);
     }
-    m->d_theta.assign(n_devices, nullptr); m->d_cost.assign(n_devices, nullptr); m->d_all.assign(n_devices, nullptr);
+    m->d_theta.assign(n_devices, nullptr); m->d_send.assign(n_devices, nullptr); m->d_all.assign(n_devices, nullptr);
+    m->ev.assign(n_devices, nullptr);
 #define MCREATE(expr) do { if ((expr) != 0) { rat_multi_destroy(m); return mfail(RAT_ERR_HIP, std::string("rat_create_multi: ") + #expr + " failed: " + rat_last_error()); } } while (0)
     for (int g = 0; g < n_devices; ++g) {
         MCREATE(rat_create(opts, m->chunk_max, spec_eps, m->dev[g], &m->h[g]));
         MCREATE((int)hipSetDevice(m->dev[g]));
         MCREATE((int)hipMalloc((void **)&m->d_theta[g], sizeof(double) * m->chunk_max));
-        MCREATE((int)hipMalloc((void **)&m->d_cost[g], sizeof(double) * m->chunk_max));
-        MCREATE((int)hipMalloc((void **)&m->d_all[g], sizeof(double) * m->chunk_max * n_devices));
+        MCREATE((int)hipMalloc((void **)&m->d_send[g], block_bytes(m->chunk_max)));
+        MCREATE((int)hipMalloc((void **)&m->d_all[g], block_bytes(m->chunk_max) * n_devices));
+        MCREATE((int)hipEventCreateWithFlags(&m->ev[g], hipEventDisableTiming));
     }
-    MCREATE((int)hipHostMalloc((void **)&m->h_stage, sizeof(double) * ((size_t)max_batch + (size_t)m->chunk_max * n_devices), hipHostMallocDefault));
+    MCREATE((int)hipHostMalloc((void **)&m->h_stage, sizeof(double) * (size_t)max_batch + block_bytes(m->chunk_max) * n_devices, hipHostMallocDefault));
     const char *force = getenv("RATILQR_MULTI_FORCE_RCCL");
-    if (n_devices > 1 || (force && force[0] == '1')) {
+    if (!logical && (n_devices > 1 || (force && force[0] == '1'))) {
         rat_rc rc = load_rccl();
         if (rc) { rat_multi_destroy(m); return rc; }
         m->comm.assign(n_devices, nullptr);
@@ -142,6 +164,7 @@ extern "C" int32_t rat_multi_n_devices(rat_multi m) { return m ? m->G : 0; }
 extern "C" rat_handle rat_multi_handle(rat_multi m, int32_t i) { return (m && i >= 0 && i < m->G) ? m->h[i] : nullptr; }
 extern "C" int64_t rat_multi_allgathers(rat_multi m) { return m ? m->n_allgathers : -1; }
 extern "C" int32_t rat_multi_uses_rccl(rat_multi m) { return (m && !m->comm.empty()) ? 1 : 0; }
+extern "C" int32_t rat_multi_is_logical(rat_multi m) { return (m && m->logical) ? 1 : 0; }
 
 extern "C" rat_rc rat_multi_problem_set(rat_multi m, const rat_problem_desc *d) {
     if (!m || !d) return mfail(RAT_ERR_ARG, "null");
@@ -154,78 +177,135 @@ extern "C" rat_rc rat_multi_set_initial(rat_multi m, const double *x0, const dou
     return RAT_OK;
 }
 
-// compute_cost (cross_entropy_bilevel_optimization.jl:173-195) over all devices: cost_i = value_i + kl_bound / theta_i, +Inf for failures.
-extern "C" rat_rc rat_multi_ce_compute_cost(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B, double kl_bound,
-                                            double *cost) {
+// On any failure after work has been enqueued: wait for every device before handing control back (other devices' launches are still
+// reading d_theta and the pinned stage).
+static void sync_all(rat_multi m) {
+    for (int g = 0; g < m->G; ++g) {
+        if (hipSetDevice(m->dev[g]) != hipSuccess) continue;
+        (void)hipStreamSynchronize((hipStream_t)rat_stream(m->h[g]));
+    }
+}
+
+// compute_cost (cross_entropy_bilevel_optimization.jl:173-195) over all devices: cost_i = value_i + kl_bound / theta_i, +Inf for failures;
+// with the per-sample status / iteration count / line-search count of every shard gathered beside the costs (any of them may be NULL).
+static rat_rc multi_batch(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B, double kl_bound, bool as_value,
+                          double *cost, int32_t *status, int32_t *iters, int32_t *ls_evals) {
     if (!m || !theta || !cost) return mfail(RAT_ERR_ARG, "null");
     if (B < 1 || B > m->Bmax) return mfail(RAT_ERR_ARG, "batch size exceeds max_batch of rat_create_multi");
     if (x0 && u0) MRC(rat_multi_set_initial(m, x0, u0));
     const int G = m->G;
     const int64_t chunk = (B + G - 1) / G;
-    double *p_theta = m->h_stage, *p_all = m->h_stage + m->Bmax;
+    const size_t bb = block_bytes(chunk);                        // one rank's block in this batch
+    double *p_theta = reinterpret_cast<double *>(m->h_stage);
+    char *p_all = m->h_stage + sizeof(double) * (size_t)m->Bmax;
     memcpy(p_theta, theta, sizeof(double) * B);
-    const double nan = std::nan("");
-    bool polled = false;
+    std::vector<int64_t> lo((size_t)G), hi((size_t)G);
+    for (int g = 0; g < G; ++g) MRC(rat_shard_bounds(B, G, g, &lo[(size_t)g], &hi[(size_t)g]));
+    auto sect = [&](int g, int which) {                          // sections of device g's block: 0 cost, 1 status, 2 iters, 3 ls_evals
+        return m->d_send[g] + (which == 0 ? 0 : (size_t)chunk * 8 + (size_t)(which - 1) * (size_t)chunk * 4);
+    };
+    std::vector<int> polled;
+    rat_rc rc = RAT_OK;
     // every device: its theta block in, its solves enqueued -- all asynchronous on the device's own stream, no host wait in this loop
-    for (int g = 0; g < G; ++g) {
-        int64_t lo, hi;
-        MRC(rat_shard_bounds(B, G, g, &lo, &hi));
-        MHIP(hipSetDevice(m->dev[g]));
+    for (int g = 0; g < G && rc == RAT_OK; ++g) {
+        const int64_t nb = hi[(size_t)g] - lo[(size_t)g];
+        if (hipSetDevice(m->dev[g]) != hipSuccess) { rc = mfail(RAT_ERR_HIP, "hipSetDevice failed"); break; }
         hipStream_t s = (hipStream_t)rat_stream(m->h[g]);
-        if (hi - lo < chunk) {                                   // pad slots of a short (or empty) block: NaN, never read back
-            std::vector<double> pad((size_t)chunk, nan);
-            MHIP(hipMemcpyAsync(m->d_cost[g], pad.data(), sizeof(double) * chunk, hipMemcpyHostToDevice, s));
-            MHIP(hipStreamSynchronize(s));                       // (pad is a stack-lifetime buffer; ragged batches only)
-        }
-        if (hi > lo) {
-            MHIP(hipMemcpyAsync(m->d_theta[g], p_theta + lo, sizeof(double) * (hi - lo), hipMemcpyHostToDevice, s));
-            if (rat_batch_is_single_launch(m->h[g], hi - lo)) MRC(rat_ce_compute_cost_enqueue(m->h[g], m->d_theta[g], hi - lo, kl_bound, m->d_cost[g]));
-            else polled = true;
+        // pad slots of a short (or empty) block: all-ones bytes (NaN costs, -1 counters), never read back; filled on the device, in
+        // stream order before the solves -- no host buffer, no wait (ragged batches only)
+        if (nb < chunk && hipMemsetAsync(m->d_send[g], 0xFF, bb, s) != hipSuccess) { rc = mfail(RAT_ERR_HIP, "hipMemsetAsync failed"); break; }
+        if (nb > 0) {
+            if (hipMemcpyAsync(m->d_theta[g], p_theta + lo[(size_t)g], sizeof(double) * nb, hipMemcpyHostToDevice, s) != hipSuccess) {
+                rc = mfail(RAT_ERR_HIP, "hipMemcpyAsync(theta) failed"); break;
+            }
+            if (rat_batch_is_single_launch(m->h[g], nb))
+                rc = rat_batch_outputs_dev(m->h[g], m->d_theta[g], nb, kl_bound, as_value, (double *)sect(g, 0), (int32_t *)sect(g, 1), (int32_t *)sect(g, 2),
+                                           (int32_t *)sect(g, 3), false);
+            else polled.push_back(g);
         }
     }
-    if (polled) {
+    if (rc != RAT_OK) { sync_all(m); return rc; }
+    if (!polled.empty()) {
         // Shards on the round-based path (speculative step sizes on a shard too large for one generation of workgroups): its host loop
         // polls the device between rounds, so one calling thread would process the devices one after the other.  A helper thread per
-        // such device instead, joined before the collective; their error messages come back through rc / msg.
-        std::vector<std::thread> th;
-        std::vector<rat_rc> rcs((size_t)G, RAT_OK);
-        std::vector<std::string> msgs((size_t)G);
-        for (int g = 0; g < G; ++g) {
-            int64_t lo, hi;
-            MRC(rat_shard_bounds(B, G, g, &lo, &hi));
-            if (hi <= lo || rat_batch_is_single_launch(m->h[g], hi - lo)) continue;
-            th.emplace_back([m, g, lo, hi, kl_bound, &rcs, &msgs]() {
-                if (hipSetDevice(m->dev[g]) != hipSuccess) { rcs[(size_t)g] = RAT_ERR_HIP; msgs[(size_t)g] = "hipSetDevice failed in a shard thread"; return; }
-                rcs[(size_t)g] = rat_ce_compute_cost_dev(m->h[g], m->d_theta[g], hi - lo, kl_bound, m->d_cost[g]);
-                if (rcs[(size_t)g] != RAT_OK) msgs[(size_t)g] = rat_last_error();
-            });
+        // such device instead, ALWAYS joined before anything else happens; their error messages come back through rcs / msgs.
+        std::vector<rat_rc> rcs(polled.size(), RAT_OK);
+        std::vector<std::string> msgs(polled.size());
+        {
+            std::vector<std::thread> th;
+            struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{th};
+            th.reserve(polled.size());                           // (no reallocation, and a throwing emplace_back still joins what runs)
+            for (size_t q = 0; q < polled.size(); ++q) {
+                const int g = polled[q];
+                const int64_t nb = hi[(size_t)g] - lo[(size_t)g];
+                double *c_ = (double *)sect(g, 0); int32_t *s_ = (int32_t *)sect(g, 1), *i_ = (int32_t *)sect(g, 2), *l_ = (int32_t *)sect(g, 3);
+                th.emplace_back([m, g, q, nb, kl_bound, as_value, c_, s_, i_, l_, &rcs, &msgs]() {
+                    if (hipSetDevice(m->dev[g]) != hipSuccess) { rcs[q] = RAT_ERR_HIP; msgs[q] = "hipSetDevice failed in a shard thread"; return; }
+                    rcs[q] = rat_batch_outputs_dev(m->h[g], m->d_theta[g], nb, kl_bound, as_value, c_, s_, i_, l_, true);
+                    if (rcs[q] != RAT_OK) msgs[q] = rat_last_error();
+                });
+            }
         }
-        for (auto &t : th) t.join();
-        for (int g = 0; g < G; ++g) if (rcs[(size_t)g] != RAT_OK) return mfail(rcs[(size_t)g], msgs[(size_t)g]);
+        for (size_t q = 0; q < polled.size(); ++q) if (rcs[q] != RAT_OK) { sync_all(m); return mfail(rcs[q], msgs[q]); }
     }
     if (!m->comm.empty()) {
-        // ONE collective per batch: every rank contributes `chunk` doubles and receives G * chunk, ordered behind its solves on its stream
-        MNCCL(g_rccl.GroupStart());
-        for (int g = 0; g < G; ++g)
-            MNCCL(g_rccl.AllGather(m->d_cost[g], m->d_all[g], (size_t)chunk, NCCL_FLOAT64_, m->comm[g], (hipStream_t)rat_stream(m->h[g])));
-        MNCCL(g_rccl.GroupEnd());
+        // ONE collective per batch: every rank contributes its block of `bb` bytes and receives G of them, ordered behind its solves on its stream
+        ncclResult_t e = g_rccl.GroupStart();
+        for (int g = 0; g < G && e == NCCL_SUCCESS_; ++g)
+            e = g_rccl.AllGather(m->d_send[g], m->d_all[g], bb, NCCL_INT8_, m->comm[g], (hipStream_t)rat_stream(m->h[g]));
+        const ncclResult_t e2 = g_rccl.GroupEnd();
+        if (e == NCCL_SUCCESS_) e = e2;
+        if (e != NCCL_SUCCESS_) { sync_all(m); return mfail(RAT_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(e)); }
         m->n_allgathers++;
-        MHIP(hipSetDevice(m->dev[0]));
-        MHIP(hipMemcpyAsync(p_all, m->d_all[0], sizeof(double) * chunk * G, hipMemcpyDeviceToHost, (hipStream_t)rat_stream(m->h[0])));
-    } else {                                                     // one device, no communicator: its block is the batch
-        MHIP(hipSetDevice(m->dev[0]));
-        MHIP(hipMemcpyAsync(p_all, m->d_cost[0], sizeof(double) * chunk, hipMemcpyDeviceToHost, (hipStream_t)rat_stream(m->h[0])));
+    } else if (G > 1) {
+        // logical devices (or no communicator): the same data movement by device copies.  Block r is complete when r's stream reaches
+        // its event; every destination stream waits for every source before it copies block r into slot r of its gathered buffer.
+        for (int r = 0; r < G; ++r) {
+            MHIP(hipSetDevice(m->dev[r]));
+            MHIP(hipEventRecord(m->ev[r], (hipStream_t)rat_stream(m->h[r])));
+        }
+        for (int g = 0; g < G; ++g) {
+            MHIP(hipSetDevice(m->dev[g]));
+            hipStream_t s = (hipStream_t)rat_stream(m->h[g]);
+            for (int r = 0; r < G; ++r) {
+                if (r != g) MHIP(hipStreamWaitEvent(s, m->ev[r], 0));
+                MHIP(hipMemcpyAsync(m->d_all[g] + (size_t)r * bb, m->d_send[r], bb, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        m->n_allgathers++;
     }
+    MHIP(hipSetDevice(m->dev[0]));
+    if (G > 1 || !m->comm.empty()) MHIP(hipMemcpyAsync(p_all, m->d_all[0], bb * G, hipMemcpyDeviceToHost, (hipStream_t)rat_stream(m->h[0])));
+    else MHIP(hipMemcpyAsync(p_all, m->d_send[0], bb, hipMemcpyDeviceToHost, (hipStream_t)rat_stream(m->h[0])));   // one device, no communicator
     for (int g = 0; g < G; ++g) {                                // (every device must have finished its part of the collective)
         MHIP(hipSetDevice(m->dev[g]));
         MHIP(hipStreamSynchronize((hipStream_t)rat_stream(m->h[g])));
     }
     for (int g = 0; g < G; ++g) {
-        int64_t lo, hi;
-        MRC(rat_shard_bounds(B, G, g, &lo, &hi));
-        memcpy(cost + lo, p_all + (size_t)g * chunk, sizeof(double) * (hi - lo));
+        const size_t nb = (size_t)(hi[(size_t)g] - lo[(size_t)g]);
+        const char *blk = p_all + (size_t)g * bb;
+        memcpy(cost + lo[(size_t)g], blk, sizeof(double) * nb);
+        if (status) memcpy(status + lo[(size_t)g], blk + (size_t)chunk * 8, 4 * nb);
+        if (iters) memcpy(iters + lo[(size_t)g], blk + (size_t)chunk * 12, 4 * nb);
+        if (ls_evals) memcpy(ls_evals + lo[(size_t)g], blk + (size_t)chunk * 16, 4 * nb);
     }
     return RAT_OK;
+}
+
+extern "C" rat_rc rat_multi_ce_compute_cost_ex(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B, double kl_bound,
+                                               double *cost, int32_t *status, int32_t *iters, int32_t *ls_evals) {
+    return multi_batch(m, x0, u0, theta, B, kl_bound, false, cost, status, iters, ls_evals);
+}
+extern "C" rat_rc rat_multi_ce_compute_cost(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B, double kl_bound,
+                                            double *cost) {
+    return multi_batch(m, x0, u0, theta, B, kl_bound, false, cost, nullptr, nullptr, nullptr);
+}
+
+// The batch entry point of one handle (rat_ileqg_solve_batch; compute_value_worker over a batch, :144-167) over all devices: value (+Inf for
+// failures), status, iterations and line-search evaluations of every sample.
+extern "C" rat_rc rat_multi_ileqg_solve_batch(rat_multi m, const double *x0, const double *u0, const double *theta, int64_t B, double *value,
+                                              int32_t *status, int32_t *iters, int32_t *ls_evals) {
+    return multi_batch(m, x0, u0, theta, B, 0.0, true, value, status, iters, ls_evals);
 }
 
 // PETS (pets.jl:100-126): the S control samples of compute_cost split in contiguous blocks over the devices, all K stochastic rollouts of a

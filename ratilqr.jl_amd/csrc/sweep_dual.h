@@ -20,21 +20,57 @@
 #include "kernels.h"
 #include "layout.h"
 
+// FLY sweeps (policy evaluation of the speculative path's line-search candidates, LQ family): the record of a candidate holds only its
+// [c_x | c_u | c] row (rollin_body<.., NOTILE>); f_x | f_u and the cost Hessian of step t are formed here from x_t and the problem tables --
+// the expressions of the rollout kernels' tile stores, so the registers hold the bits a materialised record would have delivered.
+// FLY: 0 records are complete, 1 time-invariant cost tables (register images, loaded once), 2 time-varying cost tables (loaded per step)
+struct FlyCtx {
+    double zt[3], dg[3];   // register image of [A | B]; 1 on the lane that holds the diagonal element of f_x in that register
+    d4 cc;                 // register image of [[Q, 0], [P, R]] (FLY == 1)
+    double mq, kappa;
+    const double *xh;      // state history of the trajectory
+    const double *ctab;    // FLY == 2
+};
+__device__ __forceinline__ void fly_init(FlyCtx &fc, const ProblemDev &pb, const double *xh, int l, int g, int j, bool tv) {
+    fc.mq = (j < 12) ? 1.0 : 0.0;
+    fc.kappa = pb.kappa;
+    fc.xh = xh;
+    fc.ctab = pb.Ctab;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { fc.zt[r] = pb.Zt[64 * r + l]; fc.dg[r] = (j == 4 * r + g) ? 1.0 : 0.0; }
+    fc.cc = (d4){0, 0, 0, 0};
+    if (!tv) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) fc.cc[r] = pb.Ctab[64 * r + l] * fc.mq;
+        fc.cc[3] = pb.Ctab[192 + l];
+    }
+}
+
 struct DTile {
     d4 z, c;
     double x, la;          // x: lanes 0..15 = qr, lane 16 = q (register-image record, layout.h); la: own entry L[g][j] of the gain row block
+    double xj;             // FLY: x_t[j] of this lane's column
 };
 
 // HASL: recursion A evaluates a given policy (mode 7); false for initialize!'s open-loop sweep (mode 6: all gains zero, nothing to load)
-template <bool HASL>
+template <bool HASL, int FLY = 0>
 __device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, int lx, int l, int j,
-                                      const double *__restrict__ Lp, double mL, int g) {
-    const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
-    const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);            // (loop-invariant per lane; dead lanes: the record's zero pair)
-    const double2 w0 = t2[l], w1 = t2[64 + l], w2 = *reinterpret_cast<const double2 *>(tp + c34);
-    tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
-    tr.c[0] = w2.x; tr.c[1] = w2.y; tr.c[2] = tp[r5];
-    tr.c[3] = w1.y;
+                                      const double *__restrict__ Lp, double mL, int g, const FlyCtx *fc = nullptr, int t = 0) {
+    if (FLY) {
+        tr.xj = fc->xh[(long)t * XSTR + ((j < 12) ? j : 11)];
+        if (FLY == 2) {
+            const double *__restrict__ C = fc->ctab + (long)t * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr.c[r] = C[64 * r + l];
+        }
+    } else {
+        const double2 *__restrict__ t2 = reinterpret_cast<const double2 *>(tp);
+        const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);            // (loop-invariant per lane; dead lanes: the record's zero pair)
+        const double2 w0 = t2[l], w1 = t2[64 + l], w2 = *reinterpret_cast<const double2 *>(tp + c34);
+        tr.z[0] = w0.x; tr.z[1] = w0.y; tr.z[2] = w1.x; tr.z[3] = 0.0;
+        tr.c[0] = w2.x; tr.c[1] = w2.y; tr.c[2] = tp[r5];
+        tr.c[3] = w1.y;
+    }
     tr.x = tp[TS_QR + lx];
     const int jc = (j < 12) ? j : 11;
     tr.la = HASL ? Lp[g * 12 + jc] * mL : 0.0;
@@ -43,7 +79,7 @@ __device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, 
 // The elimination rounds of the two recursions are the shared elim_round (device_utils.h: rank-2 update on the matrix pipe, no LDS,
 // no fence), issued back to back: two independent pivot chains for the scheduler to interleave.
 // wls: this wavefront's LDS scratch (WLS_DUAL doubles)
-template <bool WTV, bool HASL>
+template <bool WTV, bool HASL, int FLY = 0>
 __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b, double *const wls) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
@@ -70,6 +106,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
     const double muA = (a.mode == 6) ? 0.0 : muB;
     const int N = st.N;
     const double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot) * st.tile_stride;
+    FlyCtx fc;
+    if (FLY) fly_init(fc, pb, st.xs + (long)slot * st.x_stride, l, g, j, FLY == 2);
     const double *__restrict__ Lb = st.L + (long)sel * st.l_half + (long)b * N * LSTR;
     double *__restrict__ Lout = st.L + (long)(sel ^ 1) * st.l_half + (long)b * N * LSTR;
     double *__restrict__ dlout = st.dl + (long)(sel ^ 1) * st.dl_half + (long)b * N * USTR;
@@ -132,8 +170,17 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             for (int r = 0; r < 3; ++r) { winv[r] = pb.Winv[(long)t * 192 + 64 * r + l]; wp[r] = pb.Wp[(long)t * 192 + 64 * r + l]; }
             { const double *ept = pb.epiv + (long)t * 16; epall = ((((ept[0] * ept[2]) * ept[4]) * ept[6]) * ept[8]) * ept[10]; }
         }
-        const d4 xzA = mm3(vA, cur.z, (d4){0, 0, 0, 0});
-        const d4 xzB = mm3(vB, cur.z, (d4){0, 0, 0, 0});
+        d4 cz, ccs;                                                  // the step's tile: from the record, or (FLY) formed here (see FlyCtx)
+        if (!FLY) { cz = cur.z; ccs = cur.c; }
+        else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cz[r] = fx_diag(fc.zt[r], fc.dg[r], fc.kappa, cur.xj);
+            cz[3] = 0.0;
+            if (FLY == 2) { ccs[0] = cur.c[0] * fc.mq; ccs[1] = cur.c[1] * fc.mq; ccs[2] = cur.c[2] * fc.mq; ccs[3] = cur.c[3]; }
+            else ccs = fc.cc;
+        }
+        const d4 xzA = mm3(vA, cz, (d4){0, 0, 0, 0});
+        const d4 xzB = mm3(vB, cz, (d4){0, 0, 0, 0});
         d4 tmA, tmB;
         if (theta != 0.0) {
             exA[svo] = vA[3]; exB[svo] = vB[3];
@@ -179,8 +226,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             raccB = fma(m12, fma(wp[2], vB[2], fma(wp[1], vB[1], wp[0] * vB[0])), raccB);
             tmA = xzA; tmB = xzB;
         }
-        d4 fA = mm3(cur.z, tmA, cur.c);
-        d4 fB = mm3(cur.z, tmB, cur.c);
+        d4 fA = mm3(cz, tmA, ccs);
+        d4 fB = mm3(cz, tmB, ccs);
         const double ghA = fma(muA, mH, fA[3]), ghB = fma(muB, mH, fB[3]);
         const double fvA = tmA[3] + cur.x, fvB = tmB[3] + cur.x;
         exA[g * 16 + j] = ghA; exB[g * 16 + j] = ghB;
@@ -237,18 +284,18 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
     };
 
     DTile ra, rb2;
-    dload<HASL>(ra, tile0 + (long)(N - 1) * TSTRIDE, lx, l, j, Lb + (long)(N - 1) * LSTR, mL, g);
+    dload<HASL, FLY>(ra, tile0 + (long)(N - 1) * TSTRIDE, lx, l, j, Lb + (long)(N - 1) * LSTR, mL, g, &fc, N - 1);
     BODY_MARK(a.dump, dgs + 1);
     for (int t = N - 1; t >= 0; t -= 2) {
         {
             const int tn = (t > 0) ? t - 1 : 0;
-            dload<HASL>(rb2, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
+            dload<HASL, FLY>(rb2, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g, &fc, tn);
         }
         if (step(t, ra)) break;
         if (t == 0) break;
         {
             const int tn = (t > 1) ? t - 2 : 0;
-            dload<HASL>(ra, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g);
+            dload<HASL, FLY>(ra, tile0 + (long)tn * TSTRIDE, lx, l, j, Lb + (long)tn * LSTR, mL, g, &fc, tn);
         }
         if (step(t - 1, rb2)) break;
     }

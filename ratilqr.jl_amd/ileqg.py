@@ -181,6 +181,19 @@ class Context:
         nv.check(nv.lib().rat_ce_compute_cost_enqueue(self.h, C.c_void_p(theta_ptr), C.c_int64(B), C.c_double(kl_bound),
                                                       C.c_void_p(cost_ptr)))
 
+    # ---- execution path (include/ratilqr.h RAT_PATH_*; results are identical on all of them) -------
+    PATHS = {"auto": 0, "rounds": 1, "fused": 2, "block": 3}
+
+    def set_path(self, path):
+        """Fix the execution path of this handle's batched solves: "auto" | "rounds" | "fused" | "block" (rat_set_path).  Moving between
+        the single-launch E = 1 kernels and the round-based path re-lays the state: the initial trajectory must be given again."""
+        nv.check(nv.lib().rat_set_path(self.h, C.c_int32(self.PATHS[path] if isinstance(path, str) else int(path))))
+
+    def get_path(self, B):
+        """Which path a batch of B samples takes: "rounds" | "fused" | "block" | "wide"."""
+        r = int(nv.lib().rat_get_path(self.h, C.c_int64(int(B))))
+        return {1: "rounds", 2: "fused", 3: "block", 4: "wide"}.get(r)
+
     @property
     def stream(self):
         """The handle's HIP stream (hipStream_t) as an integer, e.g. for ``torch.cuda.ExternalStream``."""

@@ -56,6 +56,26 @@ class MultiContext:
                                                     C.c_double(kl_bound), nv.P(cost)))
         return cost
 
+    is_logical = property(lambda s: bool(nv.lib().rat_multi_is_logical(s.m_)))
+
+    def compute_cost_ex(self, x0, u, theta, kl_bound):
+        """compute_cost with the gathered per-sample statistics of every shard: (cost, status, iters, ls_evals)."""
+        theta = nv.f64(theta)
+        B = theta.size
+        cost, st, it, ls = np.zeros(B), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+        nv.check(nv.lib().rat_multi_ce_compute_cost_ex(self.m_, nv.P(nv.f64(x0)), nv.P(nv.f64(u)), nv.P(theta), C.c_int64(B),
+                                                       C.c_double(kl_bound), nv.P(cost), nv.PI(st), nv.PI(it), nv.PI(ls)))
+        return cost, st, it, ls
+
+    def solve_batch(self, x0, u, theta):
+        """rat_ileqg_solve_batch over all devices: (value, status, iters, ls_evals)."""
+        theta = nv.f64(theta)
+        B = theta.size
+        val, st, it, ls = np.zeros(B), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+        nv.check(nv.lib().rat_multi_ileqg_solve_batch(self.m_, nv.P(nv.f64(x0)), nv.P(nv.f64(u)), nv.P(theta), C.c_int64(B),
+                                                      nv.P(val), nv.PI(st), nv.PI(it), nv.PI(ls)))
+        return val, st, it, ls
+
     def ce_step(self, c: nv.CeSolver, x0, u, kl_bound):                   # step!  :252-335
         B = int(c.num_samples)
         th, cost = np.zeros(B), np.zeros(B)

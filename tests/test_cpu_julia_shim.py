@@ -208,8 +208,8 @@ def test_positional_struct_constructors_pass_every_field():
 def test_bound_surface():
     bound = {c[0] for c in parse_ccalls()}
     not_bound = set(PROTOS) - bound
-    allowed = {"rat_default_ileqg_opts", "rat_set_ileqg_opts", "rat_ileqg_solve_batch_dev", "rat_ce_default", "rat_ce_seed", "rat_ce_stream_pos",
-               "rat_ce_get_positive_samples", "rat_ce_begin_step", "rat_ce_draw", "rat_ce_update", "rat_ce_draw_stream", "rat_pets_initialize",
+    allowed = {"rat_default_ileqg_opts", "rat_set_ileqg_opts", "rat_ileqg_solve_batch_dev", "rat_ce_default", "rat_ce_seed",
+               "rat_ce_get_positive_samples", "rat_ce_draw", "rat_ce_draw_stream", "rat_pets_initialize",
                "rat_pets_sample_controls", "rat_pets_update", "rat_profile_enable", "rat_profile_reset", "rat_profile_get", "rat_layout_info"}
     assert not_bound <= allowed, sorted(not_bound - allowed)
     # the reference's exported names (src/RATiLQR.jl:20-53) exist under their own names

@@ -1,6 +1,7 @@
 """rat_multi -- several devices behind the C ABI, one calling thread -- on this one-GPU box: n_devices = 1 with and without the RCCL
-collective (one-rank communicator, test hook), against the single-handle entry points (bit for bit) and the oracle.  The shard
-arithmetic for n_devices > 1 is covered on CPU (tests/test_cpu_abi.py, tests/test_cpu_distributed.py)."""
+collective (one-rank communicator, test hook), and n_devices = 2, 3, 8 LOGICAL devices (RATILQR_MULTI_LOGICAL=1: several handles and
+streams on the one GPU, the all-gather carried out by stream-ordered device copies into the slots RCCL would fill) -- every line of the
+G > 1 code but the ncclAllGather call itself -- against the single-handle entry points (bit for bit) and the oracle."""
 import ctypes as C
 
 import numpy as np
@@ -89,3 +90,91 @@ def test_multi_shards_on_the_round_based_path_run_on_helper_threads(monkeypatch)
     assert "solve_block" not in [k for k, p in ctx.profile_get().items() if p["launches"]]      # (the round-based path indeed)
     assert np.array_equal(cost[:-1], (v + 0.1 / theta)[:-1]) and np.isposinf(cost[-1]) and st[-1] == 1 and mc.allgathers == 1
     assert np.array_equal(mc.compute_cost(x0, u, theta[:100], 0.1), cost[:100])                    # a block-kernel shard right after
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_logical_devices_run_the_multi_device_code(G, monkeypatch):
+    """n_devices > 1 on a one-GPU box (logical devices): contiguous ragged shards (B = 10, 13 on 8 devices: empty and short blocks whose
+    pad slots must never be read), one gather per batch, and the gathered status / iteration / line-search counts of every shard equal
+    the single handle's, as do the costs, bit for bit; then the whole CE solve."""
+    monkeypatch.setenv("RATILQR_MULTI_LOGICAL", "1")
+    prob, x0, u = rat.synthetic_lq_problem(kappa=0.03)
+    rng = np.random.default_rng(20 + G)
+    Bmax = 1024
+    mc = rat.MultiContext(prob, max_batch=Bmax, devices=tuple(range(G)))
+    assert mc.n_devices == G and mc.is_logical and not mc.uses_rccl
+    ctx = rat.Context(prob, max_batch=Bmax)
+    n_g = 0
+    for B in (10, 13, 1024, 5, 1):
+        theta = np.abs(1.0 + 2.0 * rng.standard_normal(B))
+        theta[B // 2] = 70.0                                                # an infeasible sample in some shard
+        if B > 3:
+            theta[1] = 0.0                                                  # theta = 0: cost = value + kl / 0 = Inf, status OK
+        v, st, it, ls = ctx.solve_batch(x0, u, theta)
+        cost, st_m, it_m, ls_m = mc.compute_cost_ex(x0, u, theta, 0.1)
+        n_g += 1
+        with np.errstate(divide="ignore"):
+            assert np.array_equal(cost, v + 0.1 / theta)
+        assert np.array_equal(st_m, st) and np.array_equal(it_m, it) and np.array_equal(ls_m, ls)
+        assert st_m[B // 2] == 1 and np.isposinf(cost[B // 2]) and (st_m >= 0).all()          # (pad slots hold -1 / NaN: never seen)
+        assert mc.allgathers == n_g
+        v_m, st_v, it_v, ls_v = mc.solve_batch(x0, u, theta)
+        n_g += 1
+        assert np.array_equal(v_m, v) and np.array_equal(st_v, st) and np.array_equal(it_v, it) and np.array_equal(ls_v, ls)
+    # the whole RAT iLQR solve through rat_multi_ce_solve == rat_ce_solve on one handle, same injected stream
+    z = np.random.default_rng(11).standard_normal(20000)
+    ref_solver = rat.CrossEntropyBilevelOptimizationSolver(num_samples=100, num_elite=12)
+    ref = ce.solve_(ref_solver, prob, x0, u, z, kl_bound=0.1)
+    c = nv.CeSolver()
+    nv.lib().rat_ce_default(C.byref(c))
+    c.num_samples, c.num_elite = 100, 12
+    mc.set_stream(z)
+    got = mc.ce_solve(c, x0, u, 0.1)
+    assert got[0] == ref[0] and got[4] == ref[4] and got[5] == ref[5] and got[6] == ref[6] and np.array_equal(got[3], ref[3])
+    assert c.n_solves == ref_solver.c.n_solves and mc.allgathers == n_g + c.n_solves // 100
+
+
+def test_logical_devices_with_polled_shards(monkeypatch):
+    """Speculation width 8 on 2 logical devices with shards of 300 samples: every shard runs the round-based path on its own helper thread
+    (two host loops polling two streams of the one GPU at once); statuses and counts come back with the costs."""
+    monkeypatch.setenv("RATILQR_MULTI_LOGICAL", "1")
+    prob, x0, u = rat.synthetic_lq_problem(kappa=0.05)
+    B = 600
+    theta = np.abs(1.0 + 2.0 * np.random.default_rng(9).standard_normal(B))
+    theta[17] = 90.0
+    mc = rat.MultiContext(prob, max_batch=B, spec_eps=8, devices=(0, 1))
+    cost, st_m, it_m, ls_m = mc.compute_cost_ex(x0, u, theta, 0.1)
+    ctx = rat.Context(prob, max_batch=B, spec_eps=8)
+    assert ctx.get_path(300) == "rounds" and ctx.get_path(B) == "rounds"
+    v, st, it, ls = ctx.solve_batch(x0, u, theta)
+    assert np.array_equal(cost, v + 0.1 / theta) and np.array_equal(st_m, st) and np.array_equal(it_m, it) and np.array_equal(ls_m, ls)
+    assert st[17] == 1 and it.max() >= 3 and mc.allgathers == 1
+
+
+def test_set_path_per_handle():
+    """rat_set_path: the execution path is a property of the handle, not of the process environment; results do not depend on it."""
+    prob, x0, u = rat.synthetic_lq_problem(kappa=0.04)
+    theta = np.abs(1.0 + 2.0 * np.random.default_rng(4).standard_normal(64)); theta[5] = 60.0
+    ctx = rat.Context(prob, max_batch=64)
+    assert ctx.get_path(64) == "block"
+    ref = ctx.solve_batch(x0, u, theta)
+    for path in ("fused", "rounds", "block", "auto"):
+        ctx.set_path(path)
+        assert ctx.get_path(64) == (path if path != "auto" else "block")
+        ctx.profile(True)
+        got = ctx.solve_batch(x0, u, theta)
+        kinds = {k for k, p in ctx.profile_get().items() if p["launches"]}
+        ctx.profile(False); ctx.profile_reset()
+        assert ("solve_fused" in kinds) == (path == "fused") and ("solve_block" in kinds) == (path in ("block", "auto")), (path, kinds)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), path
+    c8 = rat.Context(prob, max_batch=64, spec_eps=8)
+    assert c8.get_path(64) == "block"
+    with pytest.raises(rat.RatError):
+        c8.set_path("fused")                                                # no one-wavefront kernel for E = 8
+    c8.set_path("rounds")
+    got = c8.solve_batch(x0, u, theta)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    with pytest.raises(rat.RatError):
+        rat.Context(prob, max_batch=4, spec_eps=3).set_path("block")
