@@ -91,6 +91,11 @@ def draw_theta(B, seed):
     return np.array(out[:B])
 
 
+def block_bytes(chunk):
+    """One rank's contribution to the all-gather (csrc/multi.cpp block_bytes): chunk x (f64 cost + 3 x i32), 8-B aligned."""
+    return (chunk * 20 + 7) & ~7
+
+
 def shard_bounds(B, world, rank):
     """Contiguous theta block [lo, hi) of a rank (ratilqr.jl_amd.distributed.shard_bounds; blocks differ by at most one sample)."""
     base, rem = divmod(B, world)
@@ -311,8 +316,15 @@ class Workload:
         self.ctx.set_initial(x0, u0)
         self.theta = torch.as_tensor(theta_local, dtype=torch.float64, device=D.dev)
         self.chunk = -(-G // D.world)                     # padded shard length of the gather
-        self.cost = torch.full((self.chunk,), float("nan"), dtype=torch.float64, device=D.dev)
-        self.cost_all = torch.empty(D.world * self.chunk, dtype=torch.float64, device=D.dev) if D.multi else self.cost
+        # what a rank contributes to the ONE all-gather of a batch (cost + status): a byte block
+        # [cost f64 x chunk | status i32 x chunk | iters i32 x chunk | ls_evals i32 x chunk] (rat_multi's layout, csrc/multi.cpp);
+        # pad slots of a short shard stay all-ones bytes (NaN / -1) and are never read
+        self.bb = block_bytes(self.chunk)
+        self.blk = torch.full((self.bb,), 0xFF, dtype=torch.uint8, device=D.dev)
+        c = self.chunk
+        self.cost = self.blk[: 8 * c].view(torch.float64)
+        self.status, self.iters, self.ls = (self.blk[8 * c + 4 * c * q: 8 * c + 4 * c * (q + 1)].view(torch.int32) for q in range(3))
+        self.blk_all = torch.empty(D.world * self.bb, dtype=torch.uint8, device=D.dev) if D.multi else self.blk
         # the handle's own HIP stream, seen by torch: the batch, the cost all-gather and the next batch are ordered on it on the
         # device, with no host round trip between steps (the timed region ends with a device synchronisation)
         self.hstream = torch.cuda.ExternalStream(self.ctx.stream, device=D.dev)
@@ -323,15 +335,16 @@ class Workload:
         # device (one kernel launch on the fused path), then the per-sample costs go to every rank
         D, torch = self.D, self.D.torch
         if self.nloc:
-            self.ctx.compute_cost_enqueue(self.theta.data_ptr(), self.nloc, self.kl, self.cost.data_ptr())
+            self.ctx.compute_cost_enqueue_ex(self.theta.data_ptr(), self.nloc, self.kl, self.cost.data_ptr(), self.status.data_ptr(),
+                                             self.iters.data_ptr(), self.ls.data_ptr())
         if D.multi and D.backend == "nccl":
             with torch.cuda.stream(self.hstream):             # RCCL waits for the batch and the next batch waits for RCCL
-                D.dist.all_gather_into_tensor(self.cost_all, self.cost)
+                D.dist.all_gather_into_tensor(self.blk_all, self.blk)
         elif D.multi:                                         # host-staged collective (test hook)
             self.hstream.synchronize()
-            parts = [torch.empty(self.chunk, dtype=torch.float64) for _ in range(D.world)]
-            D.dist.all_gather(parts, self.cost.cpu())
-            self.cost_all.copy_(torch.cat(parts))
+            parts = [torch.empty(self.bb, dtype=torch.uint8) for _ in range(D.world)]
+            D.dist.all_gather(parts, self.blk.cpu())
+            self.blk_all.copy_(torch.cat(parts))
 
     def outputs(self):
         """Untimed: per-sample value / status / iteration and line-search counts of the same shard (also checks the timed path's costs)."""
@@ -344,19 +357,36 @@ class Workload:
         torch.cuda.synchronize()
         v = value.cpu().numpy()[: self.nloc]
         assert np.array_equal(self.cost.cpu().numpy()[: self.nloc], v + self.kl / self.theta_h), "compute_cost disagrees with value + kl/theta"
+        out = v, status.cpu().numpy()[: self.nloc], iters.cpu().numpy()[: self.nloc], ls.cpu().numpy()[: self.nloc]
+        for a, b in zip(out[1:], (self.status, self.iters, self.ls)):
+            assert np.array_equal(a, b.cpu().numpy()[: self.nloc]), "the counters written beside the costs differ from rat_ileqg_solve_batch_dev's"
         self.value_t = value
-        return v, status.cpu().numpy()[: self.nloc], iters.cpu().numpy()[: self.nloc], ls.cpu().numpy()[: self.nloc]
+        return out
 
-    def check_gather(self):
-        """Every rank holds every shard's costs after the gather: rank r's block at [r * chunk, r * chunk + its shard length)."""
+    def gathered(self):
+        """What every rank holds after the gather, as the global batch in order: (cost, status, iters, ls_evals); rank r's block sits at
+        [r * block_bytes, ...) and carries its shard length of live entries."""
         D = self.D
-        got = self.cost_all.cpu().numpy()
+        raw = self.blk_all.cpu().numpy()
+        c = self.chunk
+        cols = ([], [], [], [])
         for r in range(D.world):
             lo, hi = shard_bounds(self.G, D.world, r)
-            blk = got[r * self.chunk: r * self.chunk + (hi - lo)]
-            assert not np.any(np.isnan(blk)), f"rank {r}'s block of the gathered costs was never written"
-            if r == D.rank:
-                assert np.array_equal(blk, self.cost.cpu().numpy()[: self.nloc]), "all-gather lost this rank's block"
+            b = raw[r * self.bb: (r + 1) * self.bb]
+            cols[0].append(b[: 8 * c].view(np.float64)[: hi - lo])
+            for q in range(3):
+                cols[q + 1].append(b[8 * c + 4 * c * q: 8 * c + 4 * c * (q + 1)].view(np.int32)[: hi - lo])
+        return tuple(np.concatenate(x) for x in cols)
+
+    def check_gather(self):
+        """Every rank holds every shard's costs and counters after the gather."""
+        D = self.D
+        cost, st, it, ls = self.gathered()
+        assert cost.size == self.G and not np.any(np.isnan(cost)), "a block of the gathered costs was never written"
+        assert (st >= 0).all() and (it >= 0).all() and (ls >= 0).all(), "a block of the gathered counters was never written"
+        lo, hi = shard_bounds(self.G, D.world, D.rank)
+        assert np.array_equal(cost[lo:hi], self.cost.cpu().numpy()[: self.nloc]), "all-gather lost this rank's block"
+        assert np.array_equal(st[lo:hi], self.status.cpu().numpy()[: self.nloc]), "all-gather lost this rank's statuses"
 
 
 def roofline_of(w, prof_main, main_kind, iters_h, ls_h):
@@ -437,6 +467,9 @@ def rank_main(args):
     prob, x0, u0 = rat.synthetic_lq_problem(n=12, m=4, N=50, seed=0)
     theta_global = draw_theta(G, seed=1000)                  # the ONE CE batch every rank knows (same N(0,1) stream on every rank)
     lo, hi = shard_bounds(G, world, rank)
+    # The CPU baseline runs FIRST (rank 0, N = 1): the GPU legs then form one contiguous stretch at the end of the run, long enough for
+    # an external utilisation sampler to see the device at work.
+    cpu = cpu_baseline(prob, x0, u0, args.cpu_seconds) if (rank == 0 and world == 1 and not args.no_cpu) else None
 
     # ---- primary: the BASELINE configuration -- one CE batch of G = 1024 samples over all ranks (strong scaling) -------------
     w = Workload(D, prob, x0, u0, theta_global[lo:hi], G, E)
@@ -471,9 +504,10 @@ def rank_main(args):
     prof = w.ctx.profile_get()
     w.ctx.profile(False)
     v_h, st_h, it_h, ls_h = w.outputs()
-    if D.multi:
-        w.check_gather()
-    feasible = float(np.mean((st_h == 0) | (st_h == 3))) if st_h.size else 1.0
+    w.check_gather()
+    # statistics of the WHOLE batch, from what the timed step's own all-gather left on this rank (not from this rank's shard)
+    _, st_g, it_g, ls_g = w.gathered()
+    feasible = float(np.mean((st_g == 0) | (st_g == 3))) if st_g.size else 1.0
     strong = {"value": G * K / elapsed, "unit": "solves/s", "ms_per_step": elapsed / K * 1e3, "global_batch": G,
               "solves_per_gpu": [shard_bounds(G, world, r)[1] - shard_bounds(G, world, r)[0] for r in range(world)], "spec_eps": E}
 
@@ -490,7 +524,8 @@ def rank_main(args):
             K8 = max(3, K // 3)
             e8 = D.timed(w8.step, K8, max(2, W))
             strong8 = {"value": G * K8 / e8, "unit": "solves/s", "ms_per_step": e8 / K8 * 1e3, "steps": K8, "global_batch": G,
-                       "spec_eps": 8, "costs_identical_to_primary": bool(torch.equal(w8.cost[: w8.nloc], w.cost[: w.nloc]))}
+                       "spec_eps": 8, "costs_identical_to_primary": bool(torch.equal(w8.cost[: w8.nloc], w.cost[: w.nloc])),
+                       "mean_ls_evals": float(w8.gathered()[3].mean())}
             del w8
 
     # ---- single-GPU secondaries ---------------------------------------------------------------------------------------------------
@@ -501,7 +536,7 @@ def rank_main(args):
     dev = D.dev
     if world == 1 and not args.no_second:
         # steady state: >= 1 s of back-to-back batches, one HIP event per batch on the handle's stream
-        n_ss = int(min(20000, max(200, 1.15 / max(elapsed / K, 1e-5))))
+        n_ss = int(min(40000, max(200, args.steady_seconds / max(elapsed / K, 1e-5))))
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ss + 1)]
         D.sync()
         t0 = time.perf_counter()
@@ -512,7 +547,7 @@ def rank_main(args):
         D.sync()
         wall = time.perf_counter() - t0
         per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_ss)])
-        steady = {"batches": n_ss, "wall_s": wall, "value": B * n_ss / wall, "unit": "solves/s",
+        steady = {"seconds_requested": args.steady_seconds, "batches": n_ss, "wall_s": wall, "value": B * n_ss / wall, "unit": "solves/s",
                   "per_batch_ms": {"median": float(np.median(per)), "min": float(per.min()), "mean": float(per.mean()),
                                    "p95": float(np.percentile(per, 95)), "max": float(per.max())},
                   "value_from_median": B / (float(np.median(per)) * 1e-3),
@@ -606,11 +641,96 @@ def rank_main(args):
             large[str(Bl)] = {"value": Bl * Kl / el, "unit": "solves/s", "ms_per_step": el / Kl * 1e3, "steps": Kl}
             del ctxl
 
+    shard_lat = pets_sec = nm_sec = None
+    if world == 1 and not args.no_second:
+        # What each rank of an N-GPU run of the BASELINE metric executes: ONE launch over 1024 / N samples.  A strong-scaling shard costs
+        # one solve's latency whatever its size, so these driver-timed figures are the scaling curve's proxy when no multi-GPU node is
+        # available: value(N) ~ 1024 / (shard_latency_ms(1024 / N) + all-gather).
+        shard_lat = {}
+        for Bs in (512, 256, 128):
+            cs = rat.Context(prob, max_batch=Bs, spec_eps=E, device=D.local_rank)
+            cs.set_initial(x0, u0)
+            ths = torch.as_tensor(theta_global[:Bs], dtype=torch.float64, device=dev)
+            cst = torch.empty(Bs, dtype=torch.float64, device=dev)
+            t_c = time.perf_counter()
+            while time.perf_counter() - t_c < 0.1:
+                cs.compute_cost_dev(ths.data_ptr(), Bs, 0.1, cst.data_ptr())
+            Ks = max(20, K)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(Ks):
+                cs.compute_cost_enqueue(ths.data_ptr(), Bs, 0.1, cst.data_ptr())
+            torch.cuda.synchronize()
+            es = time.perf_counter() - ts
+            shard_lat[str(Bs)] = {"ms_per_batch": es / Ks * 1e3, "steps": Ks, "path": cs.get_path(Bs),
+                                  "costs_identical_to_primary": bool(torch.equal(cst, w.cost[:Bs]))}
+            del cs
+
+        # BASELINE config 5: PETS forward simulation (src/pets.jl:128-157), 100 control samples x 100 stochastic rollouts = 10k
+        # trajectories, N = 30, n = 12, m = 4, cubic drift, Gaussian process noise from the device Philox generator
+        from ratilqr.jl_amd import pets
+        rp = np.random.default_rng(8)
+        Ap = 0.9 * np.linalg.qr(rp.standard_normal((12, 12)))[0]
+        Bp = rp.standard_normal((12, 4)) / np.sqrt(12)
+        gprob = rat.LQGenerativeProblem(Ap, Bp, 30, ("gaussian", np.zeros(12), 0.03 * np.eye(12)), Q=np.eye(12), R=0.1 * np.eye(4), Qf=np.eye(12),
+                                        kappa=-0.01)
+        xp0 = rp.standard_normal(12)
+        pets_sec = {"workload": "PETS compute_cost (pets.jl:128-157): stochastic rollouts with running cost, N=30, n=12, m=4, cubic drift, Gaussian "
+                                "noise from the device Philox generator; host buffers in and out", "runs": {}}
+        for S_, K_ in ((100, 100), (1000, 1000)):
+            ds = rat.CrossEntropyDirectOptimizationSolver(np.zeros((30, 4)), np.stack([np.eye(4)] * 30), num_control_samples=S_,
+                                                          num_trajectory_samples=K_, device=D.local_rank)
+            ctrl = 0.3 * rp.standard_normal((S_, 30, 4))
+            for _ in range(3):
+                cpets = pets.compute_cost_serial(ds, gprob, xp0, ctrl, None, False, seed=11)
+            pctx = ds.context(gprob)
+            pctx.profile(True, kinds=["pets"])
+            pctx.profile_reset()
+            reps = 20
+            tp = time.perf_counter()
+            for i in range(reps):
+                cpets = pets.compute_cost_serial(ds, gprob, xp0, ctrl, None, False, seed=11 + i)
+            ep = (time.perf_counter() - tp) / reps
+            pk = pctx.profile_get()["pets"]
+            pctx.profile(False)
+            assert np.all(np.isfinite(cpets))
+            kern_ms = pk["ms"] / max(pk["launches"], 1)
+            # per trajectory step: stage cost 2 x 16 x 16 + dynamics 2 x 12 x 16 + noise factor 2 x 12 x 12 flops (the generator's integer
+            # rounds and the Box-Muller transcendentals are not counted)
+            fl = S_ * K_ * 30 * (2 * 16 * 16 + 2 * 12 * 16 + 2 * 12 * 12)
+            pets_sec["runs"][f"{S_}x{K_}"] = {
+                "control_samples": S_, "rollouts_per_sample": K_, "trajectories": S_ * K_, "ms_per_call": ep * 1e3,
+                "trajectories_per_s": S_ * K_ / ep, "steps_per_s": S_ * K_ * 30 / ep, "kernel_ms": kern_ms,
+                "kernel_trajectories_per_s": S_ * K_ / (kern_ms * 1e-3) if kern_ms > 0 else None,
+                "roofline": {"bound": "fp64 vector ALU (Philox + Box-Muller + three small mat-vecs per lane and step; 4 trajectories per "
+                                      "wavefront; no HBM stream: 1.3 KB in, 8 B out per trajectory)",
+                             "achieved": fl / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": fl / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if kern_ms > 0 else None}}
+            del ds
+        pets_sec["value"] = pets_sec["runs"]["100x100"]["trajectories_per_s"]
+        pets_sec["unit"] = "trajectories/s (BASELINE config 5: 10k trajectories per call)"
+
+        # BASELINE config 4: RAT iLQR++ (src/nelder_mead_bilevel_optimization.jl:276-352) on the headline problem: every Nelder-Mead
+        # iteration is one batched device call of the <= 6 vertices the sequential rule can ask for
+        from ratilqr.jl_amd import nelder_mead as nm
+        nms = rat.NelderMeadBilevelOptimizationSolver(device=D.local_rank)
+        for _ in range(2):
+            nm.solve_(nms, prob, x0, u0, 0.1)
+        reps = 5
+        tn0 = time.perf_counter()
+        for _ in range(reps):
+            th_nm, _, _, _, val_nm = nm.solve_(nms, prob, x0, u0, 0.1)
+        enm = (time.perf_counter() - tn0) / reps
+        ns0, nb0 = int(nms.c.n_solves), int(nms.c.n_batches)
+        th_nm, _, _, _, val_nm = nm.solve_(nms, prob, x0, u0, 0.1)
+        nm_sec = {"workload": "one NelderMeadBilevelOptimizationSolver solve! (defaults) on the headline problem, kl_bound = 0.1",
+                  "ms_per_solve": enm * 1e3, "nm_iterations": int(nms.c.iter_current), "batched_device_calls": int(nms.c.n_batches) - nb0,
+                  "sequential_ileqg_solves_replaced": int(nms.c.n_solves) - ns0, "theta_opt": th_nm, "objective": val_nm}
+
     if fused and world == 1 and not args.no_second:
         # per-phase breakdown of the same batch on the round-based path (one launch per phase; what the fused kernel replaces)
-        os.environ["RATILQR_FUSED"] = "0"
         ctxu = rat.Context(prob, max_batch=B, spec_eps=E, device=D.local_rank)
-        del os.environ["RATILQR_FUSED"]
+        ctxu.set_path("rounds")
         ctxu.set_initial(x0, u0)
         vu = torch.empty(B, dtype=torch.float64, device=dev)
         for _ in range(2):
@@ -656,7 +776,8 @@ def rank_main(args):
                             "W=1e-3 I, theta ~ N(1,2)>0, kl=0.1, iLEQG defaults",
                 "global_batch": G, "ce_batch_per_gpu": strong["solves_per_gpu"], "spec_eps": E,
                 "parallelism": f"theta-shards x{world} (contiguous blocks), one cost all-gather per batch" if world > 1 else "single GPU",
-                "feasible_fraction": feasible, "mean_iters": float(it_h.mean()), "mean_ls_evals": float(ls_h.mean()),
+                "feasible_fraction": feasible, "mean_iters": float(it_g.mean()), "mean_ls_evals": float(ls_g.mean()),
+                "statistics_from": "the status / iteration / line-search counts gathered with the costs by the timed step's one collective",
             },
             "strong": strong,
             "roofline": roofline_of(w, prof[main_kind], main_kind, it_h, ls_h),
@@ -676,8 +797,11 @@ def rank_main(args):
             out["secondary_nonlinear"] = nonlin
         if large:
             out["secondary_large_batch"] = large
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(prob, x0, u0, args.cpu_seconds)
+        for key, val in (("shard_latency_ms", shard_lat), ("secondary_pets", pets_sec), ("secondary_nm", nm_sec)):
+            if val is not None:
+                out[key] = val
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if D.multi:
         D.dist.destroy_process_group()
@@ -693,6 +817,7 @@ def parse(argv):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-second", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--steady-seconds", type=float, default=4.0, help="length of the steady_state leg (back-to-back batches)")
     ap.add_argument("--condition-seconds", type=float, default=0.3, help="untimed batches before the warm-up steps (clock ramp)")
     return ap.parse_args(argv)
 

@@ -225,6 +225,10 @@ rat_rc rat_ce_compute_cost_dev(rat_handle h, const double *theta_dev, int64_t B,
  * rat_ce_compute_cost_dev).  theta_dev / cost_dev must stay valid, and cost_dev unread, until work ordered after it on that stream
  * (or a synchronisation of it) has passed -- lets a caller chain batch -> cost all-gather -> next batch without host round trips. */
 rat_rc rat_ce_compute_cost_enqueue(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev);
+/* the same with the per-sample status (RAT_ST_*), iteration count and line-search evaluation count written beside the costs (device
+ * pointers, any of the three may be NULL): what a rank contributes to the cost + status all-gather of a sharded CE batch */
+rat_rc rat_ce_compute_cost_enqueue_ex(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev,
+                                      int32_t *status_dev, int32_t *iters_dev, int32_t *ls_evals_dev);
 /* The bookkeeping half of step! (:291-334) for hosts that evaluate costs themselves (multi-GPU: the
  * host all-gathers cost shards between rat_ce_draw and rat_ce_update).
  *   rat_ce_draw   : theta[num_samples] for the current iteration (uses mu_init/sigma_init in iteration 1)
@@ -396,7 +400,9 @@ int32_t rat_get_path(rat_handle h, int64_t B);
 #define RAT_K_SOLVE_FUSED 7  /* one persistent wavefront per sample runs the whole solve! (E = 1): every phase above in one launch */
 #define RAT_K_SOLVE_BLOCK 8  /* one workgroup per sample runs the whole solve!: a wavefront per line-search candidate + a gain-sweep wavefront */
 #define RAT_K_SOLVE_WIDE  9  /* general-size solve kernel (n <= 32, m <= 32 beyond the 12 + 4 tile): a workgroup per sample, whole solve! */
-#define RAT_K_COUNT     10
+#define RAT_K_PETS       10  /* PETS stochastic rollouts (pets_rollout_kernel + the per-sample mean) */
+#define RAT_K_MATERIALIZE 11 /* completion of an accepted trajectory's step records on the tile-free speculative path */
+#define RAT_K_COUNT     12
 /* When enabled, kernel launches are bracketed by HIP events on the handle's stream.
  * on = 0: off; on = 1: every kernel kind; otherwise on = (mask << 1) | 1 with bit k of mask selecting kind RAT_K_k.
  * Launches of a surplus round (no live sample left) are not counted. */

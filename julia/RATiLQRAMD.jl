@@ -589,6 +589,15 @@ function compute_cost_dev!(s::CrossEntropyBilevelOptimizationSolver, problem, θ
     end
     nothing
 end
+"compute_cost_dev!(...; enqueue = true) with the per-sample status / iteration / line-search counts written beside the costs (device
+pointers to Int32 arrays, any may be C_NULL): a rank's contribution to the cost + status all-gather of a sharded CE batch"
+function compute_cost_enqueue_ex!(s::CrossEntropyBilevelOptimizationSolver, problem, θ_dev::Ptr{Float64}, B::Integer, kl_bound::Float64,
+                                  cost_dev::Ptr{Float64}, status_dev::Ptr{Int32}, iters_dev::Ptr{Int32}, ls_dev::Ptr{Int32})
+    h = handle!(s, problem, B)
+    check(ccall((:rat_ce_compute_cost_enqueue_ex, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                single(h), θ_dev, B, kl_bound, cost_dev, status_dev, iters_dev, ls_dev))
+    nothing
+end
 hip_stream(s::CrossEntropyBilevelOptimizationSolver) = ccall((:rat_stream, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), single(s.h))
 
 # The reference's step! / solve! consume `rng` exactly as far as get_positive_samples needs (:233-246): a hand-driven loop of step! with

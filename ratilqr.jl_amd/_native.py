@@ -20,7 +20,8 @@ RC_NAMES = {0: "RAT_OK", 1: "RAT_ERR_ARG", 2: "RAT_ERR_UNSUPPORTED", 3: "RAT_ERR
             5: "RAT_ERR_STREAM_DRY", 6: "RAT_ERR_DIVERGED"}
 ST_RUNNING, ST_OK, ST_M_NOT_PD_INIT, ST_M_NOT_PD_GAIN, ST_ITER_MAX, ST_DOMAIN, ST_MU_DIVERGED, ST_SINGULAR, \
     ST_LS_DIVERGED = -1, 0, 1, 2, 3, 4, 5, 6, 7
-K_NAMES = ("rollout", "linearize", "sweep_eval", "sweep_gain", "select", "sweep_init", "sweep_dual", "solve_fused", "solve_block", "solve_wide")
+K_NAMES = ("rollout", "linearize", "sweep_eval", "sweep_gain", "select", "sweep_init", "sweep_dual", "solve_fused", "solve_block", "solve_wide",
+           "pets", "materialize")
 
 
 class RatError(RuntimeError):
@@ -84,7 +85,7 @@ EXPORTS = [
     "rat_shard_bounds", "rat_create_multi", "rat_multi_destroy", "rat_multi_n_devices", "rat_multi_handle", "rat_multi_uses_rccl",
     "rat_multi_allgathers", "rat_multi_problem_set", "rat_multi_set_initial", "rat_multi_ce_compute_cost", "rat_multi_ce_step",
     "rat_multi_ce_solve", "rat_multi_pets_problem_set", "rat_multi_pets_compute_cost",
-    "rat_multi_ce_compute_cost_ex", "rat_multi_ileqg_solve_batch", "rat_multi_is_logical", "rat_set_path", "rat_get_path",
+    "rat_multi_ce_compute_cost_ex", "rat_multi_ileqg_solve_batch", "rat_multi_is_logical", "rat_set_path", "rat_get_path", "rat_ce_compute_cost_enqueue_ex",
 ]
 
 _lib = None

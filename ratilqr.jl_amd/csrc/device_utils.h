@@ -150,6 +150,27 @@ __device__ __forceinline__ double fx_diag(double zt, double dg, double kappa, do
     return __builtin_fma(dg, d, zt);
 }
 
+// One term of c = [x;u]' (1/2 C [x;u] + lin) + q0 (ileqg.jl:296): xu (1/2 cxu + lin), one rounding order in every rollout kernel
+__device__ __forceinline__ double cost_term(double xu, double cxu, double lin) {
+#pragma clang fp contract(off)
+    const double h = __builtin_fma(0.5, cxu, lin);
+    return xu * h;
+}
+
+// The four 16-lane rows of x, each broadcast to every row (v_permlane32_swap + v_permlane16_swap, gfx950; tools/ubench/xlane.hip checks
+// the pattern lane by lane): r[g] on lane (., j) = x of lane (g, j).
+__device__ __forceinline__ void rows_bcast(double x, double (&r)[4]) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto s32l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);        // [0] = rows (0, 1, 0, 1), [1] = rows (2, 3, 2, 3)
+    const auto s32h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const auto al = __builtin_amdgcn_permlane16_swap(s32l[0], s32l[0], false, false);   // [0] = row 0 everywhere, [1] = row 1 everywhere
+    const auto ah = __builtin_amdgcn_permlane16_swap(s32h[0], s32h[0], false, false);
+    const auto bl = __builtin_amdgcn_permlane16_swap(s32l[1], s32l[1], false, false);   // rows 2, 3
+    const auto bh = __builtin_amdgcn_permlane16_swap(s32h[1], s32h[1], false, false);
+    r[0] = __hiloint2double((int)ah[0], (int)al[0]); r[1] = __hiloint2double((int)ah[1], (int)al[1]);
+    r[2] = __hiloint2double((int)bh[0], (int)bl[0]); r[3] = __hiloint2double((int)bh[1], (int)bl[1]);
+}
+
 __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base.isapprox, rtol = sqrt(eps), atol = 0
     if (x == y) return true;
     if (!isfinite(x) || !isfinite(y)) return false;

@@ -52,6 +52,7 @@ struct rat_handle_s {
     bool block_shape = true;         // RATILQR_BLOCK_SHAPE=0: plain two-wave workgroups, placement left to the dispatcher
     bool block_helpers = true;       // RATILQR_BLOCK_HELPERS=0: no spare linearise waves at one workgroup per CU
     int path_fixed = RAT_PATH_AUTO;  // rat_set_path
+    bool fly_multi = true;           // ... and the rollouts of a sample's candidates share one wavefront (rollin_multi_kernel); RATILQR_FLY_MULTI=0
     bool fly = true;                 // round-based path, E > 1, LQ family: line-search candidates are evaluated without tile records in HBM
                                      // (their sweeps form the step's tile from x_t; accepted trajectories are completed on demand); RATILQR_FLY=0
     rat_ileqg_opts opts;
@@ -158,6 +159,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_BLOCK_SHAPE")) h->block_shape = (e[0] != '0');
     if (const char *e = getenv("RATILQR_BLOCK_HELPERS")) h->block_helpers = (e[0] != '0');
     if (const char *e = getenv("RATILQR_FLY")) h->fly = (e[0] != '0');
+    if (const char *e = getenv("RATILQR_FLY_MULTI")) h->fly_multi = (e[0] != '0');
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     // E = 1 batches beyond one sample per SIMD: two samples per SIMD in 256 registers each beat two generations of the 342-register
     // paired kernel (measured +6..10 %); RATILQR_FUSED_OCC2=0 disables, =B0 moves the threshold
@@ -457,8 +459,18 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
         // the kernels eliminate 2x2 blocks {p, p+1}: lane p (even) multiplies det(P) by 1 / (e_p e_{p+1})
         for (int p = 0; p < 12; p += 2) { epiv[(size_t)k * 16 + p] = 1.0 / (pivs[p] * pivs[p + 1]); epiv[(size_t)k * 16 + p + 1] = 1.0; }
     }
+    // time-invariant diagonal W: the sweeps fold inv(W) into the inverse of M (ProblemDev.W_diag)
+    std::vector<double> Wdg(16, 1.0);
+    pb.W_diag = pb.W_tv ? 0 : 1;
+    if (!pb.W_tv) {
+        for (int i = 0; i < n; ++i)
+            for (int jj = 0; jj < n; ++jj) if (i != jj && d->W[i + n * jj] != 0.0) pb.W_diag = 0;
+        for (int i = 0; i < n; ++i) Wdg[i] = Winv[i * 16 + i];
+    }
+    if (const char *e = getenv("RATILQR_WDIAG")) { if (e[0] == '0') pb.W_diag = 0; }      // test override: the general-W arithmetic
     rat_rc rc;
 #define UP(field, vec) if ((rc = dev_upload(h, h->pb_allocs, &pb.field, vec))) return rc
+    UP(Wdg, Wdg);
     UP(Zt, Zt); UP(Ctab, Ctab); UP(lin, lin); UP(q0, q0); UP(Qf, Qf); UP(qvf, qvf);
     UP(Winv, Winv); UP(Wp, Wp); UP(epiv, epiv); UP(logdetW, ldw);
 #undef UP
@@ -568,11 +580,12 @@ static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
 static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     const int slot = round % CTR_RING;
     const int64_t nc = (int64_t)st.B * st.E;
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0; ra.multi = 0;
     // no tile records for line-search candidates (LQ family, E > 1): the evaluation sweeps form each step's tile from x_t themselves, and
     // only an accepted trajectory that the plain gain sweep of the next step! will read is completed (materialize, after the accept rule)
     const bool fly = h->fly && !h->speculate && rollin_notile_supported(h->pb, st);
     ra.notile = fly ? 1 : 0;
+    ra.multi = (fly && h->fly_multi) ? 1 : 0;
     if (h->dual) {
         // fused path (E = 1): the plain gain sweep only serves samples whose fused gain recursion was abandoned (H not PD)
         prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
@@ -591,7 +604,7 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
           prof_begin(h, RAT_K_SWEEP_DUAL, st.B); launch_sweep_dual(sd, st.B, h->stream); prof_end(h); }
         if (st.E > 1) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
         prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
-        if (fly) launch_materialize(st, h->pb, h->stream);
+        if (fly) { prof_begin(h, RAT_K_MATERIALIZE, st.B); launch_materialize(st, h->pb, h->stream); prof_end(h); }
         HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
         return RAT_OK;
@@ -610,7 +623,7 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
       prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(se, (int)nc, false, false, h->stream); prof_end(h); }
     if (h->speculate) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
     prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
-    if (fly) launch_materialize(st, h->pb, h->stream);
+    if (fly) { prof_begin(h, RAT_K_MATERIALIZE, st.B); launch_materialize(st, h->pb, h->stream); prof_end(h); }
     HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
     return RAT_OK;
@@ -704,7 +717,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
     if (path == PATH_ROUNDS) launch_init_state(st, h->opd, theta_dev, h->stream);     // (the single-launch solves initialise each sample themselves)
     // initialize!  (ileqg.jl:214-236): open-loop rollout, L = 0, linearise, open-loop policy evaluation; the first gain
     // sweep (step! number 1 re-linearises the same trajectory, App. B.1) runs speculatively beside it.
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0; ra.multi = 0;
     if (path != PATH_ROUNDS) {       // the whole state machine below, per sample, inside one launch
         FusedArgs fa;
         fa.sw = sweep_args(h, st, 0);
@@ -844,6 +857,12 @@ rat_rc rat_batch_outputs_dev(rat_handle h, const double *theta_dev, int64_t B, d
     }
     if (rounds || wait) HIPCHK(hipStreamSynchronize(h->stream));
     return RAT_OK;
+}
+
+extern "C" rat_rc rat_ce_compute_cost_enqueue_ex(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev,
+                                                 int32_t *status_dev, int32_t *iters_dev, int32_t *ls_evals_dev) {
+    if (!cost_dev) return fail(RAT_ERR_ARG, "null");
+    return rat_batch_outputs_dev(h, theta_dev, B, kl_bound, false, cost_dev, status_dev, iters_dev, ls_evals_dev, false);
 }
 
 extern "C" rat_rc rat_ce_compute_cost_enqueue(rat_handle h, const double *theta_dev, int64_t B, double kl_bound, double *cost_dev) {
@@ -1144,7 +1163,7 @@ extern "C" rat_rc rat_rollout_open(rat_handle h, const double *x0, const double 
     if (rc) return rc;
     StateDev st;
     if ((rc = op_prepare(h, 0.0, 0.0, h->opts.delta_0, &st))) return rc;
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 0; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0; ra.multi = 0;
     launch_rollout(ra, h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> xp;
@@ -1177,7 +1196,7 @@ extern "C" rat_rc rat_rollout_feedback(rat_handle h, const double *xbar, const d
     HIPCHK(hipMemset(st.dl, 0, (size_t)h->N * USTR * 8));
     const int one = 1;
     HIPCHK(hipMemcpy(st.ls_active, &one, 4, hipMemcpyHostToDevice));
-    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0;
+    RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0; ra.multi = 0;
     launch_rollout(ra, h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> xp, up;
@@ -2029,7 +2048,9 @@ rat_rc rat_pets_enqueue(rat_handle h, const double *x0, const double *controls, 
             a.zu = h->d_pzu;
         }
     }
+    prof_begin(h, RAT_K_PETS, (int64_t)ntraj);
     launch_pets(a, h->stream);
+    prof_end(h);
     HIPCHK(hipMemcpyAsync(cost, h->d_pcost, (size_t)S * 8, hipMemcpyDeviceToHost, h->stream));
     return RAT_OK;
 }

@@ -30,6 +30,7 @@ struct RolloutArgs {
     const double *u0;      // [N*4]
     double *dump;          // diagnostic builds only
     int notile;            // mode 1, rollin_stage_kernel: candidate records keep only [c_x | c_u | c] (see SweepArgs.fly, launch_materialize)
+    int multi;             // mode 1 with notile, E <= 16: all candidates of a sample in one wavefront (rollin_multi_kernel)
 };
 
 struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per sample (E = 1)

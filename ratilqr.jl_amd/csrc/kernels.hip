@@ -92,7 +92,7 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
 // wls: this wavefront's LDS scratch (WLS_SWEEP doubles).
 // SWZ: the elimination's row exchange through the LDS crossbar (ds_swizzle) instead of vector-ALU lane swaps: identical values, fewer
 // vector instructions, longer latency -- for the kernel that runs two samples per SIMD, which is short of issue slots, not of latency.
-template <bool GAIN, bool DUMP, bool WTV, bool HASL, bool SWZ = false, int FLY = 0>
+template <bool GAIN, bool DUMP, int WM, bool HASL, bool SWZ = false, int FLY = 0>
 __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, double *const wls) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase: keeps the per-lane constants of one phase from being shared with
@@ -174,7 +174,15 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
     // noise tables (time-invariant case is hoisted out of the time loop)
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
     double epall = 1.0;                     // prod over the six pivot blocks of 1/(e_k e_k+1), e = pivots of inv(W) (wave-uniform)
-    if (!WTV) {
+    // WM == 2 (W diagonal, time-invariant): (D S)[A|B] is formed as V M^-1 inv(W) [A|B] -- D S = S M^-1 inv(W) exactly, since
+    // inv(W) = M + theta S -- with inv(W) folded into the rows of M^-1's A operand: 6 MFMAs where X = V [A|B], theta M^-1 X and
+    // X + V (theta M^-1 X) take 9.  nwrow[r] = -inv(W)_ii of this lane's row i = 4 r + g (the sweep leaves -M^-1).
+    double nwrow[3] = {0.0, 0.0, 0.0};
+    if (WM == 2) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) nwrow[r] = -pb.Wdg[4 * r + g];
+    }
+    if (WM != 1) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             winv[r] = pb.Winv[64 * r + l];
@@ -223,7 +231,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
             int l = l_, g = g_, j = j_;
             asm volatile("" : "+v"(l), "+v"(g), "+v"(j));
             DIAG_START();
-            if (WTV) {          // time-varying W(k): separate instantiation, so that the common case keeps a static load count
+            if (WM == 1) {          // time-varying W(k): separate instantiation, so that the common case keeps a static load count
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     winv[r] = pb.Winv[(long)t * 192 + 64 * r + l];
@@ -243,8 +251,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
                 else ccs = fc.cc;
             }
             // X = V[:, 0:12] [A|B] (rows 0..11 = S [A|B], row 12 = s_vec'[A|B]).  Issued first: it does not depend on the
-            // inverse, so the matrix pipe works through it while the VALU runs the elimination below.
-            const d4 xz = mm3(v, cz, (d4){0, 0, 0, 0});
+            // inverse, so the matrix pipe works through it while the VALU runs the elimination below.  (Diagonal W: only theta == 0 needs it.)
+            d4 xz = {0, 0, 0, 0};
+            if (WM != 2 || theta == 0.0) xz = mm3(v, cz, (d4){0, 0, 0, 0});
             if (HASL) lbuf[l] = cur.la;                                     // rows of [L | dl] to every lane (read after the next fence)
             const double qc = readlane_f64(cur.x, 16);                      // c (ileqg.jl:296)
             d4 tm;
@@ -272,20 +281,32 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
                 elim_round<5, SWZ>(m, em, pdmin, nsum, rprod);
                 DIAG_STAMP(1, m[0]);
                 if (!(pdmin > 0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
-                // theta M^-1 (the sweep left -M^-1); padded columns cleared
-                d4 minv;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) minv[r] = nth12 * m[r];
-                minv[3] = 0.0;
                 // (the product is renormalised once per step: one log() per sweep instead of twelve per step)
                 rexp += __builtin_amdgcn_frexp_exp(rprod);
                 rprod = __builtin_amdgcn_frexp_mant(rprod);
-                // theta s_vec' M^-1 s_vec (:387): the constant term never feeds back into S, s_vec or the gains, so it is
-                // accumulated per lane (sum_ij (theta M^-1)_ij s_i s_j) and reduced once per sweep with the other scalars
-                racc += SVB(j) * (minv[0] * SVB(g) + minv[1] * SVB(4 + g) + minv[2] * SVB(8 + g));
-                // T = (D S)[A|B] = X + V (theta M^-1 X): rows 0..11 = (D S)[A|B], row 12 = (D s_vec)'[A|B]   (:367)
-                const d4 y2 = mm3(minv, xz, (d4){0, 0, 0, 0});
-                tm = mm3(v, y2, xz);
+                if (WM == 2) {
+                    // theta s_vec' M^-1 s_vec (:387), per lane: (-theta s_j) sum_i (-M^-1)_ij s_i (columns >= 12 of the sweep's result are zero)
+                    racc += (nth12 * SVB(j)) * (m[0] * SVB(g) + m[1] * SVB(4 + g) + m[2] * SVB(8 + g));
+                    // T = V M^-1 inv(W) [A|B]: rows 0..11 = (D S)[A|B], row 12 = (D s_vec)'[A|B]   (:367)
+                    d4 mw;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) mw[r] = m[r] * nwrow[r];
+                    mw[3] = 0.0;
+                    const d4 y2 = mm3(mw, cz, (d4){0, 0, 0, 0});
+                    tm = mm3(v, y2, (d4){0, 0, 0, 0});
+                } else {
+                    // theta M^-1 (the sweep left -M^-1); padded columns cleared
+                    d4 minv;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) minv[r] = nth12 * m[r];
+                    minv[3] = 0.0;
+                    // theta s_vec' M^-1 s_vec (:387): the constant term never feeds back into S, s_vec or the gains, so it is
+                    // accumulated per lane (sum_ij (theta M^-1)_ij s_i s_j) and reduced once per sweep with the other scalars
+                    racc += SVB(j) * (minv[0] * SVB(g) + minv[1] * SVB(4 + g) + minv[2] * SVB(8 + g));
+                    // T = (D S)[A|B] = X + V (theta M^-1 X): rows 0..11 = (D S)[A|B], row 12 = (D s_vec)'[A|B]   (:367)
+                    const d4 y2 = mm3(minv, xz, (d4){0, 0, 0, 0});
+                    tm = mm3(v, y2, xz);
+                }
                 DIAG_STAMP(2, tm[0]);
             } else {
                 // theta == 0: D = I ; 0.5 tr(W S)   (ileqg.jl:385).  The reference still forms M = inv(W) - 0 S and asserts
@@ -448,16 +469,17 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
 #undef SVB
 }
 
-template <bool GAIN, bool DUMP, bool WTV, bool HASL, int FLY = 0>
+template <bool GAIN, bool DUMP, int WM, bool HASL, int FLY = 0>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     __shared__ double wls[WLS_SWEEP];
-    sweep_body<GAIN, DUMP, WTV, HASL, false, FLY>(a, blockIdx.x, wls);
+    sweep_body<GAIN, DUMP, WM, HASL, false, FLY>(a, blockIdx.x, wls);
 }
 
 template <bool GAIN, bool DUMP, bool HASL>
 static void launch_sweep_w(const SweepArgs &a, dim3 grid, hipStream_t s) {
-    if (a.pb.W_tv) hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, true, HASL>), grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, false, HASL>), grid, dim3(64), 0, s, a);
+    if (a.pb.W_tv) hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, 1, HASL>), grid, dim3(64), 0, s, a);
+    else if (a.pb.W_diag) hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, 2, HASL>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, 0, HASL>), grid, dim3(64), 0, s, a);
 }
 
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s) {
@@ -469,14 +491,10 @@ void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream
     } else if (a.mode == 2) {                      // initialize!: zero gains
         launch_sweep_w<false, false, false>(a, grid, s);
     } else if (a.fly && a.mode == 1 && !dump) {    // candidates whose records hold only [c_x | c_u | c]: tiles formed in the sweep
-        const bool wtv = a.pb.W_tv != 0;
-        if (a.pb.cost_tv) {
-            if (wtv) hipLaunchKernelGGL((sweep_kernel<false, false, true, true, 2>), grid, dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((sweep_kernel<false, false, false, true, 2>), grid, dim3(64), 0, s, a);
-        } else {
-            if (wtv) hipLaunchKernelGGL((sweep_kernel<false, false, true, true, 1>), grid, dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((sweep_kernel<false, false, false, true, 1>), grid, dim3(64), 0, s, a);
-        }
+#define FLY_LAUNCH(W) do { if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 2>), grid, dim3(64), 0, s, a); \
+                           else hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1>), grid, dim3(64), 0, s, a); } while (0)
+        if (a.pb.W_tv) FLY_LAUNCH(1); else if (a.pb.W_diag) FLY_LAUNCH(2); else FLY_LAUNCH(0);
+#undef FLY_LAUNCH
     } else {
         if (dump) launch_sweep_w<false, true, true>(a, grid, s);
         else launch_sweep_w<false, false, true>(a, grid, s);
@@ -887,7 +905,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
             cx = MFMA(cf[3], u, cx);
             const double acc = ((cx[0] * pm[0] + cx[1] * pm[1]) + cx[2] * pm[2]) + cx[3] * pm[3];    // packed (lanes j < 4), 0 elsewhere
             // c = [x;u]' (1/2 C [x;u] + lin) + q0  (:296): 16 packed terms, summed per row and then over the four rows
-            const double w = row_sum16(pk * (0.5 * acc + clin));     // pk = 0 on the idle lanes
+            const double w = row_sum16(cost_term(pk, acc, clin));    // pk = 0 on the idle lanes
             const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
             tp[qoff] = fma(m_l4, part + cq00, m_j4 * (acc + clin));  // [c_x | c_u] = C [x;u] + [qv;rv]  (:297,:299), c, pad (0.0)
         } else {
@@ -962,10 +980,10 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
             for (int e = l; e < 144; e += 64) tp[TT_Q + e] = pb.Qf[e];
             double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q < 12; ++q) acc += pb.Qf[jx * 12 + q] * shxu[q];
+            for (int q = 0; q < 12; ++q) acc = fma(pb.Qf[jx * 12 + q], shxu[q], acc);
             const double qvf = pb.qvf[jx];
             if (l < 12) tp[TT_QV + l] = acc + qvf;
-            const double part = row_sum16((j < 12) ? shxu[jx] * (0.5 * acc + qvf) : 0.0);
+            const double part = row_sum16((j < 12) ? cost_term(shxu[jx], acc, qvf) : 0.0);
             if (l == 0) tp[TT_q] = part + pb.q0f;
         } else {
             for (int e = l; e < 144; e += 64) tp[TT_Q + e] = 0.0;
@@ -1214,7 +1232,7 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
         cx = MFMA(cf[2], xb[2], cx);
         cx = MFMA(cf[3], u, cx);
         const double acc = ((cx[0] * pm[0] + cx[1] * pm[1]) + cx[2] * pm[2]) + cx[3] * pm[3];
-        const double w = row_sum16(pk * (0.5 * acc + clin));
+        const double w = row_sum16(cost_term(pk, acc, clin));
         const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
         tp[qoff] = fma(m_l4, part + cq00, m_j4 * (acc + clin));
     }
@@ -1233,10 +1251,10 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
         for (int e = l; e < 144; e += 64) tp[TT_Q + e] = pb.Qf[e];
         double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < 12; ++q) acc += pb.Qf[jx * 12 + q] * shxu[q];
+        for (int q = 0; q < 12; ++q) acc = fma(pb.Qf[jx * 12 + q], shxu[q], acc);
         const double qvf = pb.qvf[jx];
         if (l < 12) tp[TT_QV + l] = acc + qvf;
-        const double part = row_sum16((j < 12) ? shxu[jx] * (0.5 * acc + qvf) : 0.0);
+        const double part = row_sum16((j < 12) ? cost_term(shxu[jx], acc, qvf) : 0.0);
         if (l == 0) tp[TT_q] = part + pb.q0f;
         WAVE_SYNC();
     }
@@ -1260,6 +1278,169 @@ __global__ __launch_bounds__(512) void rollin_stage_kernel(RolloutArgs a) {
     __shared__ double shxu[8][16];
     __shared__ double stg[STG_DOUBLES];
     rollin_body<MODEL, 1, CTV, true, false, ROLLIN_PREFETCH, NOTILE>(a, b * a.st.E + k, shxu[(threadIdx.x >> 6) & 7], stg);
+}
+
+// =====================================================================================================
+// rollin_multi_kernel: the closed-loop rollouts of ALL E <= 16 line-search candidates of a sample in ONE wavefront (speculative path,
+// LQ family, candidate records without tiles: NOTILE).  In rollin_body a vector in B-form is replicated across the 16 columns of the
+// MFMA's B operand; here column j carries candidate j -- x_t^(j), u_t^(j) = l_t + eps_j dl_t + L_t (x_t^(j) - xbar_t) -- so the very same
+// 11 MFMAs per step ([A|B][x;u]: 4, L dx: 3, C [x;u]: 4) advance 16 trajectories instead of one.  An MFMA forms every element of D from
+// its own row of A and column of B in a fixed order, whatever the other columns hold, and every vector instruction below is the
+// per-lane expression of rollin_body: each candidate's x, u, [c_x | c_u], c, d are the bits the one-candidate kernels produce (tested).
+// The sample's operands (L, xbar, l, dl) are staged in LDS once for all candidates; what differs per column is eps_j and the slot the
+// lane stores to.  Row sums over the 16 components of a candidate -- which the one-candidate kernels take over a packed vector with DPP
+// rotations and v_readlane -- are taken in the same order with the rows brought together by lane swaps (rows_bcast).
+// One wavefront per sample: 1024 waves instead of 8192 for BASELINE config 3.
+// =====================================================================================================
+template <bool CTV>
+__global__ __launch_bounds__(64) void rollin_multi_kernel(RolloutArgs a) {
+    __shared__ double stg[STG_DOUBLES];
+    __shared__ double shx[16][16];                               // x_N of candidate i by component
+    const int l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    const int N = st.N, E = st.E;
+    const int b = blockIdx.x;
+    const int v_act = st.ls_active[b], v_nom = st.slot_nom[b], v_lsel = st.lsel[b];
+    const int s_act = wave_uniform(v_act), nom = wave_uniform(v_nom), lsel = wave_uniform(v_lsel);
+    const double eps_in = st.ls_eps[b];
+    if (!s_act) return;
+    const bool live = j < E;                                    // this lane's column carries a candidate
+    const int k = live ? j : E - 1;
+    const int slot_n = b * (E + 1) + nom, slot_o = cand_slot(b, k, nom, E);
+    const double *__restrict__ xbar = st.xs + (long)slot_n * st.x_stride;
+    const double *__restrict__ lnom = st.us + (long)slot_n * st.u_stride;
+    const double *__restrict__ Lb = st.L + (long)lsel * st.l_half + (long)b * N * LSTR;
+    const double *__restrict__ dlb = st.dl + (long)lsel * st.dl_half + (long)b * N * USTR;
+    double *const xo = st.xs + (long)slot_o * st.x_stride, *const uo = st.us + (long)slot_o * st.u_stride;
+    double *const tile0 = st.tiles + tile_slot(st, b, slot_o) * st.tile_stride;
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    double eps = eps_in;
+    for (int q = 0; q < E; ++q) if (q < k) eps *= a.op.lambda;   // eps_k = eps * lambda^k by repeated multiplication (:530,:557)
+    const double mq = (j < 12) ? 1.0 : 0.0;
+    const int jx = (j < 12) ? j : 11, j3 = j & 3;
+    double zA[4], cf[4] = {0, 0, 0, 0}, lin[4] = {0, 0, 0, 0}, es[3], cq00 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) zA[s] = pb.Zt[jx * 16 + 4 * s + g] * mq;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) es[s] = (j == 4 * s + g) ? 1.0 : 0.0;
+    if (!CTV) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { cf[s] = pb.Ctab[64 * s + l]; lin[s] = pb.lin[4 * s + g]; }
+        cq00 = pb.q0[0];
+    }
+    // per-lane store targets: live columns write their candidate's slot, the others a sink (every store stays unconditional)
+    double *const sk = st.sink + l;
+    double *const px = live ? xo + g : sk, *const pu = live ? uo + g : sk, *const pq = live ? tile0 + TS_QR + g : sk;
+    const long sx = live ? XSTR : 0, su = live ? USTR : 0, sq = live ? TSTRIDE : 0;
+    const int o4 = live ? 4 : 0;
+    double *const pc = (live && g == 0) ? tile0 + TS_q : ((live && g == 1) ? tile0 + TS_PAD : sk);   // c, and the record's zero slot
+    const long sc = (live && g < 2) ? TSTRIDE : 0;
+    const double mc = (g == 0) ? 1.0 : 0.0;
+    // the sample's operands into LDS (rollin_body's STAGE layout)
+    constexpr int cL = STG_CL, cX = STG_CX, cU = STG_CU;
+    double *const sL = stg, *const sX = stg + cL * 64, *const sl = sX + cX * 64, *const sdl = sl + cU * 64;
+    {
+        double tL[cL], tX[cX], tl[cU], tdl[cU];
+#pragma unroll
+        for (int q = 0; q < cL; ++q) { const int e = 64 * q + l; tL[q] = Lb[(e < N * LSTR) ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < cX; ++q) { const int e = 64 * q + l; tX[q] = xbar[(e < (N + 1) * XSTR) ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < cU; ++q) { const int e = 64 * q + l; tl[q] = lnom[(e < N * USTR) ? e : 0]; tdl[q] = dlb[(e < N * USTR) ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < cL; ++q) sL[64 * q + l] = tL[q];
+#pragma unroll
+        for (int q = 0; q < cX; ++q) sX[64 * q + l] = tX[q];
+#pragma unroll
+        for (int q = 0; q < cU; ++q) { sl[64 * q + l] = tl[q]; sdl[64 * q + l] = tdl[q]; }
+        WAVE_SYNC();
+    }
+    double xb[3];                                                // x_t of this column's candidate in B-form (all candidates start at xbar_0)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) xb[s] = sX[4 * s + g];
+    double dmax = -INFINITY;
+    bool dnan = false;
+    for (int t = 0; t < N; ++t) {
+        const double c_l = sl[t * USTR + g], c_dl = sdl[t * USTR + g];
+        double c_xb[3], c_La[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { c_xb[s] = sX[t * XSTR + 4 * s + g]; c_La[s] = sL[t * LSTR + j3 * 12 + 4 * s + g]; }
+        if (CTV) {
+            const double *__restrict__ C = pb.Ctab + (long)t * 256;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { cf[s] = C[64 * s + l]; lin[s] = pb.lin[(long)t * 16 + 4 * s + g]; }
+            cq00 = pb.q0[t];
+        }
+        d4 xa = MFMA(zA[0], xb[0], zero4);                        // x-part of [A|B][x; u]
+        xa = MFMA(zA[1], xb[1], xa);
+        xa = MFMA(zA[2], xb[2], xa);
+        d4 fb = MFMA(c_La[0], xb[0] - c_xb[0], zero4);            // L_t (x_t - xbar_t)   (:82)
+        fb = MFMA(c_La[1], xb[1] - c_xb[1], fb);
+        fb = MFMA(c_La[2], xb[2] - c_xb[2], fb);
+        const double lnew = c_l + eps * c_dl;                     // l + eps dl           (:509)
+        const double u = lnew + fb[0];
+        // d = maximum(norm(l_t - u_t))  (:517-519): squared norms, rooted once after the loop, rows added in rollin_body's order
+        const double du = c_l - u, dsq = du * du;
+        double dr[4];
+        rows_bcast(dsq, dr);
+        const double dn2 = ((dr[0] + dr[1]) + dr[2]) + dr[3];
+        dnan |= (dn2 != dn2);
+        dmax = (dn2 > dmax) ? dn2 : dmax;
+        xa = MFMA(zA[3], u, xa);
+        // [x_t; u_t] of every candidate
+        px[(long)t * sx] = xb[0]; px[(long)t * sx + o4] = xb[1]; px[(long)t * sx + 2 * o4] = xb[2];
+        pu[(long)t * su] = u;
+        // [c_x | c_u] = C [x;u] + [qv; rv]  (:297,:299) and c (:296)
+        d4 cx = MFMA(cf[0], xb[0], zero4);
+        cx = MFMA(cf[1], xb[1], cx);
+        cx = MFMA(cf[2], xb[2], cx);
+        cx = MFMA(cf[3], u, cx);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pq[(long)t * sq + s * o4] = cx[s] + lin[s];
+        // the packed vector of rollin_body holds component 4 s + g on lane (g, s): its row sum runs (a0 + a2) + (a1 + a3), rows in order
+        const double a0 = cost_term(xb[0], cx[0], lin[0]), a1 = cost_term(xb[1], cx[1], lin[1]);
+        const double a2 = cost_term(xb[2], cx[2], lin[2]), a3 = cost_term(u, cx[3], lin[3]);
+        const double w = (a0 + a2) + (a1 + a3);
+        double wr[4];
+        rows_bcast(w, wr);
+        const double part = ((wr[0] + wr[1]) + wr[2]) + wr[3];
+        pc[(long)t * sc] = mc * (part + cq00);                    // row 0: c; row 1: 0.0 to the record's zero slot
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xb[r] = xa[r] + pb.kappa * (xb[r] * xb[r] * xb[r]);
+    }
+    // x_N of every candidate by component: row i of D = sum_s xb[s]' es[s] is candidate i's state vector
+    {
+        d4 tj = MFMA(xb[0], es[0], zero4);
+        tj = MFMA(xb[1], es[1], tj);
+        tj = MFMA(xb[2], es[2], tj);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) shx[4 * r + g][j] = tj[r];
+        WAVE_SYNC();
+    }
+    // terminal tile of candidate 4 it + g on the lanes of row g: h, h_x, h_xx at x_N   (ileqg.jl:314-316), as rollin_body
+    for (int it = 0; 4 * it < E; ++it) {
+        const int i = 4 * it + g;
+        const bool on = i < E;
+        const int ii = on ? i : E - 1;
+        const int so = cand_slot(b, ii, nom, E);
+        double *__restrict__ tp = st.tiles + tile_slot(st, b, so) * st.tile_stride + (long)N * TSTRIDE;
+        double *__restrict__ xoi = st.xs + (long)so * st.x_stride;
+        const double x = (j < 12) ? shx[ii][j] : 0.0;
+        if (on && j < 12) xoi[(long)N * XSTR + j] = x;
+        if (on) for (int e = j; e < 144; e += 16) tp[TT_Q + e] = pb.Qf[e];
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) acc = fma(pb.Qf[jx * 12 + q], shx[ii][q], acc);
+        const double qvf = pb.qvf[jx];
+        if (on && j < 12) tp[TT_QV + j] = acc + qvf;
+        const double part = row_sum16((j < 12) ? cost_term(shx[ii][jx], acc, qvf) : 0.0);
+        if (on && j == 0) tp[TT_q] = part + pb.q0f;
+    }
+    if (live && g == 0) {
+        st.d_c[b * E + j] = dnan ? NAN : sqrt(dmax);
+        st.flag_c[b * E + j] = 0;
+    }
 }
 
 // The rest of the step records of a trajectory whose candidate records hold only [c_x | c_u | c] (rollin_body<.., NOTILE>): f_x | f_u and
@@ -1300,6 +1481,11 @@ bool rollin_notile_supported(const ProblemDev &pb, const StateDev &st) { return 
 void launch_rollin(const RolloutArgs &a, hipStream_t s) {
     const int ncand = (a.mode == 0) ? a.st.B : a.st.B * a.st.E;
     if (ncand <= 0) return;
+    if (a.mode == 1 && a.notile && a.multi && a.pb.model == 1 && a.st.E > 1 && a.st.E <= 16 && a.st.N <= ROLLIN_NST) {
+        if (a.pb.cost_tv) hipLaunchKernelGGL((rollin_multi_kernel<true>), dim3(a.st.B), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((rollin_multi_kernel<false>), dim3(a.st.B), dim3(64), 0, s, a);
+        return;
+    }
     if (a.mode == 1 && a.pb.model == 1 && a.st.E > 1 && a.st.N <= ROLLIN_NST) {
         const dim3 g2(a.st.B * ((a.st.E + 7) / 8)), b2(64 * (a.st.E < 8 ? a.st.E : 8));
         if (a.notile) {
@@ -1634,7 +1820,7 @@ __device__ __forceinline__ void gather_body(const StateDev &st, const int b, dou
 
 // OCC2: the compiler is held to 256 registers so that TWO samples share a SIMD (only offered without DUALF / STG: one recursion per pass,
 // 2 KB of LDS per wave) -- the direct test of "hide a wave's dependency stalls with a second sample" for batches beyond one per SIMD.
-template <int MODEL, bool CTV, bool WTV, bool DUALF, bool STG, bool OCC2 = false>
+template <int MODEL, bool CTV, int WM, bool DUALF, bool STG, bool OCC2 = false>
 __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs fa) {
     const int b = blockIdx.x;
     const StateDev &st = fa.sw.st;
@@ -1656,7 +1842,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
         PHASE_MARK();
         if (DUALF) {
             SweepArgs sa = fa.sw; sa.mode = 6;
-            sweep_dual_body<WTV, false>(sa, b, wls);
+            sweep_dual_body<WM, false>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             if (threadIdx.x == 0) commit_init_body(st, b);
@@ -1664,7 +1850,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
             PHASE_MARK();
         } else {
             SweepArgs sa = fa.sw; sa.mode = 2;
-            sweep_body<false, false, WTV, false, OCC2>(sa, b, wls);
+            sweep_body<false, false, WM, false, OCC2>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1676,7 +1862,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp!  (ileqg.jl:598-613)
             SweepArgs sa = fa.sw; sa.mode = 0;
-            sweep_body<true, false, WTV, false, OCC2>(sa, b, wls);
+            sweep_body<true, false, WM, false, OCC2>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1698,10 +1884,10 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
             }
             if (pair) {
                 SweepArgs sa = fa.sw; sa.mode = 7;
-                sweep_dual_body<WTV, true>(sa, b, wls);
+                sweep_dual_body<WM, true>(sa, b, wls);
             } else {
                 SweepArgs sa = fa.sw; sa.mode = 1;
-                sweep_body<false, false, WTV, true, OCC2>(sa, b, wls);
+                sweep_body<false, false, WM, true, OCC2>(sa, b, wls);
             }
             PHASE_MARK();
             PHASE_FENCE();
@@ -1719,7 +1905,7 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
     const int B = fa.sw.st.B;
     if (B <= 0) return;
     const dim3 grid(B), block(64);
-    const bool wtv = fa.sw.pb.W_tv != 0;
+    const int wm = fa.sw.pb.W_tv ? 1 : (fa.sw.pb.W_diag ? 2 : 0);
     const bool stg = fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST;
 #define FUSED_LAUNCH(M, C, W) do { \
         if (fa.occ2) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false, true>), grid, block, 0, s, fa); \
@@ -1727,10 +1913,10 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
         else if (fa.dual) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, false>), grid, block, 0, s, fa); \
         else hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.model == 1) {
-        if (fa.sw.pb.cost_tv) { if (wtv) FUSED_LAUNCH(1, true, true); else FUSED_LAUNCH(1, true, false); }
-        else { if (wtv) FUSED_LAUNCH(1, false, true); else FUSED_LAUNCH(1, false, false); }
+        if (fa.sw.pb.cost_tv) { if (wm == 1) FUSED_LAUNCH(1, true, 1); else if (wm == 2) FUSED_LAUNCH(1, true, 2); else FUSED_LAUNCH(1, true, 0); }
+        else { if (wm == 1) FUSED_LAUNCH(1, false, 1); else if (wm == 2) FUSED_LAUNCH(1, false, 2); else FUSED_LAUNCH(1, false, 0); }
     } else {
-        if (wtv) FUSED_LAUNCH(2, false, true); else FUSED_LAUNCH(2, false, false);
+        if (wm == 1) FUSED_LAUNCH(2, false, 1); else if (wm == 2) FUSED_LAUNCH(2, false, 2); else FUSED_LAUNCH(2, false, 0);
     }
 #undef FUSED_LAUNCH
 }
@@ -1768,7 +1954,7 @@ __device__ __forceinline__ int hw_cu_key() {
 }
 __device__ __forceinline__ int hw_simd_id() { return (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u); }
 
-template <int MODEL, bool CTV, bool WTV, int NW, bool GW, bool STG, bool PAD4>
+template <int MODEL, bool CTV, int WM, int NW, bool GW, bool STG, bool PAD4>
 __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
     static_assert(!PAD4 || NW == 2, "PAD4 is the two-wave (E = 1) geometry");
     constexpr int E = GW ? NW - 1 : NW;          // candidate waves
@@ -1856,10 +2042,10 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     BLK_MARK();
     if (wave == 0) {                             // open-loop policy evaluation (:234) ...
         SweepArgs sa = fa.sw; sa.mode = 2;
-        sweep_body<false, false, WTV, false>(sa, b, wls);
+        sweep_body<false, false, WM, false>(sa, b, wls);
     } else if (GW && wave == WG) {               // ... beside the first step!'s gain sweep on the same tiles (speculative until initialize! succeeds)
         SweepArgs sa = fa.sw; sa.mode = 5;
-        sweep_body<true, false, WTV, false>(sa, b, wls);
+        sweep_body<true, false, WM, false>(sa, b, wls);
     }
     BLK_MARK();
     __syncthreads();
@@ -1876,7 +2062,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp! with no valid speculative sweep  (ileqg.jl:598-613)
             if (wave == WG) {
                 SweepArgs sa = fa.sw; sa.mode = 0;
-                sweep_body<true, false, WTV, false>(sa, b, wls);
+                sweep_body<true, false, WM, false>(sa, b, wls);
             }
             BLK_MARK();
     __syncthreads();
@@ -1902,7 +2088,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     BLK_MARK();
         if (wave < E) {                                       // their policy evaluations  (:522-536)
             SweepArgs sa = fa.sw; sa.mode = 1;
-            sweep_body<false, false, WTV, true>(sa, b * E + wave, wls);
+            sweep_body<false, false, WM, true>(sa, b * E + wave, wls);
         } else if (wave == WG) {                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
             if (helpers && (threadIdx.x & 63) == 0) {         // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
                 st.d_c[b * E] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
@@ -1915,7 +2101,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
             const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
             if (!ends) {
                 SweepArgs sa = fa.sw; sa.mode = 4;
-                sweep_body<true, false, WTV, false>(sa, b, wls);
+                sweep_body<true, false, WM, false>(sa, b, wls);
             }
         }
         BLK_MARK();
@@ -1936,22 +2122,22 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
 template <int NW, bool GW>
 static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {
     const dim3 grid(fa.sw.st.B), block(64 * NW);
-    const bool wtv = fa.sw.pb.W_tv != 0;
+    const int wm = fa.sw.pb.W_tv ? 1 : (fa.sw.pb.W_diag ? 2 : 0);
     const bool stg = fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST;
 #define BLOCK_LAUNCH(M, C, W, S) do { \
         if (NW == 2 && fa.census) hipLaunchKernelGGL((solve_block_kernel<M, C, W, NW, GW, S, NW == 2>), grid, dim3(256), 0, s, fa); \
         else hipLaunchKernelGGL((solve_block_kernel<M, C, W, NW, GW, S, false>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.model == 1) {
         if (stg) {
-            if (fa.sw.pb.cost_tv) { if (wtv) BLOCK_LAUNCH(1, true, true, true); else BLOCK_LAUNCH(1, true, false, true); }
-            else { if (wtv) BLOCK_LAUNCH(1, false, true, true); else BLOCK_LAUNCH(1, false, false, true); }
+#define BLOCK_W(M, C, S) do { if (wm == 1) BLOCK_LAUNCH(M, C, 1, S); else if (wm == 2) BLOCK_LAUNCH(M, C, 2, S); else BLOCK_LAUNCH(M, C, 0, S); } while (0)
+            if (fa.sw.pb.cost_tv) BLOCK_W(1, true, true); else BLOCK_W(1, false, true);
         } else {
-            if (fa.sw.pb.cost_tv) { if (wtv) BLOCK_LAUNCH(1, true, true, false); else BLOCK_LAUNCH(1, true, false, false); }
-            else { if (wtv) BLOCK_LAUNCH(1, false, true, false); else BLOCK_LAUNCH(1, false, false, false); }
+            if (fa.sw.pb.cost_tv) BLOCK_W(1, true, false); else BLOCK_W(1, false, false);
         }
     } else {
-        if (wtv) BLOCK_LAUNCH(2, false, true, false); else BLOCK_LAUNCH(2, false, false, false);
+        BLOCK_W(2, false, false);
     }
+#undef BLOCK_W
 #undef BLOCK_LAUNCH
 }
 

@@ -81,6 +81,7 @@
 
 struct ProblemDev {
     int model, n, m, N, cost_tv, W_tv;
+    int W_diag;          // 1: W is time-invariant and diagonal (the sweeps then fold inv(W) into M^-1: see sweep_body)
     const double *Zt;    // [192]      [A|B] 12x16 row-major, zero padded
     const double *Ctab;  // [Nc][256]  [[Q,P'],[P,R]] 16x16 row-major, padded R diagonal = 1
     const double *lin;   // [Nc][16]   [qv | rv]
@@ -93,6 +94,7 @@ struct ProblemDev {
     const double *Wp;    // [Nw][192]  W(k), zero padded
     const double *epiv;  // [Nw][16]   even k: 1/(e_k e_k+1), e = elimination pivots of the padded inv(W(k)); odd k: 1 (logdet pairing)
     const double *logdetW; // [Nw]
+    const double *Wdg;   // [16]       W_diag: the diagonal of inv(W), padded entries 1
 };
 
 // All per-sample / per-slot device state of one handle.

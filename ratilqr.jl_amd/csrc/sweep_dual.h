@@ -79,7 +79,7 @@ __device__ __forceinline__ void dload(DTile &tr, const double *__restrict__ tp, 
 // The elimination rounds of the two recursions are the shared elim_round (device_utils.h: rank-2 update on the matrix pipe, no LDS,
 // no fence), issued back to back: two independent pivot chains for the scheduler to interleave.
 // wls: this wavefront's LDS scratch (WLS_DUAL doubles)
-template <bool WTV, bool HASL, int FLY = 0>
+template <int WM, bool HASL, int FLY = 0>
 __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b, double *const wls) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase (see sweep_body)
@@ -139,7 +139,12 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
 
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};
     double epall = 1.0;
-    if (!WTV) {
+    double nwrow[3] = {0.0, 0.0, 0.0};                           // WM == 2 (W diagonal): see sweep_body
+    if (WM == 2) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) nwrow[r] = -pb.Wdg[4 * r + g];
+    }
+    if (WM != 1) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) { winv[r] = pb.Winv[64 * r + l]; wp[r] = pb.Wp[64 * r + l]; }
         epall = ((((pb.epiv[0] * pb.epiv[2]) * pb.epiv[4]) * pb.epiv[6]) * pb.epiv[8]) * pb.epiv[10];
@@ -165,7 +170,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
     auto step = [&](const int t, const DTile &cur) -> int {
         int l = l_, g = g_, j = j_;
         asm volatile("" : "+v"(l), "+v"(g), "+v"(j));
-        if (WTV) {
+        if (WM == 1) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) { winv[r] = pb.Winv[(long)t * 192 + 64 * r + l]; wp[r] = pb.Wp[(long)t * 192 + 64 * r + l]; }
             { const double *ept = pb.epiv + (long)t * 16; epall = ((((ept[0] * ept[2]) * ept[4]) * ept[6]) * ept[8]) * ept[10]; }
@@ -179,8 +184,11 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             if (FLY == 2) { ccs[0] = cur.c[0] * fc.mq; ccs[1] = cur.c[1] * fc.mq; ccs[2] = cur.c[2] * fc.mq; ccs[3] = cur.c[3]; }
             else ccs = fc.cc;
         }
-        const d4 xzA = mm3(vA, cz, (d4){0, 0, 0, 0});
-        const d4 xzB = mm3(vB, cz, (d4){0, 0, 0, 0});
+        d4 xzA = {0, 0, 0, 0}, xzB = {0, 0, 0, 0};
+        if (WM != 2 || theta == 0.0) {
+            xzA = mm3(vA, cz, (d4){0, 0, 0, 0});
+            xzB = mm3(vB, cz, (d4){0, 0, 0, 0});
+        }
         d4 tmA, tmB;
         if (theta != 0.0) {
             exA[svo] = vA[3]; exB[svo] = vB[3];
@@ -205,18 +213,31 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             elim_round<5, true>(mB, em, pdB, nsB, rprodB);
             if (!(pdA > 0) || !(nsA * 0.0 == 0.0)) { failA = 1; return 1; }       // @assert isposdef(M) (:440)
             if (!deadB && (!(pdB > 0) || !(nsB * 0.0 == 0.0))) deadB = 2;         // @assert isposdef(M) (:366)
-            d4 minvA, minvB;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { minvA[r] = nth12 * mA[r]; minvB[r] = nth12 * mB[r]; }
-            minvA[3] = 0.0; minvB[3] = 0.0;
             rexpA += __builtin_amdgcn_frexp_exp(rprodA); rprodA = __builtin_amdgcn_frexp_mant(rprodA);
             rexpB += __builtin_amdgcn_frexp_exp(rprodB); rprodB = __builtin_amdgcn_frexp_mant(rprodB);
-            raccA += exA[84 + j] * (minvA[0] * exA[84 + g] + minvA[1] * exA[84 + 4 + g] + minvA[2] * exA[84 + 8 + g]);
-            raccB += exB[84 + j] * (minvB[0] * exB[84 + g] + minvB[1] * exB[84 + 4 + g] + minvB[2] * exB[84 + 8 + g]);
-            const d4 y2A = mm3(minvA, xzA, (d4){0, 0, 0, 0});
-            const d4 y2B = mm3(minvB, xzB, (d4){0, 0, 0, 0});
-            tmA = mm3(vA, y2A, xzA);
-            tmB = mm3(vB, y2B, xzB);
+            if (WM == 2) {
+                raccA += (nth12 * exA[84 + j]) * (mA[0] * exA[84 + g] + mA[1] * exA[84 + 4 + g] + mA[2] * exA[84 + 8 + g]);
+                raccB += (nth12 * exB[84 + j]) * (mB[0] * exB[84 + g] + mB[1] * exB[84 + 4 + g] + mB[2] * exB[84 + 8 + g]);
+                d4 mwA, mwB;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { mwA[r] = mA[r] * nwrow[r]; mwB[r] = mB[r] * nwrow[r]; }
+                mwA[3] = 0.0; mwB[3] = 0.0;
+                const d4 y2A = mm3(mwA, cz, (d4){0, 0, 0, 0});
+                const d4 y2B = mm3(mwB, cz, (d4){0, 0, 0, 0});
+                tmA = mm3(vA, y2A, (d4){0, 0, 0, 0});
+                tmB = mm3(vB, y2B, (d4){0, 0, 0, 0});
+            } else {
+                d4 minvA, minvB;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { minvA[r] = nth12 * mA[r]; minvB[r] = nth12 * mB[r]; }
+                minvA[3] = 0.0; minvB[3] = 0.0;
+                raccA += exA[84 + j] * (minvA[0] * exA[84 + g] + minvA[1] * exA[84 + 4 + g] + minvA[2] * exA[84 + 8 + g]);
+                raccB += exB[84 + j] * (minvB[0] * exB[84 + g] + minvB[1] * exB[84 + 4 + g] + minvB[2] * exB[84 + 8 + g]);
+                const d4 y2A = mm3(minvA, xzA, (d4){0, 0, 0, 0});
+                const d4 y2B = mm3(minvB, xzB, (d4){0, 0, 0, 0});
+                tmA = mm3(vA, y2A, xzA);
+                tmB = mm3(vB, y2B, xzB);
+            }
         } else {
             // theta == 0: the reference still asserts isposdef(inv(W) - 0 S) (:365-366 / :439-440): a non-finite S fails it
             const double nfA = fma(vA[2], 0.0, fma(vA[1], 0.0, vA[0] * 0.0)), nfB = fma(vB[2], 0.0, fma(vB[1], 0.0, vB[0] * 0.0));

@@ -1,28 +1,21 @@
 // sweep_dual.hip -- kernel wrapper and launcher of the dual-recursion sweep (body: sweep_dual.h, also a phase of solve_fused_kernel)
 #include "sweep_dual.h"
 
-template <bool WTV, bool HASL, int FLY = 0>
+template <int WM, bool HASL, int FLY = 0>
 __global__ __launch_bounds__(64) void sweep_dual_kernel(SweepArgs a) {
     __shared__ double wls[WLS_DUAL];
-    sweep_dual_body<WTV, HASL, FLY>(a, blockIdx.x, wls);
+    sweep_dual_body<WM, HASL, FLY>(a, blockIdx.x, wls);
 }
 
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s) {
     if (nsamples <= 0) return;
     const dim3 grid(nsamples), block(64);
-    if (a.mode == 7 && a.fly) {                    // candidate 0's record holds only [c_x | c_u | c]: tiles formed in the sweep
-        if (a.pb.cost_tv) {
-            if (a.pb.W_tv) hipLaunchKernelGGL((sweep_dual_kernel<true, true, 2>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((sweep_dual_kernel<false, true, 2>), grid, block, 0, s, a);
-        } else {
-            if (a.pb.W_tv) hipLaunchKernelGGL((sweep_dual_kernel<true, true, 1>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((sweep_dual_kernel<false, true, 1>), grid, block, 0, s, a);
-        }
-    } else if (a.mode == 7) {
-        if (a.pb.W_tv) hipLaunchKernelGGL((sweep_dual_kernel<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((sweep_dual_kernel<false, true>), grid, block, 0, s, a);
-    } else {
-        if (a.pb.W_tv) hipLaunchKernelGGL((sweep_dual_kernel<true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((sweep_dual_kernel<false, false>), grid, block, 0, s, a);
-    }
+#define DUAL_LAUNCH(W) do { \
+        if (a.mode == 7 && a.fly) {                    /* candidate 0's record holds only [c_x | c_u | c]: tiles formed in the sweep */ \
+            if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_dual_kernel<W, true, 2>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((sweep_dual_kernel<W, true, 1>), grid, block, 0, s, a); \
+        } else if (a.mode == 7) hipLaunchKernelGGL((sweep_dual_kernel<W, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((sweep_dual_kernel<W, false>), grid, block, 0, s, a); } while (0)
+    if (a.pb.W_tv) DUAL_LAUNCH(1); else if (a.pb.W_diag) DUAL_LAUNCH(2); else DUAL_LAUNCH(0);
+#undef DUAL_LAUNCH
 }

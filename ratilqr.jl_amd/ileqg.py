@@ -181,6 +181,11 @@ class Context:
         nv.check(nv.lib().rat_ce_compute_cost_enqueue(self.h, C.c_void_p(theta_ptr), C.c_int64(B), C.c_double(kl_bound),
                                                       C.c_void_p(cost_ptr)))
 
+    def compute_cost_enqueue_ex(self, theta_ptr, B, kl_bound, cost_ptr, status_ptr=None, iters_ptr=None, ls_ptr=None):
+        """compute_cost_enqueue with the per-sample status / iteration / line-search counts written beside the costs."""
+        nv.check(nv.lib().rat_ce_compute_cost_enqueue_ex(self.h, C.c_void_p(theta_ptr), C.c_int64(B), C.c_double(kl_bound), C.c_void_p(cost_ptr),
+                                                         C.c_void_p(status_ptr), C.c_void_p(iters_ptr), C.c_void_p(ls_ptr)))
+
     # ---- execution path (include/ratilqr.h RAT_PATH_*; results are identical on all of them) -------
     PATHS = {"auto": 0, "rounds": 1, "fused": 2, "block": 3}
 
