@@ -37,6 +37,8 @@ for seed in range(NS):
         Q, R, Pm = spd(n, 1.0), spd(m, 0.2), 0.03 * rng.standard_normal((m, n))
         qv, rv, q0 = 0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(m), float(rng.standard_normal())
         W = spd(n, 1e-3)
+        if seed % 4 == 1:                      # diagonal W (the sweeps' inv(W)-folded arithmetic, ProblemDev.W_diag), entries over a decade
+            W = np.diag(1e-3 * 10.0 ** rng.uniform(-0.5, 0.5, n))
     kappa = float(rng.choice([0.0, 0.02, -0.02, 0.04]))
     prob = rat.LQRiskSensitiveProblem(A, B, Q=Q, R=R, P=Pm, qv=qv, rv=rv, q0=q0, N=N, W=W, Qf=spd(n, 1.0),
                                       qvf=0.2 * rng.standard_normal(n), q0f=float(rng.standard_normal()), kappa=kappa)
@@ -57,6 +59,8 @@ for seed in range(NS):
     gkw = dict(kw)
     if "adaptive_eps_init" in gkw: gkw["adaptive_eps_init"] = bool(gkw["adaptive_eps_init"])
     ctx = rat.Context(prob, rat.ileqg.make_opts(**gkw), max_batch=theta.size, spec_eps=E)
+    if os.environ.get('SOAK_WIDE') != '1' and seed % 2 == 1:
+        ctx.set_path("rounds")                 # E > 1: candidates without tile records (fly sweeps, all candidates of a sample in one rollout wave)
     vg, sg, ig, lg = ctx.solve_batch(x0, u, theta)
     fin = np.isfinite(vo)
     ok = np.array_equal(sg, so) and np.array_equal(ig, io) and np.array_equal(lg, lo) and np.array_equal(fin, np.isfinite(vg)) \

@@ -29,6 +29,8 @@ def lq(rng):
         Q, R, P = spd(n, 1.0), spd(m, 0.2), 0.03 * rng.standard_normal((m, n))
         qv, rv, q0 = 0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(m), float(rng.standard_normal())
     W = np.stack([spd(n, 1e-3 * (0.5 + rng.random())) for _ in range(N)]) if rng.integers(0, 2) else spd(n, 1e-3)
+    if rng.integers(0, 3) == 0:
+        W = np.diag(1e-3 * 10.0 ** rng.uniform(-0.5, 0.5, n))           # diagonal W: the inv(W)-folded sweep arithmetic
     prob = rat.LQRiskSensitiveProblem(A, B, Q=Q, R=R, P=P, qv=qv, rv=rv, q0=q0, N=N, W=W, Qf=spd(n, 1.0), qvf=0.2 * rng.standard_normal(n),
                                       q0f=0.3, kappa=float(rng.choice([0.0, 0.02, -0.02, 0.04])))
     return prob, rng.uniform(0.3, 1.0) * rng.standard_normal(n), 0.1 * rng.standard_normal((N, m)), 10.0 ** rng.uniform(-2, 2.2)
@@ -41,11 +43,11 @@ def powerlaw(rng):
     return prob, np.abs(0.3 * rng.standard_normal(n)), 0.1 + 0.05 * rng.random((N, n)), 2.0
 
 
-def ctx_for(prob, B, env):
+def ctx_for(prob, B, env, E=1):
     for k, v in env.items():
         os.environ[k] = v
     try:
-        return rat.Context(prob, max_batch=B)
+        return rat.Context(prob, max_batch=B, spec_eps=E)
     finally:
         for k in env:
             del os.environ[k]
@@ -59,7 +61,10 @@ def main():
         prob, x0, u, scale = powerlaw(rng) if rng.random() < 0.2 else lq(rng)
         B = int(rng.choice([1, 5, 100, 300, 512, 513, 800, 1024, 1025, 1500]))
         theta = np.concatenate([[0.0], np.abs(rng.normal(0.0, scale, B - 1))]) if B > 1 else np.array([scale])
-        dflt, ref = ctx_for(prob, B, {}), ctx_for(prob, B, {"RATILQR_FUSED": "0"})
+        # speculation widths too: the default path (block kernel within one generation of workgroups, beyond it rounds whose candidates
+        # carry no tile records and roll out in one wavefront per sample) against rounds with materialised tiles and one wave per candidate
+        E = int(rng.choice([1, 1, 1, 2, 4, 8, 3])) if B <= 1024 else 1
+        dflt, ref = ctx_for(prob, B, {}, E), ctx_for(prob, B, {"RATILQR_FUSED": "0", "RATILQR_FLY": "0"}, E)
         dflt.profile(True)
         a, b = dflt.solve_batch(x0, u, theta), ref.solve_batch(x0, u, theta)
         for k, p in dflt.profile_get().items():
@@ -68,7 +73,7 @@ def main():
         launches += 1
         if not all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a, b)):
             bad += 1
-            print("MISMATCH", type(prob).__name__, dict(n=prob.n, m=prob.m, N=prob.N, B=B), flush=True)
+            print("MISMATCH", type(prob).__name__, dict(n=prob.n, m=prob.m, N=prob.N, B=B, E=E), flush=True)
     print(f"stress done: {launches} batches on the default path compared with the round-based path, {bad} mismatches, kernels {kinds}, {time.time() - t0:.0f} s")
 
 
