@@ -39,6 +39,7 @@ struct rat_handle_s {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // speculative gain sweeps run here, concurrently with the evaluation sweep
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    bool dual_forced = false;        // RATILQR_DUAL was given: no automatic choice between paired and separate speculative gain sweeps
     bool dual = false;               // paired evaluation + next-gain-sweep wavefronts on the round-based path (default for E > 1; RATILQR_DUAL)
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
     bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
@@ -150,7 +151,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
     if (const char *e = getenv("RATILQR_SPECULATE")) h->speculate = (e[0] == '1');
     h->dual = spec_eps > 1;          // E > 1: candidate 0 in paired wavefronts beside the other candidates' evaluation (+3.5 % at E = 8)
-    if (const char *e = getenv("RATILQR_DUAL")) h->dual = (e[0] == '1');
+    if (const char *e = getenv("RATILQR_DUAL")) { h->dual = (e[0] == '1'); h->dual_forced = true; }
     if (const char *e = getenv("RATILQR_FUSED")) h->fused = (e[0] != '0');
     if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
     if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
@@ -282,7 +283,7 @@ static rat_rc alloc_state(rat_handle h) {
     AL(st.theta, B); AL(st.mu, B); AL(st.delta, B); AL(st.value, B); AL(st.d_cur, B); AL(st.eps_init, B); AL(st.ls_eps, B);
     AL(st.status, B); AL(st.iter, B); AL(st.ls_active, B); AL(st.ls_count, B); AL(st.slot_nom, B); AL(st.n_ls, B); AL(st.hist_n, B);
     AL(st.value_c, (size_t)B * E); AL(st.d_c, (size_t)B * E); AL(st.flag_c, (size_t)B * E);
-    AL(st.counters, 2 * CTR_RING); AL(st.sink, 64);
+    AL(st.counters, 2 * CTR_RING); AL(st.sink, (size_t)SINK_SLOTS * 64);
     st.hist = nullptr; st.hist_cap = 0;
     AL(h->d_x0, XSTR); AL(h->d_u0, (size_t)N * USTR); AL(h->d_theta, B); AL(h->d_val, B);
     AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);
@@ -577,16 +578,29 @@ static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
 // trajectory, mu, Delta), so results are unchanged; the serial depth of a 2-iteration solve drops from 5 sweeps to 3 and
 // each SIMD holds two waves whose VALU (elimination) and MFMA phases overlap.
 // Samples never wait for each other: one that needs another line-search round simply gets no gain sweep this round.
+// E > 1 on the round-based path: how the speculative gain sweep of the next step! (on candidate 0's trajectory) is scheduled.
+//   paired  : in candidate 0's wavefront, beside its policy evaluation (sweep_dual_kernel: one pass, two recursions) -- the better use of a
+//             SIMD once every SIMD has work of its own (+3.5 % at 1024 samples x 8 candidates);
+//   separate: its own wavefronts on a second stream beside the evaluation sweeps of ALL candidates -- a batch that leaves SIMDs idle
+//             (B (E + 1) waves within two per SIMD) pays one sweep's latency per round instead of a paired sweep's (~1.8x that).
+// Same arithmetic either way (tested bit for bit).  RATILQR_SPECULATE=1 / RATILQR_DUAL=1 force one or the other.
+static bool use_separate_spec(const rat_handle h, const StateDev &st) {
+    if (h->speculate) return true;
+    if (!h->dual || h->dual_forced || st.E == 1) return false;
+    return (int64_t)st.B * (st.E + 1) <= (int64_t)8 * h->n_cu;
+}
+
 static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     const int slot = round % CTR_RING;
     const int64_t nc = (int64_t)st.B * st.E;
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0; ra.multi = 0;
     // no tile records for line-search candidates (LQ family, E > 1): the evaluation sweeps form each step's tile from x_t themselves, and
     // only an accepted trajectory that the plain gain sweep of the next step! will read is completed (materialize, after the accept rule)
-    const bool fly = h->fly && !h->speculate && rollin_notile_supported(h->pb, st);
+    const bool fly = h->fly && rollin_notile_supported(h->pb, st);
+    const bool spec = use_separate_spec(h, st);
     ra.notile = fly ? 1 : 0;
     ra.multi = (fly && h->fly_multi) ? 1 : 0;
-    if (h->dual) {
+    if (h->dual && !spec) {
         // fused path (E = 1): the plain gain sweep only serves samples whose fused gain recursion was abandoned (H not PD)
         prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
         prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);
@@ -609,19 +623,20 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
         HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
         return RAT_OK;
     }
-    if (!h->speculate || st.E > 1) {     // E > 1: a candidate k > 0 may be accepted, whose gain sweep was not speculated
+    if (!spec || st.E > 1) {             // E > 1: a candidate k > 0 may be accepted, whose gain sweep was not speculated
         prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
     }
     prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);        // fused rollout + linearise
-    if (h->speculate) {
+    if (spec) {
         HIPCHK(hipEventRecord(h->ev_a, h->stream));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_a, 0));
-        prof_begin(h, RAT_K_SWEEP_GAIN, st.B, h->stream2); launch_sweep(sweep_args(h, st, 4), st.B, true, false, h->stream2); prof_end(h, h->stream2);
+        SweepArgs sg = sweep_args(h, st, 4); sg.fly = fly;
+        prof_begin(h, RAT_K_SWEEP_GAIN, st.B, h->stream2); launch_sweep(sg, st.B, true, false, h->stream2); prof_end(h, h->stream2);
         HIPCHK(hipEventRecord(h->ev_b, h->stream2));
     }
     { SweepArgs se = sweep_args(h, st, 1); se.fly = fly;
       prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(se, (int)nc, false, false, h->stream); prof_end(h); }
-    if (h->speculate) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
+    if (spec) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
     prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
     if (fly) { prof_begin(h, RAT_K_MATERIALIZE, st.B); launch_materialize(st, h->pb, h->stream); prof_end(h); }
     HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -739,18 +754,19 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         return RAT_OK;
     }
     prof_begin(h, RAT_K_ROLLOUT, B); launch_rollin(ra, h->stream); prof_end(h);         // fused rollout + linearise
-    if (h->dual) {
+    const bool spec = use_separate_spec(h, st);
+    if (h->dual && !spec) {
         prof_begin(h, RAT_K_SWEEP_DUAL, B); launch_sweep_dual(sweep_args(h, st, 6), B, h->stream); prof_end(h);
         launch_commit_init(st, h->stream);
     } else {
-    if (h->speculate) {
+    if (spec) {
         HIPCHK(hipEventRecord(h->ev_a, h->stream));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_a, 0));
         prof_begin(h, RAT_K_SWEEP_GAIN, B, h->stream2); launch_sweep(sweep_args(h, st, 5), B, true, false, h->stream2); prof_end(h, h->stream2);
         HIPCHK(hipEventRecord(h->ev_b, h->stream2));
     }
     prof_begin(h, RAT_K_SWEEP_INIT, B); launch_sweep(sweep_args(h, st, 2), B, false, false, h->stream); prof_end(h);
-    if (h->speculate) {
+    if (spec) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
         launch_commit_init(st, h->stream);
     }

@@ -166,7 +166,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
     const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
 
     const int svo = (g == 0) ? 84 + j : 104 + l, fbo = (g == 0) ? 64 + j : 104 + l;
-    double *const pgl = (j < 12) ? Lout + g * 12 + j : (j == 12 ? dlout + g : st.sink + l);
+    double *const pgl = (j < 12) ? Lout + g * 12 + j : (j == 12 ? dlout + g : sample_sink(st, b) + l);
     const long sgl = (j < 12) ? LSTR : (j == 12 ? USTR : 0);
     const int lx = (l < 17) ? l : TS_PAD - TS_QR;            // [qr | q] row: lanes past q read the record's zero slot
     const int lq = g * 12 + ((j < 12) ? j : 11);             // own entry of L_t (4 x 12 row-major), clamped
@@ -469,10 +469,13 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
 #undef SVB
 }
 
-template <bool GAIN, bool DUMP, int WM, bool HASL, int FLY = 0>
+// SWZ: the elimination's row exchange through the LDS crossbar (fewer vector instructions, longer latency; identical values): for launches
+// that put several waves on a SIMD, where the datapath is saturated (profiles/r03_rocprof_summary.md: two evaluation waves per SIMD issue
+// 50 % each) and only the instruction count matters
+template <bool GAIN, bool DUMP, int WM, bool HASL, int FLY = 0, bool SWZ = false>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     __shared__ double wls[WLS_SWEEP];
-    sweep_body<GAIN, DUMP, WM, HASL, false, FLY>(a, blockIdx.x, wls);
+    sweep_body<GAIN, DUMP, WM, HASL, SWZ, FLY>(a, blockIdx.x, wls);
 }
 
 template <bool GAIN, bool DUMP, bool HASL>
@@ -485,13 +488,20 @@ static void launch_sweep_w(const SweepArgs &a, dim3 grid, hipStream_t s) {
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s) {
     if (ntraj <= 0) return;
     dim3 grid(ntraj);
-    if (gain) {
+    if (gain && a.fly && a.mode == 4 && !dump) {   // speculative gain sweep on a candidate whose record holds only [c_x | c_u | c]
+#define FLYG_LAUNCH(W) do { if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_kernel<true, false, W, false, 2>), grid, dim3(64), 0, s, a); \
+                            else hipLaunchKernelGGL((sweep_kernel<true, false, W, false, 1>), grid, dim3(64), 0, s, a); } while (0)
+        if (a.pb.W_tv) FLYG_LAUNCH(1); else if (a.pb.W_diag) FLYG_LAUNCH(2); else FLYG_LAUNCH(0);
+#undef FLYG_LAUNCH
+    } else if (gain) {
         if (dump) launch_sweep_w<true, true, false>(a, grid, s);
         else launch_sweep_w<true, false, false>(a, grid, s);
     } else if (a.mode == 2) {                      // initialize!: zero gains
         launch_sweep_w<false, false, false>(a, grid, s);
     } else if (a.fly && a.mode == 1 && !dump) {    // candidates whose records hold only [c_x | c_u | c]: tiles formed in the sweep
+        const bool many = ntraj > 2048;            // more than two waves per SIMD on an MI355X: the datapath is saturated
 #define FLY_LAUNCH(W) do { if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 2>), grid, dim3(64), 0, s, a); \
+                           else if (many) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1, true>), grid, dim3(64), 0, s, a); \
                            else hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1>), grid, dim3(64), 0, s, a); } while (0)
         if (a.pb.W_tv) FLY_LAUNCH(1); else if (a.pb.W_diag) FLY_LAUNCH(2); else FLY_LAUNCH(0);
 #undef FLY_LAUNCH
@@ -1329,14 +1339,14 @@ __global__ __launch_bounds__(64) void rollin_multi_kernel(RolloutArgs a) {
         for (int s = 0; s < 4; ++s) { cf[s] = pb.Ctab[64 * s + l]; lin[s] = pb.lin[4 * s + g]; }
         cq00 = pb.q0[0];
     }
-    // per-lane store targets: live columns write their candidate's slot, the others a sink (every store stays unconditional)
-    double *const sk = st.sink + l;
-    double *const px = live ? xo + g : sk, *const pu = live ? uo + g : sk, *const pq = live ? tile0 + TS_QR + g : sk;
-    const long sx = live ? XSTR : 0, su = live ? USTR : 0, sq = live ? TSTRIDE : 0;
-    const int o4 = live ? 4 : 0;
-    double *const pc = (live && g == 0) ? tile0 + TS_q : ((live && g == 1) ? tile0 + TS_PAD : sk);   // c, and the record's zero slot
-    const long sc = (live && g < 2) ? TSTRIDE : 0;
-    const double mc = (g == 0) ? 1.0 : 0.0;
+    // per-lane store targets.  Columns j >= E carry a copy of candidate E - 1 (k is clamped): they compute the same values and store them
+    // to the same addresses as column E - 1, so every store stays unconditional without a shared dump location (1024 waves writing one
+    // cache line on every step serialise on its L2 channel: measured 80 us per launch with such a sink).
+    double *const px = xo + g, *const pu = uo + g, *const pq = tile0 + TS_QR + g;
+    constexpr long sx = XSTR, su = USTR, sq = TSTRIDE;
+    constexpr int o4 = 4;
+    double *const pc = tile0 + ((g == 0) ? TS_q : TS_PAD + (g & 1));      // row 0: c; rows 1..3: 0.0 to the record's zero pair
+    constexpr long sc = TSTRIDE;
     // the sample's operands into LDS (rollin_body's STAGE layout)
     constexpr int cL = STG_CL, cX = STG_CX, cU = STG_CU;
     double *const sL = stg, *const sX = stg + cL * 64, *const sl = sX + cX * 64, *const sdl = sl + cU * 64;
@@ -1361,11 +1371,19 @@ __global__ __launch_bounds__(64) void rollin_multi_kernel(RolloutArgs a) {
     for (int s = 0; s < 3; ++s) xb[s] = sX[4 * s + g];
     double dmax = -INFINITY;
     bool dnan = false;
-    for (int t = 0; t < N; ++t) {
-        const double c_l = sl[t * USTR + g], c_dl = sdl[t * USTR + g];
-        double c_xb[3], c_La[3];
+    // operands of step t + 1 are read from LDS during step t (one wave per SIMD: nothing else hides the LDS latency)
+    double n_l = sl[g], n_dl = sdl[g], n_xb[3], n_La[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) { c_xb[s] = sX[t * XSTR + 4 * s + g]; c_La[s] = sL[t * LSTR + j3 * 12 + 4 * s + g]; }
+    for (int s = 0; s < 3; ++s) { n_xb[s] = sX[4 * s + g]; n_La[s] = sL[j3 * 12 + 4 * s + g]; }
+    for (int t = 0; t < N; ++t) {
+        const double c_l = n_l, c_dl = n_dl;
+        const double c_xb[3] = {n_xb[0], n_xb[1], n_xb[2]}, c_La[3] = {n_La[0], n_La[1], n_La[2]};
+        {
+            const int tn = (t + 1 < N) ? t + 1 : t;
+            n_l = sl[tn * USTR + g]; n_dl = sdl[tn * USTR + g];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) { n_xb[s] = sX[tn * XSTR + 4 * s + g]; n_La[s] = sL[tn * LSTR + j3 * 12 + 4 * s + g]; }
+        }
         if (CTV) {
             const double *__restrict__ C = pb.Ctab + (long)t * 256;
 #pragma unroll
@@ -1405,7 +1423,7 @@ __global__ __launch_bounds__(64) void rollin_multi_kernel(RolloutArgs a) {
         double wr[4];
         rows_bcast(w, wr);
         const double part = ((wr[0] + wr[1]) + wr[2]) + wr[3];
-        pc[(long)t * sc] = mc * (part + cq00);                    // row 0: c; row 1: 0.0 to the record's zero slot
+        pc[(long)t * sc] = (g == 0) ? part + cq00 : 0.0;          // row 0: c; rows 1..3: exact zeros to the record's zero pair
 #pragma unroll
         for (int r = 0; r < 3; ++r) xb[r] = xa[r] + pb.kappa * (xb[r] * xb[r] * xb[r]);
     }

@@ -118,9 +118,12 @@ struct StateDev {
     int *flag_c;                               // [B*E] 0 ok, 1 DP failed (M not PD), 2 domain failure
     double *hist; int hist_cap;                // [B][2*hist_cap] or null
     int *counters;                             // [CTR_RING][2]: per round {samples still in line search, samples running}
-    double *sink;                              // [64] write-only: idle lanes of unconditional stores (a lane-conditional store splits
-                                               // the basic block the scheduler works on)
+    double *sink;                              // [SINK_SLOTS][64] write-only: idle lanes of unconditional stores (a lane-conditional store
+                                               // splits the basic block the scheduler works on); one slot per sample (mod SINK_SLOTS): a
+                                               // single slot would have every wavefront of a launch write the same cache lines on every step
 };
+#define SINK_SLOTS 1024
+__host__ __device__ inline double *sample_sink(const StateDev &st, int b) { return st.sink + (long)(b & (SINK_SLOTS - 1)) * 64; }
 
 struct OptsDev {
     double mu_min, delta_0, lambda, d, eps_init, eps_min;

@@ -134,7 +134,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
     const int gaoff = (j == 12) ? (64 + 12 + g) : 80;
     const int lx = (l < 17) ? l : TS_PAD - TS_QR;
     const int svo = (g == 0) ? 84 + j : 104 + l, fbo = (g == 0) ? 64 + j : 104 + l;
-    double *const pgl = (j < 12) ? Lout + g * 12 + j : (j == 12 ? dlout + g : st.sink + l);
+    double *const pgl = (j < 12) ? Lout + g * 12 + j : (j == 12 ? dlout + g : sample_sink(st, b) + l);
     const long sgl = (j < 12) ? LSTR : (j == 12 ? USTR : 0);
 
     d4 winv = {0, 0, 0, 0}, wp = {0, 0, 0, 0};

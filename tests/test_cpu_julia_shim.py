@@ -230,3 +230,64 @@ def test_solvers_rebind_their_handle_to_the_problem_argument():
             continue                                                 # forwarded to the reference / composed from operators that bind
         if "ccall" in body:
             assert "bind!(" in body or "handle!(" in body, f"{name}({m.group(2)}, problem, ...) calls the library without binding the problem"
+
+
+def _jl_signatures():
+    """name -> list of (min_positional, max_positional) over the method definitions of the shim (`function name(...)` and `name(...) = ...`)."""
+    sigs = {}
+    for m in re.finditer(r"(?m)^(?:function\s+)?([A-Za-z_μΔϵθ][\w!μΔϵθ]*)\(", JL):
+        name = m.group(1)
+        if JL[max(0, m.start() - 1): m.start()] not in ("", "\n"):
+            continue
+        depth, j = 1, m.end()
+        while depth:
+            depth += JL[j] in "({["
+            depth -= JL[j] in ")}]"
+            j += 1
+        if not (JL[m.start():].startswith("function") or re.match(r"\s*(where\b[^=\n]*)?=[^=]", JL[j:j + 40])):
+            continue
+        inner = JL[m.end(): j - 1]
+        pos = split_top(inner.split(";")[0]) if inner.strip() else []
+        pos = [a for a in pos if a.strip()]
+        nmax = len(pos)
+        nmin = len([a for a in pos if "=" not in a])
+        sigs.setdefault(name, []).append((nmin, nmax))
+    return sigs
+
+
+def test_runtests_jl_uses_only_names_and_arities_the_shim_defines():
+    """julia/runtests.jl (the reference's tests restated on the device families, plus the reference-vs-device timing) cannot run here:
+    every exported RATiLQRAMD function it calls must exist with a method of that positional arity, every struct it builds with that
+    many fields, and every ILEQGSolver field it reads must be a field of the shim's struct."""
+    RT = open(os.path.join(ROOT, "julia", "runtests.jl")).read()
+    RT = "\n".join(ln.split("#")[0] if not ln.lstrip().startswith("#") else "" for ln in RT.split("\n"))
+    exports = set(re.findall(r"[\w!μΔϵθ]+", re.search(r"\nexport\b(.*?)\nend", JL, flags=re.S).group(1)))
+    sigs = _jl_signatures()
+    structs = {m.group(1): len([f for f in re.split(r"[;\n]", m.group(2)) if re.match(r"\s*\w[\w!μΔϵθ]*::", f)])
+               for m in re.finditer(r"\n(?:mutable )?struct (\w+)(?: <: \w+)?\n(.*?)\nend", JL, flags=re.S)}
+    used = 0
+    for m in re.finditer(r"(?<![\w.!])([A-Za-z_μΔϵθ][\w!μΔϵθ]*)\(", RT):
+        name = m.group(1)
+        if name not in exports or RT[max(0, m.start() - 8): m.start()].endswith("RATiLQR."):
+            continue
+        depth, j = 1, m.end()
+        while depth:
+            depth += RT[j] in "({["
+            depth -= RT[j] in ")}]"
+            j += 1
+        inner = RT[m.end(): j - 1]
+        npos = len([a for a in split_top(inner.split(";")[0]) if a.strip() and not re.match(r"\s*[\wμΔϵθ]+\s*=[^=]", a)]) if inner.strip() else 0
+        line = RT.count("\n", 0, m.start()) + 1
+        used += 1
+        if name in sigs:
+            assert any(lo <= npos <= hi for lo, hi in sigs[name]), f"julia/runtests.jl:{line}: {name} called with {npos} positional arguments; the shim defines {sigs[name]}"
+        else:
+            assert name in structs, f"julia/runtests.jl:{line}: {name} is exported but has no method or struct in the shim"
+            if name in ("LQRiskSensitiveProblem",):
+                assert npos == structs[name], f"julia/runtests.jl:{line}: {name}(...) has {npos} arguments, the struct has {structs[name]} fields"
+    assert used > 40
+    fields = set(re.findall(r"(\w[\w!μΔϵθ_]*)::", re.search(r"\nmutable struct ILEQGSolver\n(.*?)\nend", JL, flags=re.S).group(1)))
+    for f in re.findall(r"\b(?:solver|sr|sp|s3|s4)\.([\w!μΔϵθ_]+)", RT):
+        assert f in fields, f"julia/runtests.jl reads ILEQGSolver.{f}, which the shim's struct does not have"
+    for f in re.findall(r"\bs2\.c\.(\w+)", RT):
+        assert f in re.search(r"\nmutable struct CeState\n(.*?)\nend", JL, flags=re.S).group(1)
