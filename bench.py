@@ -594,6 +594,14 @@ def rank_main(args):
             second["roofline"] = {"bound": "hbm", "achieved": ach8, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach8 / HBM_PEAK_GBS,
                                   "trajectories_per_launch": p8["trajectories"] / max(p8["launches"], 1),
                                   "avg_launch_ms": p8["ms"] / max(p8["launches"], 1)}
+            # counter traffic (rocprofv3 PMC passes kept under profiles/): the evaluation launch, and everything one batch moves.  The
+            # candidates carry no tile records on this path (their sweeps form each step's tile from x_t), so the measured bytes are
+            # far BELOW the algorithmic figure of the unfused three-kernel formulation that `achieved` is priced with.
+            tr8, tn8 = traffic_for(f"sweep_eval_E8_B{B}")
+            second["roofline"]["traffic"], second["roofline"]["traffic_source"] = tr8, tn8
+            tb8, _ = traffic_for(f"batch_E8_B{B}")
+            second["hbm_traffic_per_batch"] = tb8
+            second["hbm_traffic_per_solve"] = tb8 / B if tb8 else None
         del ctx8
 
     if world == 1 and not args.no_second:
