@@ -165,6 +165,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     // E = 1 batches beyond one sample per SIMD: two samples per SIMD in 256 registers each beat two generations of the 342-register
     // paired kernel (measured +6..10 %); RATILQR_FUSED_OCC2=0 disables, =B0 moves the threshold
     h->fused_occ2 = 4 * h->n_cu + 1;
+    if (!getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = 2 * h->n_cu;      // E = 1: a workgroup per sample while every sample can have two SIMDs
     if (const char *e = getenv("RATILQR_FUSED_OCC2")) h->fused_occ2 = atoi(e);
     CREATECHK(hipMalloc((void **)&h->d_census, sizeof(int) * CENSUS_SLOTS));
     CREATECHK(hipMemset(h->d_census, 0, sizeof(int) * CENSUS_SLOTS));
