@@ -764,6 +764,18 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
     const int c34 = TS_REG(3, l), r5 = TS_REG(5, l);            // C rows 0..11: live lanes compact, dead lanes (j >= 12) to the zero pair
     const double pm[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
     const double m_j4 = (j < 4) ? 1.0 : 0.0, m_l4 = (l == 4) ? 1.0 : 0.0;
+    // QB (LQ family, time-invariant cost): the cost gradients of a GROUP of RD steps in one set of four MFMAs.  C [x_t; u_t] is off the
+    // recursion's dependency chain, and in B-form a vector is replicated over the 16 columns of the B operand -- so column d of a second
+    // operand set (xq) collects [x_t; u_t] of step t0 + d as the group goes, and at its end C xq gives [c_x | c_u] - lin of all RD steps:
+    // 4 MFMAs per group instead of 4 per step (RD = 5: 7.8 instead of 11 per closed-loop step).  Each column of an MFMA is formed from
+    // its own column of B in a fixed order, and the per-lane expressions are those of the per-step form (row sums in its order: see
+    // rollin_multi_kernel), so the records hold the same bits (the block kernel's rolllin_body keeps the per-step form: tested against it).
+    constexpr bool QB = lq && !CTV;
+    double xq[4] = {0.0, 0.0, 0.0, 0.0}, lin4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (QB) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) lin4[s] = pb.lin[4 * s + g];
+    }
     double xb[3];                                               // x_t in B-form
 #pragma unroll
     for (int s = 0; s < 3; ++s) xb[s] = (MODE == 0) ? a.x0[4 * s + g] : xbar[4 * s + g];
@@ -845,7 +857,7 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
 #ifdef RAT_DIAG
     dg_loop0 = __builtin_readcyclecounter();
 #endif
-    auto step = [&](const int t, const StepIn &cur) {
+    auto step = [&](const int t, const StepIn &cur, const int d, const bool last) {      // d: position in the group; last: last step before a flush
         DIAG_START();
         const double c_l = cur.l, c_dl = cur.dl;
         const double c_xb[3] = {cur.xb[0], cur.xb[1], cur.xb[2]}, c_La[3] = {cur.La[0], cur.La[1], cur.La[2]};
@@ -909,15 +921,24 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
                 *reinterpret_cast<double2 *>(tp + c34) = make_double2(cq0, cq1);     // dead lanes: (0, 0) to the zero pair
                 tp[r5] = cq2;
             }
-            d4 cx = MFMA(cf[0], xb[0], zero4);                      // C [x;u] in B-form
-            cx = MFMA(cf[1], xb[1], cx);
-            cx = MFMA(cf[2], xb[2], cx);
-            cx = MFMA(cf[3], u, cx);
-            const double acc = ((cx[0] * pm[0] + cx[1] * pm[1]) + cx[2] * pm[2]) + cx[3] * pm[3];    // packed (lanes j < 4), 0 elsewhere
-            // c = [x;u]' (1/2 C [x;u] + lin) + q0  (:296): 16 packed terms, summed per row and then over the four rows
-            const double w = row_sum16(cost_term(pk, acc, clin));    // pk = 0 on the idle lanes
-            const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
-            tp[qoff] = fma(m_l4, part + cq00, m_j4 * (acc + clin));  // [c_x | c_u] = C [x;u] + [qv;rv]  (:297,:299), c, pad (0.0)
+            if (QB) {
+                // column d of xq <- [x_t; u_t]; the last step before a flush also fills the columns behind it (they then mirror a live
+                // column: every store of the flush stays unconditional, duplicates carry identical values to identical addresses)
+                const bool me = (j == d) || (last && j > d);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) xq[s] = me ? xb[s] : xq[s];
+                xq[3] = me ? u : xq[3];
+            } else {
+                d4 cx = MFMA(cf[0], xb[0], zero4);                      // C [x;u] in B-form
+                cx = MFMA(cf[1], xb[1], cx);
+                cx = MFMA(cf[2], xb[2], cx);
+                cx = MFMA(cf[3], u, cx);
+                const double acc = ((cx[0] * pm[0] + cx[1] * pm[1]) + cx[2] * pm[2]) + cx[3] * pm[3];    // packed (lanes j < 4), 0 elsewhere
+                // c = [x;u]' (1/2 C [x;u] + lin) + q0  (:296): 16 packed terms, summed per row and then over the four rows
+                const double w = row_sum16(cost_term(pk, acc, clin));    // pk = 0 on the idle lanes
+                const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
+                tp[qoff] = fma(m_l4, part + cq00, m_j4 * (acc + clin));  // [c_x | c_u] = C [x;u] + [qv;rv]  (:297,:299), c, pad (0.0)
+            }
         } else {
             // power-law family (n == m <= 4): every derivative is diagonal, and row g's entries sit on the lanes of row g
             double val = 0.0, cv = 0.0;
@@ -949,6 +970,23 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
         for (int r = 0; r < 3; ++r) xb[r] = xn[r];
         DIAG_STAMP(2, xb[0]);
     };
+    // the cost-gradient rows and costs of steps t0 .. t0 + cnt - 1 (columns 0 .. cnt - 1 of xq; the columns behind mirror the last one)
+    auto flush = [&](const int t0, const int cnt) {
+        d4 cx = MFMA(cf[0], xq[0], zero4);                          // C [x;u] of every step of the group
+        cx = MFMA(cf[1], xq[1], cx);
+        cx = MFMA(cf[2], xq[2], cx);
+        cx = MFMA(cf[3], xq[3], cx);
+        double *__restrict__ rp = tile0 + (long)(t0 + ((j < cnt) ? j : cnt - 1)) * TSTRIDE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rp[TS_QR + 4 * s + g] = cx[s] + lin4[s];                    // [c_x | c_u] = C [x;u] + [qv;rv]  (:297,:299)
+        // c = [x;u]' (1/2 C [x;u] + lin) + q0  (:296), summed in the per-step form's order: (a0 + a2) + (a1 + a3) per row, rows in order
+        const double a0 = cost_term(xq[0], cx[0], lin4[0]), a1 = cost_term(xq[1], cx[1], lin4[1]);
+        const double a2 = cost_term(xq[2], cx[2], lin4[2]), a3 = cost_term(xq[3], cx[3], lin4[3]);
+        double wr[4];
+        rows_bcast((a0 + a2) + (a1 + a3), wr);
+        const double part = ((wr[0] + wr[1]) + wr[2]) + wr[3];
+        rp[(g == 0) ? TS_q : TS_PAD + (g & 1)] = (g == 0) ? part + cq00 : 0.0;                  // row 0: c; rows 1..3: the record's zero pair
+    };
     // single-exit main loop over whole groups of RD steps (a second exit would put a path from the middle of the group
     // back to the loop header into the control-flow graph and cap the header's vmcnt at that path's count), then the tail
     int t0 = 0;
@@ -962,12 +1000,17 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
             // boundary (SEP); with two waves per SIMD (E > 1) the other wave fills the gaps and the freer schedule measured 5 % faster.
             if (!staged && SEP) __builtin_amdgcn_sched_barrier(0);
             issue(buf[(d + RD - 1) % RD], t0 + d + RD - 1);
-            step(t0 + d, buf[d]);
+            step(t0 + d, buf[d], d, d == RD - 1);
         }
+        if (QB) flush(t0, RD);
     }
+    {
+        const int nt = N - t0;                                  // N mod RD steps: their operands are already in buf[0..]
 #pragma unroll
-    for (int d = 0; d < RD - 1; ++d)                            // N mod RD steps: their operands are already in buf[0..]
-        if (t0 + d < N) step(t0 + d, buf[d]);
+        for (int d = 0; d < RD - 1; ++d)
+            if (d < nt) step(t0 + d, buf[d], d, d == nt - 1);
+        if (QB && nt > 0) flush(t0, nt);
+    }
 #ifdef RAT_DIAG
     if (l == 0 && blockIdx.x < 8 && a.dump) {
         for (int q = 0; q < 3; ++q) a.dump[64 + blockIdx.x * 8 + q] = (double)dg_acc[q];
@@ -2268,7 +2311,7 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
                 else {
                     const double rad = sqrt(-2.0 * log(1.0 - u1));
                     double sn, cs;
-                    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+                    sincospi(2.0 * u2, &sn, &cs);               // (argument in [0, 2): no range reduction by pi -- a third of the lane's time before)
                     z = rad * cs; znext = rad * sn;
                 }
             } else z = znext;
@@ -2358,7 +2401,7 @@ __global__ __launch_bounds__(64) void noisy_rollout_kernel(NoisyArgs a) {
                 philox4x32_10((unsigned)k, (unsigned)(k >> 32), (unsigned)(t >> 1), (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
                 const double rad = sqrt(-2.0 * log(1.0 - u01(r[0], r[1])));
                 double sn, cs;
-                sincos(6.283185307179586476925286766559 * u01(r[2], r[3]), &sn, &cs);
+                sincospi(2.0 * u01(r[2], r[3]), &sn, &cs);
                 z = rad * cs; znext = rad * sn;
             } else z = znext;
         }
@@ -2417,18 +2460,21 @@ void launch_noisy_rollout(const NoisyArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(noisy_rollout_kernel, dim3((unsigned)((a.K + 3) / 4)), dim3(64), 0, s, a);
 }
 
-// mean over the K rollouts of each control sample, summed in trajectory order (deterministic)   (pets.jl:150)
-__global__ void pets_mean_kernel(PetsArgs a) {
-    const long ii = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ii >= a.S) return;
+// mean over the K rollouts of each control sample (pets.jl:150): one wavefront per sample, lane l sums rollouts l, l + 64, ... in
+// order, then the 64 partial sums in a fixed tree -- deterministic, independent of the launch geometry (a thread per sample summing K
+// values one after the other took 160 us at K = 1000)
+__global__ __launch_bounds__(64) void pets_mean_kernel(PetsArgs a) {
+    const long ii = blockIdx.x;
+    const int l = threadIdx.x;
     double s = 0.0;
-    for (long kk = 0; kk < a.K; ++kk) s += a.traj_cost[ii * a.K + kk];
-    a.cost[ii] = s / (double)a.K;
+    for (long kk = l; kk < a.K; kk += 64) s += a.traj_cost[ii * a.K + kk];
+    s = wave_sum(s);
+    if (l == 0) a.cost[ii] = s / (double)a.K;
 }
 
 void launch_pets(const PetsArgs &a, hipStream_t s) {
     const long ntraj = a.S * a.K;
     if (ntraj <= 0) return;
     hipLaunchKernelGGL(pets_rollout_kernel, dim3((unsigned)((ntraj + 3) / 4)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(pets_mean_kernel, dim3((unsigned)((a.S + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pets_mean_kernel, dim3((unsigned)a.S), dim3(64), 0, s, a);
 }

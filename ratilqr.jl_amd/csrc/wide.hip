@@ -26,7 +26,10 @@ namespace {
 struct Ws {
     double *S, *U, *Z, *DS, *T, *At, *Bm, *F, *G, *Lt, *H, *Hc;
     double *sv, *z, *dsv, *qv, *sv0, *xt, *xb, *g, *dlv, *rv, *ut, *hv;
-    double *idle;          // [WIDE_MAX]: what lanes without a column of their own work on in the lockstep factorisation
+    double *idle;          // [WIDE_MAX]: what lanes without a column of their own READ in the lockstep factorisation (they store nothing)
+                           // Invariant of U / Hc: chol_fwd leaves the factor in the UPPER triangle; its matrix lanes also overwrite the
+                           // strictly lower triangle of their column with intermediate values, so every consumer (back_all, the
+                           // products forming D S) reads entries (i, j) with i <= j only
 };
 
 // sum over the wavefront, the same bits on every lane: DPP rotations inside the 16-lane rows, then the four row sums through scalar
@@ -93,7 +96,9 @@ __device__ bool chol_fwd(double *Um, const int k, const int ld, double *Rm, cons
         const double d = readlane_f64(acc, i);
         if (!(d > 0.0)) return false;
         const double r = sqrt(d), ri = fast_rcp(r);
-        col[i] = (isM && lane == i) ? r : acc * ri;
+        // (lanes without a column run the same loop on the shared `idle` vector -- uninitialised, possibly NaN, never part of a result --
+        //  and do not write it: no two lanes ever store to one address)
+        if (isM || isR) col[i] = (isM && lane == i) ? r : acc * ri;
         if (lane == i) { yv = (vec[i] - dot) * ri; myr = r; }
         __syncthreads();
     }
@@ -111,7 +116,7 @@ __device__ void back_all(const double *Um, const int k, const int ld, double *Rm
         for (int q = i + 1; q < k; ++q) acc -= Um[i + (size_t)ld * q] * col[q];
         const double dot = wsum((lane > i && lane < k) ? Um[i + (size_t)ld * lane] * yv : 0.0);
         const double ri = fast_rcp(Um[i + (size_t)ld * i]);
-        col[i] = acc * ri;
+        if (isR) col[i] = acc * ri;                       // (idle lanes read the shared idle vector and store nothing)
         if (lane == i) yv = (yv - dot) * ri;
         __syncthreads();
     }
