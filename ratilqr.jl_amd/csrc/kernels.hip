@@ -796,10 +796,20 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
     constexpr int kStoresPerStep = 6;
     struct StepIn { double l, dl, xb[3], La[3]; };
     StepIn buf[RD];
-    constexpr bool staged = STAGE && MODE == 1;
+    constexpr bool staged = STAGE;                // (open loop: the nominal controls alone -- its time loop then issues no global load either)
     constexpr int cL = STG_CL, cX = STG_CX, cU = STG_CU;
-    double *const sL = stg, *const sX = stg + (staged ? cL * 64 : 0), *const sl = sX + (staged ? cX * 64 : 0), *const sdl = sl + (staged ? cU * 64 : 0);
-    if (staged) {
+    // (open loop: only the controls, at the start of the area -- STG_CU * 64 doubles are enough for a kernel that runs nothing else)
+    double *const sL = stg, *const sX = stg + (staged ? cL * 64 : 0), *const sl = (MODE == 0) ? stg : sX + (staged ? cX * 64 : 0),
+                 *const sdl = sl + (staged ? cU * 64 : 0);
+    if (staged && MODE == 0) {
+        double tl[cU];
+#pragma unroll
+        for (int q = 0; q < cU; ++q) { const int e = 64 * q + l; tl[q] = lnom[(e < N * USTR) ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < cU; ++q) sl[64 * q + l] = tl[q];
+        WAVE_SYNC();
+    }
+    if (staged && MODE == 1) {
         double tL[cL], tX[cX], tl[cU], tdl[cU];
 #pragma unroll
         for (int q = 0; q < cL; ++q) { const int e = 64 * q + l; tL[q] = Lb[(e < N * LSTR) ? e : 0]; }
@@ -822,11 +832,13 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
         for (int s = 0; s < 3; ++s) in.xb[s] = in.La[s] = 0.0;
         if (staged) {
             in.l = sl[tn * USTR + g];
-            in.dl = sdl[tn * USTR + g];
+            if (MODE == 1) {
+                in.dl = sdl[tn * USTR + g];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                in.xb[s] = sX[tn * XSTR + 4 * s + g];
-                in.La[s] = sL[tn * LSTR + j3 * 12 + 4 * s + g];
+                for (int s = 0; s < 3; ++s) {
+                    in.xb[s] = sX[tn * XSTR + 4 * s + g];
+                    in.La[s] = sL[tn * LSTR + j3 * 12 + 4 * s + g];
+                }
             }
             return;
         }
@@ -1316,7 +1328,10 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
 template <int MODEL, int MODE, bool CTV, bool SEP>
 __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     __shared__ double shxu[16];
-    rollin_body<MODEL, MODE, CTV, false, SEP>(a, blockIdx.x, shxu);
+    constexpr bool ST0 = (MODE == 0) && (MODEL == 1);          // open loop, LQ family: the nominal controls staged in LDS (N <= ROLLIN_NST)
+    __shared__ double stg0[ST0 ? STG_CU * 64 : 1];
+    if (ST0 && a.st.N <= ROLLIN_NST) rollin_body<MODEL, MODE, CTV, ST0, SEP>(a, blockIdx.x, shxu, stg0);
+    else rollin_body<MODEL, MODE, CTV, false, SEP>(a, blockIdx.x, shxu);
 }
 
 // The E line-search candidates of a sample as the waves of ONE workgroup (eight per workgroup; N <= ROLLIN_NST): they share the sample's operands
@@ -1897,7 +1912,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
     PHASE_FENCE();
     {
         RolloutArgs ra = fa.ro; ra.mode = 0;
-        rollin_body<MODEL, 0, CTV, false, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH>(ra, b, shxu);
+        rollin_body<MODEL, 0, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH>(ra, b, shxu, stg);
         PHASE_MARK();
         PHASE_FENCE();
         PHASE_MARK();
@@ -2096,7 +2111,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         epoch += st.N + 2;
     } else if (wave == 0) {
         RolloutArgs ra = fa.ro; ra.mode = 0;
-        rollin_body<MODEL, 0, CTV>(ra, b, shxu);
+        rollin_body<MODEL, 0, CTV, STG>(ra, b, shxu, stg);
     }
     BLK_MARK();
     __syncthreads();
