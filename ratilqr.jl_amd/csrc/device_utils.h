@@ -103,9 +103,15 @@ __device__ __forceinline__ void elim_masks(ElimMasks &em, int g, int j) {
 //                recursions, whose two chains hide each other's latency and which are short of issue slots.
 //   SWZ = false: v_permlane16_swap (gfx950) of the register with itself, then a select by row parity: two copies, a swap and a
 //                select per word, all VALU (short latency).  For the single recursion, which is bound by its dependency chain.
-template <bool SWZ>
+// XCH selects how a round moves data across lanes (identical values every way):
+//   0  v_permlane16_swap row exchange, pivot block through v_readlane       -- all vector ALU, shortest latency: single recursions
+//   1  ds_swizzle row exchange (LDS crossbar), pivot block through v_readlane -- fewer vector instructions: paired recursions, OCC2
+// (Tried and dropped, round 3: the pivot block through ds_bpermute instead of v_readlane -- it lands in vector registers, so the round
+//  loses its six v_readlane and the v_mov the constant-bus limit forces: 15 instead of 23 vector instructions.  The saturated E = 8
+//  evaluation launch did not move: 1.301 -> 1.294 ms per batch, 232 instead of 202 registers.)
+template <int XCH>
 __device__ __forceinline__ double row_partner(double x, bool odd) {
-    if (SWZ)
+    if (XCH)
         return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F));
     const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
     const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [0] = (r0, r0, r2, r2), [1] = (r1, r1, r3, r3)
@@ -115,19 +121,19 @@ __device__ __forceinline__ double row_partner(double x, bool odd) {
 // Leading minors p11 > 0 and det P > 0 of every block <=> isposdef(M) (:366).  A non-NaN double is > 0 iff its high word, read as a
 // signed integer, is > 0 (a positive subnormal below 2^-1022 * 2^-20 counts as singular), so the running minimum is an integer
 // minimum over high words: one SALU op for p11 (it lives in SGPRs) and one VALU op for det -- v_min_f64 would cost three with the
-// canonicalisation that fmin() carries.  NaNs are caught by the running sum nsum.
-template <int KB, bool SWZ>
-__device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, int &pdmin, double &nsum, double &rprod) {
+// canonicalisation that fmin() carries.  NaNs (and infinities) are caught through the running product of the determinants, rprod, which
+// the caller tests once per step.
+template <int KB, int XCH>
+__device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, int &pdmin, double &rprod) {
     constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
     const double p11 = readlane_f64(m[kr], kg * 16 + k);
     const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
     const double p22 = readlane_f64(m[kr], (kg + 1) * 16 + k + 1);
     const double t = fma(m[kr], em.tm[KB], em.wa[KB]);          // pivot rows, -I in the pivot block, zero elsewhere
-    const double other = row_partner<SWZ>(t, em.odd);
+    const double other = row_partner<XCH>(t, em.odd);
     const double det = fma(p11, p22, -(p12 * p12));
     const double idet = fast_rcp1(det);
     pdmin = min(pdmin, min(__double2hiint(p11), __double2hiint(det)));
-    nsum += det;
     rprod *= det;            // logdet(W M) = sum_k log(det P_k / (e_k e_k+1))  (:387): wave-uniform running product; the caller
                              // multiplies the step's prod_k 1/(e_k e_k+1) in once (before the rounds) and renormalises per step
     // -(Bk t) on the pivot-row lanes (Bk = adj(P) / det): row k: -(p22 t_k - p12 t_k+1) / det, row k+1: -(p11 t_k+1 - p12 t_k) / det

@@ -92,7 +92,7 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
 // wls: this wavefront's LDS scratch (WLS_SWEEP doubles).
 // SWZ: the elimination's row exchange through the LDS crossbar (ds_swizzle) instead of vector-ALU lane swaps: identical values, fewer
 // vector instructions, longer latency -- for the kernel that runs two samples per SIMD, which is short of issue slots, not of latency.
-template <bool GAIN, bool DUMP, int WM, bool HASL, bool SWZ = false, int FLY = 0>
+template <bool GAIN, bool DUMP, int WM, bool HASL, int SWZ = 0, int FLY = 0>
 __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, double *const wls) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase: keeps the per-lane constants of one phase from being shared with
@@ -252,8 +252,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
             }
             // X = V[:, 0:12] [A|B] (rows 0..11 = S [A|B], row 12 = s_vec'[A|B]).  Issued first: it does not depend on the
             // inverse, so the matrix pipe works through it while the VALU runs the elimination below.  (Diagonal W: only theta == 0 needs it.)
-            d4 xz = {0, 0, 0, 0};
-            if (WM != 2 || theta == 0.0) xz = mm3(v, cz, (d4){0, 0, 0, 0});
+            // (WM == 2 forms it inside the theta == 0 branch: a conditionally defined xz costs a zero fill of eight registers per step)
+            d4 xz;
+            if (WM != 2) xz = mm3(v, cz, (d4){0, 0, 0, 0});
             if (HASL) lbuf[l] = cur.la;                                     // rows of [L | dl] to every lane (read after the next fence)
             const double qc = readlane_f64(cur.x, 16);                      // c (ileqg.jl:296)
             d4 tm;
@@ -271,16 +272,16 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
                 //   m'_ij = base_ij - vi1 U1_j - vi2 U2_j,   U_j = Bk [v1_j; v2_j],   base = 0 on pivot rows/columns, m elsewhere.
                 // Leading minors p11 > 0, det P > 0 for every block  <=>  isposdef(M)  (:366); det P = d_k d_{k+1}.
                 int pdmin = 1;                                               // min over the high words of the leading minors (elim_round)
-                double nsum = 0.0;                                           // NaN/Inf tripwire
                 rprod *= epall;
-                elim_round<0, SWZ>(m, em, pdmin, nsum, rprod);
-                elim_round<1, SWZ>(m, em, pdmin, nsum, rprod);
-                elim_round<2, SWZ>(m, em, pdmin, nsum, rprod);
-                elim_round<3, SWZ>(m, em, pdmin, nsum, rprod);
-                elim_round<4, SWZ>(m, em, pdmin, nsum, rprod);
-                elim_round<5, SWZ>(m, em, pdmin, nsum, rprod);
+                elim_round<0, SWZ>(m, em, pdmin, rprod);
+                elim_round<1, SWZ>(m, em, pdmin, rprod);
+                elim_round<2, SWZ>(m, em, pdmin, rprod);
+                elim_round<3, SWZ>(m, em, pdmin, rprod);
+                elim_round<4, SWZ>(m, em, pdmin, rprod);
+                elim_round<5, SWZ>(m, em, pdmin, rprod);
                 DIAG_STAMP(1, m[0]);
-                if (!(pdmin > 0) || !(nsum * 0.0 == 0.0)) { fail = 1; return 1; }
+                // (a NaN or infinite pivot block poisons the running product of the determinants: the tripwire beside the sign test)
+                if (!(pdmin > 0) || !(rprod * 0.0 == 0.0)) { fail = 1; return 1; }
                 // (the product is renormalised once per step: one log() per sweep instead of twelve per step)
                 rexp += __builtin_amdgcn_frexp_exp(rprod);
                 rprod = __builtin_amdgcn_frexp_mant(rprod);
@@ -315,7 +316,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
                 if (__ballot(nf != nf) & 0x0FFF0FFF0FFF0FFFull) { fail = 1; return 1; }      // lanes j < 12 hold S
                 // (explicit fma: the same contraction in every instantiation and in sweep_dual_body -- the paths are tested bit for bit)
                 racc = fma(m12, fma(wp[2], v[2], fma(wp[1], v[1], wp[0] * v[0])), racc);
-                tm = xz;
+                if (WM == 2) tm = mm3(v, cz, (d4){0, 0, 0, 0}); else tm = xz;
             }
             // F = [A|B]' T + [[Q,P'],[P,R]]  (:369-370 and the Q + A'DSA term of :390)
             d4 f = mm3(cz, tm, ccs);
@@ -472,7 +473,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
 // SWZ: the elimination's row exchange through the LDS crossbar (fewer vector instructions, longer latency; identical values): for launches
 // that put several waves on a SIMD, where the datapath is saturated (profiles/r03_rocprof_summary.md: two evaluation waves per SIMD issue
 // 50 % each) and only the instruction count matters
-template <bool GAIN, bool DUMP, int WM, bool HASL, int FLY = 0, bool SWZ = false>
+template <bool GAIN, bool DUMP, int WM, bool HASL, int FLY = 0, int SWZ = 0>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     __shared__ double wls[WLS_SWEEP];
     sweep_body<GAIN, DUMP, WM, HASL, SWZ, FLY>(a, blockIdx.x, wls);
@@ -501,7 +502,7 @@ void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream
     } else if (a.fly && a.mode == 1 && !dump) {    // candidates whose records hold only [c_x | c_u | c]: tiles formed in the sweep
         const bool many = ntraj > 2048;            // more than two waves per SIMD on an MI355X: the datapath is saturated
 #define FLY_LAUNCH(W) do { if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 2>), grid, dim3(64), 0, s, a); \
-                           else if (many) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1, true>), grid, dim3(64), 0, s, a); \
+                           else if (many) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1, 1>), grid, dim3(64), 0, s, a); \
                            else hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1>), grid, dim3(64), 0, s, a); } while (0)
         if (a.pb.W_tv) FLY_LAUNCH(1); else if (a.pb.W_diag) FLY_LAUNCH(2); else FLY_LAUNCH(0);
 #undef FLY_LAUNCH

@@ -184,8 +184,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             if (FLY == 2) { ccs[0] = cur.c[0] * fc.mq; ccs[1] = cur.c[1] * fc.mq; ccs[2] = cur.c[2] * fc.mq; ccs[3] = cur.c[3]; }
             else ccs = fc.cc;
         }
-        d4 xzA = {0, 0, 0, 0}, xzB = {0, 0, 0, 0};
-        if (WM != 2 || theta == 0.0) {
+        d4 xzA, xzB;                                                 // (WM == 2: formed inside the theta == 0 branch, see sweep_body)
+        if (WM != 2) {
             xzA = mm3(vA, cz, (d4){0, 0, 0, 0});
             xzB = mm3(vB, cz, (d4){0, 0, 0, 0});
         }
@@ -197,22 +197,21 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             for (int r = 0; r < 3; ++r) { mA[r] = fma(nth12, vA[r], winv[r]); mB[r] = fma(nth12, vB[r], winv[r]); }
             mA[3] = 0.0; mB[3] = 0.0;
             int pdA = 1, pdB = 1;
-            double nsA = 0.0, nsB = 0.0;
             rprodA *= epall; rprodB *= epall;
-            elim_round<0, true>(mA, em, pdA, nsA, rprodA);
-            elim_round<0, true>(mB, em, pdB, nsB, rprodB);
-            elim_round<1, true>(mA, em, pdA, nsA, rprodA);
-            elim_round<1, true>(mB, em, pdB, nsB, rprodB);
-            elim_round<2, true>(mA, em, pdA, nsA, rprodA);
-            elim_round<2, true>(mB, em, pdB, nsB, rprodB);
-            elim_round<3, true>(mA, em, pdA, nsA, rprodA);
-            elim_round<3, true>(mB, em, pdB, nsB, rprodB);
-            elim_round<4, true>(mA, em, pdA, nsA, rprodA);
-            elim_round<4, true>(mB, em, pdB, nsB, rprodB);
-            elim_round<5, true>(mA, em, pdA, nsA, rprodA);
-            elim_round<5, true>(mB, em, pdB, nsB, rprodB);
-            if (!(pdA > 0) || !(nsA * 0.0 == 0.0)) { failA = 1; return 1; }       // @assert isposdef(M) (:440)
-            if (!deadB && (!(pdB > 0) || !(nsB * 0.0 == 0.0))) deadB = 2;         // @assert isposdef(M) (:366)
+            elim_round<0, 1>(mA, em, pdA, rprodA);
+            elim_round<0, 1>(mB, em, pdB, rprodB);
+            elim_round<1, 1>(mA, em, pdA, rprodA);
+            elim_round<1, 1>(mB, em, pdB, rprodB);
+            elim_round<2, 1>(mA, em, pdA, rprodA);
+            elim_round<2, 1>(mB, em, pdB, rprodB);
+            elim_round<3, 1>(mA, em, pdA, rprodA);
+            elim_round<3, 1>(mB, em, pdB, rprodB);
+            elim_round<4, 1>(mA, em, pdA, rprodA);
+            elim_round<4, 1>(mB, em, pdB, rprodB);
+            elim_round<5, 1>(mA, em, pdA, rprodA);
+            elim_round<5, 1>(mB, em, pdB, rprodB);
+            if (!(pdA > 0) || !(rprodA * 0.0 == 0.0)) { failA = 1; return 1; }    // @assert isposdef(M) (:440)
+            if (!deadB && (!(pdB > 0) || !(rprodB * 0.0 == 0.0))) deadB = 2;      // @assert isposdef(M) (:366)
             rexpA += __builtin_amdgcn_frexp_exp(rprodA); rprodA = __builtin_amdgcn_frexp_mant(rprodA);
             rexpB += __builtin_amdgcn_frexp_exp(rprodB); rprodB = __builtin_amdgcn_frexp_mant(rprodB);
             if (WM == 2) {
@@ -245,7 +244,8 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             if (!deadB && (__ballot(nfB != nfB) & 0x0FFF0FFF0FFF0FFFull)) deadB = 2;
             raccA = fma(m12, fma(wp[2], vA[2], fma(wp[1], vA[1], wp[0] * vA[0])), raccA);
             raccB = fma(m12, fma(wp[2], vB[2], fma(wp[1], vB[1], wp[0] * vB[0])), raccB);
-            tmA = xzA; tmB = xzB;
+            if (WM == 2) { tmA = mm3(vA, cz, (d4){0, 0, 0, 0}); tmB = mm3(vB, cz, (d4){0, 0, 0, 0}); }
+            else { tmA = xzA; tmB = xzB; }
         }
         d4 fA = mm3(cz, tmA, ccs);
         d4 fB = mm3(cz, tmB, ccs);
