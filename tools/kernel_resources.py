@@ -10,12 +10,12 @@ print("| kernel | VGPR | AGPR | SGPR | scratch B/lane | SGPR spills | VGPR spill
 print("|---|---|---|---|---|---|---|---|---|")
 for b in re.split(r"remark: Function Name: ", txt)[1:]:
     name = b.split()[0]
-    if not any(f in name for f in filt):
-        continue
     try:
         name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
     except Exception:
         pass
+    if not any(f in name for f in filt):           # (filters match the demangled name, template arguments included)
+        continue
     g = lambda k: re.search(re.escape(k) + r": (\d+)", b).group(1)
     cols = [g(k) for k in ("VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "SGPRs Spill", "VGPRs Spill", "LDS Size [bytes/block]",
                            "Occupancy [waves/SIMD]")]
