@@ -133,6 +133,31 @@ end
     end
 end
 
+@testset "getting-started example of the reference's documentation (docs/source/getting-started.md:40-118)" begin
+    # 2-D single integrator x' = x + dt u, c = x'Qx/2 + u'Ru/2, h = x'Qx/2, W = 0.1 dt I, N = 10: an LQ-family problem as it stands
+    dt, N = 0.1, 10
+    problem = LQRiskSensitiveProblem(copy(I2), dt * I2, copy(I2), 0.01 * I2, zeros(2, 2), zeros(2), zeros(2), [0.0], copy(I2), zeros(2), 0.0, 0.0,
+                                     0.1 * dt * I2, N)
+    solver = CrossEntropyBilevelOptimizationSolver()                               # the defaults of the example
+    rng = MersenneTwister(12345)
+    x_0 = [5.0, 5.0]; u_array = [zeros(2) for _ in 1:N]
+    θ_opt, x_array, l_array, L_array, value, θ_min, θ_max = solve!(solver, problem, x_0, u_array, rng, kl_bound=0.1)
+    @test isfinite(value) && θ_opt > 0 && θ_min <= θ_opt <= θ_max
+    @test norm(x_array[end]) < 0.2 * norm(x_0)                                      # the policy steers the state to the origin
+    @test all([norm(x_array[ii + 1]) < norm(x_array[ii]) for ii in 1:N])
+    @test length(L_array) == N && size(L_array[1]) == (2, 2) && maximum(abs.(L_array[1])) > 0.1
+    # with RATiLQR loaded, the reference's own solve! from the same generator state draws the same θ and must agree
+    if isdefined(Main, :RATiLQR)
+        f(x, u) = x + dt * u
+        ref_problem = Main.RATiLQR.FiniteHorizonRiskSensitiveOptimalControlProblem(f, (k, x, u) -> 0.5 * dot(x, x) + 0.005 * dot(u, u), x -> 0.5 * dot(x, x),
+                                                                                   k -> Matrix(0.1 * dt * I, 2, 2), N)
+        ref_solver = Main.RATiLQR.CrossEntropyBilevelOptimizationSolver()
+        θ_ref, x_ref, _, _, value_ref, _, _ = Main.RATiLQR.solve!(ref_solver, ref_problem, x_0, u_array, MersenneTwister(12345), kl_bound=0.1, verbose=false)
+        @test isapprox(θ_opt, θ_ref, rtol=1e-9) && isapprox(value, value_ref, rtol=1e-9)
+        @test maximum(norm.(x_array .- x_ref)) < 1e-9
+    end
+end
+
 # ---- Part 2: the reference on the host cores beside the device, same problem, same θ (SURVEY section 8d) ---------------------------------
 function survey_problem_tables(; n=12, m=4, N=50, w=1e-3, seed=0)
     rng = MersenneTwister(seed)                        # (any seeded draw serves the comparison: both sides get the SAME tables)
