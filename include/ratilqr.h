@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RAT_VERSION 201
+#define RAT_VERSION 301
 
 /* ---- return codes (API level) ---------------------------------------------------------------- */
 typedef int32_t rat_rc;

@@ -129,6 +129,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
         slot = b * (st.E + 1) + s_nom;
     }
     double mu = (a.mode == 2) ? 0.0 : (a.mode == 3 ? a.mu_op : mu_in);
+    // a speculative gain sweep running as its own wavefront shares its SIMD with evaluation waves of the same round and is the longer
+    // chain: it takes issue priority (the evaluation wave beside it fills the slots this wave's dependency stalls leave)
+    if (GAIN && a.mode >= 4) __builtin_amdgcn_s_setprio(3);
     const int N = st.N;
     const double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot) * st.tile_stride;
     FlyCtx fc;
