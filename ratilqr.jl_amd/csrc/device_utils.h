@@ -177,6 +177,46 @@ __device__ __forceinline__ void rows_bcast(double x, double (&r)[4]) {
     r[2] = __hiloint2double((int)bh[0], (int)bl[0]); r[3] = __hiloint2double((int)bh[1], (int)bl[1]);
 }
 
+// One round of TWO independent eliminations (the paired recursions of sweep_dual_body), phased so that neither chain waits for its row
+// exchange: both pull their pivot block and pivot rows and issue the ds_swizzle first, run the wave-uniform pivot arithmetic of both
+// (determinant, reciprocal, the partner-free half of nu) under the crossbar's latency, and only then touch the exchanged rows.  The
+// operations and their operands are those of elim_round<KB, 1> for each chain -- identical values; only their order in the wave's
+// instruction stream differs.  (Issued chain after chain, every round parked the wave on lgkmcnt(0) five instructions after its swizzle.)
+template <int KB>
+__device__ __forceinline__ void elim_round_pair(d4 &mA, d4 &mB, const ElimMasks &em, int &pdminA, int &pdminB, double &rprodA, double &rprodB) {
+    constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;
+    const double a11 = readlane_f64(mA[kr], kg * 16 + k), a12 = readlane_f64(mA[kr], kg * 16 + k + 1), a22 = readlane_f64(mA[kr], (kg + 1) * 16 + k + 1);
+    const double tA = fma(mA[kr], em.tm[KB], em.wa[KB]);
+    const double otherA = row_partner<1>(tA, em.odd);
+    const double b11 = readlane_f64(mB[kr], kg * 16 + k), b12 = readlane_f64(mB[kr], kg * 16 + k + 1), b22 = readlane_f64(mB[kr], (kg + 1) * 16 + k + 1);
+    const double tB = fma(mB[kr], em.tm[KB], em.wa[KB]);
+    const double otherB = row_partner<1>(tB, em.odd);
+    __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise regroups the round chain by chain)
+    const double detA = fma(a11, a22, -(a12 * a12));
+    const double idetA = fast_rcp1(detA);
+    pdminA = min(pdminA, min(__double2hiint(a11), __double2hiint(detA)));
+    rprodA *= detA;
+    const double pdA = em.e0[kg >> 1] * a22 + em.e1[kg >> 1] * a11;
+    const double ptA = pdA * tA;
+    const double detB = fma(b11, b22, -(b12 * b12));
+    const double idetB = fast_rcp1(detB);
+    pdminB = min(pdminB, min(__double2hiint(b11), __double2hiint(detB)));
+    rprodB *= detB;
+    const double pdB = em.e0[kg >> 1] * b22 + em.e1[kg >> 1] * b11;
+    const double ptB = pdB * tB;
+    __builtin_amdgcn_sched_barrier(0);
+    mA[0] *= (kr == 0 ? em.crm[KB] : em.cm[KB]);
+    mA[1] *= (kr == 1 ? em.crm[KB] : em.cm[KB]);
+    mA[2] *= (kr == 2 ? em.crm[KB] : em.cm[KB]);
+    const double nuA = fma(a12, otherA, -ptA) * idetA;
+    mA = MFMA(tA, nuA, mA);
+    mB[0] *= (kr == 0 ? em.crm[KB] : em.cm[KB]);
+    mB[1] *= (kr == 1 ? em.crm[KB] : em.cm[KB]);
+    mB[2] *= (kr == 2 ? em.crm[KB] : em.cm[KB]);
+    const double nuB = fma(b12, otherB, -ptB) * idetB;
+    mB = MFMA(tB, nuB, mB);
+}
+
 __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base.isapprox, rtol = sqrt(eps), atol = 0
     if (x == y) return true;
     if (!isfinite(x) || !isfinite(y)) return false;

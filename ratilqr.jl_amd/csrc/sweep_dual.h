@@ -167,9 +167,11 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
     int rexpA = 0, rexpB = 0;
     int failA = 0, deadB = 0;        // deadB: 1 = H not PD (needs the restart loop of the plain kernel), 2 = M not PD
 
+    DIAG_DECL
     auto step = [&](const int t, const DTile &cur) -> int {
         int l = l_, g = g_, j = j_;
         asm volatile("" : "+v"(l), "+v"(g), "+v"(j));
+        DIAG_START();
         if (WM == 1) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) { winv[r] = pb.Winv[(long)t * 192 + 64 * r + l]; wp[r] = pb.Wp[(long)t * 192 + 64 * r + l]; }
@@ -198,18 +200,14 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             mA[3] = 0.0; mB[3] = 0.0;
             int pdA = 1, pdB = 1;
             rprodA *= epall; rprodB *= epall;
-            elim_round<0, 1>(mA, em, pdA, rprodA);
-            elim_round<0, 1>(mB, em, pdB, rprodB);
-            elim_round<1, 1>(mA, em, pdA, rprodA);
-            elim_round<1, 1>(mB, em, pdB, rprodB);
-            elim_round<2, 1>(mA, em, pdA, rprodA);
-            elim_round<2, 1>(mB, em, pdB, rprodB);
-            elim_round<3, 1>(mA, em, pdA, rprodA);
-            elim_round<3, 1>(mB, em, pdB, rprodB);
-            elim_round<4, 1>(mA, em, pdA, rprodA);
-            elim_round<4, 1>(mB, em, pdB, rprodB);
-            elim_round<5, 1>(mA, em, pdA, rprodA);
-            elim_round<5, 1>(mB, em, pdB, rprodB);
+            DIAG_STAMP(0, mA[0]);
+            elim_round_pair<0>(mA, mB, em, pdA, pdB, rprodA, rprodB);
+            elim_round_pair<1>(mA, mB, em, pdA, pdB, rprodA, rprodB);
+            elim_round_pair<2>(mA, mB, em, pdA, pdB, rprodA, rprodB);
+            elim_round_pair<3>(mA, mB, em, pdA, pdB, rprodA, rprodB);
+            elim_round_pair<4>(mA, mB, em, pdA, pdB, rprodA, rprodB);
+            elim_round_pair<5>(mA, mB, em, pdA, pdB, rprodA, rprodB);
+            DIAG_STAMP(1, mA[0]);
             if (!(pdA > 0) || !(rprodA * 0.0 == 0.0)) { failA = 1; return 1; }    // @assert isposdef(M) (:440)
             if (!deadB && (!(pdB > 0) || !(rprodB * 0.0 == 0.0))) deadB = 2;      // @assert isposdef(M) (:366)
             rexpA += __builtin_amdgcn_frexp_exp(rprodA); rprodA = __builtin_amdgcn_frexp_mant(rprodA);
@@ -247,6 +245,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             if (WM == 2) { tmA = mm3(vA, cz, (d4){0, 0, 0, 0}); tmB = mm3(vB, cz, (d4){0, 0, 0, 0}); }
             else { tmA = xzA; tmB = xzB; }
         }
+        DIAG_STAMP(2, tmA[0]);
         d4 fA = mm3(cz, tmA, ccs);
         d4 fB = mm3(cz, tmB, ccs);
         const double ghA = fma(muA, mH, fA[3]), ghB = fma(muB, mH, fB[3]);
@@ -254,6 +253,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
         exA[g * 16 + j] = ghA; exB[g * 16 + j] = ghB;
         exA[fbo] = fvA; exB[fbo] = fvB;
         if (HASL) lbufA[l] = cur.la;                            // rows of [L | dl] of the given policy to every lane
+        DIAG_STAMP(3, ghB);
         WAVE_SYNC();
         // ---- A: given policy (:446-451) ----
         const double hA0 = exA[hoff[0]], hA1 = exA[hoff[1]], hA2 = exA[hoff[2]], hA3 = exA[hoff[3]];
@@ -291,6 +291,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
         const double qc = readlane_f64(cur.x, 16);
         fxA[3] = fma(fvA, mA_, (2.0 * qc + vA[3]) * mB_);
         fxB[3] = fma(fvB, mA_, (2.0 * qc + vB[3]) * mB_);
+        DIAG_STAMP(4, uaB);
         d4 vnB = MFMA(laB, uaB, fxB);
         vnB = MFMA(gaB, laB, vnB);
         if (HASL) {
@@ -300,6 +301,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
             vA = fxA;                                           // zero gains: V = Fx
         }
         vB = vnB;
+        DIAG_STAMP(5, vB[0]);
         WAVE_SYNC();
         return 0;
     };
@@ -321,6 +323,10 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
         if (step(t - 1, rb2)) break;
     }
     BODY_MARK(a.dump, dgs + 2);
+#ifdef RAT_DIAG
+    if (l_ == 0 && blockIdx.x < 8 && a.dump)
+        for (int q = 0; q < 6; ++q) a.dump[128 + blockIdx.x * 8 + q] = (double)dg_acc[q];
+#endif
     const double totA = 0.5 * wave_sum(raccA) + ((theta != 0.0) ? coef * (log(rprodA) + (double)rexpA * 0.6931471805599453094) : 0.0);
     (void)raccB; (void)rprodB; (void)rexpB;          // B's value s_1 is not used by step! (only L, dl, mu, Delta are)
     if (l == 12) {
