@@ -1,4 +1,5 @@
 #!/bin/bash
+# full GPU suite + the randomised parity soak and the path stress runs (profiles/r03_soak.md)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 cd $R
 timeout 2000 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
