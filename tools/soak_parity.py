@@ -12,7 +12,8 @@ from oracle import oracle as orc
 bad = 0
 t0 = time.time()
 NS = int(os.environ.get('SOAK_N', '240'))
-for seed in range(NS):
+S0 = int(os.environ.get('SOAK_SEED0', '0'))     # first problem seed: SOAK_SEED0=3000 SOAK_N=3000 runs problems 3000..5999
+for seed in range(S0, S0 + NS):
     rng = np.random.default_rng(5000 + seed)
     n, m, N = int(rng.integers(1, 13)), int(rng.integers(1, 5)), int(rng.integers(1, 61))
     if os.environ.get('SOAK_WIDE') == '1':
