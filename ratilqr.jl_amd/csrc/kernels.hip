@@ -1911,18 +1911,24 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
     __shared__ double wls[DUALF ? WLS_DUAL : WLS_SWEEP];
     __shared__ double shxu[16];
     __shared__ double stg[STG ? STG_DOUBLES : 1];
+    // The headline geometry (LQ family, paired recursions, staged rollouts) keeps NO tiles in HBM: every sweep of the solve forms f_x | f_u
+    // and the cost Hessian of step t from x_t and the problem tables (FLY sweeps, as on the speculative path), so the rollouts store per
+    // step only [x_t; u_t] and the [c_x | c_u | c] row -- 0.3 KB instead of 3.4 KB; the registers of a sweep hold the bits a record
+    // would have delivered (fx_diag), so results are identical to the tile-materialising paths.
+    constexpr int FLYF = (MODEL == 1 && DUALF && STG && !OCC2) ? (CTV ? 2 : 1) : 0;
+    constexpr bool NT = FLYF != 0;
     // the sample's own wave initialises its state and, at the end, writes its outputs: a batch is ONE launch
     if (threadIdx.x == 0) init_state_body(st, fa.sw.op, fa.theta_in, b);
     PHASE_FENCE();
     {
         RolloutArgs ra = fa.ro; ra.mode = 0;
-        rollin_body<MODEL, 0, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH>(ra, b, shxu, stg);
+        rollin_body<MODEL, 0, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH, NT>(ra, b, shxu, stg);
         PHASE_MARK();
         PHASE_FENCE();
         PHASE_MARK();
         if (DUALF) {
             SweepArgs sa = fa.sw; sa.mode = 6;
-            sweep_dual_body<WM, false>(sa, b, wls);
+            sweep_dual_body<WM, false, FLYF>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             if (threadIdx.x == 0) commit_init_body(st, b);
@@ -1942,7 +1948,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp!  (ileqg.jl:598-613)
             SweepArgs sa = fa.sw; sa.mode = 0;
-            sweep_body<true, false, WM, false, OCC2>(sa, b, wls);
+            sweep_body<true, false, WM, false, OCC2, FLYF>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1950,7 +1956,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
         }
         {                                                    // one candidate of line_search!  (ileqg.jl:504-581)
             RolloutArgs ra = fa.ro; ra.mode = 1;
-            rollin_body<MODEL, 1, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH>(ra, b, shxu, stg);
+            rollin_body<MODEL, 1, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH, NT>(ra, b, shxu, stg);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -1964,10 +1970,10 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
             }
             if (pair) {
                 SweepArgs sa = fa.sw; sa.mode = 7;
-                sweep_dual_body<WM, true>(sa, b, wls);
+                sweep_dual_body<WM, true, FLYF>(sa, b, wls);
             } else {
                 SweepArgs sa = fa.sw; sa.mode = 1;
-                sweep_body<false, false, WM, true, OCC2>(sa, b, wls);
+                sweep_body<false, false, WM, true, OCC2, FLYF>(sa, b, wls);
             }
             PHASE_MARK();
             PHASE_FENCE();
