@@ -207,9 +207,13 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int i = 4 * r + g;
-            v[r] = (j < 12) ? tt[TT_Q + i * 12 + j] : (j == 12 ? tt[TT_QV + i] : 0.0);
+            // (one unconditional load per register, the address selected per lane: conditional loads compile to a chain of divergent
+            //  branches, each waiting for its own round trip -- 4.3 k cycles of prologue measured in the fused kernel)
+            const double te = tt[(j < 12) ? TT_Q + i * 12 + j : TT_QV + i];
+            v[r] = (j <= 12) ? te : 0.0;
         }
-        v[3] = (g == 0) ? (j < 12 ? tt[TT_QV + j] : (j == 12 ? 2.0 * tt[TT_q] : 0.0)) : 0.0;
+        const double t3 = tt[(j < 12) ? TT_QV + j : TT_q];
+        v[3] = (g == 0 && j <= 12) ? (j < 12 ? t3 : 2.0 * t3) : 0.0;
         racc = 0.0;
         rprod = 1.0;
         rexp = 0;

@@ -105,6 +105,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
     }
     const double muA = (a.mode == 6) ? 0.0 : muB;
     const int N = st.N;
+    if (a.mode == 7) BODY_MARK(a.dump, 28);
     const double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot) * st.tile_stride;
     FlyCtx fc;
     if (FLY) fly_init(fc, pb, st.xs + (long)slot * st.x_stride, l, g, j, FLY == 2);
@@ -158,11 +159,18 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int i = 4 * r + g;
-            vA[r] = (j < 12) ? tt[TT_Q + i * 12 + j] : (j == 12 ? tt[TT_QV + i] : 0.0);
+            // (one unconditional load per register, the address selected per lane: conditional loads compile to a chain of divergent
+            //  branches, each waiting for its own round trip -- 4.3 k cycles of prologue measured in the fused kernel)
+            const double te = tt[(j < 12) ? TT_Q + i * 12 + j : TT_QV + i];
+            vA[r] = (j <= 12) ? te : 0.0;
         }
-        vA[3] = (g == 0) ? (j < 12 ? tt[TT_QV + j] : (j == 12 ? 2.0 * tt[TT_q] : 0.0)) : 0.0;
+        const double t3 = tt[(j < 12) ? TT_QV + j : TT_q];
+        vA[3] = (g == 0 && j <= 12) ? (j < 12 ? t3 : 2.0 * t3) : 0.0;
         vB = vA;
     }
+#ifdef RAT_DIAG_PHASES
+    if (a.mode == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BODY_MARK(a.dump, 29); }
+#endif
     double raccA = 0.0, raccB = 0.0, rprodA = 1.0, rprodB = 1.0;
     int rexpA = 0, rexpB = 0;
     int failA = 0, deadB = 0;        // deadB: 1 = H not PD (needs the restart loop of the plain kernel), 2 = M not PD
@@ -306,6 +314,7 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
         return 0;
     };
 
+    if (a.mode == 7) BODY_MARK(a.dump, 30);
     DTile ra, rb2;
     dload<HASL, FLY>(ra, tile0 + (long)(N - 1) * TSTRIDE, lx, l, j, Lb + (long)(N - 1) * LSTR, mL, g, &fc, N - 1);
     BODY_MARK(a.dump, dgs + 1);

@@ -39,3 +39,5 @@ for th in (0.0, 1.0):
             continue
         dd = np.diff(m, axis=1).mean(0)
         print(f"     {nm:16s} {dd[0]:8.0f} / {dd[1]:8.0f} / {dd[2]:8.0f}")
+    ex = inner[:, 28:31] - inner[:, 24:25]
+    print("   dual eval+gain prologue marks (cycles after entry): scalars in", ex[:, 0].mean(), "terminal tile in", ex[:, 1].mean(), "setup done", ex[:, 2].mean())
