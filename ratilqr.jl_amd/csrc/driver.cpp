@@ -147,8 +147,9 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
         return fail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     CREATECHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATECHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    CREATECHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
-    CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
+    // (ev_a / ev_b order the handle's two streams on ONE device: no system-scope fence)
+    CREATECHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming | hipEventDisableSystemFence));
+    CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming | hipEventDisableSystemFence));
     if (const char *e = getenv("RATILQR_SPECULATE")) h->speculate = (e[0] == '1');
     h->dual = spec_eps > 1;          // E > 1: candidate 0 in paired wavefronts beside the other candidates' evaluation (+3.5 % at E = 8)
     if (const char *e = getenv("RATILQR_DUAL")) { h->dual = (e[0] == '1'); h->dual_forced = true; }
@@ -494,7 +495,8 @@ static void prof_begin(rat_handle h, int kind, int64_t ntraj, hipStream_t s = nu
     if (!s) s = h->stream;
     if (h->ev_used == h->evs.size()) {
         EvRec e;
-        (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+        // (timing events: nothing on the host reads device memory through them, so no system-scope fence rides on the record)
+        (void)hipEventCreateWithFlags(&e.a, hipEventDisableSystemFence); (void)hipEventCreateWithFlags(&e.b, hipEventDisableSystemFence);
         h->evs.push_back(e);
     }
     EvRec &e = h->evs[h->ev_used];
