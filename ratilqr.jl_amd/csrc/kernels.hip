@@ -1223,7 +1223,8 @@ __device__ __forceinline__ void rollrec_body(const RolloutArgs &a, const int b, 
 }
 
 // the steps first, first + stride, ... of the trajectory (and, first == 0, the terminal tile)
-template <int MODE, bool CTV, bool HELP>
+// NT: no tile records (the sweeps of the same workgroup are fly sweeps): only [x_t; u_t] and the [c_x | c_u | c] row are stored
+template <int MODE, bool CTV, bool HELP, bool NT = false>
 __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, double *const shxu, const double *const xu, int *const prog, const int epoch,
                                              const int first, const int stride, unsigned long long *const d_acc) {
     int lane_ = threadIdx.x & 63;
@@ -1292,14 +1293,16 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
             cq00 = pb.q0[t];
         }
         pxu[(long)t * sxu] = pk;
-        const double z0 = fx_diag(zt0, dgz[0], pb.kappa, xb[0]);
-        const double z1 = fx_diag(zt1, dgz[1], pb.kappa, xb[1]);
-        const double z2 = fx_diag(zt2, dgz[2], pb.kappa, xb[2]);
-        double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
-        t2[l] = make_double2(z0, z1);
-        t2[64 + l] = make_double2(z2, cpr);
-        *reinterpret_cast<double2 *>(tp + c34) = make_double2(cq0, cq1);
-        tp[r5] = cq2;
+        if (!NT) {
+            const double z0 = fx_diag(zt0, dgz[0], pb.kappa, xb[0]);
+            const double z1 = fx_diag(zt1, dgz[1], pb.kappa, xb[1]);
+            const double z2 = fx_diag(zt2, dgz[2], pb.kappa, xb[2]);
+            double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
+            t2[l] = make_double2(z0, z1);
+            t2[64 + l] = make_double2(z2, cpr);
+            *reinterpret_cast<double2 *>(tp + c34) = make_double2(cq0, cq1);
+            tp[r5] = cq2;
+        }
         d4 cx = MFMA(cf[0], xb[0], zero4);                      // C [x;u] in B-form
         cx = MFMA(cf[1], xb[1], cx);
         cx = MFMA(cf[2], xb[2], cx);
@@ -2052,6 +2055,10 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     constexpr int HWAVES = PAD4 ? 4 : NW;
     // two waves, LQ family, staged operands: the rollouts are split over both waves (rollrec_body / rolllin_body)
     constexpr bool SPLIT = (NW == 2) && GW && STG && (MODEL == 1);
+    // the split geometry keeps no tiles in HBM either (see solve_fused_kernel): its linearising waves store [x; u] and the cost-gradient
+    // row, its sweeps form f_x | f_u and the Hessian in registers
+    constexpr int FLYB = SPLIT ? (CTV ? 2 : 1) : 0;
+    constexpr bool NTB = FLYB != 0;
     const int b = blockIdx.x;
     const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const StateDev &st = fa.sw.st;
@@ -2117,10 +2124,10 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         RolloutArgs ra = fa.ro; ra.mode = 0;
         if (helpers) {
             if (wave == 0) rollrec_body<0, HELP>(ra, b, stg, xu, &prog, epoch, d_acc);
-            else rolllin_body<0, CTV, HELP>(ra, b, shxu, xu, &prog, epoch, wave - 1, nlin, d_acc);
+            else rolllin_body<0, CTV, HELP, NTB>(ra, b, shxu, xu, &prog, epoch, wave - 1, nlin, d_acc);
         } else {
             if (wave == 0) rollrec_body<0, false>(ra, b, stg, xu, &prog, epoch, d_acc);
-            else rolllin_body<0, CTV, false>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc);
+            else rolllin_body<0, CTV, false, NTB>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc);
         }
         epoch += st.N + 2;
     } else if (wave == 0) {
@@ -2132,10 +2139,10 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     BLK_MARK();
     if (wave == 0) {                             // open-loop policy evaluation (:234) ...
         SweepArgs sa = fa.sw; sa.mode = 2;
-        sweep_body<false, false, WM, false>(sa, b, wls);
+        sweep_body<false, false, WM, false, 0, FLYB>(sa, b, wls);
     } else if (GW && wave == WG) {               // ... beside the first step!'s gain sweep on the same tiles (speculative until initialize! succeeds)
         SweepArgs sa = fa.sw; sa.mode = 5;
-        sweep_body<true, false, WM, false>(sa, b, wls);
+        sweep_body<true, false, WM, false, 0, FLYB>(sa, b, wls);
     }
     BLK_MARK();
     __syncthreads();
@@ -2152,7 +2159,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp! with no valid speculative sweep  (ileqg.jl:598-613)
             if (wave == WG) {
                 SweepArgs sa = fa.sw; sa.mode = 0;
-                sweep_body<true, false, WM, false>(sa, b, wls);
+                sweep_body<true, false, WM, false, 0, FLYB>(sa, b, wls);
             }
             BLK_MARK();
     __syncthreads();
@@ -2163,10 +2170,10 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
             RolloutArgs ra = fa.ro; ra.mode = 1;
             if (helpers) {
                 if (wave == 0) rollrec_body<1, HELP>(ra, b, stg, xu, &prog, epoch, d_acc);
-                else rolllin_body<1, CTV, HELP>(ra, b, shxu, xu, &prog, epoch, wave - 1, nlin, d_acc);
+                else rolllin_body<1, CTV, HELP, NTB>(ra, b, shxu, xu, &prog, epoch, wave - 1, nlin, d_acc);
             } else {
                 if (wave == 0) rollrec_body<1, false>(ra, b, stg, xu, &prog, epoch, d_acc);
-                else rolllin_body<1, CTV, false>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc);
+                else rolllin_body<1, CTV, false, NTB>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc);
             }
             epoch += st.N + 2;
         } else if (wave < E) {                                // candidates of this line-search round  (ileqg.jl:504-521)
@@ -2178,7 +2185,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     BLK_MARK();
         if (wave < E) {                                       // their policy evaluations  (:522-536)
             SweepArgs sa = fa.sw; sa.mode = 1;
-            sweep_body<false, false, WM, true>(sa, b * E + wave, wls);
+            sweep_body<false, false, WM, true, 0, FLYB>(sa, b * E + wave, wls);
         } else if (wave == WG) {                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
             if (helpers && (threadIdx.x & 63) == 0) {         // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
                 st.d_c[b * E] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
@@ -2191,7 +2198,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
             const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
             if (!ends) {
                 SweepArgs sa = fa.sw; sa.mode = 4;
-                sweep_body<true, false, WM, false>(sa, b, wls);
+                sweep_body<true, false, WM, false, 0, FLYB>(sa, b, wls);
             }
         }
         BLK_MARK();
