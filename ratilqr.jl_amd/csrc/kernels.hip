@@ -2055,9 +2055,9 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     constexpr int HWAVES = PAD4 ? 4 : NW;
     // two waves, LQ family, staged operands: the rollouts are split over both waves (rollrec_body / rolllin_body)
     constexpr bool SPLIT = (NW == 2) && GW && STG && (MODEL == 1);
-    // the split geometry keeps no tiles in HBM either (see solve_fused_kernel): its linearising waves store [x; u] and the cost-gradient
-    // row, its sweeps form f_x | f_u and the Hessian in registers
-    constexpr int FLYB = SPLIT ? (CTV ? 2 : 1) : 0;
+    // LQ family with staged rollouts (N <= ROLLIN_NST): no tiles in HBM either (see solve_fused_kernel) -- the rollouts (split or one wave
+    // per candidate) store [x; u] and the cost-gradient row, every sweep forms f_x | f_u and the Hessian in registers
+    constexpr int FLYB = (MODEL == 1 && STG) ? (CTV ? 2 : 1) : 0;
     constexpr bool NTB = FLYB != 0;
     const int b = blockIdx.x;
     const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2132,7 +2132,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         epoch += st.N + 2;
     } else if (wave == 0) {
         RolloutArgs ra = fa.ro; ra.mode = 0;
-        rollin_body<MODEL, 0, CTV, STG>(ra, b, shxu, stg);
+        rollin_body<MODEL, 0, CTV, STG, true, ROLLIN_PREFETCH, NTB>(ra, b, shxu, stg);
     }
     BLK_MARK();
     __syncthreads();
@@ -2178,7 +2178,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
             epoch += st.N + 2;
         } else if (wave < E) {                                // candidates of this line-search round  (ileqg.jl:504-521)
             RolloutArgs ra = fa.ro; ra.mode = 1;
-            rollin_body<MODEL, 1, CTV, STG, false>(ra, b * E + wave, shxu, stg);
+            rollin_body<MODEL, 1, CTV, STG, false, ROLLIN_PREFETCH, NTB>(ra, b * E + wave, shxu, stg);
         }
         BLK_MARK();
     __syncthreads();
