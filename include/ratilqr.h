@@ -401,7 +401,7 @@ int32_t rat_get_path(rat_handle h, int64_t B);
 #define RAT_K_SOLVE_BLOCK 8  /* one workgroup per sample runs the whole solve!: a wavefront per line-search candidate + a gain-sweep wavefront */
 #define RAT_K_SOLVE_WIDE  9  /* general-size solve kernel (n <= 32, m <= 32 beyond the 12 + 4 tile): a workgroup per sample, whole solve! */
 #define RAT_K_PETS       10  /* PETS stochastic rollouts (pets_rollout_kernel + the per-sample mean) */
-#define RAT_K_MATERIALIZE 11 /* completion of an accepted trajectory's step records on the tile-free speculative path */
+#define RAT_K_MATERIALIZE 11 /* reserved (round 3's completion of accepted trajectories' records: every gain sweep forms its tiles now) */
 #define RAT_K_COUNT     12
 /* When enabled, kernel launches are bracketed by HIP events on the handle's stream.
  * on = 0: off; on = 1: every kernel kind; otherwise on = (mask << 1) | 1 with bit k of mask selecting kind RAT_K_k.

@@ -146,8 +146,8 @@ __device__ __forceinline__ void elim_round(d4 &m, const ElimMasks &em, int &pdmi
 }
 
 // f_x of the LQ family, one register of the [A | B] image: A_ij, + 3 kappa x_i^2 on the lane that holds a diagonal element (dg = 1 there,
-// 0 elsewhere; x = that lane's own state component).  Formed by the rollout kernels (tile records), the fly sweeps (in registers) and
-// materialize_kernel: one rounding order everywhere, whatever the surrounding code lets the compiler contract.
+// 0 elsewhere; x = that lane's own state component).  Formed by the rollout kernels (tile records) and the fly sweeps (in registers):
+// one rounding order everywhere, whatever the surrounding code lets the compiler contract.
 __device__ __forceinline__ double fx_diag(double zt, double dg, double kappa, double x) {
 #pragma clang fp contract(off)
     const double k3 = 3.0 * kappa;

@@ -597,15 +597,16 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
     const int slot = round % CTR_RING;
     const int64_t nc = (int64_t)st.B * st.E;
     RolloutArgs ra; ra.st = st; ra.pb = h->pb; ra.op = h->opd; ra.dump = h->d_dump; ra.mode = 1; ra.x0 = h->d_x0; ra.u0 = h->d_u0; ra.notile = 0; ra.multi = 0;
-    // no tile records for line-search candidates (LQ family, E > 1): the evaluation sweeps form each step's tile from x_t themselves, and
-    // only an accepted trajectory that the plain gain sweep of the next step! will read is completed (materialize, after the accept rule)
+    // no tile records for line-search candidates (LQ family, E > 1): the evaluation sweeps form each step's tile from x_t themselves, and so
+    // do the gain sweeps (speculative on candidate 0, plain on whatever was accepted): nothing is completed afterwards
     const bool fly = h->fly && rollin_notile_supported(h->pb, st);
     const bool spec = use_separate_spec(h, st);
     ra.notile = fly ? 1 : 0;
     ra.multi = (fly && h->fly_multi) ? 1 : 0;
     if (h->dual && !spec) {
         // fused path (E = 1): the plain gain sweep only serves samples whose fused gain recursion was abandoned (H not PD)
-        prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
+        { SweepArgs sg0 = sweep_args(h, st, 0); sg0.fly = fly;       // (tile-free path: the plain gain sweep forms its tiles too -- nothing to materialise)
+          prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sg0, st.B, true, false, h->stream); prof_end(h); }
         prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);
         if (st.E > 1) {              // candidates 1 .. E-1: plain policy evaluation, beside candidate 0's paired wavefronts (second stream)
             HIPCHK(hipEventRecord(h->ev_a, h->stream));
@@ -621,13 +622,13 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
           prof_begin(h, RAT_K_SWEEP_DUAL, st.B); launch_sweep_dual(sd, st.B, h->stream); prof_end(h); }
         if (st.E > 1) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
         prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
-        if (fly) { prof_begin(h, RAT_K_MATERIALIZE, st.B); launch_materialize(st, h->pb, h->stream); prof_end(h); }
         HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
         return RAT_OK;
     }
     if (!spec || st.E > 1) {             // E > 1: a candidate k > 0 may be accepted, whose gain sweep was not speculated
-        prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sweep_args(h, st, 0), st.B, true, false, h->stream); prof_end(h);
+        SweepArgs sg0 = sweep_args(h, st, 0); sg0.fly = fly;
+        prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sg0, st.B, true, false, h->stream); prof_end(h);
     }
     prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);        // fused rollout + linearise
     if (spec) {
@@ -641,7 +642,6 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
       prof_begin(h, RAT_K_SWEEP_EVAL, nc); launch_sweep(se, (int)nc, false, false, h->stream); prof_end(h); }
     if (spec) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
     prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
-    if (fly) { prof_begin(h, RAT_K_MATERIALIZE, st.B); launch_materialize(st, h->pb, h->stream); prof_end(h); }
     HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipEventRecord(h->round_ev[slot], h->stream));
     return RAT_OK;

@@ -29,7 +29,7 @@ struct RolloutArgs {
     const double *x0;      // [12]
     const double *u0;      // [N*4]
     double *dump;          // diagnostic builds only
-    int notile;            // mode 1, rollin_stage_kernel: candidate records keep only [c_x | c_u | c] (see SweepArgs.fly, launch_materialize)
+    int notile;            // mode 1, rollin_stage_kernel: candidate records keep only [c_x | c_u | c] (see SweepArgs.fly)
     int multi;             // mode 1 with notile, E <= 16: all candidates of a sample in one wavefront (rollin_multi_kernel)
 };
 
@@ -101,6 +101,5 @@ void launch_init_state(const StateDev &st, const OptsDev &op, const double *thet
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s);   // modes 6 (initialize! + first gain sweep), 7 (candidate 0 + next gain sweep)
 void launch_commit_init(const StateDev &st, hipStream_t s);
-void launch_materialize(const StateDev &st, const ProblemDev &pb, hipStream_t s);   // complete records of accepted trajectories the plain gain sweep will read
 bool rollin_notile_supported(const ProblemDev &pb, const StateDev &st);              // the speculative path can run without candidate tiles
 void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, double *cost, double kl_bound, hipStream_t s);

@@ -496,7 +496,8 @@ static void launch_sweep_w(const SweepArgs &a, dim3 grid, hipStream_t s) {
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s) {
     if (ntraj <= 0) return;
     dim3 grid(ntraj);
-    if (gain && a.fly && a.mode == 4 && !dump) {   // speculative gain sweep on a candidate whose record holds only [c_x | c_u | c]
+    if (gain && a.fly && (a.mode == 4 || a.mode == 0) && !dump) {   // gain sweep on a trajectory whose record may hold only [c_x | c_u | c]: the
+                                                                    // speculative one on candidate 0, and the plain one of a step! on whatever was accepted
 #define FLYG_LAUNCH(W) do { if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_kernel<true, false, W, false, 2>), grid, dim3(64), 0, s, a); \
                             else hipLaunchKernelGGL((sweep_kernel<true, false, W, false, 1>), grid, dim3(64), 0, s, a); } while (0)
         if (a.pb.W_tv) FLYG_LAUNCH(1); else if (a.pb.W_diag) FLYG_LAUNCH(2); else FLYG_LAUNCH(0);
@@ -696,8 +697,8 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
 // shxu: 16 doubles of this wavefront's LDS (terminal tile); stg: STG_DOUBLES of LDS shared by the waves of the workgroup (STAGE), else null
 // NOTILE (line-search candidates of the speculative path, LQ family): the step record keeps only [c_x | c_u], c and its zero pair; the
 // sweeps that evaluate the candidate form f_x | f_u and the cost Hessian of step t from (x_t, u_t) and the problem tables themselves
-// (load_tile<.., FLY>), and only an ACCEPTED candidate whose tiles a later gain sweep reads gets the rest of its records
-// (materialize_kernel) -- as the reference keeps approximate_model's result only for the trajectory it accepts (ileqg.jl:514-555).
+// (load_tile<.., FLY>); the gain sweeps that may read an accepted candidate's records are fly sweeps too, so the rest of a record is never
+// written -- the reference keeps approximate_model's result only for the trajectory it accepts (ileqg.jl:514-555), this path for none.
 template <int MODEL, int MODE, bool CTV, bool STAGE = false, bool SEP = true, int PF = ROLLIN_PREFETCH, bool NOTILE = false>
 __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, double *const shxu, double *const stg = nullptr) {
     int lane_ = threadIdx.x & 63;        // (rollin_stage_kernel runs the E candidates of a sample as the waves of one workgroup)
@@ -1528,40 +1529,6 @@ __global__ __launch_bounds__(64) void rollin_multi_kernel(RolloutArgs a) {
         st.d_c[b * E + j] = dnan ? NAN : sqrt(dmax);
         st.flag_c[b * E + j] = 0;
     }
-}
-
-// The rest of the step records of a trajectory whose candidate records hold only [c_x | c_u | c] (rollin_body<.., NOTILE>): f_x | f_u and
-// the cost Hessian, in the expressions of rollin_body's own stores.  Runs after the accept rule for the samples whose NEXT step! will read
-// the accepted trajectory's tiles with the plain gain sweep (no valid speculative sweep): approximate_model of step! (ileqg.jl:604) for
-// exactly the trajectories the reference keeps it for.  One wavefront per (sample, step).
-__global__ __launch_bounds__(256) void materialize_kernel(StateDev st, ProblemDev pb) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
-    const int N = st.N;
-    const int nchunk = (N + 3) / 4;
-    const int b = blockIdx.x / nchunk;
-    const int t = (blockIdx.x - b * nchunk) * 4 + w;
-    if (t >= N) return;
-    if (st.status[b] != ST_RUNNING || st.ls_active[b] != 0) return;      // finished, or the next step!'s gain sweep is already committed
-    const int slot = b * (st.E + 1) + st.slot_nom[b];
-    const double *__restrict__ xp = st.xs + (long)slot * st.x_stride + (long)t * XSTR;
-    double *__restrict__ tp = st.tiles + tile_slot(st, b, slot) * st.tile_stride + (long)t * TSTRIDE;
-    const double mq = (j < 12) ? 1.0 : 0.0;
-    const double xj = xp[(j < 12) ? j : 11];
-    const double *__restrict__ C = pb.Ctab + (pb.cost_tv ? (long)t * 256 : 0);
-    double z[3], cf[4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) z[r] = fx_diag(pb.Zt[64 * r + l], (j == 4 * r + g) ? 1.0 : 0.0, pb.kappa, xj);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cf[r] = C[64 * r + l];
-    double2 *__restrict__ t2 = reinterpret_cast<double2 *>(tp);
-    t2[l] = make_double2(z[0], z[1]);
-    t2[64 + l] = make_double2(z[2], cf[3]);
-    *reinterpret_cast<double2 *>(tp + TS_REG(3, l)) = make_double2(cf[0] * mq, cf[1] * mq);     // dead lanes: (0, 0) to the zero pair
-    tp[TS_REG(5, l)] = cf[2] * mq;
-}
-void launch_materialize(const StateDev &st, const ProblemDev &pb, hipStream_t s) {
-    if (st.B <= 0) return;
-    hipLaunchKernelGGL(materialize_kernel, dim3(st.B * ((st.N + 3) / 4)), dim3(256), 0, s, st, pb);
 }
 
 bool rollin_notile_supported(const ProblemDev &pb, const StateDev &st) { return pb.model == 1 && st.E > 1 && st.N <= ROLLIN_NST; }
