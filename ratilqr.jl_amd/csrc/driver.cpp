@@ -80,6 +80,10 @@ struct rat_handle_s {
     char *h_io = nullptr;            // pinned staging of the host-pointer batch entry point: theta | value | status | iters | ls_evals, [Bmax] each
     hipEvent_t round_ev[CTR_RING] = {};
     bool have_initial = false;
+    // initialize!'s open-loop trajectory of the current (x_0, u_array), shared by every sample of every batch (FusedArgs.init_*)
+    double *d_init_x = nullptr, *d_init_u = nullptr, *d_init_t = nullptr;
+    bool init_traj_valid = false;
+    bool init_share = true;          // RATILQR_INIT_SHARE=0: every sample rolls initialize!'s trajectory out for itself (A/B and test override)
     int pred_rounds = 1;             // rounds the previous batch needed: that many are enqueued before the host first polls
     // profiling
     bool prof = false, prof_cur = false;
@@ -159,6 +163,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_BLOCK")) h->block_mode = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
     if (const char *e = getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = atoi(e);
     if (const char *e = getenv("RATILQR_BLOCK_SHAPE")) h->block_shape = (e[0] != '0');
+    if (const char *e = getenv("RATILQR_INIT_SHARE")) h->init_share = (e[0] != '0');
     if (const char *e = getenv("RATILQR_BLOCK_HELPERS")) h->block_helpers = (e[0] != '0');
     if (const char *e = getenv("RATILQR_FLY")) h->fly = (e[0] != '0');
     if (const char *e = getenv("RATILQR_FLY_MULTI")) h->fly_multi = (e[0] != '0');
@@ -290,10 +295,14 @@ static rat_rc alloc_state(rat_handle h) {
     AL(h->d_x0, XSTR); AL(h->d_u0, (size_t)N * USTR); AL(h->d_theta, B); AL(h->d_val, B);
     AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);
     AL(h->d_opout, 2); AL(h->d_dump, (size_t)(N + 1) * DUMP_STRIDE); AL(h->d_dlin, (size_t)N * USTR);
+    AL(h->d_init_x, (size_t)st.x_stride); AL(h->d_init_u, (size_t)st.u_stride); AL(h->d_init_t, (size_t)st.tile_stride);
+    h->init_traj_valid = false;
 #undef AL
     // padded lanes of the slot pools must be exact zeros
     HIPCHK(hipMemsetAsync(st.xs, 0, slots * st.x_stride * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(st.us, 0, slots * st.u_stride * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_init_x, 0, (size_t)st.x_stride * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_init_u, 0, (size_t)st.u_stride * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(st.L, 0, (size_t)2 * st.l_half * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(st.dl, 0, (size_t)2 * st.dl_half * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(st.lsel, 0, (size_t)B * sizeof(int), h->stream));
@@ -376,7 +385,7 @@ static rat_rc problem_set_wide(rat_handle h, const rat_problem_desc *d) {
     memset(&h->pb, 0, sizeof(h->pb));
     h->pb.model = d->model; h->pb.n = n; h->pb.m = m; h->pb.N = N;
     h->wpb = wp; h->n = n; h->m = m; h->N = N;
-    h->have_problem = true; h->have_initial = false;
+    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false;
     if (realloc_state && (rc = alloc_state_wide(h))) return rc;
     return RAT_OK;
 }
@@ -483,7 +492,7 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
     // control step) keeps its buffers: every live lane is rewritten by the next solve.
     const bool realloc_state = !h->have_problem || h->wide || h->N != N || h->n != n || h->m != m;
     h->pb = pb; h->n = n; h->m = m; h->N = N;
-    h->have_problem = true; h->have_initial = false;
+    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false;
     if (realloc_state && (rc = alloc_state(h))) return rc;
     return RAT_OK;
 }
@@ -703,7 +712,7 @@ extern "C" rat_rc rat_set_path(rat_handle h, int32_t path) {
     if (h->have_problem && !h->wide && was_alias != h->fused) {
         rat_rc rc = alloc_state(h);
         if (rc) return rc;
-        h->have_initial = false; h->x0_host.clear(); h->u0_host.clear();
+        h->have_initial = false; h->init_traj_valid = false; h->x0_host.clear(); h->u0_host.clear();
     }
     return RAT_OK;
 }
@@ -746,6 +755,20 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.theta_in = theta_dev;
         fa.out_value = out.value; fa.out_status = out.status; fa.out_iters = out.iters; fa.out_ls = out.ls;
         fa.out_cost = out.cost; fa.kl_bound = out.kl_bound;
+        // initialize!'s rollout is the same for every sample of every batch on this (x_0, u_array): rolled out once (the per-phase kernel,
+        // one wavefront) into a slot of its own; the tile-free kernels copy it instead of repeating it per sample
+        fa.init_x = fa.init_u = fa.init_t = nullptr;
+        if (h->init_share && h->pb.model == 1 && st.N <= ROLLIN_NST) {
+            if (!h->init_traj_valid) {
+                StateDev si = h->st;
+                si.B = 1; si.xs = h->d_init_x; si.us = h->d_init_u; si.tiles = h->d_init_t;
+                launch_init_state(si, h->opd, theta_dev, h->stream);     // (sample 0's control words; the batch initialises its samples again)
+                RolloutArgs ri = ra; ri.st = si;
+                launch_rollin(ri, h->stream);
+                h->init_traj_valid = true;
+            }
+            fa.init_x = h->d_init_x; fa.init_u = h->d_init_u; fa.init_t = h->d_init_t;
+        }
         // two-wave workgroups padded to one wave per SIMD (ticketed SIMD pairs): only while two workgroups per CU hold the batch -- the
         // register slots of the two waves that exit at once stay charged to the workgroup until it ends, so a third padded workgroup
         // per CU would have to wait for a whole solve (measured: 768 samples 0.515 ms padded, 0.420 ms plain)
@@ -816,6 +839,7 @@ extern "C" rat_rc rat_set_initial(rat_handle h, const double *x0, const double *
     }
     // (the bilevel drivers pass the same x_0 / u_array for every batch of a solve: upload only what changed)
     if (h->have_initial && xp == h->x0_host && up == h->u0_host) return RAT_OK;
+    h->init_traj_valid = false;
     HIPCHK(hipMemcpyAsync(h->d_x0, xp.data(), xp.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_u0, up.data(), up.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

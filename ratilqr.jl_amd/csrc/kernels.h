@@ -47,6 +47,11 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     // solve_block_kernel only:
     int *census;                       // [CENSUS_SLOTS] per-CU workgroup tickets of the two-wave geometry, or null: see solve_block_kernel
     int helpers;                       // 1: one workgroup per CU (B <= n_cu): the two spare waves of a padded workgroup help linearising
+    // initialize!'s rollout (ileqg.jl:225-228) does not depend on theta: every sample of a batch -- and every batch on the same (x_0,
+    // u_array) -- runs the same open-loop trajectory.  The driver rolls it out ONCE per rat_set_initial into a slot of its own (rollin_kernel,
+    // the code the samples would run themselves) and the tile-free kernels copy what they read of it: x, u, the [c_x | c_u | c] rows and
+    // the terminal tile.  Null: every sample rolls out for itself.
+    const double *init_x, *init_u, *init_t;
 };
 #define CENSUS_SLOTS 4096              /* (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID / HW_REG_XCC_ID: 4 + 3 + 1 + 4 bits */
 

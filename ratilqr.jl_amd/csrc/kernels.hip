@@ -1863,6 +1863,44 @@ __device__ __forceinline__ double uniform_load_f64(const double *p) { return rea
 #define PHASE_MARK() do {} while (0)
 #endif
 
+// initialize!'s open-loop trajectory, rolled out once per (x_0, u_array) by the driver (FusedArgs.init_*): one wave copies the parts of its
+// slot the tile-free kernels read -- the state and control histories, the [c_x | c_u | c] row of every step record (positions TS_QR ..
+// TSTRIDE - 1) and the terminal tile -- into the sample's nominal slot: the bits rollin_body<.., 0, .., NOTILE> would have stored there.
+__device__ __forceinline__ void copy_initial(const StateDev &st, const FusedArgs &fa, const int b) {
+    const int l = threadIdx.x & 63;
+    const int N = st.N;                                               // <= ROLLIN_NST (the tile-free geometries are the staged ones)
+    const int slot = b * (st.E + 1);                                 // (init_state_body: slot_nom = 0)
+    double *__restrict__ xo = st.xs + (long)slot * st.x_stride;
+    double *__restrict__ uo = st.us + (long)slot * st.u_stride;
+    double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot) * st.tile_stride;
+    constexpr int RW = TSTRIDE - TS_QR;                               // the [c_x | c_u], c, pad row of a step record
+    constexpr int QX = ((ROLLIN_NST + 1) * XSTR + 63) / 64, QU = (ROLLIN_NST * USTR + 63) / 64, QR = (ROLLIN_NST * RW + 63) / 64, QT = (TTERM + 63) / 64;
+    const int nx = (N + 1) * XSTR, nu = N * USTR, nr = N * RW;
+    // every load first (clamped addresses, ~35 in flight per lane), then the stores: one round trip instead of one per element
+    double rx[QX], ru[QU], rr[QR], rt[QT];
+    long orr[QR];
+#pragma unroll
+    for (int q = 0; q < QX; ++q) { const int e = l + 64 * q; rx[q] = fa.init_x[e < nx ? e : 0]; }
+#pragma unroll
+    for (int q = 0; q < QU; ++q) { const int e = l + 64 * q; ru[q] = fa.init_u[e < nu ? e : 0]; }
+#pragma unroll
+    for (int q = 0; q < QR; ++q) {
+        const int e = l + 64 * q, ec = e < nr ? e : 0, t = ec / RW;
+        orr[q] = (long)t * TSTRIDE + TS_QR + (ec - t * RW);
+        rr[q] = fa.init_t[orr[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < QT; ++q) { const int e = l + 64 * q; rt[q] = fa.init_t[(long)N * TSTRIDE + (e < TTERM ? e : 0)]; }
+#pragma unroll
+    for (int q = 0; q < QX; ++q) { const int e = l + 64 * q; if (e < nx) xo[e] = rx[q]; }
+#pragma unroll
+    for (int q = 0; q < QU; ++q) { const int e = l + 64 * q; if (e < nu) uo[e] = ru[q]; }
+#pragma unroll
+    for (int q = 0; q < QR; ++q) { const int e = l + 64 * q; if (e < nr) tile0[orr[q]] = rr[q]; }
+#pragma unroll
+    for (int q = 0; q < QT; ++q) { const int e = l + 64 * q; if (e < TTERM) tile0[(long)N * TSTRIDE + e] = rt[q]; }
+}
+
 // DUALF: where the next step!'s gain sweep reads the very tiles a policy evaluation is about to read -- initialize!'s sweep and the
 // first step!, a line-search candidate and the step! that follows its acceptance -- ONE pass runs both recursions in the wave
 // (sweep_dual_body: two independent dependency chains interleaved in one basic block, tiles read once; every expression is the one
@@ -1895,8 +1933,12 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
     if (threadIdx.x == 0) init_state_body(st, fa.sw.op, fa.theta_in, b);
     PHASE_FENCE();
     {
-        RolloutArgs ra = fa.ro; ra.mode = 0;
-        rollin_body<MODEL, 0, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH, NT>(ra, b, shxu, stg);
+        if (NT && fa.init_x) {
+            copy_initial(st, fa, b);
+        } else {
+            RolloutArgs ra = fa.ro; ra.mode = 0;
+            rollin_body<MODEL, 0, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH, NT>(ra, b, shxu, stg);
+        }
         PHASE_MARK();
         PHASE_FENCE();
         PHASE_MARK();
@@ -2087,7 +2129,9 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     BLK_MARK();
     const bool helpers = HELP && fa.helpers;
     const int nlin = helpers ? 3 : 1;            // linearise waves: the gain wave (+ the two spare waves)
-    if (SPLIT) {                                 // initialize!: open-loop rollout (wave 0) + linearise (the other waves)   (ileqg.jl:214-233)
+    if (NTB && fa.init_x) {                      // initialize!'s rollout was run once for the whole batch (FusedArgs.init_*)
+        if (wave == 0) copy_initial(st, fa, b);
+    } else if (SPLIT) {                          // initialize!: open-loop rollout (wave 0) + linearise (the other waves)   (ileqg.jl:214-233)
         RolloutArgs ra = fa.ro; ra.mode = 0;
         if (helpers) {
             if (wave == 0) rollrec_body<0, HELP>(ra, b, stg, xu, &prog, epoch, d_acc);
