@@ -152,3 +152,29 @@ def test_handles_release_their_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 30 create / destroy cycles"
+
+
+@pytest.mark.parametrize("B", [96, 640])
+def test_shared_initial_trajectory_follows_x0_and_u(B, monkeypatch):
+    """initialize!'s open-loop rollout (ileqg.jl:225-228) is rolled out once per (x_0, u_array) and copied by the samples of every batch
+    (FusedArgs.init_*): a handle that is given another x_0, another u_array or another problem must not reuse the old trajectory, and the
+    results equal those of per-sample rollouts (RATILQR_INIT_SHARE=0) bit for bit.  B = 96: workgroup-per-sample kernel, 640: fused kernel."""
+    prob, x0, u = rat.synthetic_lq_problem(seed=0)
+    rng = np.random.default_rng(3)
+    theta = np.abs(1.0 + 2.0 * rng.standard_normal(B)) + 1e-3
+    x1, u1 = x0 * 0.7 + 0.1, u + 0.05 * rng.standard_normal(u.shape)
+    prob2, _, _ = rat.synthetic_lq_problem(seed=5)
+    ctx = rat.Context(prob, max_batch=B)
+    seq = [(prob, x0, u), (prob, x1, u), (prob, x1, u1), (prob, x0, u), (prob2, x0, u), (prob, x0, u)]
+    got = []
+    for p, xa, ua in seq:
+        if p is not ctx.problem:
+            ctx.set_problem(p)
+        got.append(ctx.solve_batch(xa, ua, theta))
+    monkeypatch.setenv("RATILQR_INIT_SHARE", "0")
+    for (p, xa, ua), g in zip(seq, got):
+        ref = rat.Context(p, max_batch=B).solve_batch(xa, ua, theta)
+        for a, b in zip(g, ref):
+            assert np.array_equal(a, b)
+    assert np.array_equal(got[0][0], got[3][0]) and np.array_equal(got[0][0], got[5][0])
+    assert not np.array_equal(got[0][0], got[1][0]) and not np.array_equal(got[1][0], got[2][0]) and not np.array_equal(got[0][0], got[4][0])
