@@ -44,7 +44,7 @@ struct rat_handle_s {
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
     bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
     std::vector<double> x0_host, u0_host;   // padded copies of what d_x0 / d_u0 hold (rat_set_initial skips identical uploads)
-    int fused_occ2 = 0;              // RATILQR_FUSED_OCC2=B0: batches of at least B0 samples run the 256-register one-recursion-per-pass variant, two samples per SIMD
+    int fused_occ2 = 0;              // RATILQR_FUSED_OCC2=B0: batches of at least B0 samples run the 256-register one-recursion-per-pass variant, two samples per SIMD (0: never, the default)
     bool fused_dual = true;          // ... with policy evaluation + following gain sweep paired in one pass (RATILQR_FUSED_DUAL=0: separate)
     int block_mode = -1;             // workgroup-per-sample solve kernel (solve_block_kernel): -1 auto, 0 never, 1 whenever it is supported (RATILQR_BLOCK)
     int block_max_b = 512;           // auto, E = 1: used for batches up to this size (RATILQR_BLOCK_MAX_B)
@@ -168,9 +168,11 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (const char *e = getenv("RATILQR_FLY")) h->fly = (e[0] != '0');
     if (const char *e = getenv("RATILQR_FLY_MULTI")) h->fly_multi = (e[0] != '0');
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
-    // E = 1 batches beyond one sample per SIMD: two samples per SIMD in 256 registers each beat two generations of the 342-register
-    // paired kernel (measured +6..10 %); RATILQR_FUSED_OCC2=0 disables, =B0 moves the threshold
-    h->fused_occ2 = 4 * h->n_cu + 1;
+    // E = 1 batches beyond one sample per SIMD run the paired kernel in generations.  (Rounds 2-3: two samples per SIMD in 256 registers each,
+    // one recursion per pass, beat two generations of the paired kernel by 6..10 % -- until that kernel stopped writing tile records: the
+    // 256-register variant cannot stage its rollouts in LDS, so it keeps its tiles, and now loses 1..3 % at 2048..8192 samples.
+    // RATILQR_FUSED_OCC2=B0 still selects it for batches of at least B0 samples.)
+    h->fused_occ2 = 0;
     if (!getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = 2 * h->n_cu;      // E = 1: a workgroup per sample while every sample can have two SIMDs
     if (const char *e = getenv("RATILQR_FUSED_OCC2")) h->fused_occ2 = atoi(e);
     CREATECHK(hipMalloc((void **)&h->d_census, sizeof(int) * CENSUS_SLOTS));

@@ -364,7 +364,7 @@ def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
     fused_plain = run_all()                          # fused, one recursion per pass
     monkeypatch.delenv("RATILQR_FUSED_DUAL")
     monkeypatch.setenv("RATILQR_FUSED_OCC2", "1")
-    fused_occ2 = run_all()                           # fused, the 256-register variant that puts two samples on a SIMD (default beyond 1024 samples)
+    fused_occ2 = run_all()                           # fused, the 256-register variant that puts two samples on a SIMD (an option since round 3)
     monkeypatch.delenv("RATILQR_FUSED_OCC2")
     monkeypatch.setenv("RATILQR_FUSED", "0")
     rounds = run_all()                               # one launch per phase

@@ -5,7 +5,7 @@
 #   block128   B = 128,  E = 1  solve_block_kernel: the per-GPU shard of the headline at 8 GPUs
 #   e8_1024    B = 1024, E = 8  round-based path without candidate tiles: BASELINE config 3 on one GPU (rollin_multi_kernel, fly sweeps)
 #   e8_128     B = 128,  E = 8  solve_block_kernel: config 3's shard at 8 GPUs
-#   occ2_4096  B = 4096, E = 1  two samples per SIMD
+#   fused_4096 B = 4096, E = 1  the paired kernel in four generations
 # Outputs under gpurun_out/r03/prof/; summarised into profiles/ by tools/profile_r03_report.py.   usage: profile_r03.sh [config ...]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03/prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -24,5 +24,5 @@ CUR=fused;     want "$@" && run fused --batch 1024
 CUR=block128;  want "$@" && run block128 --batch 128
 CUR=e8_1024;   want "$@" && run e8_1024 --batch 1024 --spec-eps 8
 CUR=e8_128;    want "$@" && run e8_128 --batch 128 --spec-eps 8
-CUR=occ2_4096; want "$@" && run occ2_4096 --batch 4096
+CUR=fused_4096; want "$@" && run fused_4096 --batch 4096
 find $O -name "*.csv" | wc -l

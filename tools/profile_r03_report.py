@@ -9,7 +9,7 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 O = os.path.join(ROOT, "gpurun_out", "r03", "prof")
-CFG = {"fused": (1, 1024), "block128": (1, 128), "e8_1024": (8, 1024), "e8_128": (8, 128), "occ2_4096": (1, 4096)}
+CFG = {"fused": (1, 1024), "block128": (1, 128), "e8_1024": (8, 1024), "e8_128": (8, 128), "fused_4096": (1, 4096)}
 # kernel-name pattern -> the key bench.py uses (traffic_for(f"{kind}_E{E}_B{B}")); first match wins
 KINDS = [("solve_fused_kernel", "solve_fused"), ("solve_block_kernel", "solve_block"), ("sweep_dual_kernel", "sweep_dual"),
          ("rollin_multi_kernel", "rollout_multi"), ("rollin_stage_kernel", "rollout"), ("rollin_kernel", "rollout_init"),
