@@ -720,6 +720,17 @@ extern "C" rat_rc rat_set_path(rat_handle h, int32_t path) {
 }
 
 // outputs of a batch (device pointers, any may be null); cost = value + kl_bound / theta  (cross_entropy...jl:193)
+// initialize!'s open-loop trajectory of the current (x_0, u_array), rolled out once into the handle's own slot (d_init_*): see FusedArgs.init_*
+static void ensure_init_traj(rat_handle h, const RolloutArgs &ra, const double *theta_dev) {
+    if (h->init_traj_valid) return;
+    StateDev si = h->st;
+    si.B = 1; si.xs = h->d_init_x; si.us = h->d_init_u; si.tiles = h->d_init_t;
+    launch_init_state(si, h->opd, theta_dev, h->stream);     // (sample 0's control words; the batch initialises its samples again)
+    RolloutArgs ri = ra; ri.st = si; ri.mode = 0; ri.notile = 0; ri.multi = 0;
+    launch_rollin(ri, h->stream);
+    h->init_traj_valid = true;
+}
+
 struct BatchOut { double *value = nullptr; int *status = nullptr, *iters = nullptr, *ls = nullptr; double *cost = nullptr; double kl_bound = 0.0; };
 
 static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const BatchOut &out = BatchOut()) {
@@ -761,14 +772,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         // one wavefront) into a slot of its own; the tile-free kernels copy it instead of repeating it per sample
         fa.init_x = fa.init_u = fa.init_t = nullptr;
         if (h->init_share && h->pb.model == 1 && st.N <= ROLLIN_NST) {
-            if (!h->init_traj_valid) {
-                StateDev si = h->st;
-                si.B = 1; si.xs = h->d_init_x; si.us = h->d_init_u; si.tiles = h->d_init_t;
-                launch_init_state(si, h->opd, theta_dev, h->stream);     // (sample 0's control words; the batch initialises its samples again)
-                RolloutArgs ri = ra; ri.st = si;
-                launch_rollin(ri, h->stream);
-                h->init_traj_valid = true;
-            }
+            ensure_init_traj(h, ra, theta_dev);
             fa.init_x = h->d_init_x; fa.init_u = h->d_init_u; fa.init_t = h->d_init_t;
         }
         // two-wave workgroups padded to one wave per SIMD (ticketed SIMD pairs): only while two workgroups per CU hold the batch -- the
@@ -781,10 +785,19 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         prof_end(h);
         return RAT_OK;
     }
-    prof_begin(h, RAT_K_ROLLOUT, B); launch_rollin(ra, h->stream); prof_end(h);         // fused rollout + linearise
     const bool spec = use_separate_spec(h, st);
+    // tile-free speculative path with the paired first sweep: initialize!'s rollout comes from the handle's shared slot (one copy kernel
+    // instead of B rollouts) and the paired sweep forms its tiles like every later sweep
+    const bool share0 = h->init_share && h->dual && !spec && h->fly && rollin_notile_supported(h->pb, st);
+    if (share0) {
+        ensure_init_traj(h, ra, theta_dev);              // (its init_state writes to sample 0 what the batch's own has just written)
+        prof_begin(h, RAT_K_ROLLOUT, B); launch_copy_initial(st, h->d_init_x, h->d_init_u, h->d_init_t, h->stream); prof_end(h);
+    } else {
+        prof_begin(h, RAT_K_ROLLOUT, B); launch_rollin(ra, h->stream); prof_end(h);     // fused rollout + linearise
+    }
     if (h->dual && !spec) {
-        prof_begin(h, RAT_K_SWEEP_DUAL, B); launch_sweep_dual(sweep_args(h, st, 6), B, h->stream); prof_end(h);
+        SweepArgs s6 = sweep_args(h, st, 6); s6.fly = share0 ? 1 : 0;
+        prof_begin(h, RAT_K_SWEEP_DUAL, B); launch_sweep_dual(s6, B, h->stream); prof_end(h);
         launch_commit_init(st, h->stream);
     } else {
     if (spec) {

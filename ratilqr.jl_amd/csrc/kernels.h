@@ -103,6 +103,7 @@ void launch_solve_fused(const FusedArgs &a, hipStream_t s);   // complete solve!
 void launch_solve_block(const FusedArgs &a, hipStream_t s);   // complete solve! per sample by a workgroup of wavefronts (E = 1, 2, 4, 8)
 bool solve_block_supported(int E);
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
+void launch_copy_initial(const StateDev &st, const double *init_x, const double *init_u, const double *init_t, hipStream_t s);   // round-based path: FusedArgs.init_* per sample
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s);   // modes 6 (initialize! + first gain sweep), 7 (candidate 0 + next gain sweep)
 void launch_commit_init(const StateDev &st, hipStream_t s);

@@ -1866,7 +1866,8 @@ __device__ __forceinline__ double uniform_load_f64(const double *p) { return rea
 // initialize!'s open-loop trajectory, rolled out once per (x_0, u_array) by the driver (FusedArgs.init_*): one wave copies the parts of its
 // slot the tile-free kernels read -- the state and control histories, the [c_x | c_u | c] row of every step record (positions TS_QR ..
 // TSTRIDE - 1) and the terminal tile -- into the sample's nominal slot: the bits rollin_body<.., 0, .., NOTILE> would have stored there.
-__device__ __forceinline__ void copy_initial(const StateDev &st, const FusedArgs &fa, const int b) {
+__device__ __forceinline__ void copy_initial(const StateDev &st, const double *__restrict__ init_x, const double *__restrict__ init_u,
+                                             const double *__restrict__ init_t, const int b) {
     const int l = threadIdx.x & 63;
     const int N = st.N;                                               // <= ROLLIN_NST (the tile-free geometries are the staged ones)
     const int slot = b * (st.E + 1);                                 // (init_state_body: slot_nom = 0)
@@ -1880,17 +1881,17 @@ __device__ __forceinline__ void copy_initial(const StateDev &st, const FusedArgs
     double rx[QX], ru[QU], rr[QR], rt[QT];
     long orr[QR];
 #pragma unroll
-    for (int q = 0; q < QX; ++q) { const int e = l + 64 * q; rx[q] = fa.init_x[e < nx ? e : 0]; }
+    for (int q = 0; q < QX; ++q) { const int e = l + 64 * q; rx[q] = init_x[e < nx ? e : 0]; }
 #pragma unroll
-    for (int q = 0; q < QU; ++q) { const int e = l + 64 * q; ru[q] = fa.init_u[e < nu ? e : 0]; }
+    for (int q = 0; q < QU; ++q) { const int e = l + 64 * q; ru[q] = init_u[e < nu ? e : 0]; }
 #pragma unroll
     for (int q = 0; q < QR; ++q) {
         const int e = l + 64 * q, ec = e < nr ? e : 0, t = ec / RW;
         orr[q] = (long)t * TSTRIDE + TS_QR + (ec - t * RW);
-        rr[q] = fa.init_t[orr[q]];
+        rr[q] = init_t[orr[q]];
     }
 #pragma unroll
-    for (int q = 0; q < QT; ++q) { const int e = l + 64 * q; rt[q] = fa.init_t[(long)N * TSTRIDE + (e < TTERM ? e : 0)]; }
+    for (int q = 0; q < QT; ++q) { const int e = l + 64 * q; rt[q] = init_t[(long)N * TSTRIDE + (e < TTERM ? e : 0)]; }
 #pragma unroll
     for (int q = 0; q < QX; ++q) { const int e = l + 64 * q; if (e < nx) xo[e] = rx[q]; }
 #pragma unroll
@@ -1934,7 +1935,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
     PHASE_FENCE();
     {
         if (NT && fa.init_x) {
-            copy_initial(st, fa, b);
+            copy_initial(st, fa.init_x, fa.init_u, fa.init_t, b);
         } else {
             RolloutArgs ra = fa.ro; ra.mode = 0;
             rollin_body<MODEL, 0, CTV, STG, true, OCC2 ? OCC2_PREFETCH : ROLLIN_PREFETCH, NT>(ra, b, shxu, stg);
@@ -2130,7 +2131,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     const bool helpers = HELP && fa.helpers;
     const int nlin = helpers ? 3 : 1;            // linearise waves: the gain wave (+ the two spare waves)
     if (NTB && fa.init_x) {                      // initialize!'s rollout was run once for the whole batch (FusedArgs.init_*)
-        if (wave == 0) copy_initial(st, fa, b);
+        if (wave == 0) copy_initial(st, fa.init_x, fa.init_u, fa.init_t, b);
     } else if (SPLIT) {                          // initialize!: open-loop rollout (wave 0) + linearise (the other waves)   (ileqg.jl:214-233)
         RolloutArgs ra = fa.ro; ra.mode = 0;
         if (helpers) {
@@ -2265,6 +2266,14 @@ void launch_solve_block(const FusedArgs &fa, hipStream_t s) {
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s) {
     const int n = st.B > 2 * CTR_RING ? st.B : 2 * CTR_RING;
     hipLaunchKernelGGL(init_state_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, op, theta_dev);
+}
+// round-based tile-free path: the samples' nominal slots <- initialize!'s shared trajectory (one wavefront per sample)
+__global__ __launch_bounds__(64) void copy_initial_kernel(StateDev st, const double *init_x, const double *init_u, const double *init_t) {
+    copy_initial(st, init_x, init_u, init_t, blockIdx.x);
+}
+void launch_copy_initial(const StateDev &st, const double *init_x, const double *init_u, const double *init_t, hipStream_t s) {
+    if (st.B <= 0) return;
+    hipLaunchKernelGGL(copy_initial_kernel, dim3(st.B), dim3(64), 0, s, st, init_x, init_u, init_t);
 }
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s) {
     hipLaunchKernelGGL(ls_select_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, op, slot);

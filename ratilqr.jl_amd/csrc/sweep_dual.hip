@@ -15,7 +15,10 @@ void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s) {
             if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_dual_kernel<W, true, 2>), grid, block, 0, s, a); \
             else hipLaunchKernelGGL((sweep_dual_kernel<W, true, 1>), grid, block, 0, s, a); \
         } else if (a.mode == 7) hipLaunchKernelGGL((sweep_dual_kernel<W, true>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((sweep_dual_kernel<W, false>), grid, block, 0, s, a); } while (0)
+        else if (a.fly) {                              /* initialize!'s trajectory came from the shared slot: [x; u] and cost-gradient rows only */ \
+            if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_dual_kernel<W, false, 2>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((sweep_dual_kernel<W, false, 1>), grid, block, 0, s, a); \
+        } else hipLaunchKernelGGL((sweep_dual_kernel<W, false>), grid, block, 0, s, a); } while (0)
     if (a.pb.W_tv) DUAL_LAUNCH(1); else if (a.pb.W_diag) DUAL_LAUNCH(2); else DUAL_LAUNCH(0);
 #undef DUAL_LAUNCH
 }
