@@ -13,6 +13,7 @@ CFG = {"fused": (1, 1024), "block128": (1, 128), "e8_1024": (8, 1024), "e8_128":
 # kernel-name pattern -> the key bench.py uses (traffic_for(f"{kind}_E{E}_B{B}")); first match wins
 KINDS = [("solve_fused_kernel", "solve_fused"), ("solve_block_kernel", "solve_block"), ("sweep_dual_kernel", "sweep_dual"),
          ("rollin_multi_kernel", "rollout_multi"), ("rollin_stage_kernel", "rollout"), ("rollin_kernel", "rollout_init"),
+         ("copy_initial_kernel", "copy_initial"),
          ("sweep_kernel<false", "sweep_eval"), ("sweep_kernel<true", "sweep_gain"), ("materialize_kernel", "materialize"),
          ("ls_select_kernel", "select")]
 STEPS = 10 + 2 + 5            # launches of a once-per-batch kernel in one bench.py run of profile_r03.sh (timed + warm-up + profiled pass), + conditioning
@@ -85,15 +86,20 @@ for name, (E, B) in CFG.items():
         elif k in ("rollout", "rollout_multi"):
             alg = (a["rollout_candidate"] + a["linearise"]) * B * E
         elif k == "rollout_init":
+            alg = (a["rollout_init"] + a["linearise"]) * (1 if "copy_initial" in rows else B)
+        elif k == "copy_initial":
             alg = (a["rollout_init"] + a["linearise"]) * B
         md.append(f"| {name}: B = {B}, E = {E} | `{kname[:70]}` | {calls} | {avg:.1f} | {t / 1e6:.1f} | {alg / 1e6 if alg else float('nan'):.1f} |"
                   if t is not None else f"| {name}: B = {B}, E = {E} | `{kname[:70]}` | {calls} | {avg:.1f} | - | {alg / 1e6 if alg else float('nan'):.1f} |")
         if E > 1 and k not in ("solve_block",):
-            runs = runs or rows.get("rollout_init", rows.get("sweep_dual"))[1]          # batches in the run
-            per_batch += avg * calls
-            per_batch_t += (t or 0.0) * calls
+            # batches in the run: one copy of the shared initialize! trajectory per batch (the rollin_kernel launch is then the ONE
+            # rollout per rat_set_initial); before round 3's sharing: one initial rollout per batch
+            runs = runs or rows.get("copy_initial", rows.get("rollout_init", rows.get("sweep_dual")))[1]
+            if not (k == "rollout_init" and "copy_initial" in rows):
+                per_batch += avg * calls
+                per_batch_t += (t or 0.0) * calls
     if E > 1 and runs and "solve_block" not in rows:
-        batches = rows["rollout_init"][1] if "rollout_init" in rows else runs
+        batches = runs
         traffic[f"batch_E{E}_B{B}"] = per_batch_t / batches
         md.append(f"| {name}: per batch (all kernels) | | {batches} batches | {per_batch / batches:.1f} | {per_batch_t / batches / 1e6:.1f} | "
                   f"{B * (368312 + 2 * 188864 + 2 * E * 395608) / 1e6:.1f} |")
