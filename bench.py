@@ -126,6 +126,19 @@ def traffic_for(key):
     return float(tj[key]), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {tj.get('kernels_sha')} ({tj.get('round', '?')})"
 
 
+def sq_for(key):
+    """SQ-counter digest of a kernel from the committed rocprofv3 --pmc SQ_* passes (profiles/traffic.json, section "sq"; same source
+    stamp as the traffic figures), or None: issue_frac = share of the waves' lifetime in which the FP64 datapath issues vector or matrix
+    work, parked_frac = SQ_WAIT_ANY share, wait_inst_frac = SQ_WAIT_INST_ANY share."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return None
+    if tj.get("kernels_sha") != kernel_source_hash():
+        return None
+    return tj.get("sq", {}).get(key)
+
+
 # ---- host cores the CPU baseline may use ---------------------------------------------------------------------------------------
 def cgroup_cpu_limit():
     for p in ("/sys/fs/cgroup/cpu.max",):
@@ -306,13 +319,15 @@ class Workload:
     """One CE batch on this rank: `nloc` theta-samples of a (global) batch `G`, solved by one rat_handle with E speculative step
     sizes, followed -- when there is more than one rank -- by the all-gather of the per-sample costs."""
 
-    def __init__(self, D, prob, x0, u0, theta_local, G, E, kl_bound=0.1):
+    def __init__(self, D, prob, x0, u0, theta_local, G, E, kl_bound=0.1, debug=()):
         import ratilqr.jl_amd as rat
         torch = D.torch
         self.D, self.G, self.E, self.kl = D, G, E, kl_bound
         self.nloc = int(theta_local.size)
         self.theta_h = theta_local
         self.ctx = rat.Context(prob, max_batch=max(self.nloc, 1), spec_eps=E, device=D.local_rank)
+        for key, val in debug:                            # execution switches (rat_debug_set): the contract leg, A/B profiles
+            self.ctx.debug_set(key, val)
         self.ctx.set_initial(x0, u0)
         self.theta = torch.as_tensor(theta_local, dtype=torch.float64, device=D.dev)
         self.chunk = -(-G // D.world)                     # padded shard length of the gather
@@ -390,7 +405,13 @@ class Workload:
 
 
 def roofline_of(w, prof_main, main_kind, iters_h, ls_h):
-    """`roofline` of the dominant kernel of workload w from the HIP events recorded inside the timed region."""
+    """`roofline` of the dominant kernel of workload w from the HIP events recorded inside the timed region.
+
+    `achieved` / `frac` keep SURVEY 8(d)'s contract: ALGORITHMIC bytes of the unfused three-kernel formulation per launch / the launch's
+    duration / the 8 TB/s HBM peak.  They are NOT what the kernel moves -- the single-launch solves keep no tile records in HBM -- so the
+    object also says, as top-level scalars, what does bound the launch: `bound` = "fp64" (vector + f64 matrix instructions share one
+    datapath and issue serially), `issue_frac` (share of a wave's lifetime in which that datapath issues: SQ counters), `fp64_frac`
+    (algorithmic flops against the 78.6 TFLOP/s peak) and `hbm_real_gbs` / `hbm_real_frac` (counter traffic / time / peak)."""
     lay = w.ctx.layout_info()
     avg_ms = prof_main["ms"] / max(prof_main["launches"], 1)
     traj_per_launch = prof_main["trajectories"] / max(prof_main["launches"], 1)
@@ -404,20 +425,35 @@ def roofline_of(w, prof_main, main_kind, iters_h, ls_h):
         bytes_per_traj = algo_bytes_per_candidate()
         bytes_per_launch = bytes_per_traj * traj_per_launch
         kernel_name = "sweep_kernel<eval> (policy-evaluation Riccati sweep of line-search candidates)"
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, tnote = traffic_for(f"{main_kind}_E{w.E}_B{w.nloc}")
+    sec = avg_ms * 1e-3
+    achieved = bytes_per_launch / sec / 1e9 if sec > 0 else 0.0
+    key = f"{main_kind}_E{w.E}_B{w.nloc}"
+    traffic, tnote = traffic_for(key)
+    sq = sq_for(key)
     r = {
-        "bound": "hbm", "kernel": kernel_name,
+        "bound": "fp64" if fused else "hbm",
+        "bound_is": ("the FP64 datapath: v_mfma_f64 and f64 vector instructions issue serially on one pipe (profiles/r01_ubench_fp64_pipe.md); "
+                     "`achieved` / `frac` are SURVEY 8(d)'s algorithmic-bytes figure (the contract), not bytes moved: see hbm_real_*") if fused
+                    else "HBM stream of tile records",
+        "kernel": kernel_name,
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "algorithmic_equivalent_gbs": achieved,
         "traffic": traffic, "traffic_source": tnote,
+        "hbm_real_gbs": (traffic / sec / 1e9) if (traffic and sec > 0) else None,
+        "hbm_real_frac": (traffic / sec / 1e9 / HBM_PEAK_GBS) if (traffic and sec > 0) else None,
+        "issue_frac": sq["issue_frac"] if sq else None,
+        "parked_frac": sq["parked_frac"] if sq else None,
+        "wait_inst_frac": sq["wait_inst_frac"] if sq else None,
         "bytes_per_trajectory": bytes_per_traj, "hbm_record_bytes_per_trajectory": lay["tile_bytes"] + lay["L_bytes"] + 8,
         "trajectories_per_launch": traj_per_launch,
         "avg_launch_ms": avg_ms, "launches": prof_main["launches"],
     }
-    if fused:           # the sweep sits at the fp64 ridge -- report the FP64 fraction of the same launches beside the HBM one
+    if fused:           # the sweep sits at the fp64 ridge -- the FP64 fraction of the same launches
         fl = algo_flops_of_solves(iters_h, ls_h)
-        r["fp64"] = {"achieved": fl / (avg_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": fl / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_per_solve": fl / max(len(iters_h), 1)}
+        r["fp64_achieved_tflops"] = fl / sec / 1e12
+        r["fp64_peak_tflops"] = FP64_PEAK_TFLOPS
+        r["fp64_frac"] = fl / sec / 1e12 / FP64_PEAK_TFLOPS
+        r["flops_per_solve"] = fl / max(len(iters_h), 1)
     return r
 
 
@@ -472,7 +508,8 @@ def rank_main(args):
     cpu = cpu_baseline(prob, x0, u0, args.cpu_seconds) if (rank == 0 and world == 1 and not args.no_cpu) else None
 
     # ---- primary: the BASELINE configuration -- one CE batch of G = 1024 samples over all ranks (strong scaling) -------------
-    w = Workload(D, prob, x0, u0, theta_global[lo:hi], G, E)
+    dbg = tuple((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.debug)
+    w = Workload(D, prob, x0, u0, theta_global[lo:hi], G, E, debug=dbg)
     # conditioning (untimed, before the W warm-up steps): a batch is < 0.5 ms, so W = 3 steps after an idle period are over before the
     # chip has left its idle clocks -- `steady_state` below (>= 1 s of batches) showed the first ~10 ms running 5 % slow.  0.3 s of the
     # same batches first; the timed region is still EXACTLY `steps` batches.
@@ -588,20 +625,21 @@ def rank_main(args):
                   "algorithmic_GBps": bytes8 * K8 / e8 / 1e9, "algorithmic_bytes_per_solve": bytes8 / B,
                   "kernel_ms_per_step": {k: v["ms"] / K8 for k, v in p8all.items() if v["launches"]},
                   "dominant_kernel": k8}
-        if k8 == "sweep_eval":
-            bpt = algo_bytes_per_candidate(prob)
-            ach8 = bpt * (p8["trajectories"] / max(p8["launches"], 1)) / (p8["ms"] / max(p8["launches"], 1) * 1e-3) / 1e9
-            second["roofline"] = {"bound": "hbm", "achieved": ach8, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach8 / HBM_PEAK_GBS,
-                                  "trajectories_per_launch": p8["trajectories"] / max(p8["launches"], 1),
-                                  "avg_launch_ms": p8["ms"] / max(p8["launches"], 1)}
-            # counter traffic (rocprofv3 PMC passes kept under profiles/): the evaluation launch, and everything one batch moves.  The
-            # candidates carry no tile records on this path (their sweeps form each step's tile from x_t), so the measured bytes are
-            # far BELOW the algorithmic figure of the unfused three-kernel formulation that `achieved` is priced with.
-            tr8, tn8 = traffic_for(f"sweep_eval_E8_B{B}")
-            second["roofline"]["traffic"], second["roofline"]["traffic_source"] = tr8, tn8
-            tb8, _ = traffic_for(f"batch_E8_B{B}")
-            second["hbm_traffic_per_batch"] = tb8
-            second["hbm_traffic_per_solve"] = tb8 / B if tb8 else None
+        # The two streams of a round overlap (candidates 1..7 on one, candidate 0 paired with the next gain sweep on the other), so a
+        # per-kernel duration -- and a per-kernel roofline fraction -- is ambiguous; the per-BATCH figure is the robust one: algorithmic bytes
+        # of the whole E = 8 batch / its wall time, beside the counter traffic of everything the batch launches (rocprofv3 PMC passes under
+        # profiles/).  The candidates carry no tile records on this path, so the bytes moved are far BELOW the algorithmic figure.
+        tb8, tn8 = traffic_for(f"batch_E8_B{B}")
+        sec8 = e8 / K8
+        second["roofline"] = {"bound": "fp64", "scope": "one batch (all kernels, two overlapping streams)",
+                              "achieved": bytes8 / sec8 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes8 / sec8 / 1e9 / HBM_PEAK_GBS,
+                              "algorithmic_equivalent_gbs": bytes8 / sec8 / 1e9,
+                              "traffic": tb8, "traffic_source": tn8,
+                              "hbm_real_gbs": tb8 / sec8 / 1e9 if tb8 else None,
+                              "hbm_real_frac": tb8 / sec8 / 1e9 / HBM_PEAK_GBS if tb8 else None,
+                              "issue_frac_sweep_eval": (sq_for(f"sweep_eval_E8_B{B}") or {}).get("issue_frac")}
+        second["hbm_traffic_per_batch"] = tb8
+        second["hbm_traffic_per_solve"] = tb8 / B if tb8 else None
         del ctx8
 
     if world == 1 and not args.no_second:
@@ -648,6 +686,87 @@ def rank_main(args):
             el = time.perf_counter() - tl
             large[str(Bl)] = {"value": Bl * Kl / el, "unit": "solves/s", "ms_per_step": el / Kl * 1e3, "steps": Kl}
             del ctxl
+
+    contract = ce_sec = host_sec = e8_shard = None
+    if world == 1 and fused and E == 1 and not args.no_second:
+        # SURVEY 8(d) to the letter: "tiles must be materialised per trajectory per step" and every sample runs its own initialize! --
+        # the same batch on the same kernel with its tile records put back (rollouts write 3.4 KB per step, sweeps load them) and the
+        # shared initial trajectory switched off.  Bit-identical costs; the number the headline's tile-free / shared-init form is an
+        # optimisation OF.
+        wc = Workload(D, prob, x0, u0, theta_global[lo:hi], G, E, debug=(("materialize", 1), ("init_share", 0)))
+        ec = D.timed(wc.step, K, max(W, 3))
+        trc, _ = traffic_for(f"solve_fused_mat_E{E}_B{wc.nloc}")
+        contract = {"what": "same batch, same kernel, switches materialize = 1 and init_share = 0: tile records in HBM (written by the rollouts, "
+                            "loaded by the sweeps), initialize! rolled out by every sample", "value": G * K / ec, "unit": "solves/s",
+                    "ms_per_step": ec / K * 1e3, "steps": K, "costs_identical_to_primary": bool(torch.equal(wc.cost[: wc.nloc], w.cost[: w.nloc])),
+                    "algorithmic_GBps": algo_bytes_of_solves(it_h, ls_h) * K / ec / 1e9,
+                    "frac_of_hbm_peak_on_algorithmic_bytes": algo_bytes_of_solves(it_h, ls_h) * K / ec / 1e9 / HBM_PEAK_GBS,
+                    "traffic": trc, "hbm_real_frac": (trc / (ec / K) / 1e9 / HBM_PEAK_GBS) if trc else None}
+        del wc
+
+    if world == 1 and not args.no_second:
+        # The user-facing calls, host buffers in and out (what the reference's signatures are):
+        #  * compute_cost (cross_entropy...jl:173-195): theta[1024] on the host -> cost[1024] on the host;
+        #  * one RAT iLQR solve! (:364-415): 5 CE iterations of 1024 samples (draws, elite selection, mu / sigma update) + the final
+        #    iLEQG solve at theta_opt returning x / l / L -- what a receding-horizon controller pays per control step.
+        from ratilqr.jl_amd import cross_entropy as cemod
+        ces = rat.CrossEntropyBilevelOptimizationSolver(num_samples=B, num_elite=max(3, B // 10), spec_eps=E, device=D.local_rank)
+        th_host = np.array(theta_global[:B])
+        for _ in range(5):
+            c_host = cemod.compute_cost(ces, prob, x0, u0, th_host, 0.1)
+        reps = 100
+        th0 = time.perf_counter()
+        for _ in range(reps):
+            c_host = cemod.compute_cost(ces, prob, x0, u0, th_host, 0.1)
+        eh = (time.perf_counter() - th0) / reps
+        host_sec = {"what": "compute_cost with host arrays in and out (one H2D of theta, one D2H of the costs, one host wait per call)",
+                    "ms_per_call": eh * 1e3, "value": B / eh, "unit": "solves/s", "calls": reps,
+                    "costs_identical_to_primary": bool(np.array_equal(c_host, w.cost[:B].cpu().numpy())),
+                    "device_resident_ms_per_step": strong["ms_per_step"]}
+        for rep in range(3):
+            cemod.solve_(ces, prob, x0, u0, 1234 + rep, kl_bound=0.1)
+        ts = []
+        for rep in range(50):
+            t0 = time.perf_counter()
+            out_ce = cemod.solve_(ces, prob, x0, u0, 99 + rep, kl_bound=0.1)
+            ts.append(time.perf_counter() - t0)
+        cctx = ces.context(prob)
+        cctx.profile(True)
+        cctx.profile_reset()
+        cemod.solve_(ces, prob, x0, u0, 7, kl_bound=0.1)
+        prc = {k: v for k, v in cctx.profile_get().items() if v["launches"]}
+        cctx.profile(False)
+        kms = sum(v["ms"] for v in prc.values())
+        n_solves_ce = int(ces.c.n_solves)
+        ts = np.array(ts)
+        ce_sec = {"what": "one CrossEntropyBilevelOptimizationSolver solve! (rat_ce_solve): 5 CE iterations x 1024 samples + the final solve at "
+                          "theta_opt; host x_0 / u_array in, (theta_opt, x, l, L, value) out; built-in generator",
+                  "ms_per_solve": {"median": float(np.median(ts)) * 1e3, "min": float(ts.min()) * 1e3, "p95": float(np.percentile(ts, 95)) * 1e3},
+                  "calls": int(ts.size), "kernel_ms_sum": kms, "kernel_launches": int(sum(v["launches"] for v in prc.values())),
+                  "host_share": 1.0 - kms / (float(np.median(ts)) * 1e3) if kms > 0 else None,
+                  "ileqg_solves_per_call": 5 * B + 1,
+                  "solves_per_s_equivalent": (5 * B + 1) / float(np.median(ts)), "theta_opt": float(out_ce[0])}
+        del ces, n_solves_ce
+
+    if world == 1 and E != 8 and not args.no_second:
+        # BASELINE config 3's shard on 8 GPUs: 128 samples x 8 speculative step sizes in one launch
+        c8s = rat.Context(prob, max_batch=128, spec_eps=8, device=D.local_rank)
+        c8s.set_initial(x0, u0)
+        th8 = torch.as_tensor(theta_global[:128], dtype=torch.float64, device=dev)
+        co8 = torch.empty(128, dtype=torch.float64, device=dev)
+        t_c = time.perf_counter()
+        while time.perf_counter() - t_c < 0.1:
+            c8s.compute_cost_dev(th8.data_ptr(), 128, 0.1, co8.data_ptr())
+        K8s = max(20, K)
+        torch.cuda.synchronize()
+        t8s = time.perf_counter()
+        for _ in range(K8s):
+            c8s.compute_cost_enqueue(th8.data_ptr(), 128, 0.1, co8.data_ptr())
+        torch.cuda.synchronize()
+        e8s = (time.perf_counter() - t8s) / K8s
+        e8_shard = {"what": "config 3's per-GPU shard at 8 GPUs: 128 samples x 8 speculative step sizes", "ms_per_batch": e8s * 1e3, "steps": K8s,
+                    "path": c8s.get_path(128), "costs_identical_to_primary": bool(torch.equal(co8, w.cost[:128]))}
+        del c8s
 
     shard_lat = pets_sec = nm_sec = None
     if world == 1 and not args.no_second:
@@ -795,11 +914,37 @@ def rank_main(args):
                 "parallelism": f"theta-shards x{world} (contiguous blocks), one cost all-gather per batch" if world > 1 else "single GPU",
                 "feasible_fraction": feasible, "mean_iters": float(it_g.mean()), "mean_ls_evals": float(ls_g.mean()),
                 "statistics_from": "the status / iteration / line-search counts gathered with the costs by the timed step's one collective",
+                # what the timed kernel does NOT do that SURVEY 8(d)'s byte model prices (both bit-identical to doing it; the
+                # `secondary_contract` leg measures the same batch with both switched back):
+                "tile_free": bool(fused and not w.ctx.debug_get("materialize")),
+                "init_shared": bool(fused and w.ctx.debug_get("init_share")),
+                "tile_free_means": "no tile records in HBM: rollouts store [x_t; u_t] and the [c_x | c_u | c] row, every sweep forms f_x | f_u and "
+                                   "the cost Hessian of step t in registers from x_t and the problem tables (per trajectory, per step)",
+                "init_shared_means": "initialize!'s open-loop rollout depends on (x_0, u_array) only, not on theta: rolled out once per "
+                                     "rat_set_initial, copied by the samples",
+                "path": w.ctx.get_path(max(w.nloc, 1)),
             },
             "strong": strong,
             "roofline": roofline_of(w, prof[main_kind], main_kind, it_h, ls_h),
             "kernel_ms_per_step": {k: v["ms"] / n_all for k, v in prof_all.items()},
         }
+        # one scalar per secondary at the top level (a parser that keeps only scalars still sees every leg)
+        flat = {
+            "contract_solves_per_s": contract["value"] if contract else None,
+            "e8_solves_per_s": second["value"] if second else None,
+            "e8_shard128_ms": e8_shard["ms_per_batch"] if e8_shard else None,
+            "nonlinear_solves_per_s": nonlin["value"] if nonlin else None,
+            "shard512_ms": shard_lat["512"]["ms_per_batch"] if shard_lat else None,
+            "shard256_ms": shard_lat["256"]["ms_per_batch"] if shard_lat else None,
+            "shard128_ms": shard_lat["128"]["ms_per_batch"] if shard_lat else None,
+            "ce_solve_ms": ce_sec["ms_per_solve"]["median"] if ce_sec else None,
+            "compute_cost_host_ms": host_sec["ms_per_call"] if host_sec else None,
+            "nm_ms_per_solve": nm_sec["ms_per_solve"] if nm_sec else None,
+            "pets_traj_per_s": pets_sec["value"] if pets_sec else None,
+            "pets_1m_traj_per_s": pets_sec["runs"]["1000x1000"]["trajectories_per_s"] if pets_sec else None,
+            "steady_solves_per_s": steady["value"] if steady else None,
+        }
+        out.update({k: v for k, v in flat.items() if v is not None})
         if weak is not None:
             out["weak"] = weak
         if strong8 is not None:
@@ -814,7 +959,9 @@ def rank_main(args):
             out["secondary_nonlinear"] = nonlin
         if large:
             out["secondary_large_batch"] = large
-        for key, val in (("shard_latency_ms", shard_lat), ("secondary_pets", pets_sec), ("secondary_nm", nm_sec)):
+        for key, val in (("secondary_contract", contract), ("secondary_compute_cost_host", host_sec), ("secondary_ce_solve", ce_sec),
+                         ("secondary_spec_eps8_shard128", e8_shard),
+                         ("shard_latency_ms", shard_lat), ("secondary_pets", pets_sec), ("secondary_nm", nm_sec)):
             if val is not None:
                 out[key] = val
         if cpu is not None:
@@ -833,7 +980,9 @@ def parse(argv):
     ap.add_argument("--spec-eps", type=int, default=1, help="E speculative line-search step sizes per sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-second", action="store_true", help="skip the secondary measurements")
-    ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
+                    help="execution switch of the primary workload's handle (rat_debug_set), e.g. --debug materialize=1 --debug init_share=0")
     ap.add_argument("--steady-seconds", type=float, default=4.0, help="length of the steady_state leg (back-to-back batches)")
     ap.add_argument("--condition-seconds", type=float, default=0.3, help="untimed batches before the warm-up steps (clock ramp)")
     return ap.parse_args(argv)

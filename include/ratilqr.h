@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RAT_VERSION 301
+#define RAT_VERSION 401
 
 /* ---- return codes (API level) ---------------------------------------------------------------- */
 typedef int32_t rat_rc;
@@ -376,11 +376,11 @@ rat_rc  rat_multi_pets_compute_cost(rat_multi m, const double *x0, const double 
 /* ---- execution path of the batched solves of a handle ------------------------------------------
  * Results are identical on every path (tested bit for bit); AUTO picks by batch size, speculation width E and the device's CU count:
  *   E = 1: BLOCK up to 2 n_cu samples (a sample's evaluation and gain recursions side by side on two SIMDs), FUSED beyond (in-wave
- *          pairing; from 4 n_cu + 1 samples on, its two-samples-per-SIMD variant);
+ *          pairing; batches beyond one sample per SIMD run that kernel in generations of workgroups);
  *   E = 2 / 4 / 8: BLOCK while the batch fits one generation of workgroups (n_cu * floor(8 / (E + 1)) samples; E = 8: n_cu), ROUNDS beyond;
  *   any other E, and the operator entry points: ROUNDS.
- * rat_set_path fixes the path of the handle (RAT_ERR_UNSUPPORTED when the handle's E has no such kernel); the RATILQR_* environment
- * variables read at rat_create remain as test overrides of the defaults. */
+ * rat_set_path fixes the path of the handle (RAT_ERR_UNSUPPORTED when the handle's E has no such kernel) and overrides the `block` /
+ * `fused` switches below; RAT_PATH_AUTO returns to what those switches say (a handle created on the round-based path stays there). */
 #define RAT_PATH_AUTO   0
 #define RAT_PATH_ROUNDS 1   /* one launch per phase, rounds polled by the host */
 #define RAT_PATH_FUSED  2   /* one persistent wavefront per sample: whole solve! in one launch (E = 1) */
@@ -388,6 +388,30 @@ rat_rc  rat_multi_pets_compute_cost(rat_multi m, const double *x0, const double 
 rat_rc  rat_set_path(rat_handle h, int32_t path);
 /* the path (RAT_PATH_ROUNDS / _FUSED / _BLOCK; 4 = general-size kernel) a batch of B samples takes on this handle, or -1 */
 int32_t rat_get_path(rat_handle h, int64_t B);
+
+/* ---- execution switches: ONE entry point for tests, A/B tools and bench.py's contract leg ------------------------------------------
+ * Results never depend on a switch, except `wdiag` (another rounding order: ~1e-13 relative).  At rat_create every switch also takes
+ * the value of the environment variable RATILQR_<KEY IN CAPITALS> when that is set (the library reads no other environment variable
+ * besides RATILQR_MULTI_LOGICAL / RATILQR_MULTI_FORCE_RCCL of rat_create_multi).  A switch that changes the HBM layout of the handle's
+ * state (`fused`, `dual`, `speculate` on an E = 1 handle) re-lays it: give rat_set_initial again, as after rat_set_path.
+ *   key             values   meaning (default)
+ *   fused           0 / 1    E = 1: single-launch solves (1) or one launch per phase, "round-based path" (0)            (1)
+ *   block           -1/0/1   workgroup-per-sample kernel: by batch size (-1), never (0), whenever it exists (1)          (-1)
+ *   block_max_b     B        E = 1: largest batch the workgroup-per-sample kernel takes under block = -1                 (2 n_cu)
+ *   block_shape     0 / 1    two-wave workgroups padded to one wave per SIMD with ticketed SIMD pairs                   (1)
+ *   block_helpers   0 / 1    spare waves of a padded workgroup linearise (one workgroup per CU)                          (1)
+ *   fused_dual      0 / 1    policy evaluation + following gain sweep as two recursions of one wavefront                 (1)
+ *   fused_occ2      B0       batches of >= B0 samples: the 256-register one-recursion kernel, two samples per SIMD       (0 = never)
+ *   init_share      0 / 1    initialize!'s rollout (independent of theta) rolled out once per (x_0, u_array) and copied   (1)
+ *   materialize     0 / 1    one-wavefront-per-sample kernel, LQ family, time-invariant cost: tile records written by the
+ *                            rollouts and loaded by the sweeps (SURVEY 8d's wording) instead of formed in registers      (0)
+ *   fly             0 / 1    round-based path, E > 1: line-search candidates without tile records                         (1)
+ *   fly_multi       0 / 1    ... and all candidates of a sample rolled out by one wavefront                               (1)
+ *   dual            0 / 1    round-based path: candidate 0 paired with the next gain sweep in one wavefront              (E > 1)
+ *   speculate       0 / 1    round-based path: speculative gain sweeps on a second stream                                (0)
+ *   wdiag           0 / 1    diagonal time-invariant W: inv(W) folded into M^-1's operand (takes effect at the next rat_problem_set) (1) */
+rat_rc  rat_debug_set(rat_handle h, const char *key, int64_t value);
+rat_rc  rat_debug_get(rat_handle h, const char *key, int64_t *value);      /* the EFFECTIVE value on this handle */
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 #define RAT_K_ROLLOUT   0

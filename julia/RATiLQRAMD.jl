@@ -150,6 +150,14 @@ is_logical(h::MultiHandle) = ccall((:rat_multi_is_logical, LIB), Int32, (Ptr{Cvo
 const PATH_AUTO, PATH_ROUNDS, PATH_FUSED, PATH_BLOCK = Int32(0), Int32(1), Int32(2), Int32(3)
 set_path!(h::Handle, path::Integer) = check(ccall((:rat_set_path, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, path))
 get_path(h::Handle, B::Integer) = ccall((:rat_get_path, LIB), Int32, (Ptr{Cvoid}, Int64), h.ptr, B)
+# execution switches of a handle (include/ratilqr.h lists the keys: "init_share", "materialize", "wdiag", ...): what used to be
+# process-global RATILQR_* environment variables is visible to -- and settable by -- the Julia caller
+debug_set!(h::Handle, key::AbstractString, value::Integer) = check(ccall((:rat_debug_set, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), h.ptr, key, value))
+function debug_get(h::Handle, key::AbstractString)
+    v = Ref(Int64(0))
+    check(ccall((:rat_debug_get, LIB), Int32, (Ptr{Cvoid}, Cstring, Ref{Int64}), h.ptr, key, v))
+    return v[]
+end
 function shard_bounds(B::Integer, world::Integer, rank::Integer)
     lo = Ref(Int64(0)); hi = Ref(Int64(0))
     check(ccall((:rat_shard_bounds, LIB), Int32, (Int64, Int32, Int32, Ref{Int64}, Ref{Int64}), B, world, rank, lo, hi))

@@ -86,6 +86,7 @@ EXPORTS = [
     "rat_multi_allgathers", "rat_multi_problem_set", "rat_multi_set_initial", "rat_multi_ce_compute_cost", "rat_multi_ce_step",
     "rat_multi_ce_solve", "rat_multi_pets_problem_set", "rat_multi_pets_compute_cost",
     "rat_multi_ce_compute_cost_ex", "rat_multi_ileqg_solve_batch", "rat_multi_is_logical", "rat_set_path", "rat_get_path", "rat_ce_compute_cost_enqueue_ex",
+    "rat_debug_set", "rat_debug_get",
 ]
 
 _lib = None
@@ -114,6 +115,8 @@ def lib():
         _lib.rat_set_path.argtypes = [C.c_void_p, C.c_int32]
         _lib.rat_get_path.argtypes = [C.c_void_p, C.c_int64]
         _lib.rat_get_path.restype = C.c_int32
+        _lib.rat_debug_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        _lib.rat_debug_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     return _lib
 
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -42,7 +43,11 @@ struct rat_handle_s {
     bool dual_forced = false;        // RATILQR_DUAL was given: no automatic choice between paired and separate speculative gain sweeps
     bool dual = false;               // paired evaluation + next-gain-sweep wavefronts on the round-based path (default for E > 1; RATILQR_DUAL)
     bool speculate = false;          // opt-in (RATILQR_SPECULATE=1): measured slower than the plain order on MI355X
-    bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (RATILQR_FUSED=0: round-based path)
+    bool fused = true;               // E = 1: whole solve! per sample in one persistent-wavefront launch (switch fused = 0: round-based path)
+    bool fused_req = true, rounds_only = false;   // what the switches asked for (finish_switches derives `fused` / `block_mode` from them)
+    int block_req = -1;
+    bool wdiag = true;               // switch wdiag = 0: diagonal time-invariant W still runs the general-W arithmetic (applied by rat_problem_set)
+    bool materialize = false;        // switch materialize = 1: the one-wavefront-per-sample kernel writes and reads tile records (SURVEY 8d's wording)
     std::vector<double> x0_host, u0_host;   // padded copies of what d_x0 / d_u0 hold (rat_set_initial skips identical uploads)
     int fused_occ2 = 0;              // RATILQR_FUSED_OCC2=B0: batches of at least B0 samples run the 256-register one-recursion-per-pass variant, two samples per SIMD (0: never, the default)
     bool fused_dual = true;          // ... with policy evaluation + following gain sweep paired in one pass (RATILQR_FUSED_DUAL=0: separate)
@@ -131,6 +136,45 @@ static void set_opd(rat_handle h) {
     h->opd.iter_max = (int)std::min<int64_t>(h->opts.iter_max, 1 << 30); h->opd.adaptive = h->opts.adaptive_eps_init;
 }
 
+// ---- execution switches ---------------------------------------------------------------------------------------------------------
+// Every A/B and test switch of a handle lives in this ONE table.  rat_debug_set / rat_debug_get (include/ratilqr.h) reach it by key; at
+// rat_create the environment variable RATILQR_<KEY IN CAPITALS> of each entry is applied through the same setter (debug_from_env: the
+// only getenv of this file).  None of them changes a result except where the header says so (wdiag: another rounding order).
+struct DebugSwitch { const char *key; void (*set)(rat_handle, int64_t); int64_t (*get)(rat_handle); };
+static const DebugSwitch debug_switches[] = {
+    {"speculate", [](rat_handle h, int64_t v) { h->speculate = (v == 1); }, [](rat_handle h) -> int64_t { return h->speculate; }},
+    {"dual", [](rat_handle h, int64_t v) { h->dual = (v == 1); h->dual_forced = true; }, [](rat_handle h) -> int64_t { return h->dual; }},
+    {"fused", [](rat_handle h, int64_t v) { h->fused_req = (v != 0); h->rounds_only = (v == 0); }, [](rat_handle h) -> int64_t { return h->fused; }},
+    {"fused_dual", [](rat_handle h, int64_t v) { h->fused_dual = (v != 0); }, [](rat_handle h) -> int64_t { return h->fused_dual; }},
+    {"block", [](rat_handle h, int64_t v) { h->block_req = (v == 1) ? 1 : (v == 0 ? 0 : -1); }, [](rat_handle h) -> int64_t { return h->block_mode; }},
+    {"block_max_b", [](rat_handle h, int64_t v) { h->block_max_b = (int)v; }, [](rat_handle h) -> int64_t { return h->block_max_b; }},
+    {"block_shape", [](rat_handle h, int64_t v) { h->block_shape = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_shape; }},
+    {"block_helpers", [](rat_handle h, int64_t v) { h->block_helpers = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_helpers; }},
+    {"init_share", [](rat_handle h, int64_t v) { h->init_share = (v != 0); }, [](rat_handle h) -> int64_t { return h->init_share; }},
+    {"fly", [](rat_handle h, int64_t v) { h->fly = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly; }},
+    {"fly_multi", [](rat_handle h, int64_t v) { h->fly_multi = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly_multi; }},
+    {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
+    {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
+    {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
+};
+// what the requests amount to on this handle (speculation width, forced pairings)
+static void finish_switches(rat_handle h) {
+    h->fused = h->fused_req && !(h->speculate || h->dual || h->E != 1);
+    h->block_mode = h->rounds_only ? 0 : h->block_req;       // fused = 0 is "the round-based path": no single-launch solve at all
+}
+static void debug_from_env(rat_handle h) {
+    for (const DebugSwitch &sw : debug_switches) {
+        std::string name = "RATILQR_";
+        for (const char *c = sw.key; *c; ++c) name += (char)toupper((unsigned char)*c);
+        if (const char *e = getenv(name.c_str())) {
+            // (historic spellings: "B0" style numbers are plain integers; "0" / "1" flags)
+            char *end = nullptr;
+            const long long v = strtoll(e, &end, 10);
+            if (end != e) sw.set(h, (int64_t)v);
+        }
+    }
+}
+
 extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int32_t spec_eps, int32_t device, rat_handle *out) {
     if (!out || max_batch < 1 || spec_eps < 1 || spec_eps > 64) return fail(RAT_ERR_ARG, "rat_create: bad batch / spec_eps");
     rat_ileqg_opts o;
@@ -154,30 +198,20 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     // (ev_a / ev_b order the handle's two streams on ONE device: no system-scope fence)
     CREATECHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming | hipEventDisableSystemFence));
     CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming | hipEventDisableSystemFence));
-    if (const char *e = getenv("RATILQR_SPECULATE")) h->speculate = (e[0] == '1');
     h->dual = spec_eps > 1;          // E > 1: candidate 0 in paired wavefronts beside the other candidates' evaluation (+3.5 % at E = 8)
-    if (const char *e = getenv("RATILQR_DUAL")) { h->dual = (e[0] == '1'); h->dual_forced = true; }
-    if (const char *e = getenv("RATILQR_FUSED")) h->fused = (e[0] != '0');
-    if (h->speculate || h->dual || spec_eps != 1) h->fused = false;
-    if (const char *e = getenv("RATILQR_FUSED_DUAL")) h->fused_dual = (e[0] != '0');
-    if (const char *e = getenv("RATILQR_BLOCK")) h->block_mode = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : -1);
-    if (const char *e = getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = atoi(e);
-    if (const char *e = getenv("RATILQR_BLOCK_SHAPE")) h->block_shape = (e[0] != '0');
-    if (const char *e = getenv("RATILQR_INIT_SHARE")) h->init_share = (e[0] != '0');
-    if (const char *e = getenv("RATILQR_BLOCK_HELPERS")) h->block_helpers = (e[0] != '0');
-    if (const char *e = getenv("RATILQR_FLY")) h->fly = (e[0] != '0');
-    if (const char *e = getenv("RATILQR_FLY_MULTI")) h->fly_multi = (e[0] != '0');
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     // E = 1 batches beyond one sample per SIMD run the paired kernel in generations.  (Rounds 2-3: two samples per SIMD in 256 registers each,
     // one recursion per pass, beat two generations of the paired kernel by 6..10 % -- until that kernel stopped writing tile records: the
     // 256-register variant cannot stage its rollouts in LDS, so it keeps its tiles, and now loses 1..3 % at 2048..8192 samples.
-    // RATILQR_FUSED_OCC2=B0 still selects it for batches of at least B0 samples.)
+    // The debug switch fused_occ2 = B0 still selects it for batches of at least B0 samples.)
     h->fused_occ2 = 0;
-    if (!getenv("RATILQR_BLOCK_MAX_B")) h->block_max_b = 2 * h->n_cu;      // E = 1: a workgroup per sample while every sample can have two SIMDs
-    if (const char *e = getenv("RATILQR_FUSED_OCC2")) h->fused_occ2 = atoi(e);
+    h->block_max_b = 2 * h->n_cu;    // E = 1: a workgroup per sample while every sample can have two SIMDs
+    // execution switches (tests, A/B tools, bench.py's contract secondary): ONE table (debug_switches), reachable through rat_debug_set and,
+    // at creation, through the environment variable RATILQR_<KEY> of each entry -- the only place this library reads the environment
+    debug_from_env(h);
+    finish_switches(h);
     CREATECHK(hipMalloc((void **)&h->d_census, sizeof(int) * CENSUS_SLOTS));
     CREATECHK(hipMemset(h->d_census, 0, sizeof(int) * CENSUS_SLOTS));
-    if (const char *e = getenv("RATILQR_FUSED")) { if (e[0] == '0') h->block_mode = 0; }     // "round-based path": no single-launch solve at all
     CREATECHK(hipHostMalloc((void **)&h->h_counters, 2 * CTR_RING * sizeof(int), hipHostMallocDefault));
     CREATECHK(hipHostMalloc((void **)&h->h_io, std::max<size_t>((size_t)max_batch * 28, 64), hipHostMallocDefault));
     for (int i = 0; i < CTR_RING; ++i) CREATECHK(hipEventCreateWithFlags(&h->round_ev[i], hipEventDisableTiming));
@@ -481,7 +515,7 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
             for (int jj = 0; jj < n; ++jj) if (i != jj && d->W[i + n * jj] != 0.0) pb.W_diag = 0;
         for (int i = 0; i < n; ++i) Wdg[i] = Winv[i * 16 + i];
     }
-    if (const char *e = getenv("RATILQR_WDIAG")) { if (e[0] == '0') pb.W_diag = 0; }      // test override: the general-W arithmetic
+    if (!h->wdiag) pb.W_diag = 0;       // debug switch wdiag = 0: the general-W arithmetic (A/B measurements, bit-identity tests)
     rat_rc rc;
 #define UP(field, vec) if ((rc = dev_upload(h, h->pb_allocs, &pb.field, vec))) return rc
     UP(Wdg, Wdg);
@@ -672,7 +706,7 @@ static Path pick_path(const rat_handle h, int B) {
     if (h->path_fixed == RAT_PATH_FUSED) return PATH_FUSED;
     if (h->path_fixed == RAT_PATH_BLOCK) return PATH_BLOCK;
     const bool block_ok = solve_block_supported(h->E) && h->block_mode != 0 && (h->E > 1 || h->fused) && !h->speculate &&
-                          (h->E == 1 || getenv("RATILQR_DUAL") == nullptr);
+                          (h->E == 1 || !h->dual_forced);
     if (h->E == 1) {
         if (!h->fused) return PATH_ROUNDS;
         if (block_ok && (h->block_mode == 1 || B <= h->block_max_b)) return PATH_BLOCK;
@@ -700,6 +734,14 @@ extern "C" int32_t rat_get_path(rat_handle h, int64_t B) {
 // handle between them re-lays its state, so the initial trajectory has to be given again (rat_set_initial; the batch entry points that
 // take x0 / u0 do it themselves).
 static rat_rc alloc_state(rat_handle h);
+static rat_rc relayout_if_needed(rat_handle h, bool was_alias) {
+    if (h->have_problem && !h->wide && was_alias != h->fused) {      // re-laid only when the aliasing mode really changes
+        rat_rc rc = alloc_state(h);
+        if (rc) return rc;
+        h->have_initial = false; h->init_traj_valid = false; h->x0_host.clear(); h->u0_host.clear();
+    }
+    return RAT_OK;
+}
 extern "C" rat_rc rat_set_path(rat_handle h, int32_t path) {
     if (!h) return fail(RAT_ERR_ARG, "null");
     if (path < RAT_PATH_AUTO || path > RAT_PATH_BLOCK) return fail(RAT_ERR_ARG, "rat_set_path: unknown path");
@@ -709,14 +751,34 @@ extern "C" rat_rc rat_set_path(rat_handle h, int32_t path) {
     if ((path == RAT_PATH_FUSED || path == RAT_PATH_BLOCK) && (h->speculate || (h->E == 1 && h->dual)))
         return fail(RAT_ERR_UNSUPPORTED, "rat_set_path: RATILQR_SPECULATE / RATILQR_DUAL handles run the round-based path only");
     const bool was_alias = h->st.tile_alias != 0;
-    if (h->E == 1 && !h->speculate && !h->dual) h->fused = (path != RAT_PATH_ROUNDS);
+    // AUTO goes back to what the handle was created with (or switched to by rat_debug_set): a handle on the round-based path by its
+    // `fused = 0` switch stays there
+    if (path == RAT_PATH_AUTO) finish_switches(h);
+    else if (h->E == 1 && !h->speculate && !h->dual) h->fused = (path != RAT_PATH_ROUNDS);
     h->path_fixed = path;
-    if (h->have_problem && !h->wide && was_alias != h->fused) {
-        rat_rc rc = alloc_state(h);
-        if (rc) return rc;
-        h->have_initial = false; h->init_traj_valid = false; h->x0_host.clear(); h->u0_host.clear();
-    }
-    return RAT_OK;
+    return relayout_if_needed(h, was_alias);
+}
+
+// The one entry point behind every execution switch (tests, A/B tools, bench.py's contract secondary; include/ratilqr.h lists the keys).
+extern "C" rat_rc rat_debug_set(rat_handle h, const char *key, int64_t value) {
+    if (!h || !key) return fail(RAT_ERR_ARG, "null");
+    for (const DebugSwitch &sw : debug_switches)
+        if (!strcmp(sw.key, key)) {
+            const bool was_alias = h->st.tile_alias != 0;
+            sw.set(h, value);
+            finish_switches(h);
+            if (h->path_fixed != RAT_PATH_AUTO) {            // a fixed path keeps what rat_set_path derived
+                if (h->E == 1 && !h->speculate && !h->dual) h->fused = (h->path_fixed != RAT_PATH_ROUNDS);
+            }
+            return relayout_if_needed(h, was_alias);
+        }
+    return fail(RAT_ERR_ARG, std::string("rat_debug_set: unknown switch ") + key);
+}
+extern "C" rat_rc rat_debug_get(rat_handle h, const char *key, int64_t *value) {
+    if (!h || !key || !value) return fail(RAT_ERR_ARG, "null");
+    for (const DebugSwitch &sw : debug_switches)
+        if (!strcmp(sw.key, key)) { *value = sw.get(h); return RAT_OK; }
+    return fail(RAT_ERR_ARG, std::string("rat_debug_get: unknown switch ") + key);
 }
 
 // outputs of a batch (device pointers, any may be null); cost = value + kl_bound / theta  (cross_entropy...jl:193)
@@ -765,6 +827,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.max_rounds = (int)std::min<int64_t>(((int64_t)h->opd.iter_max + 1) * 4002, 2000000000);
         fa.dual = h->fused_dual ? 1 : 0;
         fa.occ2 = (path == PATH_FUSED && h->fused_dual && h->fused_occ2 > 0 && B >= h->fused_occ2) ? 1 : 0;
+        fa.mat = h->materialize ? 1 : 0;
         fa.theta_in = theta_dev;
         fa.out_value = out.value; fa.out_status = out.status; fa.out_iters = out.iters; fa.out_ls = out.ls;
         fa.out_cost = out.cost; fa.kl_bound = out.kl_bound;

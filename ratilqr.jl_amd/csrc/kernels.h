@@ -38,7 +38,9 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     RolloutArgs ro;
     int max_rounds;        // guard on phases per sample
     int dual;              // pair each policy evaluation with the gain sweep that would follow it (sweep_dual_body)
-    int occ2;              // one recursion per pass in <= 256 registers: two samples per SIMD (RATILQR_FUSED_OCC2; experiment)
+    int occ2;              // one recursion per pass in <= 256 registers: two samples per SIMD (switch fused_occ2; experiment)
+    int mat;               // solve_fused_kernel, LQ family with time-invariant cost: tile records are written by the rollouts and read back by
+                           // the sweeps (SURVEY 8d's "tiles materialised per trajectory per step"; switch materialize, bench.py's contract leg)
     // the batch's input and outputs, handled by the sample's own wave (no init / gather launches around the solve):
     const double *theta_in;            // [B]; per-sample state is initialised from it (what init_state_kernel does)
     double *out_value;                 // [B] value (Inf for failures) or null

@@ -1913,7 +1913,9 @@ __device__ __forceinline__ void gather_body(const StateDev &st, const int b, dou
 
 // OCC2: the compiler is held to 256 registers so that TWO samples share a SIMD (only offered without DUALF / STG: one recursion per pass,
 // 2 KB of LDS per wave) -- the direct test of "hide a wave's dependency stalls with a second sample" for batches beyond one per SIMD.
-template <int MODEL, bool CTV, int WM, bool DUALF, bool STG, bool OCC2 = false>
+// MAT: the tile-free geometry with its tile records put back (rollouts write them, sweeps load them): the materialised formulation SURVEY 8d
+// words its byte model on, kept as a measured variant (bit-identical: fx_diag gives a record the bits the fly sweeps form in registers).
+template <int MODEL, bool CTV, int WM, bool DUALF, bool STG, bool OCC2 = false, bool MAT = false>
 __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs fa) {
     const int b = blockIdx.x;
     const StateDev &st = fa.sw.st;
@@ -1928,7 +1930,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
     // and the cost Hessian of step t from x_t and the problem tables (FLY sweeps, as on the speculative path), so the rollouts store per
     // step only [x_t; u_t] and the [c_x | c_u | c] row -- 0.3 KB instead of 3.4 KB; the registers of a sweep hold the bits a record
     // would have delivered (fx_diag), so results are identical to the tile-materialising paths.
-    constexpr int FLYF = (MODEL == 1 && DUALF && STG && !OCC2) ? (CTV ? 2 : 1) : 0;
+    constexpr int FLYF = (MODEL == 1 && DUALF && STG && !OCC2 && !MAT) ? (CTV ? 2 : 1) : 0;
     constexpr bool NT = FLYF != 0;
     // the sample's own wave initialises its state and, at the end, writes its outputs: a batch is ONE launch
     if (threadIdx.x == 0) init_state_body(st, fa.sw.op, fa.theta_in, b);
@@ -2012,6 +2014,7 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
     const bool stg = fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST;
 #define FUSED_LAUNCH(M, C, W) do { \
         if (fa.occ2) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false, true>), grid, block, 0, s, fa); \
+        else if (fa.mat && fa.dual && stg && M == 1 && !C) hipLaunchKernelGGL((solve_fused_kernel<1, false, W, true, true, false, true>), grid, block, 0, s, fa); \
         else if (fa.dual && stg && M == 1) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, M == 1>), grid, block, 0, s, fa); \
         else if (fa.dual) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, false>), grid, block, 0, s, fa); \
         else hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false>), grid, block, 0, s, fa); } while (0)

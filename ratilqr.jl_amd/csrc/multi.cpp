@@ -51,6 +51,10 @@ rat_rc rat_batch_outputs_dev(rat_handle h, const double *theta_dev, int64_t B, d
 static rat_rc mfail(rat_rc rc, const std::string &m) { rat_set_error(m.c_str()); return rc; }
 #define MHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mfail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 #define MRC(expr) do { rat_rc r_ = (expr); if (r_ != RAT_OK) return r_; } while (0)
+// after work has been enqueued on the devices of a rat_multi `m`: a failing call waits for EVERY device before it hands control back
+// (other devices' streams may still be reading d_theta / the pinned stage and writing d_all, which the caller is free to reuse or destroy)
+#define MHIP_SYNC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { sync_all(m); \
+        return mfail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
 
 static rat_rc load_rccl() {
     if (g_rccl.so) return RAT_OK;
@@ -261,25 +265,25 @@ static rat_rc multi_batch(rat_multi m, const double *x0, const double *u0, const
         // logical devices (or no communicator): the same data movement by device copies.  Block r is complete when r's stream reaches
         // its event; every destination stream waits for every source before it copies block r into slot r of its gathered buffer.
         for (int r = 0; r < G; ++r) {
-            MHIP(hipSetDevice(m->dev[r]));
-            MHIP(hipEventRecord(m->ev[r], (hipStream_t)rat_stream(m->h[r])));
+            MHIP_SYNC(hipSetDevice(m->dev[r]));
+            MHIP_SYNC(hipEventRecord(m->ev[r], (hipStream_t)rat_stream(m->h[r])));
         }
         for (int g = 0; g < G; ++g) {
-            MHIP(hipSetDevice(m->dev[g]));
+            MHIP_SYNC(hipSetDevice(m->dev[g]));
             hipStream_t s = (hipStream_t)rat_stream(m->h[g]);
             for (int r = 0; r < G; ++r) {
-                if (r != g) MHIP(hipStreamWaitEvent(s, m->ev[r], 0));
-                MHIP(hipMemcpyAsync(m->d_all[g] + (size_t)r * bb, m->d_send[r], bb, hipMemcpyDeviceToDevice, s));
+                if (r != g) MHIP_SYNC(hipStreamWaitEvent(s, m->ev[r], 0));
+                MHIP_SYNC(hipMemcpyAsync(m->d_all[g] + (size_t)r * bb, m->d_send[r], bb, hipMemcpyDeviceToDevice, s));
             }
         }
         m->n_allgathers++;
     }
-    MHIP(hipSetDevice(m->dev[0]));
-    if (G > 1 || !m->comm.empty()) MHIP(hipMemcpyAsync(p_all, m->d_all[0], bb * G, hipMemcpyDeviceToHost, (hipStream_t)rat_stream(m->h[0])));
-    else MHIP(hipMemcpyAsync(p_all, m->d_send[0], bb, hipMemcpyDeviceToHost, (hipStream_t)rat_stream(m->h[0])));   // one device, no communicator
+    MHIP_SYNC(hipSetDevice(m->dev[0]));
+    if (G > 1 || !m->comm.empty()) MHIP_SYNC(hipMemcpyAsync(p_all, m->d_all[0], bb * G, hipMemcpyDeviceToHost, (hipStream_t)rat_stream(m->h[0])));
+    else MHIP_SYNC(hipMemcpyAsync(p_all, m->d_send[0], bb, hipMemcpyDeviceToHost, (hipStream_t)rat_stream(m->h[0])));   // one device, no communicator
     for (int g = 0; g < G; ++g) {                                // (every device must have finished its part of the collective)
-        MHIP(hipSetDevice(m->dev[g]));
-        MHIP(hipStreamSynchronize((hipStream_t)rat_stream(m->h[g])));
+        MHIP_SYNC(hipSetDevice(m->dev[g]));
+        MHIP_SYNC(hipStreamSynchronize((hipStream_t)rat_stream(m->h[g])));
     }
     for (int g = 0; g < G; ++g) {
         const size_t nb = (size_t)(hi[(size_t)g] - lo[(size_t)g]);

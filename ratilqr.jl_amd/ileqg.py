@@ -194,6 +194,15 @@ class Context:
         the single-launch E = 1 kernels and the round-based path re-lays the state: the initial trajectory must be given again."""
         nv.check(nv.lib().rat_set_path(self.h, C.c_int32(self.PATHS[path] if isinstance(path, str) else int(path))))
 
+    def debug_set(self, key, value):
+        """An execution switch of the handle (rat_debug_set; keys in include/ratilqr.h): tests, A/B tools, bench.py's contract leg."""
+        nv.check(nv.lib().rat_debug_set(self.h, key.encode(), C.c_int64(int(value))))
+
+    def debug_get(self, key):
+        v = C.c_int64(0)
+        nv.check(nv.lib().rat_debug_get(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def get_path(self, B):
         """Which path a batch of B samples takes: "rounds" | "fused" | "block" | "wide"."""
         r = int(nv.lib().rat_get_path(self.h, C.c_int64(int(B))))
