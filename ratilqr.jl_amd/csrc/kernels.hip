@@ -37,6 +37,20 @@
 #include "device_utils.h"
 #include "sweep_dual.h"
 
+// Translation-unit parts: every part sees every device body (templates, inlined where instantiated); the __global__ kernels and their
+// launchers are compiled by exactly one part.  No RAT_PART: the whole file in one unit.
+#define PART_SWEEP 1      /* sweep_kernel and its launchers */
+#define PART_ROLL 2       /* rollout / rollin / linearise kernels, per-sample control-flow kernels, small launchers */
+#define PART_FUSED 4      /* solve_fused_kernel */
+#define PART_BLOCK2 8     /* solve_block_kernel, E = 1 (two waves, padded geometry) */
+#define PART_BLOCK3 16    /* E = 2 */
+#define PART_BLOCK5 32    /* E = 4 */
+#define PART_BLOCK8 64    /* E = 8 */
+#define PART_MISC 128     /* PETS and noisy Monte-Carlo rollouts */
+#ifndef RAT_PART
+#define RAT_PART 255
+#endif
+
 #ifndef OCC2_PREFETCH
 #define OCC2_PREFETCH 3            /* the same for the two-samples-per-SIMD solve: the other wave covers the latency, registers are scarce */
 #endif
@@ -477,6 +491,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
 #undef SVB
 }
 
+#if RAT_PART & PART_SWEEP
 // SWZ: the elimination's row exchange through the LDS crossbar (fewer vector instructions, longer latency; identical values): for launches
 // that put several waves on a SIMD, where the datapath is saturated (profiles/r03_rocprof_summary.md: two evaluation waves per SIMD issue
 // 50 % each) and only the instruction count matters
@@ -520,6 +535,7 @@ void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream
     }
 }
 
+#endif  // PART_SWEEP
 // =====================================================================================================
 // rollout_kernel: four trajectories per wavefront (one per 16-lane row).  Lane j < 12 owns state
 // component j, lanes j < 4 additionally own control component j.
@@ -530,6 +546,7 @@ __device__ __forceinline__ double powchk(double bse, double e, int &dom) {
     return r;
 }
 
+#if RAT_PART & PART_ROLL
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const int row = threadIdx.x >> 4, j = threadIdx.x & 15;
     const StateDev &st = a.st;
@@ -670,6 +687,7 @@ void launch_rollout(const RolloutArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(rollout_kernel, dim3((ncand + 3) / 4), dim3(64), 0, s, a);
 }
 
+#endif  // PART_ROLL
 // =====================================================================================================
 // rollin: fused simulate_dynamics + approximate_model for the solver's hot loop (ileqg.jl:62-87 then :258-322).
 // ONE wavefront per trajectory.  The recursion x_{t+1} = [A|B][x_t; u_t], u_t = l_t + eps dl_t + L_t (x_t - xbar_t) is a
@@ -1337,6 +1355,7 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
     }
 }
 
+#if RAT_PART & PART_ROLL
 template <int MODEL, int MODE, bool CTV, bool SEP>
 __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
     __shared__ double shxu[16];
@@ -1691,16 +1710,19 @@ void launch_linearize(const LinArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(linearize_kernel, dim3(ntraj * nchunk), dim3(256), 0, s, a);
 }
 
+#endif  // PART_ROLL
 // =====================================================================================================
 // per-sample control flow (one thread per sample)
 // =====================================================================================================
 __device__ __forceinline__ void init_state_body(const StateDev &st, const OptsDev &op, const double *theta_in, const int b);
+#if RAT_PART & PART_ROLL
 __global__ void init_state_kernel(StateDev st, OptsDev op, const double *theta_in) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < 2 * CTR_RING) st.counters[b] = 0;
     if (b >= st.B) return;
     init_state_body(st, op, theta_in, b);
 }
+#endif  // PART_ROLL
 __device__ __forceinline__ void init_state_body(const StateDev &st, const OptsDev &op, const double *theta_in, const int b) {
     st.theta[b] = theta_in[b];
     st.mu[b] = 0.0;                       // initialize! sets mu = 0.0, Delta = Delta_0   (ileqg.jl:216)
@@ -1746,6 +1768,7 @@ __device__ __forceinline__ void commit_init_body(const StateDev &st, const int b
     if (st.status[b] != ST_RUNNING) { st.spec_st[b] = 0; return; }
     if (st.spec_st[b] != 0) commit_spec(st, b);
 }
+#if RAT_PART & PART_ROLL
 __global__ void commit_init_kernel(StateDev st) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= st.B) return;
@@ -1754,6 +1777,7 @@ __global__ void commit_init_kernel(StateDev st) {
 void launch_commit_init(const StateDev &st, hipStream_t s) {
     hipLaunchKernelGGL(commit_init_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st);
 }
+#endif  // PART_ROLL
 
 // Replays the sequential rule of line_search! (ileqg.jl:504-581) over the E speculatively evaluated
 // candidates of each sample, then the convergence test of solve! (:642-653).
@@ -1829,6 +1853,7 @@ __device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev
     }
 }
 
+#if RAT_PART & PART_ROLL
 __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) {                          // clear the ring entry two rounds ahead (stream order makes this race-free)
@@ -1840,6 +1865,7 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
     ls_select_body(st, op, b, st.counters + 2 * slot);
 }
 
+#endif  // PART_ROLL
 // =====================================================================================================
 // solve_fused_kernel: the COMPLETE solve! of one theta-sample in one persistent wavefront (E = 1).
 //   initialize! (open-loop rollout + linearise, open-loop policy evaluation)               ileqg.jl:214-236
@@ -2006,6 +2032,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
 }
 
 
+#if RAT_PART & PART_FUSED
 void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
     const int B = fa.sw.st.B;
     if (B <= 0) return;
@@ -2027,6 +2054,7 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
 #undef FUSED_LAUNCH
 }
 
+#endif  // PART_FUSED
 // =====================================================================================================
 // solve_block_kernel: the complete solve! of one theta-sample by a WORKGROUP of wavefronts -- one wave per speculative line-search
 // candidate (E of them) plus, when GW, one wave that runs the gain sweeps:
@@ -2253,15 +2281,34 @@ static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {
 #undef BLOCK_LAUNCH
 }
 
-// E = st.E speculative candidates per sample: E + 1 waves (the last one runs the gain sweeps) for E <= 7, E waves for E = 8
+// E = st.E speculative candidates per sample: E + 1 waves (the last one runs the gain sweeps) for E <= 7, E waves for E = 8.
+// One translation-unit part per geometry (the Makefile compiles this file once per RAT_PART: the instantiations of one geometry are a
+// minute of compile time each).
+void launch_solve_block_e1(const FusedArgs &fa, hipStream_t s);
+void launch_solve_block_e2(const FusedArgs &fa, hipStream_t s);
+void launch_solve_block_e4(const FusedArgs &fa, hipStream_t s);
+void launch_solve_block_e8(const FusedArgs &fa, hipStream_t s);
+#if RAT_PART & PART_BLOCK2
+void launch_solve_block_e1(const FusedArgs &fa, hipStream_t s) { launch_solve_block_n<2, true>(fa, s); }
+#endif
+#if RAT_PART & PART_BLOCK3
+void launch_solve_block_e2(const FusedArgs &fa, hipStream_t s) { launch_solve_block_n<3, true>(fa, s); }
+#endif
+#if RAT_PART & PART_BLOCK5
+void launch_solve_block_e4(const FusedArgs &fa, hipStream_t s) { launch_solve_block_n<5, true>(fa, s); }
+#endif
+#if RAT_PART & PART_BLOCK8
+void launch_solve_block_e8(const FusedArgs &fa, hipStream_t s) { launch_solve_block_n<8, false>(fa, s); }
+#endif
+#if RAT_PART & PART_ROLL
 bool solve_block_supported(int E) { return E == 1 || E == 2 || E == 4 || E == 8; }
 void launch_solve_block(const FusedArgs &fa, hipStream_t s) {
     if (fa.sw.st.B <= 0) return;
     switch (fa.sw.st.E) {
-        case 1: launch_solve_block_n<2, true>(fa, s); break;
-        case 2: launch_solve_block_n<3, true>(fa, s); break;
-        case 4: launch_solve_block_n<5, true>(fa, s); break;
-        case 8: launch_solve_block_n<8, false>(fa, s); break;
+        case 1: launch_solve_block_e1(fa, s); break;
+        case 2: launch_solve_block_e2(fa, s); break;
+        case 4: launch_solve_block_e4(fa, s); break;
+        case 8: launch_solve_block_e8(fa, s); break;
         default: break;
     }
 }
@@ -2282,6 +2329,7 @@ void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream
     hipLaunchKernelGGL(ls_select_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, op, slot);
 }
 
+#endif  // PART_ROLL
 // gather the outputs of a batch: value (Inf for failures), status, iters, ls_evals
 // the outputs of sample b: value (Inf for failures), status, iters, ls_evals, cost = value + kl / theta (cross_entropy...jl:193)
 __device__ __forceinline__ void gather_body(const StateDev &st, const int b, double *value, int *status, int *iters, int *ls_evals,
@@ -2294,6 +2342,7 @@ __device__ __forceinline__ void gather_body(const StateDev &st, const int b, dou
     if (ls_evals) ls_evals[b] = st.n_ls[b];
     if (cost) cost[b] = v + kl_bound / st.theta[b];
 }
+#if RAT_PART & PART_ROLL
 __global__ void gather_kernel(StateDev st, double *value, int *status, int *iters, int *ls_evals, double *cost, double kl_bound) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= st.B) return;
@@ -2303,6 +2352,9 @@ void launch_gather(const StateDev &st, double *value, int *status, int *iters, i
     hipLaunchKernelGGL(gather_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, value, status, iters, ls_evals, cost, kl_bound);
 }
 
+#endif  // PART_ROLL
+
+#if RAT_PART & PART_MISC
 // =====================================================================================================
 // PETS (pets.jl:76-157): stochastic forward rollouts with running cost, 4 trajectories per wavefront (16-lane rows).
 // Noise comes from an injected stream (parity with the oracle, serial semantics) or from Philox4x32-10 on the device.
@@ -2537,3 +2589,4 @@ void launch_pets(const PetsArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(pets_rollout_kernel, dim3((unsigned)((ntraj + 3) / 4)), dim3(64), 0, s, a);
     hipLaunchKernelGGL(pets_mean_kernel, dim3((unsigned)a.S), dim3(64), 0, s, a);
 }
+#endif  // PART_MISC
