@@ -409,6 +409,7 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   fly_multi       0 / 1    ... and all candidates of a sample rolled out by one wavefront                               (1)
  *   dual            0 / 1    round-based path: candidate 0 paired with the next gain sweep in one wavefront              (E > 1)
  *   speculate       0 / 1    round-based path: speculative gain sweeps on a second stream                                (0)
+ *   ce_device       0 / 1    rat_ce_solve keeps the CE loop on the device: draw / update kernels, one host wait per solve!        (1)
  *   wdiag           0 / 1    diagonal time-invariant W: inv(W) folded into M^-1's operand (takes effect at the next rat_problem_set) (1) */
 rat_rc  rat_debug_set(rat_handle h, const char *key, int64_t value);
 rat_rc  rat_debug_get(rat_handle h, const char *key, int64_t *value);      /* the EFFECTIVE value on this handle */
@@ -425,7 +426,7 @@ rat_rc  rat_debug_get(rat_handle h, const char *key, int64_t *value);      /* th
 #define RAT_K_SOLVE_BLOCK 8  /* one workgroup per sample runs the whole solve!: a wavefront per line-search candidate + a gain-sweep wavefront */
 #define RAT_K_SOLVE_WIDE  9  /* general-size solve kernel (n <= 32, m <= 32 beyond the 12 + 4 tile): a workgroup per sample, whole solve! */
 #define RAT_K_PETS       10  /* PETS stochastic rollouts (pets_rollout_kernel + the per-sample mean) */
-#define RAT_K_MATERIALIZE 11 /* reserved (round 3's completion of accepted trajectories' records: every gain sweep forms its tiles now) */
+#define RAT_K_CE         11  /* draw + update kernels of the device-resident Cross-Entropy loop of rat_ce_solve (one workgroup each) */
 #define RAT_K_COUNT     12
 /* When enabled, kernel launches are bracketed by HIP events on the handle's stream.
  * on = 0: off; on = 1: every kernel kind; otherwise on = (mask << 1) | 1 with bit k of mask selecting kind RAT_K_k.

@@ -14,6 +14,8 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+#include "fdlibm_pow.h"
 #endif
 
 #define MAXD 32                 /* max(n, m) supported by the stack workspaces */
@@ -166,8 +168,9 @@ static int isapprox_default(double x, double y) {
  * ---------------------------------------------------------------------------------------- */
 static const double *tv(const double *base, int tvflag, int k, size_t sz) { return base + (tvflag ? (size_t)k * sz : 0); }
 
+/* Float64 ^ Float64 of the reference: Julia's openlibm pow (fdlibm), restated in fdlibm_pow.h -- not the host libm's */
 static double powchk(double b, double e, int *dom) {
-    double r = pow(b, e);
+    double r = orc_pow(b, e);
     if (r != r && b == b) *dom = 1;     /* Julia: DomainError for negative base, non-integer exponent */
     return r;
 }
@@ -1083,4 +1086,9 @@ int orc_pets_step(orc_pets *s, const orc_gen_problem *p, const double *x0, int u
     if (cost_out) memcpy(cost_out, cost, sizeof(double) * S);
     free(controls); free(cost);
     return 0;
+}
+
+/* x^y of the reference (fdlibm_pow.h) over arrays: tests/test_cpu_pow.py, tests/test_gpu_pow.py */
+void orc_pow_array(const double *x, const double *y, long n, double *out) {
+    for (long i = 0; i < n; ++i) out[i] = orc_pow(x[i], y[i]);
 }

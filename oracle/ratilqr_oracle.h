@@ -228,4 +228,7 @@ int orc_pets_step(orc_pets *s, const orc_gen_problem *p, const double *x0, int u
 #ifdef __cplusplus
 }
 #endif
+/* Float64 ^ Float64 as Julia's openlibm computes it (fdlibm e_pow.c restated in fdlibm_pow.h), elementwise */
+void orc_pow_array(const double *x, const double *y, long n, double *out);
+
 #endif

@@ -21,7 +21,7 @@ RC_NAMES = {0: "RAT_OK", 1: "RAT_ERR_ARG", 2: "RAT_ERR_UNSUPPORTED", 3: "RAT_ERR
 ST_RUNNING, ST_OK, ST_M_NOT_PD_INIT, ST_M_NOT_PD_GAIN, ST_ITER_MAX, ST_DOMAIN, ST_MU_DIVERGED, ST_SINGULAR, \
     ST_LS_DIVERGED = -1, 0, 1, 2, 3, 4, 5, 6, 7
 K_NAMES = ("rollout", "linearize", "sweep_eval", "sweep_gain", "select", "sweep_init", "sweep_dual", "solve_fused", "solve_block", "solve_wide",
-           "pets", "materialize")
+           "pets", "ce_bookkeeping")
 
 
 class RatError(RuntimeError):

@@ -1,0 +1,22 @@
+// ce_device.h -- device-resident state of one CrossEntropyBilevelOptimizationSolver solve! (ce_device.hip; host side: driver.cpp)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define CE_ERR_DRY 1            /* the uploaded part of the standard-normal stream ran out inside a draw */
+#define CE_DEV_MAX_B 1024       /* one workgroup draws / updates: batches up to 1024 samples */
+
+struct CeDev {                  // mirrors rat_ce_solver (include/ratilqr.h) + the chain's own control words
+    double mu_init, sigma_init, mu, sigma, theta_max, theta_min, lambda;
+    long long iter_current, iter_max, num_samples, num_elite;
+    long long n_solves, n_redraws;
+    long long zpos;             // standard normals consumed so far (position in the device-resident stream)
+    double theta_opt;           // use_theta_max ? theta_max : mu after the latest committed update (solve! :375-382)
+    int use_theta_max;
+    int redraw_pending;         // the latest update asked for a redraw: the next draw belongs to the same iteration (:293-298, :306)
+    int this_is_redraw;         // the batch in flight is such a redraw (bookkeeping: n_redraws)
+    int draw_retry;             // the latest draw ran out of normals before it had num_samples: nothing consumed, repeat it
+    int error;                  // CE_ERR_*: every later kernel of the chain is a no-op
+};
+
+void launch_ce_draw(CeDev *s, const double *z, long long z_avail, double *theta, hipStream_t st);
+void launch_ce_update(CeDev *s, const double *theta, const double *cost, hipStream_t st);

@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include "layout.h"
 #include "wide.h"
+#include "ce_device.h"
 
 static thread_local std::string g_err;
 static rat_rc fail(rat_rc rc, const std::string &msg) { g_err = msg; return rc; }
@@ -115,6 +116,11 @@ struct rat_handle_s {
     std::vector<double> zfifo;       // normals of the built-in generator drawn ahead of their use while a batch runs on the device (same sequence)
     size_t zfifo_pos = 0;
     int64_t prefill_want = 0;        // set by rat_ce_step around its batch: how many normals to have ready when the batch returns
+    // device-resident Cross-Entropy loop of rat_ce_solve (ce_device.hip): state record, normal stream, theta / cost of the batch in flight
+    bool ce_device = true;           // switch ce_device = 0: the host loop (one round trip per CE iteration)
+    CeDev *d_ce = nullptr, *h_ce = nullptr;          // device record, pinned host mirror
+    double *d_cez = nullptr, *h_cez = nullptr; size_t cap_cez = 0;      // standard normals: device copy, pinned staging
+    double *d_ce_theta = nullptr, *d_ce_cost = nullptr;
 };
 
 extern "C" int32_t rat_version(void) { return RAT_VERSION; }
@@ -156,6 +162,7 @@ static const DebugSwitch debug_switches[] = {
     {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
     {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
     {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
+    {"ce_device", [](rat_handle h, int64_t v) { h->ce_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->ce_device; }},
 };
 // what the requests amount to on this handle (speculation width, forced pairings)
 static void finish_switches(rat_handle h) {
@@ -241,6 +248,9 @@ extern "C" void rat_destroy(rat_handle h) {
     if (h->h_pstage) (void)hipHostFree(h->h_pstage);
     if (h->h_sol) (void)hipHostFree(h->h_sol);
     if (h->d_census) (void)hipFree(h->d_census);
+    for (void *q : {(void *)h->d_ce, (void *)h->d_cez, (void *)h->d_ce_theta, (void *)h->d_ce_cost}) if (q) (void)hipFree(q);
+    if (h->h_ce) (void)hipHostFree(h->h_ce);
+    if (h->h_cez) (void)hipHostFree(h->h_cez);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -1079,8 +1089,11 @@ static rat_rc op_prepare(rat_handle h, double theta, double mu, double delta, St
     return RAT_OK;
 }
 
-extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *u0, double theta, double *x, double *l, double *L,
-                                  double *value, int32_t *status, int32_t *iters, double *eps_hist, int64_t hist_cap, int64_t *hist_n) {
+// theta_dev: the sample's theta already in device memory (the device-resident CE loop hands over &CeDev.theta_opt), else `theta` is
+// uploaded.  extra_*: one more device-to-host copy enqueued before the ONE host wait of the call (the CE record).
+static rat_rc ileqg_solve_impl(rat_handle h, const double *x0, const double *u0, double theta, const double *theta_dev, double *x, double *l, double *L,
+                               double *value, int32_t *status, int32_t *iters, double *eps_hist, int64_t hist_cap, int64_t *hist_n,
+                               void *extra_dst, const void *extra_src, size_t extra_bytes) {
     if (!h || !x0 || !u0) return fail(RAT_ERR_ARG, "null");
     rat_rc rc = rat_set_initial(h, x0, u0);
     if (rc) return rc;
@@ -1088,7 +1101,7 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     double *p_d = reinterpret_cast<double *>(h->h_io);            // [0] theta, then value
     int32_t *p_i = reinterpret_cast<int32_t *>(h->h_io + 16);     // status, iter, slot_nom (+ lsel, hist_n in the theta slot afterwards)
     p_d[0] = theta;
-    HIPCHK(hipMemcpyAsync(h->d_theta, p_d, 8, hipMemcpyHostToDevice, h->stream));
+    if (!theta_dev) HIPCHK(hipMemcpyAsync(h->d_theta, p_d, 8, hipMemcpyHostToDevice, h->stream));
     const int cap = (int)std::min<int64_t>(std::max<int64_t>(hist_cap, 0), 1 << 20);
     if (eps_hist && cap > 0 && cap > h->hist_dev_cap) {            // the eps-history buffer is kept (and only grown) across calls
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1118,9 +1131,10 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     double *const s_x = h->h_sol, *const s_u = s_x + nslot * xs, *const s_L = s_u + nslot * us, *const s_h = s_L + nL * Ls;
     BatchOut wo;
     if (wide) { wo.value = h->d_val; wo.status = h->d_ist; wo.iters = h->d_iit; }
-    rc = run_batch(h, h->d_theta, 1, wo);
+    rc = run_batch(h, theta_dev ? theta_dev : h->d_theta, 1, wo);
     h->st.hist = nullptr; h->st.hist_cap = 0;
     if (rc) return rc;
+    if (extra_bytes) HIPCHK(hipMemcpyAsync(extra_dst, extra_src, extra_bytes, hipMemcpyDeviceToHost, h->stream));
     int32_t *p_j = reinterpret_cast<int32_t *>(h->h_io);          // (the theta slot is free once the batch is enqueued behind its upload)
     const StateDev &st = h->st;
     HIPCHK(hipMemcpyAsync(p_d + 1, wide ? h->d_val : st.value, 8, hipMemcpyDeviceToHost, h->stream));
@@ -1159,6 +1173,11 @@ extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *
     if (l) { std::vector<double> up(s_u + (size_t)nom * us, s_u + (size_t)(nom + 1) * us); unpad_u(h, up, l); }
     if (L) { std::vector<double> Lp(s_L + (size_t)lsel * Ls, s_L + (size_t)(lsel + 1) * Ls); unpad_L(h, Lp, L); }
     return RAT_OK;
+}
+
+extern "C" rat_rc rat_ileqg_solve(rat_handle h, const double *x0, const double *u0, double theta, double *x, double *l, double *L,
+                                  double *value, int32_t *status, int32_t *iters, double *eps_hist, int64_t hist_cap, int64_t *hist_n) {
+    return ileqg_solve_impl(h, x0, u0, theta, nullptr, x, l, L, value, status, iters, eps_hist, hist_cap, hist_n, nullptr, nullptr, 0);
 }
 
 // ---- operator forms at general size (wide.hip): the C ABI's dense column-major arrays ARE the kernel's layout ---------------------
@@ -1880,6 +1899,151 @@ extern "C" rat_rc rat_ce_step(rat_handle h, rat_ce_solver *c, const double *x0, 
     return RAT_OK;
 }
 
+// ---- solve! with the Cross-Entropy loop resident on the device (ce_device.hip) -------------------------------------------------------
+// One enqueue chain per solve!: [draw -> batch -> update] x iter_max, the final solve at theta_opt, the record back, ONE host wait.  The
+// host only stays ahead of the device with standard normals: an injected stream is uploaded up front; the built-in generator (host
+// xoshiro256++ / Box-Muller: its libm transcendentals stay on the host so the sequence is the host path's) fills a pinned buffer one
+// slot ahead while the previous batch runs.  Rare events -- a redraw (:293-298, :306) consumed a slot, the uploaded normals ran out, the
+// final solve failed (:410-413) -- are seen after the wait and handled by enqueuing what is left.
+static bool ce_device_usable(rat_handle h, const rat_ce_solver *c) {
+    return h->ce_device && h->have_problem && c->num_samples >= 1 && c->num_samples <= CE_DEV_MAX_B && c->num_samples <= h->Bmax &&
+           c->num_elite >= 1 && c->num_elite <= c->num_samples && pick_path(h, (int)c->num_samples) != PATH_ROUNDS;
+}
+static rat_rc ce_ensure_buffers(rat_handle h, size_t need_z) {
+    if (!h->d_ce) {
+        HIPCHK(hipMalloc((void **)&h->d_ce, sizeof(CeDev)));
+        HIPCHK(hipHostMalloc((void **)&h->h_ce, 2 * sizeof(CeDev), hipHostMallocDefault));       // [0] upload image, [1] read-back
+        HIPCHK(hipMalloc((void **)&h->d_ce_theta, sizeof(double) * CE_DEV_MAX_B));
+        HIPCHK(hipMalloc((void **)&h->d_ce_cost, sizeof(double) * CE_DEV_MAX_B));
+    }
+    if (need_z > h->cap_cez) {                       // (grown outside any chain: the caller has synchronised)
+        const size_t cap = std::max<size_t>(need_z, 2 * h->cap_cez);
+        double *dz = nullptr, *hz = nullptr;
+        HIPCHK(hipMalloc((void **)&dz, cap * 8));
+        if (hipHostMalloc((void **)&hz, cap * 8, hipHostMallocDefault) != hipSuccess) { (void)hipFree(dz); return fail(RAT_ERR_HIP, "hipHostMalloc(normals) failed"); }
+        if (h->h_cez) { memcpy(hz, h->h_cez, h->cap_cez * 8); (void)hipHostFree(h->h_cez); }
+        if (h->d_cez) (void)hipFree(h->d_cez);
+        h->d_cez = dz; h->h_cez = hz; h->cap_cez = cap;
+    }
+    return RAT_OK;
+}
+
+static rat_rc ce_solve_device(rat_handle h, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
+                              double *theta_opt, double *x, double *l, double *L, double *value, double *theta_min, double *theta_max) {
+    const int64_t B = c->num_samples;
+    rat_rc rc = rat_set_initial(h, x0, u0);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t per_slot = (size_t)(2 * B + 64);               // normals provisioned per draw (a draw keeps P(theta > 0) of them: >= 1/2 unless sigma >> mu)
+    // what the host holds of the stream: injected -> z[zpos..nz); built-in -> the FIFO of normals drawn ahead + the generator
+    const bool internal = h->internal_rng;
+    const size_t inj_avail = internal ? 0 : (size_t)std::max<int64_t>(0, (h->z ? h->nz - h->zpos : 0));
+    if ((rc = ce_ensure_buffers(h, internal ? per_slot * (size_t)(c->iter_max + 2) : std::min(inj_avail, per_slot * (size_t)(c->iter_max + 2)) + 1))) return rc;
+    size_t filled = 0, uploaded = 0;                            // h_cez[0..filled) generated / staged, [0..uploaded) on the device
+    auto stage_to = [&](size_t want) -> rat_rc {                // make h_cez hold `want` normals (or all the injected stream has)
+        if (!internal) want = std::min(want, inj_avail);
+        if (want > h->cap_cez) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            rat_rc r = ce_ensure_buffers(h, want);
+            if (r) return r;
+            if (uploaded) HIPCHK(hipMemcpyAsync(h->d_cez, h->h_cez, uploaded * 8, hipMemcpyHostToDevice, h->stream));
+        }
+        if (internal) {
+            while (filled < want) {
+                if (h->zfifo_pos < h->zfifo.size()) h->h_cez[filled++] = h->zfifo[h->zfifo_pos++];     // drawn ahead by an earlier call
+                else h->h_cez[filled++] = raw_normal(h);
+            }
+        } else if (filled < want) {
+            memcpy(h->h_cez + filled, h->z + h->zpos + filled, (want - filled) * 8);
+            filled = want;
+        }
+        return RAT_OK;
+    };
+    auto upload = [&]() -> rat_rc {
+        if (filled > uploaded) {
+            HIPCHK(hipMemcpyAsync(h->d_cez + uploaded, h->h_cez + uploaded, (filled - uploaded) * 8, hipMemcpyHostToDevice, h->stream));
+            uploaded = filled;
+        }
+        return RAT_OK;
+    };
+    // the record
+    CeDev &up = h->h_ce[0];
+    CeDev &back = h->h_ce[1];
+    memset(&up, 0, sizeof(up));
+    up.mu_init = c->mu_init; up.sigma_init = c->sigma_init; up.mu = c->mu; up.sigma = c->sigma; up.theta_max = c->theta_max; up.theta_min = c->theta_min;
+    up.lambda = c->lambda; up.iter_current = c->iter_current; up.iter_max = c->iter_max; up.num_samples = B; up.num_elite = c->num_elite;
+    up.n_solves = c->n_solves; up.n_redraws = c->n_redraws; up.zpos = 0; up.use_theta_max = c->use_theta_max;
+    up.theta_opt = c->use_theta_max ? c->theta_max : c->mu;     // (iter_max = 0: :375-382 on the initialised solver)
+    HIPCHK(hipMemcpyAsync(h->d_ce, &up, sizeof(CeDev), hipMemcpyHostToDevice, h->stream));
+    if ((rc = stage_to(per_slot))) return rc;
+    if ((rc = upload())) return rc;
+    BatchOut out; out.cost = h->d_ce_cost; out.kl_bound = kl_bound;
+    int64_t slots = c->iter_max - c->iter_current, slots_done = 0, redraw_guard = 0;
+    for (;;) {
+        for (int64_t k = 0; k < slots; ++k) {
+            prof_begin(h, RAT_K_CE, B); launch_ce_draw(h->d_ce, h->d_cez, (long long)uploaded, h->d_ce_theta, h->stream); prof_end(h);
+            if ((rc = run_batch(h, h->d_ce_theta, (int)B, out))) return rc;
+            prof_begin(h, RAT_K_CE, B); launch_ce_update(h->d_ce, h->d_ce_theta, h->d_ce_cost, h->stream); prof_end(h);
+            ++slots_done;
+            // the next slot's normals, generated / staged while this batch runs on the device
+            if ((rc = stage_to(per_slot * (size_t)(slots_done + 1)))) return rc;
+            if ((rc = upload())) return rc;
+        }
+        // the final solve at theta_opt (:390-414), speculatively behind the chain, and the record back with its outputs
+        int32_t st = 0; double val = 0;
+        rc = ileqg_solve_impl(h, x0, u0, 0.0, &h->d_ce->theta_opt, x, l, L, &val, &st, nullptr, nullptr, 0, nullptr, &back, h->d_ce, sizeof(CeDev));
+        if (rc) return rc;
+        if (back.error == CE_ERR_DRY) {
+            // the draw needed more normals than were on the device: nothing was consumed.  Give it everything the host can (the built-in
+            // generator: four more slots' worth; an injected stream: all of it) and repeat
+            const size_t more = internal ? filled + 4 * per_slot : inj_avail;
+            if (!internal && uploaded >= inj_avail) {
+                h->zpos += (int64_t)inj_avail;
+                return fail(RAT_ERR_STREAM_DRY, "standard-normal stream exhausted");
+            }
+            if ((rc = stage_to(more))) return rc;
+            if ((rc = upload())) return rc;
+            CeDev fix = back; fix.error = 0;                    // (draw_retry stays set: the repeated draw does not advance the iteration)
+            h->h_ce[0] = fix;
+            HIPCHK(hipMemcpyAsync(h->d_ce, &h->h_ce[0], sizeof(CeDev), hipMemcpyHostToDevice, h->stream));
+            slots = (back.iter_max - back.iter_current) + 1;
+            if (++redraw_guard > 1000) return fail(RAT_ERR_DIVERGED, "get_positive_samples did not terminate");
+            continue;
+        }
+        if (back.iter_current < back.iter_max || back.redraw_pending) {      // redraws consumed slots: run what is left
+            slots = (back.iter_max - back.iter_current) + (back.redraw_pending ? 1 : 0);
+            if (++redraw_guard > 1000) return fail(RAT_ERR_DIVERGED, "CE redraw loop cut after 1000 redraws (reference would spin, App. B.11)");
+            continue;
+        }
+        // the chain is complete: mirror the record, account for the consumed normals
+        c->mu_init = back.mu_init; c->sigma_init = back.sigma_init; c->mu = back.mu; c->sigma = back.sigma;
+        c->theta_max = back.theta_max; c->theta_min = back.theta_min; c->iter_current = back.iter_current;
+        c->n_solves = back.n_solves; c->n_redraws = back.n_redraws;
+        const size_t consumed = (size_t)back.zpos;
+        h->zpos += (int64_t)consumed;
+        if (internal) {                                         // normals generated but not consumed go back to the FIFO, in order
+            std::vector<double> rest(h->h_cez + consumed, h->h_cez + filled);
+            rest.insert(rest.end(), h->zfifo.begin() + (std::ptrdiff_t)h->zfifo_pos, h->zfifo.end());
+            h->zfifo.swap(rest); h->zfifo_pos = 0;
+        }
+        double th_opt = back.theta_opt;
+        const double tmin = c->theta_min, tmax = c->theta_max;
+        for (int tries = 0;; ++tries) {                         // :390-414 (the first attempt ran behind the chain)
+            if (tries > 10000) return fail(RAT_ERR_DIVERGED, "final-solve retry loop cut (reference would spin, App. B.15)");
+            if (st == RAT_ST_OK || st == RAT_ST_ITER_MAX) {
+                *theta_opt = th_opt;
+                *value = val + kl_bound / th_opt;               // :406
+                if (theta_min) *theta_min = tmin;
+                if (theta_max) *theta_max = tmax;
+                return RAT_OK;
+            }
+            th_opt = std::max(0.0, th_opt - c->sigma);          // :412
+            c->n_final_retries++;
+            if ((rc = rat_ileqg_solve(h, x0, u0, th_opt, x, l, L, &val, &st, nullptr, nullptr, 0, nullptr))) return rc;
+        }
+    }
+}
+
 extern "C" rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
                                double *theta_opt, double *x, double *l, double *L, double *value,
                                double *theta_min, double *theta_max) {             // :364-415
@@ -1887,6 +2051,8 @@ extern "C" rat_rc rat_ce_solve(rat_handle h, rat_ce_solver *c, const double *x0,
     if (!(kl_bound >= 0)) return fail(RAT_ERR_ARG, "KL Divergence Bound must be non-negative (:368)");
     rat_ce_initialize(c);                                                           // :369
     c->n_final_retries = 0;
+    if (kl_bound > 0 && c->iter_max >= 0 && ce_device_usable(h, c) && (h->internal_rng || h->z))
+        return ce_solve_device(h, c, x0, u0, kl_bound, theta_opt, x, l, L, value, theta_min, theta_max);
     double th_opt, tmin = 0.0, tmax = 0.0;
     if (kl_bound > 0) {
         while (c->iter_current < c->iter_max) {                                     // :371-373

@@ -35,6 +35,7 @@
 #include "kernels.h"
 
 #include "device_utils.h"
+#include "rat_pow.h"
 #include "sweep_dual.h"
 
 // Translation-unit parts: every part sees every device body (templates, inlined where instantiated); the __global__ kernels and their
@@ -540,8 +541,10 @@ void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream
 // rollout_kernel: four trajectories per wavefront (one per 16-lane row).  Lane j < 12 owns state
 // component j, lanes j < 4 additionally own control component j.
 // =====================================================================================================
+// x^e of the power-law family: the reference's own arithmetic (Julia -> openlibm's fdlibm pow, rat_pow.h), not the device library's pow --
+// device and oracle agree bit for bit on every power, so long power-law iterations no longer drift apart
 __device__ __forceinline__ double powchk(double bse, double e, int &dom) {
-    const double r = pow(bse, e);
+    const double r = rat_pow(bse, e);
     if (r != r && bse == bse) dom = 1;        // Julia: DomainError for a negative base with a fractional exponent
     return r;
 }
