@@ -18,5 +18,5 @@ struct CeDev {                  // mirrors rat_ce_solver (include/ratilqr.h) + t
     int error;                  // CE_ERR_*: every later kernel of the chain is a no-op
 };
 
-void launch_ce_draw(CeDev *s, const double *z, long long z_avail, double *theta, hipStream_t st);
-void launch_ce_update(CeDev *s, const double *theta, const double *cost, hipStream_t st);
+// one launch between two batches: update on the finished batch (do_update), draw of the next one (do_draw)
+void launch_ce_step(CeDev *s, const double *z, long long z_avail, double *theta, const double *cost, int do_update, int do_draw, hipStream_t st);

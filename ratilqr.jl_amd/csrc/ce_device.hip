@@ -30,14 +30,26 @@ __device__ __forceinline__ int block_excl_scan(const bool flag, int *wsum, int &
     return base + in_wave;
 }
 
+// The record is 160 bytes: every kernel works on a copy in LDS (one coalesced load / store instead of a chain of dependent global
+// round trips by one lane) and writes it back at its end.
+#define CE_WORDS ((int)(sizeof(CeDev) / 8))
+static_assert(sizeof(CeDev) % 8 == 0, "CeDev is copied in 8-byte words");
+__device__ __forceinline__ void rec_load(CeDev *sc, const CeDev *g) {
+    if (threadIdx.x < CE_WORDS) reinterpret_cast<unsigned long long *>(sc)[threadIdx.x] = reinterpret_cast<const unsigned long long *>(g)[threadIdx.x];
+    __syncthreads();
+}
+__device__ __forceinline__ void rec_store(CeDev *g, const CeDev *sc) {
+    __syncthreads();
+    if (threadIdx.x < CE_WORDS) reinterpret_cast<unsigned long long *>(g)[threadIdx.x] = reinterpret_cast<const unsigned long long *>(sc)[threadIdx.x];
+}
+
 // get_positive_samples (:233-246) preceded by the head of step! (:259 iter_current += 1; :266-279 which (mu, sigma) to draw from).
 // The sequential rule -- take standard normals in order, keep theta = mu + sigma z > 0 until num_samples are kept -- is replayed 1024
 // stream elements at a time: an element's slot is the number of kept elements before it.
-__global__ __launch_bounds__(CE_T) void ce_draw_kernel(CeDev *s, const double *__restrict__ z, long long z_avail, double *__restrict__ theta) {
+__device__ __forceinline__ void ce_draw(CeDev *const s, const double *__restrict__ z, const long long z_avail, double *__restrict__ theta, int *wsum) {
 #pragma clang fp contract(off)
-    __shared__ int wsum[CE_T / 64];
     __shared__ double sh_mu, sh_sigma;
-    __shared__ long long sh_pos, sh_newpos;
+    __shared__ long long sh_newpos;
     __shared__ int sh_go;
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -48,7 +60,6 @@ __global__ __launch_bounds__(CE_T) void ce_draw_kernel(CeDev *s, const double *_
             const bool first = s->iter_current == 1;                                       // :266-279
             sh_mu = first ? s->mu_init : s->mu;
             sh_sigma = first ? s->sigma_init : s->sigma;
-            sh_pos = s->zpos;
             sh_newpos = -1;
         }
     }
@@ -56,7 +67,7 @@ __global__ __launch_bounds__(CE_T) void ce_draw_kernel(CeDev *s, const double *_
     if (!sh_go) return;
     const double mu = sh_mu, sigma = sh_sigma;
     const int B = (int)s->num_samples;
-    long long pos = sh_pos;
+    long long pos = s->zpos;
     int count = 0;
     bool dry = false;
     while (count < B) {
@@ -77,23 +88,35 @@ __global__ __launch_bounds__(CE_T) void ce_draw_kernel(CeDev *s, const double *_
         if (dry) { s->error = CE_ERR_DRY; s->draw_retry = 1; }                             // nothing consumed: the host tops the stream up and re-enqueues
         else { s->zpos = sh_newpos; s->draw_retry = 0; }
     }
+    __syncthreads();
+}
+
+// sort(by = cost) orders by isless on the costs -- NaN after everything, -0.0 == 0.0 -- with ties in input order (stable).  The cost is
+// mapped once to an unsigned key with the same order (sign-magnitude -> biased; every NaN -> the largest key; -0.0 -> +0.0), so that a
+// compare-exchange of the network is three integer comparisons and no branch (the comparator written on doubles, with its NaN cases,
+// compiled to nested divergent branches: 20 us per update instead of ~6).
+__device__ __forceinline__ unsigned long long elite_key(double c) {
+    if (c != c) return ~0ull;
+    c = c + 0.0;                                               // -0.0 -> +0.0 (isless(-0.0, 0.0) is false)
+    const unsigned long long b = (unsigned long long)__double_as_longlong(c);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
 // The tail of step! (:291-334) on the costs of the batch: valid count, the redraw rules, theta_min / theta_max with the reference's
 // if / elseif, elites under (isless(cost), index), mean and population standard deviation.
-__global__ __launch_bounds__(CE_T) void ce_update_kernel(CeDev *s, const double *__restrict__ theta, const double *__restrict__ cost) {
+__device__ __forceinline__ void ce_update(CeDev *const s, const double *__restrict__ theta, const double *__restrict__ cost, int *wsum) {
 #pragma clang fp contract(off)
-    __shared__ double c_sh[CE_T], th_sh[CE_T];
+    __shared__ double c_sh[CE_T], th_sh[CE_T], el_sh[CE_T];
     __shared__ int idx_sh[CE_T];
-    __shared__ int wsum[CE_T / 64];
     __shared__ double wmin[CE_T / 64], wmax[CE_T / 64];
     __shared__ int sh_mode;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (s->error != 0 || s->draw_retry) return;                                            // (uniform: the draw of this slot did not happen)
     const int B = (int)s->num_samples, ne = (int)s->num_elite;
     const bool live = tid < B;
-    const double c = live ? cost[tid] : INFINITY, th = live ? theta[tid] : 0.0;
-    c_sh[tid] = c; th_sh[tid] = th;
+    const double c = live ? cost[tid] : NAN;                                                     // (pad slots: NaN cost, index >= B: after every sample)
+    const double th = live ? theta[tid] : 0.0;
+    th_sh[tid] = th;
     const bool isinf_c = live && (c == INFINITY || c == -INFINITY);                        // isinf(cost) :291 (a NaN cost is not infinite)
     int num_inf;
     (void)block_excl_scan(isinf_c, wsum, num_inf);
@@ -122,8 +145,7 @@ __global__ __launch_bounds__(CE_T) void ce_update_kernel(CeDev *s, const double 
     // NOT theta_i < (running minimum before i) = min(theta_min_in, valid thetas before i): an exclusive prefix minimum.
     const bool valid = live && !isinf_c;
     const double tv = valid ? th : INFINITY;
-    // inclusive prefix min inside the wave, then exclusive across waves
-    double incl = tv;
+    double incl = tv;                                   // inclusive prefix minimum inside the wave, then exclusive across waves
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(incl, off, 64); if (lane >= off) incl = fmin(incl, o); }
     if (lane == 63) wmin[wave] = incl;
@@ -137,22 +159,35 @@ __global__ __launch_bounds__(CE_T) void ce_update_kernel(CeDev *s, const double 
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
     if (lane == 0) wmax[wave] = mx;
-    // elites: position of sample i in sort(by = cost) = number of samples strictly before it under (isless(cost), index): NaN last, ties
-    // in input order (a stable sort)
-    __syncthreads();
-    int rank = 0;
-    if (live) {
-        const bool xn = c != c;
-        for (int j = 0; j < B; ++j) {
-            const double y = c_sh[j];
-            const bool yn = y != y;
-            bool before_me;                         // (y, j) < (c, tid) ?
-            if (xn || yn) before_me = yn ? (xn && j < tid) : true;      // y not NaN, c NaN: y first; both NaN: by index; y NaN, c not: no
-            else before_me = (y < c) || (!(c < y) && j < tid);
-            rank += before_me ? 1 : 0;
+    // elites: sort(by = cost), stable = the strict total order (isless(cost), index): a bitonic network over the 1024 slots of the
+    // workgroup, one element per thread in registers -- partners inside a wavefront (distance < 64) exchange by lane shuffles, the ten
+    // stages at distance >= 64 through LDS.  (An O(B^2) rank count on ONE compute unit took 85 us, all 55 stages through LDS 7 us.)
+    int id = tid;
+    unsigned long long key = elite_key(c);
+    unsigned long long *const k_sh = reinterpret_cast<unsigned long long *>(c_sh);
+#pragma unroll
+    for (int k = 2; k <= CE_T; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long ok; int oi;
+            if (j >= 64) {
+                __syncthreads();
+                k_sh[tid] = key; idx_sh[tid] = id;
+                __syncthreads();
+                ok = k_sh[tid ^ j]; oi = idx_sh[tid ^ j];
+            } else {
+                ok = (unsigned long long)__shfl_xor((long long)key, j, 64); oi = __shfl_xor(id, j, 64);
+            }
+            // the lower position of a pair keeps the smaller element in an ascending block, the larger one in a descending block
+            const bool want_min = ((tid & j) == 0) == ((tid & k) == 0);
+            const bool mine_first = (key < ok) | ((key == ok) & (id < oi));
+            const bool take = want_min != mine_first;
+            key = take ? ok : key;
+            id = take ? oi : id;
         }
-        if (rank < ne) idx_sh[rank] = tid;
     }
+    __syncthreads();
+    if (tid < ne) el_sh[tid] = th_sh[id];                      // the elites' thetas in sorted order (position tid of the sorted sequence)
     __syncthreads();
     if (tid == 0) {
         double tmin = s->theta_min, tmax = s->theta_max;
@@ -160,19 +195,32 @@ __global__ __launch_bounds__(CE_T) void ce_update_kernel(CeDev *s, const double 
         for (int w = 0; w < CE_T / 64; ++w) { tmin = fmin(tmin, wmin[w]); tmax = fmax(tmax, wmax[w]); }
         s->theta_min = tmin; s->theta_max = tmax;
         double sum = 0.0;
-        for (int i = 0; i < ne; ++i) sum += th_sh[idx_sh[i]];
+#pragma unroll 8
+        for (int i = 0; i < ne; ++i) sum += el_sh[i];
         const double mu_new = sum / (double)ne;                                            // :329
         double ss = 0.0;
-        for (int i = 0; i < ne; ++i) { const double d = th_sh[idx_sh[i]] - mu_new; ss += d * d; }
+#pragma unroll 8
+        for (int i = 0; i < ne; ++i) { const double d = el_sh[i] - mu_new; ss += d * d; }
         s->mu = mu_new;
         s->sigma = sqrt(ss / (double)ne);                                                  // :330-334 (population std)
         s->theta_opt = s->use_theta_max ? tmax : mu_new;                                   // solve! :375-382, after the last iteration
     }
+    __syncthreads();
 }
 
-void launch_ce_draw(CeDev *s, const double *z, long long z_avail, double *theta, hipStream_t st) {
-    hipLaunchKernelGGL(ce_draw_kernel, dim3(1), dim3(CE_T), 0, st, s, z, z_avail, theta);
+// One bookkeeping launch between two batches: the update on the batch that has just finished (do_update), then the draw of the next one
+// (do_draw) -- the draw finds the iteration finished, a redraw pending or an error in the record and acts accordingly.
+__global__ __launch_bounds__(CE_T) void ce_step_kernel(CeDev *sg, const double *__restrict__ z, long long z_avail, double *__restrict__ theta,
+                                                       const double *__restrict__ cost, int do_update, int do_draw) {
+    __shared__ int wsum[CE_T / 64];
+    __shared__ CeDev sc;
+    rec_load(&sc, sg);
+    if (do_update) ce_update(&sc, theta, cost, wsum);
+    __syncthreads();
+    if (do_draw) ce_draw(&sc, z, z_avail, theta, wsum);
+    rec_store(sg, &sc);
 }
-void launch_ce_update(CeDev *s, const double *theta, const double *cost, hipStream_t st) {
-    hipLaunchKernelGGL(ce_update_kernel, dim3(1), dim3(CE_T), 0, st, s, theta, cost);
+
+void launch_ce_step(CeDev *s, const double *z, long long z_avail, double *theta, const double *cost, int do_update, int do_draw, hipStream_t st) {
+    hipLaunchKernelGGL(ce_step_kernel, dim3(1), dim3(CE_T), 0, st, s, z, z_avail, theta, cost, do_update, do_draw);
 }

@@ -119,7 +119,7 @@ struct rat_handle_s {
     // device-resident Cross-Entropy loop of rat_ce_solve (ce_device.hip): state record, normal stream, theta / cost of the batch in flight
     bool ce_device = true;           // switch ce_device = 0: the host loop (one round trip per CE iteration)
     CeDev *d_ce = nullptr, *h_ce = nullptr;          // device record, pinned host mirror
-    double *d_cez = nullptr, *h_cez = nullptr; size_t cap_cez = 0;      // standard normals: device copy, pinned staging
+    double *d_cez = nullptr, *h_cez = nullptr; size_t cap_cez = 0;      // standard normals: pinned host buffer and its device address (read in place)
     double *d_ce_theta = nullptr, *d_ce_cost = nullptr;
 };
 
@@ -248,7 +248,7 @@ extern "C" void rat_destroy(rat_handle h) {
     if (h->h_pstage) (void)hipHostFree(h->h_pstage);
     if (h->h_sol) (void)hipHostFree(h->h_sol);
     if (h->d_census) (void)hipFree(h->d_census);
-    for (void *q : {(void *)h->d_ce, (void *)h->d_cez, (void *)h->d_ce_theta, (void *)h->d_ce_cost}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)h->d_ce, (void *)h->d_ce_theta, (void *)h->d_ce_cost}) if (q) (void)hipFree(q);      // (d_cez aliases the pinned h_cez)
     if (h->h_ce) (void)hipHostFree(h->h_ce);
     if (h->h_cez) (void)hipHostFree(h->h_cez);
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
@@ -1917,13 +1917,16 @@ static rat_rc ce_ensure_buffers(rat_handle h, size_t need_z) {
         HIPCHK(hipMalloc((void **)&h->d_ce_cost, sizeof(double) * CE_DEV_MAX_B));
     }
     if (need_z > h->cap_cez) {                       // (grown outside any chain: the caller has synchronised)
+        // The standard normals live in pinned host memory that the draw kernel reads in place (a draw touches ~12 KB of it once): no copy
+        // command sits between a batch and the bookkeeping launch behind it.
         const size_t cap = std::max<size_t>(need_z, 2 * h->cap_cez);
-        double *dz = nullptr, *hz = nullptr;
-        HIPCHK(hipMalloc((void **)&dz, cap * 8));
-        if (hipHostMalloc((void **)&hz, cap * 8, hipHostMallocDefault) != hipSuccess) { (void)hipFree(dz); return fail(RAT_ERR_HIP, "hipHostMalloc(normals) failed"); }
+        double *hz = nullptr;
+        HIPCHK(hipHostMalloc((void **)&hz, cap * 8, hipHostMallocDefault));
         if (h->h_cez) { memcpy(hz, h->h_cez, h->cap_cez * 8); (void)hipHostFree(h->h_cez); }
-        if (h->d_cez) (void)hipFree(h->d_cez);
-        h->d_cez = dz; h->h_cez = hz; h->cap_cez = cap;
+        h->h_cez = hz; h->cap_cez = cap;
+        void *dz = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dz, hz, 0));
+        h->d_cez = (double *)dz;
     }
     return RAT_OK;
 }
@@ -1946,7 +1949,6 @@ static rat_rc ce_solve_device(rat_handle h, rat_ce_solver *c, const double *x0, 
             HIPCHK(hipStreamSynchronize(h->stream));
             rat_rc r = ce_ensure_buffers(h, want);
             if (r) return r;
-            if (uploaded) HIPCHK(hipMemcpyAsync(h->d_cez, h->h_cez, uploaded * 8, hipMemcpyHostToDevice, h->stream));
         }
         if (internal) {
             while (filled < want) {
@@ -1959,11 +1961,8 @@ static rat_rc ce_solve_device(rat_handle h, rat_ce_solver *c, const double *x0, 
         }
         return RAT_OK;
     };
-    auto upload = [&]() -> rat_rc {
-        if (filled > uploaded) {
-            HIPCHK(hipMemcpyAsync(h->d_cez + uploaded, h->h_cez + uploaded, (filled - uploaded) * 8, hipMemcpyHostToDevice, h->stream));
-            uploaded = filled;
-        }
+    auto upload = [&]() -> rat_rc {                             // (zero-copy: what is staged is visible to every launch enqueued after this point)
+        uploaded = filled;
         return RAT_OK;
     };
     // the record
@@ -1980,14 +1979,17 @@ static rat_rc ce_solve_device(rat_handle h, rat_ce_solver *c, const double *x0, 
     BatchOut out; out.cost = h->d_ce_cost; out.kl_bound = kl_bound;
     int64_t slots = c->iter_max - c->iter_current, slots_done = 0, redraw_guard = 0;
     for (;;) {
+        // draw_1 | batch_1 | update_1 + draw_2 | batch_2 | ... | update_n : one bookkeeping launch between two batches
+        if (slots > 0) { prof_begin(h, RAT_K_CE, B); launch_ce_step(h->d_ce, h->d_cez, (long long)uploaded, h->d_ce_theta, h->d_ce_cost, 0, 1, h->stream); prof_end(h); }
         for (int64_t k = 0; k < slots; ++k) {
-            prof_begin(h, RAT_K_CE, B); launch_ce_draw(h->d_ce, h->d_cez, (long long)uploaded, h->d_ce_theta, h->stream); prof_end(h);
             if ((rc = run_batch(h, h->d_ce_theta, (int)B, out))) return rc;
-            prof_begin(h, RAT_K_CE, B); launch_ce_update(h->d_ce, h->d_ce_theta, h->d_ce_cost, h->stream); prof_end(h);
             ++slots_done;
-            // the next slot's normals, generated / staged while this batch runs on the device
-            if ((rc = stage_to(per_slot * (size_t)(slots_done + 1)))) return rc;
-            if ((rc = upload())) return rc;
+            const int more = (k + 1 < slots) ? 1 : 0;
+            if (more) {            // the next draw's normals, generated / staged while this batch runs on the device
+                if ((rc = stage_to(per_slot * (size_t)(slots_done + 1)))) return rc;
+                if ((rc = upload())) return rc;
+            }
+            prof_begin(h, RAT_K_CE, B); launch_ce_step(h->d_ce, h->d_cez, (long long)uploaded, h->d_ce_theta, h->d_ce_cost, 1, more, h->stream); prof_end(h);
         }
         // the final solve at theta_opt (:390-414), speculatively behind the chain, and the record back with its outputs
         int32_t st = 0; double val = 0;
