@@ -886,11 +886,12 @@ function solve!(s::CrossEntropyDirectOptimizationSolver, problem::LQGenerativePr
 end
 
 # =====================================================================================================================================
-# Generic closures: the reference package's own CPU path
+# Generic closures: host closures (the reference package's own functions) + batched device sweeps
 # =====================================================================================================================================
 # A problem that is not one of the device model families (the reference's FiniteHorizonRiskSensitiveOptimalControlProblem(f, c, h, W, N) with
-# arbitrary closures) is handed to the reference package, when it is loaded, with a solver of the reference's own type built from the same
-# options.  Nothing is approximated or re-implemented here: generic closures run exactly the code they ran before.
+# arbitrary closures) needs the reference package loaded: its closures are evaluated by the reference's own simulate_dynamics /
+# approximate_model.  A single iLEQG solve! and Nelder-Mead are handed to the reference whole; the Cross-Entropy solver -- the one with
+# B independent solves per batch -- runs their Riccati sweeps on the device, one launch per round (below).
 reference_module() = isdefined(Main, :RATiLQR) ? getfield(Main, :RATiLQR) :
     error("this problem is not a device model family (LQRiskSensitiveProblem, PowerLawRiskSensitiveProblem, LQGenerativeProblem) and the " *
           "reference package RATiLQR is not loaded: `using RATiLQR` to run generic closures on the CPU")
@@ -901,15 +902,162 @@ function solve!(s::ILEQGSolver, problem, x_0::Vector{Float64}, u_array::Vector{V
                         adaptive_ϵ_init=s.ϵ_init_auto, ϵ_min=s.ϵ_min)
     R.solve!(ref, problem, x_0, u_array; θ=θ, verbose=verbose)
 end
+# ---- closure problems through the batched device sweeps (SURVEY 8f #3; the loop of ratilqr.jl_amd/generic.py: solve_closure_batch) -----
+# A closure problem cannot cross the C ABI, but its Riccati sweeps can: the host evaluates the user's closures with the REFERENCE'S OWN
+# functions -- `simulate_dynamics` (rollouts, with the Jacobians `f` returns when f_returns_jacobian) and `approximate_model` (ForwardDiff,
+# ileqg.jl:265-273, or the user's A / B, :302-311) -- and every solve_approximate_dp! / solve_approximate_dp of the B samples of a
+# compute_cost call runs in ONE device launch (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch).  The B per-sample solve! sequences
+# (initialize!, then step! = approximate_model -> solve_approximate_dp! -> line_search!, :598-613, until :642-653) advance in lockstep
+# rounds only so that their sweeps share launches; every decision is the reference's (accept rule :538, ε_min :558, adaptive ε_init
+# :582-591), so results equal B separate reference solves.  `closure_device[] = false` forwards to the reference package instead.
+const closure_device = Ref(true)
+
+"A device handle that only carries W(k), n, m, N of a closure problem (the sweeps read their tiles from the host-built ApproximationResult)."
+function carrier_problem(problem, n::Integer, m::Integer)
+    N = problem.N
+    Wt = cat([Matrix{Float64}(problem.W(k)) for k in 0:N-1]...; dims=3)                  # W(k), k 0-based (optimal_control_problems.jl:67-73)
+    LQRiskSensitiveProblem(zeros(n, n), zeros(n, m), Matrix{Float64}(I(n)), Matrix{Float64}(I(m)), zeros(m, n), zeros(n), zeros(m), [0.0],
+                           Matrix{Float64}(I(n)), zeros(n), 0.0, 0.0, Wt, N)
+end
+ref_ap(a) = ApproximationResult(a.q_array, a.q_vec_array, [Matrix{Float64}(Q) for Q in a.Q_array], a.r_array, [Matrix{Float64}(Rm) for Rm in a.R_array],
+                                a.P_array, a.A_array, a.B_array, a.W_array)
+
+"""
+    solve_closure_batch(opts, problem, x_0, u_array, θ_array; f_returns_jacobian=false, device=0, max_batch=length(θ_array))
+
+B complete `solve!`s (ileqg.jl:635-659) of a closure problem, one per θ: `(value, status, iterations, line-search evaluations)`, value = Inf
+where the reference would throw (compute_value_worker :163-165).  Host: the reference's `simulate_dynamics` / `approximate_model`; device:
+all sweeps of a round in one launch.
+"""
+function solve_closure_batch(o::IleqgOpts, problem, x_0::Vector{Float64}, u_array::Vector{Vector{Float64}}, θ::Vector{Float64};
+                             f_returns_jacobian::Bool=false, device::Integer=0, carrier::Union{Nothing,ILEQGSolver}=nothing)
+    R = reference_module()
+    B = length(θ); N = problem.N; n = length(x_0); m = length(u_array[1])
+    cs = carrier === nothing ? ILEQGSolver(carrier_problem(problem, n, m); μ_min=o.mu_min, Δ_0=o.delta_0, λ=o.lambda, d=o.d, iter_max=o.iter_max,
+                                           ϵ_init=o.eps_init, ϵ_min=o.eps_min, adaptive_ϵ_init=o.adaptive_eps_init != 0, max_batch=B, device=device) : carrier
+    rollout(xb, l, L) = f_returns_jacobian ? R.simulate_dynamics(problem, xb, l, L, f_returns_jacobian=true) :
+                                             (R.simulate_dynamics(problem, xb, l, L, f_returns_jacobian=false)..., nothing, nothing)
+    lin(u, x, A, Bm) = ref_ap(A === nothing ? R.approximate_model(problem, u, x) : R.approximate_model(problem, u, x, A, Bm))
+    status = fill(Int32(-1), B); value = fill(Inf, B); iters = zeros(Int32, B); ls_evals = zeros(Int32, B)
+    μ = zeros(B); Δ = fill(o.delta_0, B); d_cur = fill(Inf, B); ϵ_init = fill(o.eps_init, B)
+    # initialize! (:214-236): one rollout / linearisation serves every sample -- θ only enters the sweep
+    x0s, A0, B0 = f_returns_jacobian ? R.simulate_dynamics(problem, x_0, u_array, f_returns_jacobian=true) :
+                                       (R.simulate_dynamics(problem, x_0, u_array, f_returns_jacobian=false), nothing, nothing)
+    ap0 = lin(u_array, x0s, A0, B0)
+    x = [deepcopy(x0s) for _ in 1:B]; l = [deepcopy(u_array) for _ in 1:B]; L = [[zeros(m, n) for _ in 1:N] for _ in 1:B]
+    AB = Any[(A0, B0) for _ in 1:B]
+    v, st = solve_approximate_dp_batch(cs, fill(ap0, B), L, θ, μ)
+    for b in 1:B
+        st[b] != 0 ? (status[b] = Int32(1)) : (value[b] = v[b])                          # the uncaught @assert of initialize! (:234) -> Inf
+    end
+    dl = Vector{Any}(nothing, B); ϵ = copy(ϵ_init); count = zeros(Int, B); in_ls = falses(B)
+    while true
+        live = findall(==(Int32(-1)), status)
+        isempty(live) && break
+        need = [b for b in live if !in_ls[b]]
+        if !isempty(need)                                                                # step! (:598-613): approximate_model + solve_approximate_dp!
+            iters[need] .+= 1
+            aps = [lin(l[b], x[b], AB[b]...) for b in need]
+            Lg, dlg, μg, Δg, stg = solve_approximate_dp_batch!(cs, aps, θ[need], μ[need], Δ[need])
+            for (i, b) in enumerate(need)
+                μ[b], Δ[b] = μg[i], Δg[i]
+                if stg[i] != 0
+                    status[b] = stg[i]; value[b] = Inf; continue
+                end
+                L[b], dl[b] = Lg[i], dlg[i]
+                ϵ[b], count[b], in_ls[b] = ϵ_init[b], 0, true
+            end
+        end
+        cand = [b for b in findall(==(Int32(-1)), status) if in_ls[b]]
+        isempty(cand) && continue
+        trial = Dict{Int,Any}()
+        for b in cand                                                                    # a line_search! candidate (:504-521)
+            count[b] += 1; ls_evals[b] += 1
+            xn, un, An, Bn = rollout(x[b], l[b] .+ ϵ[b] .* dl[b], L[b])
+            trial[b] = (xn, un, lin(un, xn, An, Bn), An, Bn)
+        end
+        vn, stn = solve_approximate_dp_batch(cs, [trial[b][3] for b in cand], [L[b] for b in cand], θ[cand], μ[cand])
+        for (i, b) in enumerate(cand)
+            if count[b] > 4000
+                status[b] = Int32(7); value[b] = Inf; in_ls[b] = false; continue
+            end
+            if stn[i] != 0                                                               # :522-535: no ε_min test, no history entry
+                ϵ[b] *= o.lambda; continue
+            end
+            new, cur = vn[i], value[b]
+            if !(new ≈ cur || new < cur)                                                 # :538
+                ϵ[b] *= o.lambda                                                         # :557
+                ϵ[b] < o.eps_min || continue                                             # :558: forced accept of the rejected candidate
+            end
+            xn, un, _, An, Bn = trial[b]
+            d_cur[b] = maximum(norm.(l[b] .- un))                                        # :539 / :559
+            value[b], x[b], l[b], in_ls[b] = new, xn, un, false
+            AB[b] = (An, Bn)
+            if o.adaptive_eps_init != 0                                                  # :582-591
+                if count[b] == 1
+                    ϵ_init[b] = min(o.eps_init, ϵ[b] / o.lambda)
+                else
+                    e = ϵ[b]
+                    while e < o.eps_min; e /= o.lambda; end
+                    ϵ_init[b] = e
+                end
+            end
+            if o.d > d_cur[b] && μ[b] <= o.mu_min                                        # :642
+                status[b] = Int32(0)
+            elseif iters[b] == o.iter_max                                                # :648
+                status[b] = Int32(3)
+            end
+        end
+    end
+    [(status[b] == 0 || status[b] == 3) ? value[b] : Inf for b in 1:B], status, iters, ls_evals
+end
+
+"compute_cost (:173-195) of a closure problem: the B solves of the batch share their device sweeps"
+function compute_cost(s::CrossEntropyBilevelOptimizationSolver, problem, x::Vector{Float64}, u_array::Vector{Vector{Float64}},
+                      θ_array::Vector{Float64}, kl_bound::Float64; f_returns_jacobian::Bool=false)
+    value, _, _, _ = solve_closure_batch(s.opts, problem, x, u_array, θ_array; f_returns_jacobian=f_returns_jacobian, device=s.devices[1])
+    value .+ kl_bound ./ θ_array                                                         # :193
+end
+
+"solve! (:364-415) of a closure problem: the CE loop of the reference with compute_cost on the batched device sweeps"
 function solve!(s::CrossEntropyBilevelOptimizationSolver, problem, x_0::Vector{Float64}, u_array::Vector{Vector{Float64}}, rng::AbstractRNG;
-                kl_bound::Float64, verbose=false, serial=false)
+                kl_bound::Float64, verbose=false, serial=false, f_returns_jacobian::Bool=false)
     R = reference_module(); o = s.opts; c = s.c
-    ref = R.CrossEntropyBilevelOptimizationSolver(μ_min_ileqg=o.mu_min, Δ_0_ileqg=o.delta_0, λ_ileqg=o.lambda, d_ileqg=o.d, iter_max_ileqg=o.iter_max,
-              adaptive_ϵ_init_ileqg=o.adaptive_eps_init != 0, ϵ_init_ileqg=o.eps_init, ϵ_min_ileqg=o.eps_min, μ_init=c.mu_init, σ_init=c.sigma_init,
-              num_samples=c.num_samples, num_elite=c.num_elite, iter_max=c.iter_max, λ=c.lambda, use_θ_max=c.use_theta_max != 0)
-    out = R.solve!(ref, problem, x_0, u_array, rng; kl_bound=kl_bound, verbose=verbose, serial=serial)
-    c.mu_init, c.sigma_init = ref.μ_init, ref.σ_init                     # the reference mutates and keeps these across solve! calls (App. B.10)
-    out
+    if !closure_device[] || serial
+        ref = R.CrossEntropyBilevelOptimizationSolver(μ_min_ileqg=o.mu_min, Δ_0_ileqg=o.delta_0, λ_ileqg=o.lambda, d_ileqg=o.d, iter_max_ileqg=o.iter_max,
+                  adaptive_ϵ_init_ileqg=o.adaptive_eps_init != 0, ϵ_init_ileqg=o.eps_init, ϵ_min_ileqg=o.eps_min, μ_init=c.mu_init, σ_init=c.sigma_init,
+                  num_samples=c.num_samples, num_elite=c.num_elite, iter_max=c.iter_max, λ=c.lambda, use_θ_max=c.use_theta_max != 0)
+        out = R.solve!(ref, problem, x_0, u_array, rng; kl_bound=kl_bound, verbose=verbose, serial=serial)
+        c.mu_init, c.sigma_init = ref.μ_init, ref.σ_init                 # the reference mutates and keeps these across solve! calls (App. B.10)
+        return out
+    end
+    @assert kl_bound >= 0 "KL Divergence Bound must be non-negative"
+    initialize!(s)                                                                       # :369
+    θ_opt = 0.0
+    if kl_bound > 0
+        while c.iter_current < c.iter_max                                                # :371-373, step! :252-335 with the device-swept compute_cost
+            ccall((:rat_ce_begin_step, LIB), Int32, (Ref{CeState},), c)
+            while true
+                θs = c.iter_current == 1 ? get_positive_samples(c.mu_init, c.sigma_init, Int(c.num_samples), rng) :
+                                           get_positive_samples(c.mu, c.sigma, Int(c.num_samples), rng)
+                cost = compute_cost(s, problem, x_0, u_array, θs, kl_bound; f_returns_jacobian=f_returns_jacobian)
+                redraw = Ref(Int32(0))
+                check(ccall((:rat_ce_update, LIB), Int32, (Ref{CeState}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}), c, θs, cost, redraw))
+                redraw[] == 0 && break
+            end
+        end
+        θ_opt = c.use_theta_max != 0 ? c.theta_max : c.mu                                # :375-382
+    end
+    while true                                                                           # :390-414: final solve with the retry on failure
+        value, st, _, _ = solve_closure_batch(o, problem, x_0, u_array, [θ_opt]; f_returns_jacobian=f_returns_jacobian, device=s.devices[1])
+        if st[1] == 0 || st[1] == 3
+            ref = R.ILEQGSolver(problem; μ_min=o.mu_min, Δ_0=o.delta_0, λ=o.lambda, d=o.d, iter_max=o.iter_max, ϵ_init=o.eps_init,
+                                adaptive_ϵ_init=o.adaptive_eps_init != 0, ϵ_min=o.eps_min, f_returns_jacobian=f_returns_jacobian)
+            xa, la, La, val, _ = R.solve!(ref, problem, x_0, u_array; θ=θ_opt, verbose=false)      # the trajectory and gains of the accepted θ
+            return kl_bound > 0 ? (θ_opt, xa, la, La, val + kl_bound / θ_opt, c.theta_min, c.theta_max) : (θ_opt, xa, la, La, val, 0.0, 0.0)
+        end
+        θ_opt = max(0.0, θ_opt - c.sigma)                                                # :412
+    end
 end
 function solve!(s::NelderMeadBilevelOptimizationSolver, problem, x_0::Vector{Float64}, u_array::Vector{Vector{Float64}}; kl_bound::Float64, verbose=false)
     R = reference_module(); o = s.opts; c = s.c
@@ -922,7 +1070,7 @@ end
 export OptimalControlProblem, LQRiskSensitiveProblem, PowerLawRiskSensitiveProblem, LQGenerativeProblem,
        simulate_dynamics, simulate_dynamics_noisy, integrate_cost, ILEQGSolver, initialize!, ApproximationResult, approximate_model,
        DynamicProgrammingResult, solve_approximate_dp!, solve_approximate_dp, increase_μ_and_Δ!, decrease_μ_and_Δ!, line_search!, step!, solve!,
-       solve_batch, solve_approximate_dp_batch!, solve_approximate_dp_batch, CrossEntropyBilevelOptimizationSolver, compute_value_worker, compute_cost, compute_cost_serial, get_positive_samples,
+       solve_batch, solve_approximate_dp_batch!, solve_approximate_dp_batch, solve_closure_batch, closure_device, CrossEntropyBilevelOptimizationSolver, compute_value_worker, compute_cost, compute_cost_serial, get_positive_samples,
        set_initial!, compute_cost_dev!, NelderMeadBilevelOptimizationSolver, compute_cost_worker, CrossEntropyDirectOptimizationSolver,
-       shard_bounds, compute_cost_detail, step_stream!, solve_stream!, stream_pos, set_path!, get_path, is_logical
+       shard_bounds, compute_cost_detail, step_stream!, solve_stream!, stream_pos, set_path!, get_path, is_logical, debug_set!, debug_get
 end
