@@ -390,7 +390,7 @@ rat_rc  rat_set_path(rat_handle h, int32_t path);
 int32_t rat_get_path(rat_handle h, int64_t B);
 
 /* ---- execution switches: ONE entry point for tests, A/B tools and bench.py's contract leg ------------------------------------------
- * Results never depend on a switch, except `wdiag` (another rounding order: ~1e-13 relative).  At rat_create every switch also takes
+ * Results never depend on a switch, except `wdiag` and `block_acl` (another rounding order: ~1e-13 relative).  At rat_create every switch also takes
  * the value of the environment variable RATILQR_<KEY IN CAPITALS> when that is set (the library reads no other environment variable
  * besides RATILQR_MULTI_LOGICAL / RATILQR_MULTI_FORCE_RCCL of rat_create_multi).  A switch that changes the HBM layout of the handle's
  * state (`fused`, `dual`, `speculate` on an E = 1 handle) re-lays it: give rat_set_initial again, as after rat_set_path.
@@ -400,6 +400,8 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   block_max_b     B        E = 1: largest batch the workgroup-per-sample kernel takes under block = -1                 (2 n_cu)
  *   block_shape     0 / 1    two-wave workgroups padded to one wave per SIMD with ticketed SIMD pairs                   (1)
  *   block_helpers   0 / 1    spare waves of a padded workgroup linearise (one workgroup per CU)                          (1)
+ *   block_acl       0 / 1    E = 1 workgroup-per-sample kernel: closed-loop rollouts in deviation form (3 MFMAs on the recursion's
+ *                            chain; values agree with the other paths to rounding, ~1e-15, not bit for bit; opt-in)      (0)
  *   fused_dual      0 / 1    policy evaluation + following gain sweep as two recursions of one wavefront                 (1)
  *   fused_occ2      B0       batches of >= B0 samples: the 256-register one-recursion kernel, two samples per SIMD       (0 = never)
  *   init_share      0 / 1    initialize!'s rollout (independent of theta) rolled out once per (x_0, u_array) and copied   (1)

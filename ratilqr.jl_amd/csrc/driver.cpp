@@ -58,6 +58,8 @@ struct rat_handle_s {
     int *d_census = nullptr;         // solve_block_kernel's per-CU workgroup tickets (two-wave geometry: which SIMD pair a workgroup keeps)
     bool block_shape = true;         // RATILQR_BLOCK_SHAPE=0: plain two-wave workgroups, placement left to the dispatcher
     bool block_helpers = true;       // RATILQR_BLOCK_HELPERS=0: no spare linearise waves at one workgroup per CU
+    bool block_acl = false;          // switch block_acl = 1: deviation-form closed-loop rollouts in the split geometry (rollacl_body; opt-in: measured
+                                     // equal at 128 samples and slower at 512 -- DESIGN.md -- and not bit-identical to the other paths)
     int path_fixed = RAT_PATH_AUTO;  // rat_set_path
     bool fly_multi = true;           // ... and the rollouts of a sample's candidates share one wavefront (rollin_multi_kernel); RATILQR_FLY_MULTI=0
     bool fly = true;                 // round-based path, E > 1, LQ family: line-search candidates are evaluated without tile records in HBM
@@ -156,6 +158,7 @@ static const DebugSwitch debug_switches[] = {
     {"block_max_b", [](rat_handle h, int64_t v) { h->block_max_b = (int)v; }, [](rat_handle h) -> int64_t { return h->block_max_b; }},
     {"block_shape", [](rat_handle h, int64_t v) { h->block_shape = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_shape; }},
     {"block_helpers", [](rat_handle h, int64_t v) { h->block_helpers = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_helpers; }},
+    {"block_acl", [](rat_handle h, int64_t v) { h->block_acl = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_acl; }},
     {"init_share", [](rat_handle h, int64_t v) { h->init_share = (v != 0); }, [](rat_handle h) -> int64_t { return h->init_share; }},
     {"fly", [](rat_handle h, int64_t v) { h->fly = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly; }},
     {"fly_multi", [](rat_handle h, int64_t v) { h->fly_multi = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly_multi; }},
@@ -326,12 +329,12 @@ static rat_rc alloc_state(rat_handle h) {
     rat_rc rc;
 #define AL(ptr, cnt) if ((rc = dev_alloc(h->st_allocs, &(ptr), (cnt)))) return rc
     AL(st.tiles, (st.tile_alias ? (size_t)B : slots) * st.tile_stride);
-    AL(st.xs, slots * st.x_stride);
-    AL(st.us, slots * st.u_stride);
+    AL(st.xs, slots * st.x_stride + STG_PAD);          // (+ STG_PAD: stage_shared reads whole 64-double chunks, possibly past the last slot)
+    AL(st.us, slots * st.u_stride + STG_PAD);
     st.l_half = (long)B * N * LSTR;
     st.dl_half = (long)B * N * USTR;
-    AL(st.L, (size_t)2 * st.l_half);
-    AL(st.dl, (size_t)2 * st.dl_half);
+    AL(st.L, (size_t)2 * st.l_half + STG_PAD);
+    AL(st.dl, (size_t)2 * st.dl_half + STG_PAD);
     AL(st.lsel, B); AL(st.mu_spec, B); AL(st.delta_spec, B); AL(st.spec_st, B);
     AL(st.theta, B); AL(st.mu, B); AL(st.delta, B); AL(st.value, B); AL(st.d_cur, B); AL(st.eps_init, B); AL(st.ls_eps, B);
     AL(st.status, B); AL(st.iter, B); AL(st.ls_active, B); AL(st.ls_count, B); AL(st.slot_nom, B); AL(st.n_ls, B); AL(st.hist_n, B);
@@ -853,6 +856,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         // per CU would have to wait for a whole solve (measured: 768 samples 0.515 ms padded, 0.420 ms plain)
         fa.census = (h->block_shape && h->E == 1 && B <= 2 * h->n_cu) ? h->d_census : nullptr;
         fa.helpers = (fa.census && B <= h->n_cu && h->block_helpers) ? 1 : 0;
+        fa.acl = h->block_acl ? 1 : 0;
         prof_begin(h, path == PATH_BLOCK ? RAT_K_SOLVE_BLOCK : RAT_K_SOLVE_FUSED, B);
         if (path == PATH_BLOCK) launch_solve_block(fa, h->stream); else launch_solve_fused(fa, h->stream);
         prof_end(h);

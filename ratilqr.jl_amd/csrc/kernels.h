@@ -49,6 +49,8 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     // solve_block_kernel only:
     int *census;                       // [CENSUS_SLOTS] per-CU workgroup tickets of the two-wave geometry, or null: see solve_block_kernel
     int helpers;                       // 1: one workgroup per CU (B <= n_cu): the two spare waves of a padded workgroup help linearising
+    int acl;                           // 1: closed-loop rollouts of the split geometry in deviation form (rollacl_body: 3 MFMAs on the recursion's chain;
+                                       //    values to rounding, not bit-identical to the other paths); 0: the round-2/3 split rollouts (switch block_acl)
     // initialize!'s rollout (ileqg.jl:225-228) does not depend on theta: every sample of a batch -- and every batch on the same (x_0,
     // u_array) -- runs the same open-loop trajectory.  The driver rolls it out ONCE per rat_set_initial into a slot of its own (rollin_kernel,
     // the code the samples would run themselves) and the tile-free kernels copy what they read of it: x, u, the [c_x | c_u | c] rows and

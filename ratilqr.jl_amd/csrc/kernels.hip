@@ -1115,6 +1115,12 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
 // "data written, then progress word written" by the producer and "progress word read, then data read" by the consumer need no fence
 // beyond the compiler's (wavefront scope).  The progress word counts up over the whole solve (epoch + t + 1): no reset, no ABA.
 // =====================================================================================================
+#ifdef RAT_DIAG_PHASES
+#define ACL_MARK(dump_, wave_, slot_, val_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8 && (dump_)) \
+        (dump_)[2048 + blockIdx.x * 64 + (wave_) * 16 + (slot_)] = (double)(val_); } while (0)
+#else
+#define ACL_MARK(dump_, wave_, slot_, val_) do {} while (0)
+#endif
 #define XU_REC 20                                   /* doubles per step: [x_t; u_t] packed (16) + (l_t - u_t)^2 per control (4) */
 #define XU_DOUBLES ((ROLLIN_NST + 1) * XU_REC + 64) /* t = 0..N, + dump slots of the idle lanes */
 
@@ -1246,9 +1252,15 @@ __device__ __forceinline__ void rollrec_body(const RolloutArgs &a, const int b, 
 
 // the steps first, first + stride, ... of the trajectory (and, first == 0, the terminal tile)
 // NT: no tile records (the sweeps of the same workgroup are fly sweeps): only [x_t; u_t] and the [c_x | c_u | c] row are stored
-template <int MODE, bool CTV, bool HELP, bool NT = false>
+// UL (deviation-form rollouts, rollacl_body): the record holds x_t only; this wave forms u_t = l_t + eps dl_t + L_t (x_t - xbar_t) itself
+// (the reference's expression, :82, with rollrec_body's operands and summation order) and the squared step norms of d (:517-519).
+// pool: an LDS counter the linearising waves draw their next step from (whoever is free takes it; null: first, first + stride, ...);
+// term: 1 this wave also writes x_N and the terminal tile, 0 it does not (-1: the wave with first == 0).
+template <int MODE, bool CTV, bool HELP, bool NT = false, bool UL = false>
 __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, double *const shxu, const double *const xu, int *const prog, const int epoch,
-                                             const int first, const int stride, unsigned long long *const d_acc) {
+                                             const int first, const int stride, unsigned long long *const d_acc,
+                                             const double *const stg = nullptr, const double eps = 0.0, int *const pool = nullptr,
+                                             const int term = -1) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));
     const int l = lane_, j = l & 15, g = l >> 4;
@@ -1294,17 +1306,50 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
     };
     double dmax = 0.0;
     bool dnan = false;
-    for (int t = first; t < N; t += stride) {
+    constexpr int cL_ = STG_CL, cX_ = STG_CX, cU_ = STG_CU;
+    const double *const sL = stg, *const sX = stg + cL_ * 64, *const sl = sX + cX_ * 64, *const sdl = sl + cU_ * 64;
+    const double m_j3 = (j < 3) ? 1.0 : 0.0;
+    const int pkoff3 = (j < 3) ? 4 * j + g : 0;
+    int have = 0, nextt = 0;                            // steps are drawn from the pool two at a time (one LDS atomic round trip per pair)
+    auto draw = [&]() -> int {
+        if (!have) {
+            int v = 0;
+            if (l == 0) v = __hip_atomic_fetch_add(pool, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nextt = __builtin_amdgcn_readfirstlane(v);
+            have = 2;
+        }
+        --have;
+        return nextt++;
+    };
+    [[maybe_unused]] int nsteps = 0;
+    for (int t = pool ? draw() : first; t < N; t = pool ? draw() : t + stride) {
+        ++nsteps;
         wait_for(epoch + t + 1);
         const double *xt = xu + t * XU_REC;
-        if (HELP && MODE == 1) {                                    // d = maximum(norm(l_t - u_t))  (:517-519): same sum as rollin_body
+        if (!UL && HELP && MODE == 1) {                             // d = maximum(norm(l_t - u_t))  (:517-519): same sum as rollin_body
             const double dn2 = ((xt[16] + xt[17]) + xt[18]) + xt[19];
             dnan |= (dn2 != dn2);
             dmax = (dn2 > dmax) ? dn2 : dmax;
         }
         const double xb[3] = {xt[g], xt[4 + g], xt[8 + g]};
-        const double u = xt[12 + g];
-        const double pk = xt[pkoff] * m_j4;
+        double u, pk;
+        if (UL) {
+            const double c_l = sl[t * USTR + g], c_dl = sdl[t * USTR + g];
+            d4 fb = MFMA(sL[t * LSTR + j3 * 12 + g], xb[0] - sX[t * XSTR + g], zero4);               // L_t (x_t - xbar_t)   (:82)
+            fb = MFMA(sL[t * LSTR + j3 * 12 + 4 + g], xb[1] - sX[t * XSTR + 4 + g], fb);
+            fb = MFMA(sL[t * LSTR + j3 * 12 + 8 + g], xb[2] - sX[t * XSTR + 8 + g], fb);
+            const double lnew = c_l + eps * c_dl;                   // l + eps dl           (:509)
+            u = lnew + fb[0];
+            const double du = c_l - u;                              // d = maximum(norm(l_t - u_t))  (:517-519), as rollin_body
+            const double dsq = du * du;
+            const double dn2 = ((readlane_f64(dsq, 0) + readlane_f64(dsq, 16)) + readlane_f64(dsq, 32)) + readlane_f64(dsq, 48);
+            dnan |= (dn2 != dn2);
+            dmax = (dn2 > dmax) ? dn2 : dmax;
+            pk = xt[pkoff3] * m_j3 + u * pm[3];
+        } else {
+            u = xt[12 + g];
+            pk = xt[pkoff] * m_j4;
+        }
         double *__restrict__ tp = tile0 + (long)t * TSTRIDE;
         if (CTV) {
             const double *__restrict__ C = pb.Ctab + (long)t * 256;
@@ -1334,11 +1379,12 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
         const double part = ((readlane_f64(w, 0) + readlane_f64(w, 16)) + readlane_f64(w, 32)) + readlane_f64(w, 48);
         tp[qoff] = fma(m_l4, part + cq00, m_j4 * (acc + clin));
     }
-    if (HELP && MODE == 1 && l == 0) {
+    if (UL) ACL_MARK(a.dump, (threadIdx.x >> 6), 3, nsteps);
+    if ((HELP || UL) && MODE == 1 && l == 0) {
         atomicMax(&d_acc[0], (unsigned long long)__double_as_longlong(dmax));     // doubles >= +0 order like their bit patterns
         if (dnan) atomicOr(&d_acc[1], 1ull);
     }
-    if (first != 0) return;
+    if (term < 0 ? (first != 0) : (term == 0)) return;
     // x_N and the terminal tile: h, h_x, h_xx at x_N   (ileqg.jl:314-316), as rollin_body
     wait_for(epoch + N + 1);
     {
@@ -1356,6 +1402,212 @@ __device__ __forceinline__ void rolllin_body(const RolloutArgs &a, const int b, 
         if (l == 0) tp[TT_q] = part + pb.q0f;
         WAVE_SYNC();
     }
+}
+
+// =====================================================================================================
+// Closed-loop rollouts in DEVIATION FORM (round 4; solve_block_kernel's split geometry, LQ family): the latency-bound shards
+// (1024 / N samples per GPU, a sample owns 2..4 wavefronts) spent 100 k of their 650 k cycles in two closed-loop rollouts whose
+// recursion wave carried 7 dependent-or-queued f64 MFMAs per step (3 for L_t (x_t - xbar_t), 1 for B u_t, 3 for A x_t: ~1000 cycles).
+// With dx_t = x_t - xbar_t and the nominal pair (xbar, l) a trajectory of the same dynamics (xbar_{t+1} = f(xbar_t, l_t)),
+//     x_{t+1} = A x_t + B (l_t + eps dl_t + L_t dx_t) + kappa x_t^3                                            (ileqg.jl:82-83, f of the LQ family)
+//  => dx_{t+1} = (A + B L_t) dx_t + eps B dl_t + kappa (x_t^3 - xbar_t^3),          x_{t+1} = xbar_{t+1} + dx_{t+1}
+// so the recursion wave issues THREE MFMAs per step (Acl_t dx_t, accumulator started at eps B dl_t) and nothing else on its chain:
+// ~260 cycles per step.  Acl_t' = A' + L_t' B' and B dl_t are ONE MFMA per step (rows 0..11 and row 12 of the same product, the natural
+// [L_t | dl_t] rows being its A operand), formed by a PRODUCER wave a few steps ahead of the recursion through an LDS ring; the
+// controls u_t = l_t + eps dl_t + L_t dx_t (the reference's own expression, from the posted x_t), d = max ||l_t - u_t||, the cost
+// gradient rows and the history stores follow BEHIND the recursion on the linearising waves, as before.
+// Arithmetic: the same trajectory up to rounding (the feedback correction is formed on dx as in the reference; what differs is the order
+// of the sums: ~1e-16 relative per step), so this geometry is NOT bit-identical to the one-wave rollouts of the other paths -- values
+// agree to ~1e-13, iteration / line-search counts are equal (tests/test_gpu_block.py) and parity against the oracle is unchanged
+// (1e-9).  OPT-IN (FusedArgs.acl, switch block_acl = 1): measured on MI355X the phase went 50 k -> 37 k cycles at 128 samples per GPU (batch
+// 0.318 ms either way: the recursion wave reaches ~600 cycles per step, not 260 -- three DEPENDENT f64 MFMAs take ~300, the post /
+// poll / loop overhead of the 256-register kernel another 250 -- and the linearising waves ~1,700 per step) and is slower at 512
+// samples, where two waves share the linearisation; the default stays the round-2/3 split rollouts, bit-identical to every other path.
+// =====================================================================================================
+#define ACL_RING 8                                   /* steps the producer may run ahead of the recursion */
+
+#define ACL_REC 160                                  /* doubles per ring slot: Acl' rows 0..11 on their 48 live lanes x 3 registers (144), then B dl_t [16] */
+#define ACL_DOUBLES (ACL_RING * ACL_REC)
+
+// every wave of the workgroup copies its share of the trajectory's operands (L, xbar, l, dl: rollin_body's STAGE layout) into LDS.
+// Whole 64-double chunks, unclamped: the pools carry STG_PAD doubles of slack behind their last slot (alloc_state), the part of a chunk
+// beyond the trajectory's own data is never read back, and every load is base + immediate offset (per-lane clamped addresses, one
+// register pair per chunk, spilled to scratch in this 256-register kernel and serialised the loads: 28 k cycles instead of 2 k).
+template <int NP>
+__device__ __forceinline__ void stage_shared(const RolloutArgs &a, const int b, const int nom, const int lsel, double *const stg, const int part) {
+    const int l = threadIdx.x & 63;
+    const StateDev &st = a.st;
+    const int N = st.N;
+    const int slot_n = b * (st.E + 1) + nom;
+    const double *__restrict__ xbar = st.xs + (long)slot_n * st.x_stride + l;
+    const double *__restrict__ lnom = st.us + (long)slot_n * st.u_stride + l;
+    const double *__restrict__ Lb = st.L + (long)lsel * st.l_half + (long)b * N * LSTR + l;
+    const double *__restrict__ dlb = st.dl + (long)lsel * st.dl_half + (long)b * N * USTR + l;
+    constexpr int cL = STG_CL, cX = STG_CX, cU = STG_CU;
+    double *const sL = stg + l, *const sX = sL + cL * 64, *const sl = sX + cX * 64, *const sdl = sl + cU * 64;
+    // the gain rows are 2/3 of the bytes: dealt over all NP waves; the last wave also takes xbar, l, dl
+    constexpr int LPER = (cL + NP - 1) / NP;
+    double tL[LPER], tX[cX], tl[cU], tdl[cU];
+    const double *__restrict__ Lw = Lb + (long)part * LPER * 64;
+    const int nl = (cL - part * LPER < LPER) ? cL - part * LPER : LPER;          // (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < LPER; ++q) tL[q] = Lw[64 * q];
+    if (part == NP - 1) {
+#pragma unroll
+        for (int q = 0; q < cX; ++q) tX[q] = xbar[64 * q];
+#pragma unroll
+        for (int q = 0; q < cU; ++q) { tl[q] = lnom[64 * q]; tdl[q] = dlb[64 * q]; }
+    }
+    double *const sLw = sL + part * LPER * 64;
+#pragma unroll
+    for (int q = 0; q < LPER; ++q) if (q < nl) sLw[64 * q] = tL[q];
+    if (part == NP - 1) {
+#pragma unroll
+        for (int q = 0; q < cX; ++q) sX[64 * q] = tX[q];
+#pragma unroll
+        for (int q = 0; q < cU; ++q) { sl[64 * q] = tl[q]; sdl[64 * q] = tdl[q]; }
+    }
+}
+
+__device__ __forceinline__ void spin_until(int *const word, const int want) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - want < 0) { }
+    WAVE_SYNC();
+}
+
+// PRODUCER: Acl_t' = A' + L_t' B' (rows 0..11, register r on lane (g, j): the A operand of K-slice r of Acl_t (.)) and B dl_t (row 12)
+// of step t = 0 .. N-1 into ring slot t mod ACL_RING, at most ACL_RING steps ahead of the recursion (its progress word `prog`).
+__device__ __forceinline__ void rollprod_body(const RolloutArgs &a, const double *const stg, double *const ring, int *const pprog, int *const prog, const int epoch) {
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));
+    const int l = lane_, j = l & 15, g = l >> 4;
+    const ProblemDev &pb = a.pb;
+    const int N = a.st.N;
+    constexpr int cL = STG_CL, cX = STG_CX, cU = STG_CU;
+    const double *const sL = stg, *const sdl = stg + (cL + cX + cU) * 64;
+    const double mq = (j < 12) ? 1.0 : 0.0;
+    const int jx = (j < 12) ? j : 11;
+    d4 cA;                                              // A' in the accumulator layout = the A operand slices of [A | B] (rollrec_body's zA)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) cA[s] = pb.Zt[jx * 16 + 4 * s + g] * mq;
+    cA[3] = 0.0;
+    const double bop = pb.Zt[jx * 16 + 12 + g] * mq;    // B' as the B operand: lane (g, j) = B[j][g]
+    // natural [L_t | dl_t] rows: lane (g, j) = L_t[g][j] (j < 12), dl_t[g] (j == 12), 0 beyond
+    const int loff = (j < 12) ? g * 12 + j : 0, doff = g;
+    const double mL = (j < 12) ? 1.0 : 0.0, mD = (j == 12) ? 1.0 : 0.0;
+    // live lanes of the three registers; dead lanes (columns 12..15: zeros) all write the slot's one zero position
+    const int woff0 = (j < 12) ? 12 * g + j : 144 + 12, woff1 = (j < 12) ? 48 + 12 * g + j : 144 + 12, woff2 = (j < 12) ? 96 + 12 * g + j : 144 + 12;
+    // next step's gain rows are requested before this step's MFMA; the recursion's progress word is only polled when the last value seen
+    // does not yet free the ring slot (it runs at most ACL_RING steps behind)
+    int seen = epoch;
+    double nL = sL[loff], nD = sdl[doff];
+    for (int t = 0; t < N; ++t) {
+        const double la = nL * mL + nD * mD;
+        const int tn = (t + 1 < N) ? t + 1 : t;
+        nL = sL[tn * LSTR + loff]; nD = sdl[tn * USTR + doff];
+        const d4 acl = MFMA(la, bop, cA);
+        if (t >= ACL_RING && seen - (epoch + (t - ACL_RING) + 1) < 0) {            // the recursion has taken step t - ACL_RING's operands
+            do { seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); } while (seen - (epoch + (t - ACL_RING) + 1) < 0);
+            WAVE_SYNC();
+        }
+        double *const slot = ring + (t % ACL_RING) * ACL_REC;
+        slot[woff0] = acl[0] * mq;
+        slot[woff1] = acl[1] * mq;
+        slot[woff2] = acl[2] * mq;
+        if (g == 0) slot[144 + j] = acl[3] * mq;        // row 12 of the product: (B dl_t)[j]; columns 12..15 are zeros
+        WAVE_SYNC();
+        __hip_atomic_store(pprog, epoch + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// RECURSION: dx_{t+1} = Acl_t dx_t + eps B dl_t + kappa (x_t^3 - xbar_t^3); posts x_t = xbar_t + dx_t (packed) and the progress word.
+__device__ __forceinline__ void rollacl_body(const RolloutArgs &a, const double eps, const double *const stg, const double *const ring, double *const xu,
+                                             int *const pprog, int *const prog, const int epoch) {
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));
+    const int l = lane_, j = l & 15, g = l >> 4;
+    const int N = a.st.N;
+    const double kappa = a.pb.kappa;
+    const bool has_cubic = kappa != 0.0;
+    constexpr int cL = STG_CL;
+    const double *const sX = stg + cL * 64;
+    const double pm[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+    const int xoff = (j < 3) ? 4 * j + g : (ROLLIN_NST + 1) * XU_REC + l;         // packed x: lane (g, s), s < 3, holds component 4 s + g; idle lanes: dump
+    const int xstep = (j < 3) ? XU_REC : 0;
+    const int roff0 = (j < 12) ? 12 * g + j : 144 + 12, roff1 = (j < 12) ? 48 + 12 * g + j : 144 + 12, roff2 = (j < 12) ? 96 + 12 * g + j : 144 + 12;
+    double dx[3] = {0.0, 0.0, 0.0};                                               // x_0 = xbar_0 (:73)
+    double xb[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) xb[r] = sX[4 * r + g];
+    // The step's operands are requested one step ahead, under the MFMAs of the step before, and the producer's progress word is only
+    // polled when the last value seen does not cover the step wanted (the producer runs up to ACL_RING steps ahead: one poll per few steps).
+    int known = epoch;
+    auto ensure = [&](const int want) {
+        if (known - want < 0) {
+            do { known = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); } while (known - want < 0);
+            WAVE_SYNC();
+        }
+    };
+    // One step: `cur` holds its operands (Acl_t' slices, B dl_t), `nxt` receives step t + 1's from ring slot KN (a compile-time
+    // position: the time loop is unrolled over the ring, so no LDS address is computed per step and the two operand sets alternate
+    // without copies).  The next operands are REQUESTED before this step's MFMAs are issued: their LDS round trips run under the
+    // matrix pipe (left to the scheduler the loads sank to the top of the next iteration, each in front of its consumer: 880 cycles per step).
+    struct Ops { double a0, a1, a2, p0, p1, p2; };
+    const double *const r0 = ring + roff0, *const r1 = ring + roff1, *const r2 = ring + roff2, *const rp = ring + 144 + g;
+    double *const xup = xu + xoff;
+#ifdef RAT_DIAG_PHASES
+    unsigned long long dgs[4] = {0, 0, 0, 0}, dgt = __builtin_readcyclecounter();
+#define CH_STAMP(i_) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_readcyclecounter(); dgs[i_] += n_ - dgt; dgt = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CH_STAMP(i_) do {} while (0)
+#endif
+    auto step = [&](const int t, const int KN, const Ops &cur, Ops &nxt) {
+        double x[3], cub[3], xn[3];
+        CH_STAMP(3);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) x[r] = xb[r] + dx[r];
+        xup[t * xstep] = (x[0] * pm[0] + x[1] * pm[1]) + x[2] * pm[2];          // x_t = xbar_t + dx_t to the linearising waves
+        WAVE_SYNC();                                  // (the post and the slot's loads are issued before the word that announces them)
+        __hip_atomic_store(prog, epoch + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cub[r] = 0.0;
+        if (has_cubic) {                               // (wave-uniform: a linear f skips the 18 vector instructions of the drift term)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cub[r] = kappa * (x[r] * x[r] * x[r]) - kappa * (xb[r] * xb[r] * xb[r]);
+        }
+        d4 acc = {eps * cur.p0, eps * cur.p1, eps * cur.p2, 0.0};
+        CH_STAMP(0);
+        if (t + 1 < N) ensure(epoch + t + 2);
+        nxt.a0 = r0[KN * ACL_REC]; nxt.a1 = r1[KN * ACL_REC]; nxt.a2 = r2[KN * ACL_REC];
+        nxt.p0 = rp[KN * ACL_REC]; nxt.p1 = rp[KN * ACL_REC + 4]; nxt.p2 = rp[KN * ACL_REC + 8];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xn[r] = sX[(t + 1) * XSTR + 4 * r + g];
+        CH_STAMP(1);
+        acc = MFMA(cur.a0, dx[0], acc);
+        acc = MFMA(cur.a1, dx[1], acc);
+        acc = MFMA(cur.a2, dx[2], acc);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { dx[r] = acc[r] + cub[r]; xb[r] = xn[r]; }
+        asm volatile("" :: "v"(dx[0]), "v"(dx[1]), "v"(dx[2]));
+        CH_STAMP(2);
+    };
+    ensure(epoch + 1);
+    Ops oa, ob;
+    oa.a0 = r0[0]; oa.a1 = r1[0]; oa.a2 = r2[0]; oa.p0 = rp[0]; oa.p1 = rp[4]; oa.p2 = rp[8];
+    static_assert(ACL_RING % 2 == 0, "the operand sets alternate over an even ring");
+    for (int t0 = 0; t0 < N; t0 += ACL_RING) {
+#pragma unroll
+        for (int k = 0; k < ACL_RING; k += 2) {
+            if (t0 + k < N) step(t0 + k, (k + 1) % ACL_RING, oa, ob);
+            if (t0 + k + 1 < N) step(t0 + k + 1, (k + 2) % ACL_RING, ob, oa);
+        }
+    }
+#ifdef RAT_DIAG_PHASES
+    for (int q = 0; q < 4; ++q) ACL_MARK(a.dump, 0, 4 + q, dgs[q]);
+#endif
+    xu[N * xstep + xoff] = ((xb[0] + dx[0]) * pm[0] + (xb[1] + dx[1]) * pm[1]) + (xb[2] + dx[2]) * pm[2];      // x_N
+    WAVE_SYNC();
+    __hip_atomic_store(prog, epoch + N + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 #if RAT_PART & PART_ROLL
@@ -2110,11 +2362,12 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     __shared__ double shxu_all[HWAVES][16];
     __shared__ double stg[STG ? STG_DOUBLES : 1];
     __shared__ double xu[SPLIT ? XU_DOUBLES : 1];
-    __shared__ int prog;
+    __shared__ double aclring[SPLIT ? ACL_DOUBLES : 1];
+    __shared__ int prog, pprog, lpool;
     __shared__ unsigned long long d_acc[2];
     constexpr bool HELP = SPLIT && PAD4;         // fa.helpers: the two waves a padded workgroup does not need stay as linearise helpers
     int epoch = 0;
-    if (threadIdx.x == 0) prog = 0;
+    if (threadIdx.x == 0) { prog = 0; pprog = 0; }
     double *const wls = wls_all[hwave], *const shxu = shxu_all[hwave];
     int wave = hwave;                            // role: 0 .. E-1 candidates, WG gain sweeps
     if (PAD4) {
@@ -2212,7 +2465,31 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     BLK_MARK();
             continue;
         }
-        if (SPLIT) {                                          // the candidate of this line-search round  (ileqg.jl:504-521), split over both waves
+        if (SPLIT && fa.acl) {                                // the candidate of this line-search round in deviation form (rollacl_body)
+            RolloutArgs ra = fa.ro; ra.mode = 1;
+            int nom_, lsel_;
+            double eps_;
+            const bool act = rollout_active<1>(st, b, nom_, lsel_, eps_);       // (every wave reads the same words)
+            if (act) {
+                if (leader) { d_acc[0] = 0ull; d_acc[1] = 0ull; lpool = 0; }
+                if (helpers) stage_shared<4>(ra, b, nom_, lsel_, stg, wave); else stage_shared<2>(ra, b, nom_, lsel_, stg, wave);
+            }
+            BLK_MARK();
+            __syncthreads();
+            BLK_MARK();
+            if (act) {
+                // wave 0 runs the recursion, wave 1 produces its operands ahead of it; the steps are linearised by whoever is free (a
+                // counter in LDS hands out the next one): the spare waves from the start, the producer and the recursion wave once they
+                // are done.  The recursion wave, which holds x_N, writes the terminal tile.
+                ACL_MARK(fa.sw.dump, wave, 0, __builtin_readcyclecounter());
+                if (wave == 0) rollacl_body(ra, eps_, stg, aclring, xu, &pprog, &prog, epoch);
+                else if (wave == 1) rollprod_body(ra, stg, aclring, &pprog, &prog, epoch);
+                ACL_MARK(fa.sw.dump, wave, 1, __builtin_readcyclecounter());
+                rolllin_body<1, CTV, HELP, NTB, true>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc, stg, eps_, &lpool, wave == 0 ? 1 : 0);
+                ACL_MARK(fa.sw.dump, wave, 2, __builtin_readcyclecounter());
+            }
+            epoch += st.N + 2;
+        } else if (SPLIT) {                                   // the candidate of this line-search round  (ileqg.jl:504-521), split over both waves
             RolloutArgs ra = fa.ro; ra.mode = 1;
             if (helpers) {
                 if (wave == 0) rollrec_body<1, HELP>(ra, b, stg, xu, &prog, epoch, d_acc);
@@ -2233,11 +2510,11 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
             SweepArgs sa = fa.sw; sa.mode = 1;
             sweep_body<false, false, WM, true, 0, FLYB>(sa, b * E + wave, wls);
         } else if (wave == WG) {                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
-            if (helpers && (threadIdx.x & 63) == 0) {         // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
+            if ((helpers || (SPLIT && fa.acl)) && (threadIdx.x & 63) == 0) {      // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
                 st.d_c[b * E] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
                 st.flag_c[b * E] = 0;
             }
-            if (helpers) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (helpers || (SPLIT && fa.acl)) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             const double v_dc = *(const volatile double *)&st.d_c[b * E], v_mu = *(const volatile double *)&st.mu[b];   // it ends solve! (:642-653)
             const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
             const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);

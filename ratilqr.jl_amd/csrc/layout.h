@@ -75,6 +75,7 @@
 #define STG_CX (((ROLLIN_NST + 1) * XSTR + 63) / 64)
 #define STG_CU ((ROLLIN_NST * USTR + 63) / 64)
 #define STG_DOUBLES ((STG_CL + STG_CX + 2 * STG_CU) * 64)   /* L, xbar, l, dl of one trajectory: 29,184 B */
+#define STG_PAD (STG_CL * 64)  /* doubles of slack behind the x / u / L / dl pools: whole-chunk staging loads may run past the last slot */
 
 #define ST_RUNNING (-1)
 #define CTR_RING 8          /* per-round counter pairs kept in a ring (host polls one round behind) */

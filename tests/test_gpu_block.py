@@ -150,3 +150,26 @@ def test_padded_workgroups_with_a_co_resident_kernel():
     t2 = threading.Thread(target=drive, args=(c2, bx0, bu, th2, ref2, "backtracking"))
     t1.start(); t2.start(); t1.join(); t2.join()
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("B,kappa", [(96, 0.0), (300, 0.0), (64, 0.05)])
+def test_deviation_form_rollouts_agree_to_rounding(B, kappa):
+    """Switch block_acl = 1 (opt-in): the split geometry's closed-loop rollouts as dx_{t+1} = (A + B L_t) dx_t + eps B dl_t + drift terms
+    on the recursion wave (3 MFMAs per step), controls and cost rows by the linearising waves from a step pool.  Its own rounding order:
+    values agree with the default (bit-identical) paths to ~1e-15, every count is equal, parity against the oracle is unchanged."""
+    prob, x0, u = rat.synthetic_lq_problem(kappa=kappa)
+    theta = np.concatenate([[0.0], np.abs(1.0 + 2.0 * np.random.default_rng(B).standard_normal(B - 2)) + 0.01, [40.0]])
+    res = {}
+    for acl in (0, 1):
+        ctx = rat.Context(prob, max_batch=B)
+        ctx.debug_set("block_acl", acl)
+        assert ctx.get_path(B) == "block" and ctx.debug_get("block_acl") == acl
+        res[acl] = ctx.solve_batch(x0, u, theta)
+    (v0, s0, i0, l0), (v1, s1, i1, l1) = res[0], res[1]
+    assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1)
+    fin = np.isfinite(v0)
+    assert np.array_equal(fin, np.isfinite(v1)) and np.abs(v1[fin] - v0[fin]).max() <= 1e-12 * np.abs(v0[fin]).max()
+    vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta[:24], nthreads=8)
+    f = np.isfinite(vo)
+    assert np.array_equal(s1[:24], so) and np.array_equal(i1[:24], io) and np.array_equal(l1[:24], lo)
+    assert np.abs(v1[:24][f] - vo[f]).max() <= 1e-9 * np.abs(vo[f]).max()

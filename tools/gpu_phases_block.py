@@ -12,7 +12,9 @@ prob, x0, u = rat.synthetic_lq_problem()
 ctx = rat.Context(prob, max_batch=B, spec_eps=1)
 lib = rat.native.lib()
 lib.rat_diag_read_n.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64]
-names = ["init", "rollout 0", "init eval | gain 1", "commit", "rollout 1", "eval 1 | gain 2", "select", "rollout 2", "eval 2 | -", "select", "end"]
+names = (["init", "rollout 0", "init eval | gain 1", "commit", "stage 1", "rollout 1", "eval 1 | gain 2", "select", "stage 2", "rollout 2", "eval 2 | -", "select", "end"]
+         if os.environ.get("RATILQR_BLOCK_ACL", "1") != "0" else
+         ["init", "rollout 0", "init eval | gain 1", "commit", "rollout 1", "eval 1 | gain 2", "select", "rollout 2", "eval 2 | -", "select", "end"])
 for th in (1.0,):
     for _ in range(3):
         ctx.solve_batch(x0, u, np.full(B, th))
