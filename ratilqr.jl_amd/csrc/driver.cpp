@@ -1021,18 +1021,24 @@ extern "C" rat_rc rat_ileqg_solve_batch(rat_handle h, const double *x0, const do
     double *p_theta = reinterpret_cast<double *>(h->h_io), *p_val = p_theta + M;
     int32_t *p_st = reinterpret_cast<int32_t *>(p_val + M), *p_it = p_st + M, *p_ls = p_it + M;
     memcpy(p_theta, theta, B * 8);
-    HIPCHK(hipMemcpyAsync(h->d_theta, p_theta, B * 8, hipMemcpyHostToDevice, h->stream));
-    BatchOut out; out.value = h->d_val; out.status = h->d_ist; out.iters = h->d_iit; out.ls = h->d_ils;
-    rc = run_batch(h, h->d_theta, (int)B, out);
+    // theta is read, and every per-sample output written, IN PLACE in the pinned staging area (device-visible host memory): a sample's own
+    // wave reads its 8 bytes at the start of its solve and writes its 20 at the end -- no copy command before or behind the batch.
+    // (The round-based path, whose several kernels re-read theta, keeps the upload.)
+    const bool zc = pick_path(h, (int)B) != PATH_ROUNDS;
+    if (!zc) HIPCHK(hipMemcpyAsync(h->d_theta, p_theta, B * 8, hipMemcpyHostToDevice, h->stream));
+    BatchOut out;
+    if (zc) { out.value = p_val; out.status = status ? p_st : nullptr; out.iters = iters ? p_it : nullptr; out.ls = ls_evals ? p_ls : nullptr; }
+    else { out.value = h->d_val; out.status = h->d_ist; out.iters = h->d_iit; out.ls = h->d_ils; }
+    rc = run_batch(h, zc ? p_theta : h->d_theta, (int)B, out);
     if (rc) return rc;
-    if (pick_path(h, (int)B) == PATH_ROUNDS) {
+    if (!zc) {
         StateDev st = h->st; st.B = (int)B;
         launch_gather(st, h->d_val, h->d_ist, h->d_iit, h->d_ils, nullptr, 0.0, h->stream);
+        HIPCHK(hipMemcpyAsync(p_val, h->d_val, B * 8, hipMemcpyDeviceToHost, h->stream));
+        if (status) HIPCHK(hipMemcpyAsync(p_st, h->d_ist, B * 4, hipMemcpyDeviceToHost, h->stream));
+        if (iters) HIPCHK(hipMemcpyAsync(p_it, h->d_iit, B * 4, hipMemcpyDeviceToHost, h->stream));
+        if (ls_evals) HIPCHK(hipMemcpyAsync(p_ls, h->d_ils, B * 4, hipMemcpyDeviceToHost, h->stream));
     }
-    HIPCHK(hipMemcpyAsync(p_val, h->d_val, B * 8, hipMemcpyDeviceToHost, h->stream));
-    if (status) HIPCHK(hipMemcpyAsync(p_st, h->d_ist, B * 4, hipMemcpyDeviceToHost, h->stream));
-    if (iters) HIPCHK(hipMemcpyAsync(p_it, h->d_iit, B * 4, hipMemcpyDeviceToHost, h->stream));
-    if (ls_evals) HIPCHK(hipMemcpyAsync(p_ls, h->d_ils, B * 4, hipMemcpyDeviceToHost, h->stream));
     if (h->prefill_want > 0 && pick_path(h, (int)B) != PATH_ROUNDS) prefill_normals(h, h->prefill_want);   // host work under the batch
     HIPCHK(hipStreamSynchronize(h->stream));
     memcpy(value, p_val, B * 8);
@@ -1105,7 +1111,8 @@ static rat_rc ileqg_solve_impl(rat_handle h, const double *x0, const double *u0,
     double *p_d = reinterpret_cast<double *>(h->h_io);            // [0] theta, then value
     int32_t *p_i = reinterpret_cast<int32_t *>(h->h_io + 16);     // status, iter, slot_nom (+ lsel, hist_n in the theta slot afterwards)
     p_d[0] = theta;
-    if (!theta_dev) HIPCHK(hipMemcpyAsync(h->d_theta, p_d, 8, hipMemcpyHostToDevice, h->stream));
+    const bool th_zc = !theta_dev && pick_path(h, 1) != PATH_ROUNDS;      // single-launch solve: theta read in place from the pinned staging word
+    if (!theta_dev && !th_zc) HIPCHK(hipMemcpyAsync(h->d_theta, p_d, 8, hipMemcpyHostToDevice, h->stream));
     const int cap = (int)std::min<int64_t>(std::max<int64_t>(hist_cap, 0), 1 << 20);
     if (eps_hist && cap > 0 && cap > h->hist_dev_cap) {            // the eps-history buffer is kept (and only grown) across calls
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1135,27 +1142,35 @@ static rat_rc ileqg_solve_impl(rat_handle h, const double *x0, const double *u0,
     double *const s_x = h->h_sol, *const s_u = s_x + nslot * xs, *const s_L = s_u + nslot * us, *const s_h = s_L + nL * Ls;
     BatchOut wo;
     if (wide) { wo.value = h->d_val; wo.status = h->d_ist; wo.iters = h->d_iit; }
-    rc = run_batch(h, theta_dev ? theta_dev : h->d_theta, 1, wo);
+    rc = run_batch(h, theta_dev ? theta_dev : (th_zc ? p_d : h->d_theta), 1, wo);
     h->st.hist = nullptr; h->st.hist_cap = 0;
     if (rc) return rc;
     if (extra_bytes) HIPCHK(hipMemcpyAsync(extra_dst, extra_src, extra_bytes, hipMemcpyDeviceToHost, h->stream));
     int32_t *p_j = reinterpret_cast<int32_t *>(h->h_io);          // (the theta slot is free once the batch is enqueued behind its upload)
     const StateDev &st = h->st;
-    HIPCHK(hipMemcpyAsync(p_d + 1, wide ? h->d_val : st.value, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(p_i + 0, wide ? h->d_ist : st.status, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(p_i + 1, wide ? h->d_iit : st.iter, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(p_i + 2, wide ? h->w_nom : st.slot_nom, 4, hipMemcpyDeviceToHost, h->stream));
-    if (!wide) HIPCHK(hipMemcpyAsync(p_j + 0, st.lsel, 4, hipMemcpyDeviceToHost, h->stream));
-    if (want_hist || !wide) HIPCHK(hipMemcpyAsync(p_j + 1, wide ? h->w_hn : st.hist_n, 4, hipMemcpyDeviceToHost, h->stream));
-    if (x) HIPCHK(hipMemcpyAsync(s_x, wide ? h->w_xs : st.xs, nslot * xs * 8, hipMemcpyDeviceToHost, h->stream));
-    if (l) HIPCHK(hipMemcpyAsync(s_u, wide ? h->w_us : st.us, nslot * us * 8, hipMemcpyDeviceToHost, h->stream));
-    if (L) {
-        HIPCHK(hipMemcpyAsync(s_L, wide ? h->w_L : st.L, Ls * 8, hipMemcpyDeviceToHost, h->stream));
-        if (!wide) HIPCHK(hipMemcpyAsync(s_L + Ls, st.L + st.l_half, Ls * 8, hipMemcpyDeviceToHost, h->stream));
-    }
+    int st_h, it_h, nom, lsel, hn;
+    if (!wide) {
+        // ONE launch packs the accepted slot, the committed gain half and the scalars straight into the pinned staging area (the device
+        // writes host memory in place), then ONE host wait: no copy commands behind the solve
+        double *const s_s = reinterpret_cast<double *>(h->h_io) + 2;                 // 6 doubles of scalars (h_io holds >= 64 bytes)
+        launch_pack_solution(st, x ? s_x : nullptr, l ? s_u : nullptr, L ? s_L : nullptr, s_s, h->stream);
+        if (hist_first) HIPCHK(hipMemcpyAsync(s_h, h->d_hist, hist_first * 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        p_d[1] = s_s[0]; st_h = (int)s_s[1]; it_h = (int)s_s[2]; hn = (int)s_s[3]; nom = 0; lsel = 0;      // (the packed copies ARE the selected slot / half)
+        if ((int)s_s[4] < 0 || (size_t)s_s[4] >= nslot || (int)s_s[5] < 0 || (int)s_s[5] > 1) return fail(RAT_ERR_HIP, "rat_ileqg_solve: slot index out of range");
+    } else {
+    HIPCHK(hipMemcpyAsync(p_d + 1, h->d_val, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 0, h->d_ist, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 1, h->d_iit, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p_i + 2, h->w_nom, 4, hipMemcpyDeviceToHost, h->stream));
+    if (want_hist) HIPCHK(hipMemcpyAsync(p_j + 1, h->w_hn, 4, hipMemcpyDeviceToHost, h->stream));
+    if (x) HIPCHK(hipMemcpyAsync(s_x, h->w_xs, nslot * xs * 8, hipMemcpyDeviceToHost, h->stream));
+    if (l) HIPCHK(hipMemcpyAsync(s_u, h->w_us, nslot * us * 8, hipMemcpyDeviceToHost, h->stream));
+    if (L) HIPCHK(hipMemcpyAsync(s_L, h->w_L, Ls * 8, hipMemcpyDeviceToHost, h->stream));
     if (hist_first) HIPCHK(hipMemcpyAsync(s_h, h->d_hist, hist_first * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const int st_h = p_i[0], it_h = p_i[1], nom = p_i[2], lsel = wide ? 0 : p_j[0], hn = (want_hist || !wide) ? p_j[1] : 0;
+    st_h = p_i[0]; it_h = p_i[1]; nom = p_i[2]; lsel = 0; hn = want_hist ? p_j[1] : 0;
+    }
     if (status) *status = st_h;
     if (iters) *iters = it_h;
     if (value) *value = (st_h == 0 || st_h == 3) ? p_d[1] : INFINITY;
