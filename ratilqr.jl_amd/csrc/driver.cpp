@@ -105,9 +105,10 @@ struct rat_handle_s {
     GenDev gen;
     int gn = 0, gm = 0, gN = 0;
     std::vector<void *> gen_allocs;
-    double *d_px0 = nullptr, *d_pctrl = nullptr, *d_pzn = nullptr, *d_pzu = nullptr, *d_ptraj = nullptr, *d_pcost = nullptr;
-    size_t cap_ctrl = 0, cap_zn = 0, cap_zu = 0, cap_traj = 0, cap_cost = 0;
-    double *h_pstage = nullptr; size_t cap_pstage = 0;      // pinned staging of x0 | padded controls (asynchronous uploads)
+    double *d_pin = nullptr, *d_pzn = nullptr, *d_pzu = nullptr, *d_ptraj = nullptr, *d_pcost = nullptr;   // d_pin: x0 | padded controls
+    size_t cap_pin = 0, cap_zn = 0, cap_zu = 0, cap_traj = 0, cap_cost = 0;
+    double *h_pstage = nullptr; size_t cap_pstage = 0;      // pinned staging of x0 | padded controls (pets_stage_kernel reads it over the link)
+    double *h_pcost = nullptr; size_t cap_hpcost = 0;       // pinned landing zone of the sample costs of the synchronous call (zero-copy)
     // CE randomness
     const double *z = nullptr;
     int64_t nz = 0, zpos = 0;
@@ -119,6 +120,8 @@ struct rat_handle_s {
     size_t zfifo_pos = 0;
     int64_t prefill_want = 0;        // set by rat_ce_step around its batch: how many normals to have ready when the batch returns
     // device-resident Cross-Entropy loop of rat_ce_solve (ce_device.hip): state record, normal stream, theta / cost of the batch in flight
+    int pets_wave16 = 1;             // switch pets_wave16: 0 PETS rollouts four per wavefront (rounds 1-3); 1 sixteen as MFMA columns, generator
+                                     // wavefronts split off for small launches; 2 sixteen, never split; 3 sixteen, always split
     bool ce_device = true;           // switch ce_device = 0: the host loop (one round trip per CE iteration)
     CeDev *d_ce = nullptr, *h_ce = nullptr;          // device record, pinned host mirror
     double *d_cez = nullptr, *h_cez = nullptr; size_t cap_cez = 0;      // standard normals: pinned host buffer and its device address (read in place)
@@ -165,6 +168,7 @@ static const DebugSwitch debug_switches[] = {
     {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
     {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
     {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
+    {"pets_wave16", [](rat_handle h, int64_t v) { h->pets_wave16 = (v < 0 || v > 3) ? 1 : (int)v; }, [](rat_handle h) -> int64_t { return h->pets_wave16; }},
     {"ce_device", [](rat_handle h, int64_t v) { h->ce_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->ce_device; }},
 };
 // what the requests amount to on this handle (speculation width, forced pairings)
@@ -243,7 +247,8 @@ extern "C" void rat_destroy(rat_handle h) {
     free_list(h->pb_allocs);
     free_list(h->st_allocs);
     free_list(h->gen_allocs);
-    for (double *q : {h->d_px0, h->d_pctrl, h->d_pzn, h->d_pzu, h->d_ptraj, h->d_pcost}) if (q) (void)hipFree(q);
+    for (double *q : {h->d_pin, h->d_pzn, h->d_pzu, h->d_ptraj, h->d_pcost}) if (q) (void)hipFree(q);
+    if (h->h_pcost) (void)hipHostFree(h->h_pcost);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->h_io) (void)hipHostFree(h->h_io);
@@ -2304,48 +2309,59 @@ static rat_rc grow(double **p, size_t *cap, size_t need) {
 rat_rc rat_pets_enqueue(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K, int32_t use_true_model, const double *zn,
                         const double *zu, uint64_t seed, int64_t sample0, double *cost);
 
-extern "C" rat_rc rat_pets_compute_cost(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K,
-                                        int32_t use_true_model, const double *zn, const double *zu, uint64_t seed, double *cost) {   // pets.jl:128-157
-    rat_rc rc = rat_pets_enqueue(h, x0, controls, S, K, use_true_model, zn, zu, seed, 0, cost);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return RAT_OK;
-}
-
-rat_rc rat_pets_enqueue(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K, int32_t use_true_model, const double *zn,
-                        const double *zu, uint64_t seed, int64_t sample0, double *cost) {
-    if (!h || !x0 || !controls || !cost) return fail(RAT_ERR_ARG, "null");
+// One compute_cost evaluation enqueued on the handle's stream.  x0 and the padded controls are packed into a pinned staging area and pulled
+// into device memory by pets_stage_kernel; the costs either land in the handle's pinned h_pcost, written by pets_mean_kernel itself
+// (cost == nullptr: the synchronous call below copies them out after its wait), or are copied to `cost` by the copy engine (the several-GPU
+// driver's pinned landing zone, multi.cpp).  No copy-engine transfer sits between host and kernels on the synchronous path: each costs
+// ~10 us of engine hand-over against a 20-50 us kernel at BASELINE config 5's 10k trajectories.
+static rat_rc pets_enqueue_impl(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K, int32_t use_true_model,
+                                const double *zn, const double *zu, uint64_t seed, int64_t sample0, double *cost) {
+    if (!h || !x0 || !controls) return fail(RAT_ERR_ARG, "null");
     if (!h->have_gen) return fail(RAT_ERR_NO_PROBLEM, "rat_pets_problem_set was not called");
     if (S < 1 || K < 1) return fail(RAT_ERR_ARG, "S, K must be positive");
     HIPCHK(hipSetDevice(h->device));
     const int n = h->gn, m = h->gm, N = h->gN;
     const size_t ntraj = (size_t)S * K;
     rat_rc rc;
-    if (!h->d_px0) HIPCHK(hipMalloc((void **)&h->d_px0, XSTR * sizeof(double)));
-    if ((rc = grow(&h->d_pctrl, &h->cap_ctrl, (size_t)S * N * USTR))) return rc;
-    if ((rc = grow(&h->d_ptraj, &h->cap_traj, ntraj))) return rc;
-    if ((rc = grow(&h->d_pcost, &h->cap_cost, (size_t)S))) return rc;
-    // padded x0 and controls in a pinned staging area owned by the handle: the uploads are asynchronous and must outlive this call
     const size_t nstage = XSTR + (size_t)S * N * USTR;
+    HIPCHK(hipStreamSynchronize(h->stream));                  // (a previous enqueue may still be reading the staging area and the buffers)
+    if ((rc = grow(&h->d_pin, &h->cap_pin, nstage))) return rc;
+    if ((rc = grow(&h->d_ptraj, &h->cap_traj, ntraj))) return rc;
     if (nstage > h->cap_pstage) {
-        HIPCHK(hipStreamSynchronize(h->stream));
         if (h->h_pstage) (void)hipHostFree(h->h_pstage);
         h->h_pstage = nullptr; h->cap_pstage = 0;
         HIPCHK(hipHostMalloc((void **)&h->h_pstage, nstage * sizeof(double), hipHostMallocDefault));
         h->cap_pstage = nstage;
+    }
+    double *cost_dev = nullptr;
+    if (cost) {
+        if ((rc = grow(&h->d_pcost, &h->cap_cost, (size_t)S))) return rc;
+        cost_dev = h->d_pcost;
     } else {
-        HIPCHK(hipStreamSynchronize(h->stream));          // (a previous enqueue may still be reading the staging area)
+        if ((size_t)S > h->cap_hpcost) {
+            if (h->h_pcost) (void)hipHostFree(h->h_pcost);
+            h->h_pcost = nullptr; h->cap_hpcost = 0;
+            HIPCHK(hipHostMalloc((void **)&h->h_pcost, (size_t)S * sizeof(double), hipHostMallocDefault));
+            h->cap_hpcost = (size_t)S;
+        }
+        HIPCHK(hipHostGetDevicePointer((void **)&cost_dev, h->h_pcost, 0));
     }
     double *xp = h->h_pstage, *cp = h->h_pstage + XSTR;
-    memset(xp, 0, nstage * sizeof(double));
+    memset(xp, 0, XSTR * sizeof(double));
     for (int i = 0; i < n; ++i) xp[i] = x0[i];
-    for (int64_t ii = 0; ii < S; ++ii) for (int t = 0; t < N; ++t) for (int a = 0; a < m; ++a)
-        cp[((size_t)ii * N + t) * USTR + a] = controls[((size_t)ii * N + t) * m + a];
-    HIPCHK(hipMemcpyAsync(h->d_px0, xp, XSTR * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pctrl, cp, (size_t)S * N * USTR * 8, hipMemcpyHostToDevice, h->stream));
+    if (m == USTR) memcpy(cp, controls, (size_t)S * N * USTR * sizeof(double));
+    else {
+        memset(cp, 0, (size_t)S * N * USTR * sizeof(double));
+        for (int64_t ii = 0; ii < S; ++ii) for (int t = 0; t < N; ++t) for (int a = 0; a < m; ++a)
+            cp[((size_t)ii * N + t) * USTR + a] = controls[((size_t)ii * N + t) * m + a];
+    }
+    const double *stage_dev = nullptr;
+    HIPCHK(hipHostGetDevicePointer((void **)&stage_dev, h->h_pstage, 0));
+    launch_pets_stage(stage_dev, h->d_pin, (long)nstage, h->stream);
     PetsArgs a;
-    a.g = h->gen; a.x0 = h->d_px0; a.controls = h->d_pctrl; a.S = S; a.K = K; a.use_true = use_true_model ? 1 : 0;
-    a.zn = nullptr; a.zu = nullptr; a.seed = seed; a.traj0 = (long)(sample0 * K); a.traj_cost = h->d_ptraj; a.cost = h->d_pcost;
+    a.g = h->gen; a.x0 = h->d_pin; a.controls = h->d_pin + XSTR; a.S = S; a.K = K; a.use_true = use_true_model ? 1 : 0;
+    a.zn = nullptr; a.zu = nullptr; a.seed = seed; a.traj0 = (long)(sample0 * K); a.traj_cost = h->d_ptraj; a.cost = cost_dev;
+    a.wave16 = h->pets_wave16;
     if (zn) {
         if ((rc = grow(&h->d_pzn, &h->cap_zn, ntraj * N * n))) return rc;
         HIPCHK(hipMemcpyAsync(h->d_pzn, zn, ntraj * N * n * 8, hipMemcpyHostToDevice, h->stream));
@@ -2359,8 +2375,25 @@ rat_rc rat_pets_enqueue(rat_handle h, const double *x0, const double *controls, 
     prof_begin(h, RAT_K_PETS, (int64_t)ntraj);
     launch_pets(a, h->stream);
     prof_end(h);
-    HIPCHK(hipMemcpyAsync(cost, h->d_pcost, (size_t)S * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipGetLastError());
+    if (cost) HIPCHK(hipMemcpyAsync(cost, h->d_pcost, (size_t)S * 8, hipMemcpyDeviceToHost, h->stream));
     return RAT_OK;
+}
+
+extern "C" rat_rc rat_pets_compute_cost(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K,
+                                        int32_t use_true_model, const double *zn, const double *zu, uint64_t seed, double *cost) {   // pets.jl:128-157
+    if (!cost) return fail(RAT_ERR_ARG, "null");
+    rat_rc rc = pets_enqueue_impl(h, x0, controls, S, K, use_true_model, zn, zu, seed, 0, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(cost, h->h_pcost, (size_t)S * sizeof(double));
+    return RAT_OK;
+}
+
+rat_rc rat_pets_enqueue(rat_handle h, const double *x0, const double *controls, int64_t S, int64_t K, int32_t use_true_model, const double *zn,
+                        const double *zu, uint64_t seed, int64_t sample0, double *cost) {
+    if (!cost) return fail(RAT_ERR_ARG, "null");
+    return pets_enqueue_impl(h, x0, controls, S, K, use_true_model, zn, zu, seed, sample0, cost);
 }
 
 extern "C" rat_rc rat_pets_sample_controls(const rat_pets_solver *s, const double *zc, double *controls) {   // pets.jl:206-216

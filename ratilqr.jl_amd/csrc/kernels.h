@@ -82,8 +82,12 @@ struct PetsArgs {
     long traj0;                 // global index of this launch's first trajectory (device generator counter)
     double *traj_cost;          // [S*K]
     double *cost;               // [S]
+    int wave16;                 // 0: pets_rollout_kernel (4 trajectories per wavefront); 1 (default): 16 per wavefront as MFMA columns, noise
+                                // generation in separate wavefronts for launches of <= PETS_SPLIT_MAX_WAVES; 2: never split; 3: always split
 };
+#define PETS_SPLIT_MAX_WAVES 1536
 void launch_pets(const PetsArgs &a, hipStream_t s);
+void launch_pets_stage(const double *src, double *dst, long count, hipStream_t s);
 
 struct NoisyArgs {              // Monte-Carlo rollouts under process noise (simulate_dynamics with rng)
     ProblemDev pb;

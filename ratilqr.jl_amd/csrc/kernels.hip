@@ -2874,6 +2874,324 @@ void launch_noisy_rollout(const NoisyArgs &a, hipStream_t s) {
 // mean over the K rollouts of each control sample (pets.jl:150): one wavefront per sample, lane l sums rollouts l, l + 64, ... in
 // order, then the 64 partial sums in a fixed tree -- deterministic, independent of the launch geometry (a thread per sample summing K
 // values one after the other took 160 us at K = 1000)
+// =====================================================================================================
+// pets_rollout16_kernel (round 4): SIXTEEN stochastic rollouts per wavefront -- trajectory j is column j of every MFMA's B operand, the
+// state lives in B-form (register r of lane (g, j): component 4 r + g of trajectory j), as in rollin_multi_kernel.  Per step
+//     C [x; u]           4 MFMAs   -> stage cost  [x;u]' (1/2 C [x;u] + lin) + q0 + l1u |u|_1     (pets.jl:143), summed over a column's four rows
+//     [A | B] [x; u]     4 MFMAs   -> f(x, u) (+ kappa x^3 per lane)
+//     chol z             3 MFMAs   -> w = mean + chol z   (3 more for the second mixture component of the true model; none for uniform noise)
+// against 44 multiply-adds and 44 LDS reads per lane and step for FOUR trajectories in pets_rollout_kernel.  Every lane draws the three
+// normals of ITS components (4 r + g, r < 3) of ITS trajectory: the Philox key is the one of pets_rollout_kernel -- (trajectory, step pair,
+// component) -- so the device generator hands the SAME normals to the same (trajectory, step, component); only now all 64 lanes of the wave
+// generate useful draws (12 of every 16 before).  Sums run in the MFMA's order: costs agree with the 4-per-wave kernel and the oracle to
+// rounding (tests/test_gpu_pets.py: 1e-11 on injected noise).
+// =====================================================================================================
+__global__ __launch_bounds__(64) void pets_rollout16_kernel(PetsArgs a) {
+    const int l = threadIdx.x, g = l >> 4, j = l & 15;
+    const GenDev &gd = a.g;
+    const long ntraj = a.S * a.K;
+    const long tj = (long)blockIdx.x * 16 + j;
+    const bool live = tj < ntraj;
+    const long tjc = live ? tj : 0;
+    const long tjg = tj + a.traj0;
+    const long ii = tjc / a.K;
+    const int N = gd.N, n = gd.n;
+    const int jr = (j < 12) ? j : 11;
+    const double mq = (j < 12) ? 1.0 : 0.0;
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    // A operands: lane (g, j) of slice s holds M[row j][4 s + g]
+    double zA[4], cA[4], nA[3], tA[3], qA[3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { zA[s] = gd.Zt[jr * 16 + 4 * s + g] * mq; cA[s] = gd.Ctab[j * 16 + 4 * s + g]; }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        nA[s] = gd.nchol[jr * 16 + 4 * s + g] * mq;
+        tA[s] = gd.tchol2 ? gd.tchol2[jr * 16 + 4 * s + g] * mq : 0.0;
+        qA[s] = gd.Qf[jr * 12 + 4 * s + g] * mq;
+    }
+    // per-component constants in B-form
+    double linb[4], nmb[3], tmb[3], qvb[3], cmask[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) linb[r] = gd.lin[4 * r + g];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        nmb[r] = gd.nmean[4 * r + g]; tmb[r] = gd.tmean2 ? gd.tmean2[4 * r + g] : 0.0; qvb[r] = gd.qvf[4 * r + g];
+        cmask[r] = (4 * r + g < n) ? 1.0 : 0.0;
+    }
+    double q0t = gd.q0[0];
+    const double l1u = (g < gd.m) ? gd.l1u : 0.0;
+    const bool need_sel = a.use_true && gd.tw2 > 0.0;          // the mixture selector is only drawn when a second component exists
+    const bool gauss = gd.noise_kind == 0;
+    double xs[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) xs[r] = a.x0[4 * r + g];
+    const double *__restrict__ uc = a.controls + ii * N * USTR + g;
+    double cacc = 0.0;
+    double zn1[3] = {0.0, 0.0, 0.0};
+    double unext = uc[0];
+    for (int t = 0; t < N; ++t) {
+        if (gd.cost_tv) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { cA[s] = gd.Ctab[(long)t * 256 + j * 16 + 4 * s + g]; linb[s] = gd.lin[(long)t * 16 + 4 * s + g]; }
+            q0t = gd.q0[t];
+        }
+        const double u = unext;
+        unext = uc[(long)((t + 1 < N) ? t + 1 : t) * USTR];
+        // draws of this (trajectory, step): z (the lane's three components) and the mixture selector
+        double z[3], zsel = 1.0;
+        if (a.zn) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) z[r] = (4 * r + g < n && live) ? a.zn[((tjc * N + t) * (long)n) + 4 * r + g] : 0.0;
+            if (a.zu && live) zsel = a.zu[tjc * N + t];
+        } else {
+            if ((t & 1) == 0) {                                // one Philox block and one Box-Muller transform serve two consecutive steps
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    unsigned rr[4];
+                    philox4x32_10((unsigned)tjg, (unsigned)(tjg >> 32), (unsigned)(t >> 1), (unsigned)(4 * r + g), (unsigned)a.seed, (unsigned)(a.seed >> 32), rr);
+                    const double u1 = u01(rr[0], rr[1]), u2 = u01(rr[2], rr[3]);
+                    if (!gauss && !need_sel) { z[r] = u1; zn1[r] = u2; }
+                    else {
+                        const double rad = sqrt(-2.0 * log(1.0 - u1));
+                        double sn, cs;
+                        sincospi(2.0 * u2, &sn, &cs);
+                        z[r] = rad * cs; zn1[r] = rad * sn;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) z[r] = zn1[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) z[r] *= cmask[r];
+            if (need_sel) {
+                unsigned rs[4];
+                philox4x32_10((unsigned)tjg, (unsigned)(tjg >> 32), (unsigned)t, 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);
+                zsel = u01(rs[0], rs[1]);
+            }
+        }
+        // stage cost
+        d4 cx = MFMA(cA[0], xs[0], zero4);
+        cx = MFMA(cA[1], xs[1], cx);
+        cx = MFMA(cA[2], xs[2], cx);
+        cx = MFMA(cA[3], u, cx);
+        // dynamics
+        d4 xa = MFMA(zA[0], xs[0], zero4);
+        xa = MFMA(zA[1], xs[1], xa);
+        xa = MFMA(zA[2], xs[2], xa);
+        xa = MFMA(zA[3], u, xa);
+        double part = ((xs[0] * (0.5 * cx[0] + linb[0]) + xs[1] * (0.5 * cx[1] + linb[1])) + xs[2] * (0.5 * cx[2] + linb[2])) +
+                      (u * (0.5 * cx[3] + linb[3]) + l1u * fabs(u));
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        cacc += part + q0t;
+        // stochastic transition x <- f_stochastic(x, u, rng, use_true_model)     (pets.jl:144)
+        double w[3];
+        const bool second = a.use_true && (zsel < gd.tw2);
+        if (gauss) {
+            d4 wz = MFMA(nA[0], z[0], zero4);
+            wz = MFMA(nA[1], z[1], wz);
+            wz = MFMA(nA[2], z[2], wz);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) w[r] = nmb[r] + wz[r];
+            if (need_sel) {
+                d4 w2 = MFMA(tA[0], z[0], zero4);
+                w2 = MFMA(tA[1], z[1], w2);
+                w2 = MFMA(tA[2], z[2], w2);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) w[r] = second ? tmb[r] + w2[r] : w[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) w[r] = gd.nlo + (gd.nhi - gd.nlo) * z[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double dyn = xa[r];
+            if (gd.kappa != 0.0) dyn += gd.kappa * (xs[r] * xs[r] * xs[r]);
+            xs[r] = (dyn + w[r]) * cmask[r];
+        }
+    }
+    // terminal cost h(x_N)     (pets.jl:147)
+    d4 qx = MFMA(qA[0], xs[0], zero4);
+    qx = MFMA(qA[1], xs[1], qx);
+    qx = MFMA(qA[2], xs[2], qx);
+    double part = (xs[0] * (0.5 * qx[0] + qvb[0]) + xs[1] * (0.5 * qx[1] + qvb[1])) + xs[2] * (0.5 * qx[2] + qvb[2]);
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (live && g == 0) a.traj_cost[tj] = cacc + part + gd.q0f;
+}
+
+// pets_rollout16s_kernel: the same sixteen-column recursion with the noise generation moved OFF the recursion's wavefront.  A launch of
+// <= 1024 wavefronts of pets_rollout16_kernel (16k trajectories: BASELINE config 5 has 10k) leaves most of the chip's 1024 SIMDs idle and
+// its time is ONE wavefront's latency -- 30 steps of (Philox + Box-Muller ~2000 cycles, then eleven MFMAs ~800 cycles).  Here a workgroup
+// is four wavefronts: waves 1..3 draw component register r = wave - 1 of every lane for one step PAIR (one Philox block and one Box-Muller
+// transform yield the normals of steps 2p and 2p + 1) into a double-buffered LDS slab while wave 0 consumes the previous pair; one
+// __syncthreads() per pair hands over.  Lane (g, j) of generator wave r computes exactly what lane (g, j) computed for register r before,
+// and wave 0's arithmetic is unchanged: the costs are bit-identical to pets_rollout16_kernel's (tests/test_gpu_pets.py).
+__global__ __launch_bounds__(256) void pets_rollout16s_kernel(PetsArgs a) {
+    __shared__ double zbuf[2][2][3][64];                       // [pair parity][step of the pair][register r][lane]
+    __shared__ double sbuf[2][2][16];                          // mixture selector of trajectory column j
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, j = l & 15;
+    const GenDev &gd = a.g;
+    const long ntraj = a.S * a.K;
+    const long tj = (long)blockIdx.x * 16 + j;
+    const bool live = tj < ntraj;
+    const long tjc = live ? tj : 0;
+    const long tjg = tj + a.traj0;
+    const int N = gd.N, n = gd.n;
+    const int npair = (N + 1) >> 1;
+    const bool need_sel = a.use_true && gd.tw2 > 0.0;
+    const bool gauss = gd.noise_kind == 0;
+    if (wv > 0) {
+        const int r = wv - 1, comp = 4 * r + g;
+        const double cm = (comp < n) ? 1.0 : 0.0;
+        for (int p = 0; p <= npair; ++p) {
+            if (p < npair) {
+                const int t = 2 * p;
+                const bool two = t + 1 < N;
+                double z0, z1 = 0.0, s0 = 1.0, s1 = 1.0;
+                if (a.zn) {
+                    const bool on = comp < n && live;
+                    z0 = on ? a.zn[((tjc * N + t) * (long)n) + comp] : 0.0;
+                    if (two) z1 = on ? a.zn[((tjc * N + t + 1) * (long)n) + comp] : 0.0;
+                    if (r == 0 && a.zu && live) { s0 = a.zu[tjc * N + t]; if (two) s1 = a.zu[tjc * N + t + 1]; }
+                } else {
+                    unsigned rr[4];
+                    philox4x32_10((unsigned)tjg, (unsigned)(tjg >> 32), (unsigned)p, (unsigned)comp, (unsigned)a.seed, (unsigned)(a.seed >> 32), rr);
+                    const double u1 = u01(rr[0], rr[1]), u2 = u01(rr[2], rr[3]);
+                    if (!gauss && !need_sel) { z0 = u1; z1 = u2; }
+                    else {
+                        const double rad = sqrt(-2.0 * log(1.0 - u1));
+                        double sn, cs;
+                        sincospi(2.0 * u2, &sn, &cs);
+                        z0 = rad * cs; z1 = rad * sn;
+                    }
+                    z0 *= cm; z1 *= cm;
+                    if (r == 0 && need_sel) {
+                        unsigned rs[4];
+                        philox4x32_10((unsigned)tjg, (unsigned)(tjg >> 32), (unsigned)t, 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);
+                        s0 = u01(rs[0], rs[1]);
+                        if (two) {
+                            philox4x32_10((unsigned)tjg, (unsigned)(tjg >> 32), (unsigned)(t + 1), 0xFFFFu, (unsigned)a.seed, (unsigned)(a.seed >> 32), rs);
+                            s1 = u01(rs[0], rs[1]);
+                        }
+                    }
+                }
+                zbuf[p & 1][0][r][l] = z0; zbuf[p & 1][1][r][l] = z1;
+                if (r == 0 && g == 0) { sbuf[p & 1][0][j] = s0; sbuf[p & 1][1][j] = s1; }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const long ii = tjc / a.K;
+    const int jr = (j < 12) ? j : 11;
+    const double mq = (j < 12) ? 1.0 : 0.0;
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    double zA[4], cA[4], nA[3], tA[3], qA[3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { zA[s] = gd.Zt[jr * 16 + 4 * s + g] * mq; cA[s] = gd.Ctab[j * 16 + 4 * s + g]; }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        nA[s] = gd.nchol[jr * 16 + 4 * s + g] * mq;
+        tA[s] = gd.tchol2 ? gd.tchol2[jr * 16 + 4 * s + g] * mq : 0.0;
+        qA[s] = gd.Qf[jr * 12 + 4 * s + g] * mq;
+    }
+    double linb[4], nmb[3], tmb[3], qvb[3], cmask[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) linb[r] = gd.lin[4 * r + g];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        nmb[r] = gd.nmean[4 * r + g]; tmb[r] = gd.tmean2 ? gd.tmean2[4 * r + g] : 0.0; qvb[r] = gd.qvf[4 * r + g];
+        cmask[r] = (4 * r + g < n) ? 1.0 : 0.0;
+    }
+    double q0t = gd.q0[0];
+    const double l1u = (g < gd.m) ? gd.l1u : 0.0;
+    double xs[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) xs[r] = a.x0[4 * r + g];
+    const double *__restrict__ uc = a.controls + ii * N * USTR + g;
+    double cacc = 0.0;
+    double unext = uc[0];
+    __syncthreads();                                           // pair 0 is in the slab
+    for (int p = 0; p < npair; ++p) {
+        for (int hh = 0; hh < 2; ++hh) {
+            const int t = 2 * p + hh;
+            if (t >= N) break;
+            if (gd.cost_tv) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { cA[s] = gd.Ctab[(long)t * 256 + j * 16 + 4 * s + g]; linb[s] = gd.lin[(long)t * 16 + 4 * s + g]; }
+                q0t = gd.q0[t];
+            }
+            const double u = unext;
+            unext = uc[(long)((t + 1 < N) ? t + 1 : t) * USTR];
+            double z[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) z[r] = zbuf[p & 1][hh][r][l];
+            const double zsel = sbuf[p & 1][hh][j];
+            d4 cx = MFMA(cA[0], xs[0], zero4);
+            cx = MFMA(cA[1], xs[1], cx);
+            cx = MFMA(cA[2], xs[2], cx);
+            cx = MFMA(cA[3], u, cx);
+            d4 xa = MFMA(zA[0], xs[0], zero4);
+            xa = MFMA(zA[1], xs[1], xa);
+            xa = MFMA(zA[2], xs[2], xa);
+            xa = MFMA(zA[3], u, xa);
+            double part = ((xs[0] * (0.5 * cx[0] + linb[0]) + xs[1] * (0.5 * cx[1] + linb[1])) + xs[2] * (0.5 * cx[2] + linb[2])) +
+                          (u * (0.5 * cx[3] + linb[3]) + l1u * fabs(u));
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            cacc += part + q0t;
+            double w[3];
+            const bool second = a.use_true && (zsel < gd.tw2);
+            if (gauss) {
+                d4 wz = MFMA(nA[0], z[0], zero4);
+                wz = MFMA(nA[1], z[1], wz);
+                wz = MFMA(nA[2], z[2], wz);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) w[r] = nmb[r] + wz[r];
+                if (need_sel) {
+                    d4 w2 = MFMA(tA[0], z[0], zero4);
+                    w2 = MFMA(tA[1], z[1], w2);
+                    w2 = MFMA(tA[2], z[2], w2);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) w[r] = second ? tmb[r] + w2[r] : w[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) w[r] = gd.nlo + (gd.nhi - gd.nlo) * z[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                double dyn = xa[r];
+                if (gd.kappa != 0.0) dyn += gd.kappa * (xs[r] * xs[r] * xs[r]);
+                xs[r] = (dyn + w[r]) * cmask[r];
+            }
+        }
+        __syncthreads();
+    }
+    d4 qx = MFMA(qA[0], xs[0], zero4);
+    qx = MFMA(qA[1], xs[1], qx);
+    qx = MFMA(qA[2], xs[2], qx);
+    double part = (xs[0] * (0.5 * qx[0] + qvb[0]) + xs[1] * (0.5 * qx[1] + qvb[1])) + xs[2] * (0.5 * qx[2] + qvb[2]);
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (live && g == 0) a.traj_cost[tj] = cacc + part + gd.q0f;
+}
+
+// x0 | padded controls from the handle's pinned staging area into device memory, read over the host link by the kernel itself: a
+// copy-engine upload followed by a kernel costs ~10 us of engine hand-over, a kernel followed by a kernel ~2 us
+__global__ __launch_bounds__(256) void pets_stage_kernel(const double *__restrict__ src, double *__restrict__ dst, long count) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dst[i] = src[i];
+}
+
+void launch_pets_stage(const double *src, double *dst, long count, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(pets_stage_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src, dst, count);
+}
+
 __global__ __launch_bounds__(64) void pets_mean_kernel(PetsArgs a) {
     const long ii = blockIdx.x;
     const int l = threadIdx.x;
@@ -2886,7 +3204,13 @@ __global__ __launch_bounds__(64) void pets_mean_kernel(PetsArgs a) {
 void launch_pets(const PetsArgs &a, hipStream_t s) {
     const long ntraj = a.S * a.K;
     if (ntraj <= 0) return;
-    hipLaunchKernelGGL(pets_rollout_kernel, dim3((unsigned)((ntraj + 3) / 4)), dim3(64), 0, s, a);
+    // wave16: 0 four trajectories per wavefront; 1 sixteen (MFMA columns), generators split off into their own wavefronts while the launch is
+    // too small to occupy every SIMD with recursion waves; 2 sixteen, one wavefront does everything; 3 sixteen, always split
+    const long nw = (ntraj + 15) / 16;
+    const bool split = a.wave16 == 3 || (a.wave16 == 1 && nw <= PETS_SPLIT_MAX_WAVES);
+    if (a.wave16 == 0) hipLaunchKernelGGL(pets_rollout_kernel, dim3((unsigned)((ntraj + 3) / 4)), dim3(64), 0, s, a);
+    else if (split) hipLaunchKernelGGL(pets_rollout16s_kernel, dim3((unsigned)nw), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pets_rollout16_kernel, dim3((unsigned)nw), dim3(64), 0, s, a);
     hipLaunchKernelGGL(pets_mean_kernel, dim3((unsigned)a.S), dim3(64), 0, s, a);
 }
 #endif  // PART_MISC

@@ -111,6 +111,39 @@ def test_step_and_solve_match_oracle():
     assert ds.iter_current == 3
 
 
+@pytest.mark.parametrize("use_true", [False, True])
+@pytest.mark.parametrize("S,K,Nh", [(24, 50, 30), (7, 13, 30), (3, 16, 7), (1, 1, 30), (90, 400, 30)])
+def test_sixteen_per_wave_kernels_equal_four_per_wave(S, K, Nh, use_true):
+    """The rollout kernels -- 16 trajectories per wavefront as MFMA columns with the noise drawn by the recursion's own wavefront (switch
+    pets_wave16 = 2) or by three generator wavefronts of its workgroup (3; what small launches use under the default 1), and 4 per
+    wavefront (0) -- evaluate the same sums: 2 and 3 bit for bit, 0 to rounding, on injected streams and on the device generator too
+    (all key Philox by (trajectory, step pair, component), so a seed names the same noise in each).  K not a multiple of 16 leaves dead
+    columns; an odd horizon leaves half a step pair."""
+    prob, r = rich_problem(Nh=Nh)
+    ds = rat.CrossEntropyDirectOptimizationSolver(np.zeros((Nh, 4)), np.stack([np.eye(4)] * Nh), num_control_samples=S, num_trajectory_samples=K)
+    ctrl = 0.3 * r.standard_normal((S, Nh, 4))
+    x0 = r.standard_normal(12)
+    inject = S * K <= 2000
+    zn, zu = (r.standard_normal(S * K * Nh * 12), r.random(S * K * Nh)) if inject else (None, None)
+    streams = (zn, zu if use_true else None)
+    ctx = ds.context(prob)
+    assert ctx.debug_get("pets_wave16") == 1
+    got, gen = {}, {}
+    for mode in (1, 2, 3, 0):
+        ctx.debug_set("pets_wave16", mode)
+        if inject:
+            got[mode] = pets.compute_cost_serial(ds, prob, x0, ctrl, None, use_true, streams=streams)
+        gen[mode] = pets.compute_cost_serial(ds, prob, x0, ctrl, None, use_true, seed=9)
+    ctx.debug_set("pets_wave16", 1)
+    if inject:
+        ref = orc.pets_compute_cost(orc.GenProblem(prob), x0, ctrl, K, use_true, zn, zu if use_true else None)
+        assert np.all(np.isfinite(ref)) and np.all(np.abs(got[1] - ref) <= 1e-11 * np.abs(ref))
+        assert np.array_equal(got[2], got[3]) and np.array_equal(got[1], got[3])
+        assert np.all(np.abs(got[2] - got[0]) <= 1e-12 * np.abs(got[0]))
+    assert np.all(np.isfinite(gen[0])) and np.array_equal(gen[2], gen[3]) and np.array_equal(gen[1], gen[2])
+    assert np.all(np.abs(gen[2] - gen[0]) <= 1e-12 * np.abs(gen[0]))
+
+
 def test_device_generator_is_statistically_sane():
     """BASELINE config 5 shape: 10k trajectory samples, N = 30, device-generated noise (Philox): mean cost within a few
     standard errors of the injected-stream evaluation; reproducible for a fixed seed, different across seeds."""
