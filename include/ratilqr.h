@@ -411,7 +411,9 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   fly_multi       0 / 1    ... and all candidates of a sample rolled out by one wavefront                               (1)
  *   dual            0 / 1    round-based path: candidate 0 paired with the next gain sweep in one wavefront              (E > 1)
  *   speculate       0 / 1    round-based path: speculative gain sweeps on a second stream                                (0)
- *   pets_wave16     0 / 1    PETS rollouts sixteen per wavefront as MFMA columns (1) or four per wavefront (0); costs agree to rounding  (1)
+ *   pets_wave16     0 .. 3   PETS rollouts: 0 four per wavefront; 1 sixteen per wavefront as MFMA columns, the noise drawn by three generator
+ *                            wavefronts per workgroup while the launch is small (<= 1536 wavefronts), by the recursion's own beyond; 2 never
+ *                            split; 3 always split.  1-3 are bit-identical, 0 agrees to rounding  (1)
  *   ce_device       0 / 1    rat_ce_solve keeps the CE loop on the device: draw / update kernels, one host wait per solve!        (1)
  *   wdiag           0 / 1    diagonal time-invariant W: inv(W) folded into M^-1's operand (takes effect at the next rat_problem_set) (1) */
 rat_rc  rat_debug_set(rat_handle h, const char *key, int64_t value);

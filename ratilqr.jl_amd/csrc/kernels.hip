@@ -2034,6 +2034,27 @@ void launch_commit_init(const StateDev &st, hipStream_t s) {
 }
 #endif  // PART_ROLL
 
+__device__ __forceinline__ int uniform_load(const int *p) { return __builtin_amdgcn_readfirstlane(__atomic_load_n(p, __ATOMIC_RELAXED)); }
+__device__ __forceinline__ double uniform_load_f64(const double *p) { return readlane_f64(*(const volatile double *)p, 0); }
+// Does the sequential rule of line_search! reach its decision (accept, forced accept, failure) within the first kmax candidates of this
+// round?  The loop of ls_select_body without its side effects; uniform over the wavefront (every lane reads the same words).
+__device__ __forceinline__ bool ls_settled_within(const StateDev &st, const OptsDev &op, const int b, const int kmax) {
+    if (!uniform_load(&st.ls_active[b])) return true;
+    const double cur = uniform_load_f64(&st.value[b]);
+    double eps = uniform_load_f64(&st.ls_eps[b]);
+    const int c0 = b * st.E;
+    for (int k = 0; k < kmax; ++k) {
+        const int fl = uniform_load(&st.flag_c[c0 + k]);
+        if (fl == 2) return true;
+        if (fl == 1) { eps *= op.lambda; continue; }
+        const double nv = uniform_load_f64(&st.value_c[c0 + k]);
+        if (isapprox_default(nv, cur) || nv < cur) return true;
+        eps *= op.lambda;
+        if (eps < op.eps_min) return true;
+    }
+    return false;
+}
+
 // Replays the sequential rule of line_search! (ileqg.jl:504-581) over the E speculatively evaluated
 // candidates of each sample, then the convergence test of solve! (:642-653).
 // Counters of round `slot`: [2*slot] samples still inside their line search, [2*slot+1] samples still running.
@@ -2134,8 +2155,6 @@ __global__ void ls_select_kernel(StateDev st, OptsDev op, int slot) {
 // are visible to its later loads through the CU's write-through L1 after a workgroup-scope fence (vmcnt(0)).
 // =====================================================================================================
 #define PHASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
-__device__ __forceinline__ int uniform_load(const int *p) { return __builtin_amdgcn_readfirstlane(__atomic_load_n(p, __ATOMIC_RELAXED)); }
-__device__ __forceinline__ double uniform_load_f64(const double *p) { return readlane_f64(*(const volatile double *)p, 0); }
 
 #ifdef RAT_DIAG_PHASES
 #define PHASE_MARK() do { if (threadIdx.x == 0 && blockIdx.x < 8 && fa.sw.dump && dg_pi < 40) \
@@ -2346,7 +2365,13 @@ __device__ __forceinline__ int hw_simd_id() { return (int)((__builtin_amdgcn_s_g
 template <int MODEL, bool CTV, int WM, int NW, bool GW, bool STG, bool PAD4>
 __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(FusedArgs fa) {
     static_assert(!PAD4 || NW == 2, "PAD4 is the two-wave (E = 1) geometry");
-    constexpr int E = GW ? NW - 1 : NW;          // candidate waves
+    // LAZY (NW = 8 with a gain wave: E = 8): a CU holds eight waves of this kernel's 256 registers, so the ninth wave a gain sweep beside
+    // eight evaluations would need does not exist.  Wave 7 rolls candidate 7 out with the others, then runs the GAIN sweeps while waves
+    // 0..6 evaluate candidates 0..6; candidate 7 (eps lambda^7) is evaluated afterwards, by wave 7, only when the accept rule did not
+    // settle on one of the first seven (ls_settled_within) -- the rule reads candidates in order and stops at the first it accepts, so
+    // what it reads, and every result, is unchanged.
+    constexpr bool LAZY = GW && NW == 8;
+    constexpr int E = LAZY ? NW : (GW ? NW - 1 : NW);          // candidates
     constexpr int WG = GW ? NW - 1 : 0;          // the wave that runs gain sweeps
     constexpr int HWAVES = PAD4 ? 4 : NW;
     // two waves, LQ family, staged operands: the rollouts are split over both waves (rollrec_body / rolllin_body)
@@ -2406,8 +2431,8 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
 #ifdef RAT_DIAG_PHASES
     const unsigned long long dg_t0 = __builtin_readcyclecounter();
     int dg_pi = 0;
-#define BLK_MARK() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8 && fa.sw.dump && dg_pi < 40 && wave < 2) \
-        fa.sw.dump[1024 + blockIdx.x * 80 + wave * 40 + dg_pi] = (double)(__builtin_readcyclecounter() - dg_t0); ++dg_pi; } while (0)
+#define BLK_MARK() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8 && fa.sw.dump && dg_pi < 40 && (wave == 0 || wave == (GW ? WG : 1))) \
+        fa.sw.dump[1024 + blockIdx.x * 80 + (wave ? 40 : 0) + dg_pi] = (double)(__builtin_readcyclecounter() - dg_t0); ++dg_pi; } while (0)
 #else
 #define BLK_MARK() do {} while (0)
 #endif
@@ -2506,7 +2531,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         BLK_MARK();
     __syncthreads();
     BLK_MARK();
-        if (wave < E) {                                       // their policy evaluations  (:522-536)
+        if (wave < E && !(LAZY && wave == WG)) {              // their policy evaluations  (:522-536)
             SweepArgs sa = fa.sw; sa.mode = 1;
             sweep_body<false, false, WM, true, 0, FLYB>(sa, b * E + wave, wls);
         } else if (wave == WG) {                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
@@ -2527,6 +2552,17 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         BLK_MARK();
     __syncthreads();
     BLK_MARK();
+        if (LAZY) {                                           // the last candidate, only if the rule gets that far (every wave reads the same words)
+            if (!ls_settled_within(st, fa.sw.op, b, E - 1)) {
+                if (wave == WG) {
+                    SweepArgs sa = fa.sw; sa.mode = 1;
+                    sweep_body<false, false, WM, true, 0, FLYB>(sa, b * E + wave, wls);
+                }
+                BLK_MARK();
+    __syncthreads();
+                BLK_MARK();
+            }
+        }
         if (leader) ls_select_body(st, fa.sw.op, b, nullptr);
         BLK_MARK();
     __syncthreads();
@@ -2561,7 +2597,8 @@ static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {
 #undef BLOCK_LAUNCH
 }
 
-// E = st.E speculative candidates per sample: E + 1 waves (the last one runs the gain sweeps) for E <= 7, E waves for E = 8.
+// E = st.E speculative candidates per sample: E + 1 waves (the last one runs the gain sweeps) for E <= 7; E waves for E = 8, the last one
+// doubling as gain wave and lazy evaluator of candidate 7 (LAZY in solve_block_kernel).
 // One translation-unit part per geometry (the Makefile compiles this file once per RAT_PART: the instantiations of one geometry are a
 // minute of compile time each).
 void launch_solve_block_e1(const FusedArgs &fa, hipStream_t s);
@@ -2578,7 +2615,7 @@ void launch_solve_block_e2(const FusedArgs &fa, hipStream_t s) { launch_solve_bl
 void launch_solve_block_e4(const FusedArgs &fa, hipStream_t s) { launch_solve_block_n<5, true>(fa, s); }
 #endif
 #if RAT_PART & PART_BLOCK8
-void launch_solve_block_e8(const FusedArgs &fa, hipStream_t s) { launch_solve_block_n<8, false>(fa, s); }
+void launch_solve_block_e8(const FusedArgs &fa, hipStream_t s) { launch_solve_block_n<8, true>(fa, s); }
 #endif
 #if RAT_PART & PART_ROLL
 bool solve_block_supported(int E) { return E == 1 || E == 2 || E == 4 || E == 8; }

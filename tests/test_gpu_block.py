@@ -72,6 +72,42 @@ def test_block_kernel_against_the_oracle_on_a_backtracking_workload(E, monkeypat
     assert np.abs(r["L"] - s.L_array).max() < 1e-9 and np.abs(r["x"] - s.x_array).max() < 1e-9
 
 
+@pytest.mark.parametrize("lam,eps_min", [(0.9, 1e-6), (0.8, 0.3), (0.5, 1e-6)])
+def test_eight_candidates_with_a_lazily_evaluated_last_one(lam, eps_min, monkeypatch):
+    """E = 8: the workgroup's eighth wave runs the gain sweeps beside the evaluations of candidates 0..6 and evaluates candidate 7 only when
+    the accept rule rejects all of them.  With lambda = 0.9 a backtracking line search rejects more than eight step sizes in a row (rounds
+    in which the last candidate is needed, and whole rounds without an accepted candidate); eps_min = 0.3 forces an accept inside a round.
+    Same counts and bits as the round-based path, counts equal to the oracle's and values to 1e-9."""
+    prob, x0, u = rat.synthetic_lq_problem(kappa=0.06)
+    theta = np.array([0.0, 0.5, 2.0, 3.5, 5.0, 6.0, 7.5, 8.0, 20.0])
+    opts = rat.ileqg.make_opts(lam=lam, eps_min=eps_min, iter_max=12)
+    monkeypatch.setenv("RATILQR_BLOCK", "1")
+    ctx = rat.Context(prob, opts, max_batch=theta.size, spec_eps=8)
+    ctx.profile(True)
+    blk = ctx.solve_batch(x0, u, theta)
+    assert ctx.profile_get()["solve_block"]["launches"] == 1
+    monkeypatch.setenv("RATILQR_BLOCK", "0")
+    rnd = rat.Context(prob, opts, max_batch=theta.size, spec_eps=8).solve_batch(x0, u, theta)
+    for a, b in zip(blk, rnd):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    monkeypatch.setenv("RATILQR_BLOCK", "1")
+    P = orc.Problem(prob)
+    kw = dict(lam=lam, eps_min=eps_min, iter_max=12)
+    vg, sg, ig, lg = check_batch(ctx, P, x0, u, theta, **kw)  # statuses, iterations, line-search evaluations equal; values to 1e-9
+    for a, b in zip((vg, sg, ig, lg), blk):
+        assert np.array_equal(a, b, equal_nan=True)
+    deep = 0
+    for th in (2.0, 6.0, 8.0):
+        s = orc.ILEQGSolver(P, **kw)
+        r = ctx.solve(x0, u, th)
+        assert s.solve(x0, u, th) == r["status"]
+        h = s.eps_history
+        assert r["eps_history"].shape == h.shape and np.array_equal(r["eps_history"][:, 0], h[:, 0])
+        deep += int(np.sum(h[:, 0] <= lam ** 7 * (1 + 1e-12)))
+    if lam == 0.9:
+        assert deep > 0                                        # step sizes at or beyond the eighth candidate of a round were evaluated
+
+
 def test_block_geometries_are_bit_identical(monkeypatch):
     """E = 1 geometries of the block kernel: four-wave workgroups with ticketed SIMD pairs and linearise helper waves (one sample per CU),
     without the helpers, plain two-wave workgroups -- and rollouts split over the waves or not (N > 52: unsplit)."""
