@@ -3,7 +3,8 @@
 // The MFMA kernels of kernels.hip are specialised for n <= 12, m <= 4 (every BASELINE configuration): there [A|B] is one 12 x 16 operand
 // and the value function one accumulator tile.  The reference itself takes its dimensions from the arrays (ileqg.jl:229); this kernel
 // covers what lies beyond the tile with ONE WORKGROUP (one wavefront) PER SAMPLE and every matrix of a backward step in LDS at its own
-// size (column-major with odd leading dimensions, 6 n^2 + 4 n m + 2 m^2 doubles + padding: 104 KB at n = m = 32 of the CU's 160 KB).  The whole solve! runs inside the
+// size (column-major with odd leading dimensions, 6 n^2 + 5 n m + 2 m^2 doubles + padding: 112 KB at n = m = 32 of the CU's 160 KB; four
+// workgroups per CU up to n = 24, m = 8).  The whole solve! runs inside the
 // launch -- initialize! (ileqg.jl:214-236), then step! / line_search! until the convergence or iter_max test (:598-613, :494-592,
 // :635-659) -- with the per-sample control flow wave-uniform in registers.  Nothing is linearised into HBM: an LQ-family step's
 // derivatives are its tables plus a diagonal (f_x = A + 3 kappa diag(x^2)), so the sweep forms them from (x_t, u_t) as it goes.
@@ -14,7 +15,11 @@
 //     g = r + B' D s_vec,  G = P + B'(D S) A,  H = R + B'(D S) B + mu I;  gain sweep: H = Uh'Uh (isposdef(H), else mu, Delta are
 //     raised and the sweep restarts, :372-378), [L | dl] = -H^-1 [G | g]
 //     s, s_vec, S as in :383-391.
-// The arithmetic is plain FP64 vector code: this is the general-size path, not the measured one.
+// Round 4: the matrix products run on the matrix pipe (prod: 16 x 16 blocks, operands read from LDS straight into the MFMA's lanes), both
+// factorisations and their substitutions entirely in registers (chol_reg: a lane per column, rows broadcast by v_readlane, no LDS access
+// and no barrier per row), the step's tables are fetched once per sweep, and every LDS pointer carries its address space (ds_read /
+// ds_write instead of flat accesses).  A step is bound by the number of instructions ONE wavefront issues (~12 k at 16 x 4 for ~350
+// wave-instructions' worth of multiply-adds): masks, addressing and loops over matrices that do not fill the 64 lanes; see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -23,13 +28,14 @@
 
 namespace {
 
+// Every matrix of a step lives in LDS, and the pointers say so: through plain `double *` members the compiler can only emit FLAT
+// loads and stores (64-bit address arithmetic, the flat path's latency, vmcnt and lgkmcnt both held at zero around each) -- as rounds 1-3
+// did; with the address space in the type they are ds_read_b64 / ds_write_b64 off a 32-bit offset.
+typedef __attribute__((address_space(3))) double ldsd;
 struct Ws {
-    double *S, *U, *Z, *DS, *T, *At, *Bm, *F, *G, *Lt, *H, *Hc;
-    double *sv, *z, *dsv, *qv, *sv0, *xt, *xb, *g, *dlv, *rv, *ut, *hv;
-    double *idle;          // [WIDE_MAX]: what lanes without a column of their own READ in the lockstep factorisation (they store nothing)
-                           // Invariant of U / Hc: chol_fwd leaves the factor in the UPPER triangle; its matrix lanes also overwrite the
-                           // strictly lower triangle of their column with intermediate values, so every consumer (back_all, the
-                           // products forming D S) reads entries (i, j) with i <= j only
+    ldsd *S, *U, *Z, *DS, *T, *At, *Bm, *F, *G, *Lt, *H;
+    ldsd *sv, *z, *dsv, *qv, *sv0, *xt, *xb, *g, *dlv, *rv, *ut, *hv;
+    ldsd *Qs, *Ps, *Rs, *qvs, *rvs, *dA;     // the step's tables staged in LDS (stage_cost_tables): Q, P, R, q_vec, r_vec; diag(A)
 };
 
 // sum over the wavefront, the same bits on every lane: DPP rotations inside the 16-lane rows, then the four row sums through scalar
@@ -48,78 +54,163 @@ template <class F> __device__ __forceinline__ void each(const int rows, const in
     for (int j = lj; j < cols; j += 8)
         for (int i = li; i < rows; i += 8) f(i, j);
 }
-// C(i, j) = sum_k A(i, k) B(k, j), A(i, k) = pa(i)[k * sa], B(k, j) = pb(j)[k * sb]; store(i, j, c) for every entry
+// C(i, j) = sum_k A(i, k) B(k, j), A(i, k) = pa(i)[k * sa], B(k, j) = pb(j)[k * sb]; store(i, j, c) for every entry.
+// On the matrix pipe: C is cut into 16 x 16 blocks, a block is ceil(K / 4) v_mfma_f64_16x16x4 whose operands come straight from LDS --
+// lane (g, j) of slice s loads A(16 rb + j, 4 s + g) and B(4 s + g, 16 cb + j), zero outside the matrices (nothing in LDS is padded to
+// the block size), one ds_read_b64 each -- and leaves rows 4 r + g of column j in accumulator register r.  1024 multiply-adds per
+// instruction and two LDS reads, against one LDS read per multiply-add in the round-3 vector loop (which ran at ~130 cycles per
+// multiply-add per lane at one wavefront per SIMD: 16 x 16 x 16 took 8.6 k cycles; this takes ~0.6 k).  The A slices of a row block
+// are loaded once for all its column blocks.
+template <int NS, class PA, class PB, class ST>
+__device__ __forceinline__ void prod_ns(const int rows, const int cols, const int K, PA pa, const int sa, PB pb, const int sb, ST store) {
+    const int lane = threadIdx.x, j16 = lane & 15, g = lane >> 4;
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        const int ia = r0 + j16;
+        const bool va = ia < rows;
+        const auto ap = pa(va ? ia : 0);
+        double av[NS];
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {                      // (the address is clamped into the matrix, the value masked after the load:
+            const int kk = 4 * sl + g;                         //  no branch around any load)
+            const double v = ap[((kk < K) ? kk : 0) * sa];
+            av[sl] = (va && kk < K) ? v : 0.0;
+        }
+        for (int c0 = 0; c0 < cols; c0 += 16) {
+            const int jb = c0 + j16;
+            const bool vb = jb < cols;
+            const auto bp = pb(vb ? jb : 0);
+            double bv[NS];
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const int kk = 4 * sl + g;
+                const double v = bp[((kk < K) ? kk : 0) * sb];
+                bv[sl] = (vb && kk < K) ? v : 0.0;
+            }
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) acc = MFMA(av[sl], bv[sl], acc);
+            if (vb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int i = r0 + 4 * r + g; if (i < rows) store(i, jb, acc[r]); }
+            }
+        }
+    }
+}
 template <class PA, class PB, class ST>
 __device__ __forceinline__ void prod(const int rows, const int cols, const int K, PA pa, const int sa, PB pb, const int sb, ST store) {
-    const int li = threadIdx.x & 7, lj = threadIdx.x >> 3;
-    for (int j0 = lj; j0 < cols; j0 += 16) {
-        const int j1 = j0 + 8;
-        const bool vj = j1 < cols;
-        const double *b0 = pb(j0), *b1 = pb(vj ? j1 : j0);
-        for (int i0 = li; i0 < rows; i0 += 16) {
-            const int i1 = i0 + 8;
-            const bool vi = i1 < rows;
-            const double *a0 = pa(i0), *a1 = pa(vi ? i1 : i0);
-            double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
-            #pragma unroll 8
-            for (int k = 0; k < K; ++k) {
-                const double x0 = a0[k * sa], x1 = a1[k * sa], y0 = b0[k * sb], y1 = b1[k * sb];
-                c00 += x0 * y0; c01 += x0 * y1; c10 += x1 * y0; c11 += x1 * y1;
+    if (K <= 4) { prod_ns<1>(rows, cols, K, pa, sa, pb, sb, store); return; }
+    // K > 4: one body for every depth (slices beyond K are skipped by uniform branches) -- a body per depth tripled the code of each of
+    // the nine call sites, and a backward step already runs past the instruction cache
+    const int lane = threadIdx.x, j16 = lane & 15, g = lane >> 4;
+    const int ns = (K + 3) >> 2;                               // <= 8 slices
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        const int ia = r0 + j16;
+        const bool va = ia < rows;
+        const auto ap = pa(va ? ia : 0) + g * sa;
+        double av[8];
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) av[sl] = (va && sl < ns && 4 * sl + g < K) ? ap[(4 * sl) * sa] : 0.0;
+        for (int c0 = 0; c0 < cols; c0 += 16) {
+            const int jb = c0 + j16;
+            const bool vb = jb < cols;
+            const auto bp = pb(vb ? jb : 0) + g * sb;
+            double bv[8];
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) bv[sl] = (vb && sl < ns && 4 * sl + g < K) ? bp[(4 * sl) * sb] : 0.0;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) if (sl < ns) acc = MFMA(av[sl], bv[sl], acc);
+            if (vb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int i = r0 + 4 * r + g; if (i < rows) store(i, jb, acc[r]); }
             }
-            store(i0, j0, c00);
-            if (vj) store(i0, j1, c01);
-            if (vi) store(i1, j0, c10);
-            if (vi && vj) store(i1, j1, c11);
         }
     }
 }
 
-// Cholesky factorisation X = U'U in place (upper triangle of the k x k matrix Um, k <= 32) FUSED with the forward substitutions
-// U'Y = R for nrhs <= 32 right-hand-side columns (Rm, in place) and one more right-hand side `vec`, in lockstep over the rows: lane c < k
-// owns column c of the matrix, lane 32 + c column c of R (every lane runs the same dot-product loop against column i of U, which is
-// final by the time row i is reached), and the extra right-hand side is reduced across the lanes (lane q holds y_q).  Left-looking, so
-// each entry is M_ij - sum_k U_ki U_kj in ascending k like the textbook loop.  false <=> a pivot <= 0 or NaN: what LAPACK potrf reports
-// and isposdef tests.  yv: lane i < k ends with y_i of the extra right-hand side; sumlog = sum_i log U_ii.
-__device__ bool chol_fwd(double *Um, const int k, const int ld, double *Rm, const int nrhs, const int ldr, const double *vec, double *idle,
-                         double &yv, double &sumlog) {
+// Cholesky factorisation X = U'U of the k x k matrix Um (k <= K <= 32; its upper triangle is read) FUSED with the forward substitutions
+// U'Y = R for nrhs <= 32 right-hand-side columns (read from Rs, solution to Rm), one more right-hand side `vec`, and -- when `back` -- the back
+// substitutions U X = Y of all of them, ENTIRELY IN REGISTERS: lane c < k owns column c of the matrix, lane 32 + c column c of R, each as
+// K doubles.  Right-looking over the rows: row i is scaled by 1 / U_ii, then every later row q of every column loses U_iq U_ic -- U_iq is
+// lane q's entry of the scaled row, broadcast by v_readlane, so a row costs K - i - 1 (readlane pair + FMA) and no LDS access, no
+// barrier; each entry still is M_ij - sum_k U_ki U_kj in ascending k like the textbook loop.  (Round 3 kept the columns in LDS and ran
+// the left-looking loop with a barrier per row: ~1,400 cycles per row at either size; this form is ~250.)  false <=> a pivot <= 0 or
+// NaN: what LAPACK potrf reports and isposdef tests.  yv: lane i < k ends with entry i of the extra right-hand side's solution;
+// sumlog = sum_i log U_ii.  The factor itself is not written back: nothing reads it.
+// r = sqrt(d), ri = 1 / r for a pivot d > 0: v_rsq_f64 (~2^-26) and two Newton steps on the reciprocal root, r = d ri with one
+// correction -- both to an ulp or two, which is all a Cholesky pivot needs (nothing here is compared bit for bit) -- instead of the
+// IEEE sqrt expansion followed by a reciprocal: ~60 cycles of the row's serial chain instead of ~280.
+__device__ __forceinline__ void pivot_root(const double d, double &r, double &ri) {
+    if (!(d < 1e300) || d < 1e-290) { r = sqrt(d); ri = 1.0 / r; return; }      // (outside the range the plain iteration is safe in)
+    double y = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d;
+    y = y * (1.5 - h * (y * y));
+    y = y * (1.5 - h * (y * y));
+    double s0 = d * y;
+    s0 = fma(fma(-s0, s0, d), 0.5 * y, s0);
+    r = s0; ri = y;
+}
+template <int K>
+__device__ __noinline__ bool chol_reg(const ldsd *Um, const int k, const int ld, const ldsd *Rs, ldsd *Rm, const int nrhs, const int ldr, const ldsd *vec,
+                                      const bool back, double &yv, double &sumlog) {
     const int lane = threadIdx.x;
     const bool isM = lane < k, isR = lane >= 32 && lane - 32 < nrhs;
-    double *col = isM ? Um + (size_t)ld * lane : (isR ? Rm + (size_t)ldr * (lane - 32) : idle);
+    const ldsd *const srcp = isM ? Um + ld * lane : Rs + ldr * (isR ? lane - 32 : 0);        // (every column is read before any is written:
+    ldsd *const colp = Rm + ldr * (isR ? lane - 32 : 0);                                         //  the solution may overwrite the matrix)
+    double col[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) col[q] = ((isM ? q <= lane : isR) && q < k) ? srcp[q] : 0.0;      // (upper triangle of the matrix)
+    double accy = isM ? vec[lane] : 0.0;                  // lane c: vec_c - sum_{q < i} U_qc y_q so far; y_c once row c is done
     double myr = 1.0;
-    yv = 0.0;
-    for (int i = 0; i < k; ++i) {
-        const double *ui = Um + (size_t)ld * i;
-        double acc = col[i];
-        #pragma unroll 8
-        for (int q = 0; q < i; ++q) acc -= ui[q] * col[q];
-        const double dot = wsum((lane < i) ? ui[lane] * yv : 0.0);
-        const double d = readlane_f64(acc, i);
-        if (!(d > 0.0)) return false;
-        const double r = sqrt(d), ri = fast_rcp(r);
-        // (lanes without a column run the same loop on the shared `idle` vector -- uninitialised, possibly NaN, never part of a result --
-        //  and do not write it: no two lanes ever store to one address)
-        if (isM || isR) col[i] = (isM && lane == i) ? r : acc * ri;
-        if (lane == i) { yv = (vec[i] - dot) * ri; myr = r; }
-        __syncthreads();
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        if (i < k) {
+            const double d = readlane_f64(col[i], i);
+            if (!(d > 0.0)) return false;
+            double r, ri;
+            pivot_root(d, r, ri);
+            const double ui = col[i] * ri;                // U_ic on the matrix lanes, Y_ic on the right-hand-side lanes
+            col[i] = (lane == i) ? r : ui;
+            if (lane == i) myr = r;
+            const double yi = readlane_f64(accy, i) * ri;
+            accy = (lane == i) ? yi : ((lane > i) ? fma(-ui, yi, accy) : accy);
+#pragma unroll
+            for (int q = i + 1; q < K; ++q) {
+                const double uq = readlane_f64(ui, q);    // U_iq (0 beyond the matrix: those lanes hold zero columns)
+                col[q] = fma(-uq, ui, col[q]);
+            }
+        }
     }
     sumlog = wsum(isM ? log(myr) : 0.0);
+    if (back) {
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) {
+            if (i < k) {
+                const double ri = fast_rcp(readlane_f64(col[i], i));
+                const double dot = wsum((isM && lane > i) ? col[i] * accy : 0.0);          // sum_{q > i} U_iq x_q of the extra right-hand side
+                if (lane == i) accy = (accy - dot) * ri;
+                const double xi = isR ? col[i] * ri : 0.0;                                 // (matrix lanes keep the factor: their update is - U_qi * 0)
+                if (isR) col[i] = xi;
+#pragma unroll
+                for (int q = 0; q < i; ++q) col[q] = fma(-readlane_f64(col[q], i), xi, col[q]);
+            }
+        }
+    }
+    yv = accy;
+    if (isR) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) if (q < k) colp[q] = col[q];
+    }
+    __syncthreads();
     return true;
 }
-// back substitutions U X = Y for the nrhs columns of Rm (in place) and the extra right-hand side held in yv (lane i: y_i -> x_i)
-__device__ void back_all(const double *Um, const int k, const int ld, double *Rm, const int nrhs, const int ldr, double *idle, double &yv) {
-    const int lane = threadIdx.x;
-    const bool isR = lane >= 32 && lane - 32 < nrhs;
-    double *col = isR ? Rm + (size_t)ldr * (lane - 32) : idle;
-    for (int i = k - 1; i >= 0; --i) {
-        double acc = col[i];
-        #pragma unroll 8
-        for (int q = i + 1; q < k; ++q) acc -= Um[i + (size_t)ld * q] * col[q];
-        const double dot = wsum((lane > i && lane < k) ? Um[i + (size_t)ld * lane] * yv : 0.0);
-        const double ri = fast_rcp(Um[i + (size_t)ld * i]);
-        if (isR) col[i] = acc * ri;                       // (idle lanes read the shared idle vector and store nothing)
-        if (lane == i) yv = (yv - dot) * ri;
-        __syncthreads();
-    }
+__device__ __forceinline__ bool chol_solve(const ldsd *Um, const int k, const int ld, const ldsd *Rs, ldsd *Rm, const int nrhs, const int ldr, const ldsd *vec,
+                                           const bool back, double &yv, double &sumlog) {
+    if (k <= 4) return chol_reg<4>(Um, k, ld, Rs, Rm, nrhs, ldr, vec, back, yv, sumlog);
+    if (k <= 8) return chol_reg<8>(Um, k, ld, Rs, Rm, nrhs, ldr, vec, back, yv, sumlog);
+    if (k <= 16) return chol_reg<16>(Um, k, ld, Rs, Rm, nrhs, ldr, vec, back, yv, sumlog);
+    if (k <= 24) return chol_reg<24>(Um, k, ld, Rs, Rm, nrhs, ldr, vec, back, yv, sumlog);
+    return chol_reg<32>(Um, k, ld, Rs, Rm, nrhs, ldr, vec, back, yv, sumlog);
 }
 
 // Where a step's quadratic model comes from: the solver forms it on the fly from the trajectory (x, u) and the problem tables; the
@@ -130,10 +221,40 @@ struct Tiles {
 };
 struct Dump { double *s, *sv, *S, *g, *G, *H; };        // DynamicProgrammingResult arrays of the operator forms (any may be null)
 
+// The cost tables a backward step reads -- Q, P, R, q_vec, r_vec -- from global memory into LDS in one burst of independent
+// loads: once per sweep when they do not depend on the step, at the top of the step otherwise (time-varying cost / covariance, caller-
+// built tiles).  Round 3 read them where they were used -- inside the store of a product, inside a dot product -- each time behind its
+// own ~2 k cycles of exposed latency at one wavefront per SIMD: five to seven such waits per step.
+__device__ __forceinline__ void stage_cost_tables(const WideProblemDev &pb, Ws &w, const double *Qk, const double *Rk, const double *Pk,
+                                                  const double *qvk, const double *rvk) {
+    const int n = pb.n, m = pb.m, lane = threadIdx.x, ldn = n | 1, ldm = m | 1;
+    each(n, n, [&](int i, int j) { w.Qs[i + ldn * j] = Qk[i + n * j]; });
+    each(m, n, [&](int g, int j) { w.Ps[g + ldm * j] = Pk[g + m * j]; });
+    each(m, m, [&](int g, int g2) { w.Rs[g + ldm * g2] = Rk[g + m * g2]; });
+    if (qvk && lane < n) w.qvs[lane] = qvk[lane];
+    if (rvk && lane >= 32 && lane - 32 < m) w.rvs[lane - 32] = rvk[lane - 32];
+}
+// the entries of an n x n matrix (n <= 32) this lane visits in each(n, n, .), with a compile-time running index: f(i, j, e), e < 16
+template <class F> __device__ __forceinline__ void each16(const int n, F f) {
+    const int li = threadIdx.x & 7, lj = threadIdx.x >> 3;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) { const int i = li + 8 * ii, j = lj + 8 * jj; if (i < n && j < n) f(i, j, 4 * jj + ii); }
+}
+
 // solve_approximate_dp (gain = false, :412-465) / one pass of solve_approximate_dp! (gain = true, :341-406) over the trajectory.
 // Returns 0, 2 (M not positive definite) or -1 (H not positive definite: the caller raises mu and restarts).
-__device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const double theta, const double mu,
-                     const bool gain, const bool zeroL, double *Lg, double *dlg, const double *dlin, const Dump *dump, double &value) {
+// (The problem block, the LDS map and the tile pointers are taken into locals: through references of a function that is really called --
+//  this one is, from five places -- every pb.n, w.S, tl.x is a load through a generic pointer with a full wait behind it, hundreds per step.)
+__device__ int sweep(const WideProblemDev &pb_in, const Ws &w_in, const Tiles &tl_in, const double theta, const double mu,
+                     const bool gain, const bool zeroL, double *Lg, double *dlg, const double *dlin, const Dump *dump_in, double &value) {
+    const WideProblemDev pb = pb_in;
+    Ws w = w_in;
+    const Tiles tl = tl_in;
+    Dump dump_v = {};
+    if (dump_in) dump_v = *dump_in;
+    const Dump *const dump = dump_in ? &dump_v : nullptr;
     const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x;
     const int ldn = n | 1, ldm = m | 1;          // odd leading dimensions in LDS: a column stride of n doubles puts every lane on one bank
     const bool arr = tl.A != nullptr;
@@ -166,11 +287,31 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
         if (dump->sv && lane < n) dump->sv[(size_t)N * n + lane] = w.sv[lane];
         if (dump->S) each(n, n, [&](int i, int j) { dump->S[(size_t)N * n2 + i + n * j] = w.S[i + ldn * j]; });
     }
+    // what does not depend on the step is fetched once: the cost tables (LDS), inv(W) (registers), and -- LQ family -- A itself, whose diagonal alone
+    // changes from step to step (f_x = A + 3 kappa diag(x^2))
+    const bool cost_per_step = arr || pb.cost_tv, w_per_step = pb.W_tv != 0;
+    if (!cost_per_step) stage_cost_tables(pb, w, pb.Q, pb.R, pb.P, pb.qv, pb.rv);
+    double wreg[16];                                       // inv(W)'s entries of this lane (each16): no LDS copy, no load per step
+    if (!w_per_step) each16(n, [&](int i, int j, int e) { wreg[e] = pb.Winv[i + n * j]; });
+    if (!arr) {
+        each(n, n, [&](int i, int j) { w.At[i + ldn * j] = pb.A[i + n * j]; });
+        if (lane < n) w.dA[lane] = pb.A[lane + n * lane];
+    }
+    // (x_t, u_t) of the step after this one are fetched while this one runs
+    double xpre = 0.0, upre = 0.0;
+    if (!arr) {
+        if (lane < n) xpre = x[(size_t)(N - 1) * n + lane];
+        if (lane >= 32 && lane - 32 < m) upre = u[(size_t)(N - 1) * m + lane - 32];
+    }
+    __syncthreads();
     for (int t = N - 1; t >= 0; --t) {
         const int kc = pb.cost_tv ? t : 0, kw = pb.W_tv ? t : 0;
-        const double *Qk = arr ? tl.Q + (size_t)t * n2 : pb.Q + (size_t)kc * n2, *Rk = arr ? tl.R + (size_t)t * mm : pb.R + (size_t)kc * mm;
-        const double *Pk = arr ? tl.P + (size_t)t * nm : pb.P + (size_t)kc * nm;
-        const double *Wk = pb.W + (size_t)kw * n2, *Wik = pb.Winv + (size_t)kw * n2;
+        const double *Wk = pb.W + (size_t)kw * n2;
+        if (cost_per_step) {
+            if (arr) stage_cost_tables(pb, w, tl.Q + (size_t)t * n2, tl.R + (size_t)t * mm, tl.P + (size_t)t * nm, nullptr, nullptr);
+            else stage_cost_tables(pb, w, pb.Q + (size_t)kc * n2, pb.R + (size_t)kc * mm, pb.P + (size_t)kc * nm, pb.qv + (size_t)kc * n, pb.rv + (size_t)kc * m);
+        }
+        if (w_per_step) { const double *Wik = pb.Winv + (size_t)kw * n2; each16(n, [&](int i, int j, int e) { wreg[e] = Wik[i + n * j]; }); }
         if (!gain) {
             const double *Lt_g = Lg + (size_t)t * nm;
             each(m, n, [&](int g, int j) { w.Lt[g + ldm * j] = zeroL ? 0.0 : Lt_g[g + m * j]; });
@@ -184,45 +325,51 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
             if (lane < n) w.qv[lane] = tl.qv[(size_t)t * n + lane];
             if (lane < m) w.rv[lane] = tl.r[(size_t)t * m + lane];
             q = tl.q[t];
-        } else {                                                                           // approximate_model at (x_t, u_t)  (:294-313)
-            const double *qvk = pb.qv + (size_t)kc * n, *rvk = pb.rv + (size_t)kc * m;
-            if (lane < n) w.xt[lane] = x[(size_t)t * n + lane];
-            if (lane >= 32 && lane - 32 < m) w.ut[lane - 32] = u[(size_t)t * m + lane - 32];
             __syncthreads();
-            each(n, n, [&](int i, int j) { w.At[i + ldn * j] = pb.A[i + n * j] + ((i == j) ? 3.0 * pb.kappa * (w.xt[i] * w.xt[i]) : 0.0); });
+        } else {                                                                           // approximate_model at (x_t, u_t)  (:294-313)
+            if (lane < n) { w.xt[lane] = xpre; w.At[lane + ldn * lane] = w.dA[lane] + 3.0 * pb.kappa * (xpre * xpre); }
+            if (lane >= 32 && lane - 32 < m) w.ut[lane - 32] = upre;
+            if (t > 0) {
+                if (lane < n) xpre = x[(size_t)(t - 1) * n + lane];
+                if (lane >= 32 && lane - 32 < m) upre = u[(size_t)(t - 1) * m + lane - 32];
+            }
+            __syncthreads();
             part = 0.0;
             if (lane < n) {
                 double qx = 0.0, pu = 0.0;
                 #pragma unroll 8
-                for (int j = 0; j < n; ++j) qx += Qk[lane + n * j] * w.xt[j];
+                for (int j = 0; j < n; ++j) qx += w.Qs[lane + ldn * j] * w.xt[j];
                 #pragma unroll 8
-                for (int g = 0; g < m; ++g) pu += Pk[g + m * lane] * w.ut[g];
-                w.qv[lane] = qx + pu + qvk[lane];
-                part = w.xt[lane] * (0.5 * qx + qvk[lane]);
+                for (int g = 0; g < m; ++g) pu += w.Ps[g + ldm * lane] * w.ut[g];
+                const double qvl = w.qvs[lane];
+                w.qv[lane] = qx + pu + qvl;
+                part = w.xt[lane] * (0.5 * qx + qvl);
             } else if (lane >= 32 && lane - 32 < m) {
                 const int g = lane - 32;
                 double ru = 0.0, px = 0.0;
                 #pragma unroll 8
-                for (int g2 = 0; g2 < m; ++g2) ru += Rk[g + m * g2] * w.ut[g2];
+                for (int g2 = 0; g2 < m; ++g2) ru += w.Rs[g + ldm * g2] * w.ut[g2];
                 #pragma unroll 8
-                for (int j = 0; j < n; ++j) px += Pk[g + m * j] * w.xt[j];
-                w.rv[g] = ru + px + rvk[g];
-                part = w.ut[g] * (0.5 * ru + px + rvk[g]);
+                for (int j = 0; j < n; ++j) px += w.Ps[g + ldm * j] * w.xt[j];
+                const double rvl = w.rvs[g];
+                w.rv[g] = ru + px + rvl;
+                part = w.ut[g] * (0.5 * ru + px + rvl);
             }
             q = wsum(part) + pb.q0[kc];
         }
-        // M = inv(W) - theta S  (:365) into U;  Z <- S (right-hand sides of the forward substitution)
-        each(n, n, [&](int i, int j) { const double sij = w.S[i + ldn * j]; w.U[i + ldn * j] = Wik[i + n * j] - theta * sij; w.Z[i + ldn * j] = sij; });
+        // M = inv(W) - theta S  (:365) into U; the forward substitution reads its right-hand sides from S and leaves Z IN U (M is in
+        // registers by then)
+        each16(n, [&](int i, int j, int e) { w.U[i + ldn * j] = wreg[e] - theta * w.S[i + ldn * j]; });
         __syncthreads();
         double sumlog = 0.0, zreg = 0.0;
-        if (!chol_fwd(w.U, n, ldn, w.Z, n, ldn, w.sv, w.idle, zreg, sumlog)) return 2;       // @assert isposdef(M)  :366 / :440;  [Z | z] = U^-T [S | s_vec]
+        if (!chol_solve(w.U, n, ldn, w.S, w.Z, n, ldn, w.sv, false, zreg, sumlog)) return 2;      // @assert isposdef(M)  :366 / :440;  [Z | z] = U^-T [S | s_vec]
         if (theta == 0.0) {                          // D = I exactly, whatever the size of S: the products below must not see Z'Z
             each(n, n, [&](int i, int j) { w.Z[i + ldn * j] = 0.0; });
             zreg = 0.0;
         }
         if (lane < n) w.z[lane] = zreg;
         __syncthreads();
-        prod(n, n, n, [&](int i) { return w.Z + (size_t)ldn * i; }, 1, [&](int j) { return w.Z + (size_t)ldn * j; }, 1,
+        prod(n, n, n, [&](int i) { return w.Z + ldn * i; }, 1, [&](int j) { return w.Z + ldn * j; }, 1,
              [&](int i, int j, double c) { w.DS[i + ldn * j] = w.S[i + ldn * j] + theta * c; });          // D S  (:367; S symmetric)
         part = 0.0;
         if (lane < n) {
@@ -235,16 +382,16 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
         const double zz = wsum(part);                                                      // s_vec' M^-1 s_vec
         __syncthreads();
         prod(n, n + m, n, [&](int i) { return w.DS + i; }, ldn,
-             [&](int j) { return (j < n) ? w.At + (size_t)ldn * j : w.Bm + (size_t)ldn * (j - n); }, 1,
+             [&](int j) { return (j < n) ? w.At + ldn * j : w.Bm + ldn * (j - n); }, 1,
              [&](int i, int j, double c) { if (j < n) w.T[i + ldn * j] = c; else w.F[i + ldn * (j - n)] = c; });   // T = (D S) A,  F = (D S) B
         __syncthreads();
-        prod(m, n, n, [&](int g) { return w.Bm + (size_t)ldn * g; }, 1, [&](int j) { return w.T + (size_t)ldn * j; }, 1,
-             [&](int g, int j, double c) { w.G[g + ldm * j] = Pk[g + m * j] + c; });                              // G = P + B'(D S) A  (:369)
-        prod(m, m, n, [&](int g) { return w.Bm + (size_t)ldn * g; }, 1, [&](int g2) { return w.F + (size_t)ldn * g2; }, 1,
+        prod(m, n, n, [&](int g) { return w.Bm + ldn * g; }, 1, [&](int j) { return w.T + ldn * j; }, 1,
+             [&](int g, int j, double c) { w.G[g + ldm * j] = w.Ps[g + ldm * j] + c; });                              // G = P + B'(D S) A  (:369)
+        prod(m, m, n, [&](int g) { return w.Bm + ldn * g; }, 1, [&](int g2) { return w.F + ldn * g2; }, 1,
              [&](int g, int g2, double c) {                                                                       // H = Symmetric(R + B'(D S) B + mu I)  (:370-371)
                  if (g <= g2) {
-                     const double v = Rk[g + m * g2] + c + ((g == g2) ? mu : 0.0);
-                     w.H[g + ldm * g2] = v; w.H[g2 + ldm * g] = v; w.Hc[g + ldm * g2] = v;
+                     const double v = w.Rs[g + ldm * g2] + c + ((g == g2) ? mu : 0.0);
+                     w.H[g + ldm * g2] = v; w.H[g2 + ldm * g] = v;
                  }
              });
         if (lane < m) {                                                                    // g = r + B' D s_vec  (:368)
@@ -264,8 +411,7 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
             if (lane < m) w.hv[lane] = -w.g[lane];
             __syncthreads();
             double dreg = 0.0, dummy = 0.0;
-            if (!chol_fwd(w.Hc, m, ldm, w.Lt, n, ldm, w.hv, w.idle, dreg, dummy)) return -1; // !isposdef(H)  :372
-            back_all(w.Hc, m, ldm, w.Lt, n, ldm, w.idle, dreg);
+            if (!chol_solve(w.H, m, ldm, w.Lt, w.Lt, n, ldm, w.hv, true, dreg, dummy)) return -1; // !isposdef(H)  :372;  both substitutions
             if (lane < m) { w.dlv[lane] = dreg; dlg[(size_t)t * m + lane] = dreg; }
             double *Lt_g = Lg + (size_t)t * nm;
             each(m, n, [&](int g, int j) { Lt_g[g + m * j] = w.Lt[g + ldm * j]; });
@@ -296,19 +442,19 @@ __device__ int sweep(const WideProblemDev &pb, Ws &w, const Tiles &tl, const dou
             for (int g = 0; g < m; ++g) acc += w.Lt[g + ldm * lane] * w.hv[g] + w.G[g + ldm * lane] * w.dlv[g];
             w.sv0[lane] = acc;
         }
-        prod(m, n, m, [&](int g) { return w.H + g; }, ldm, [&](int j) { return w.Lt + (size_t)ldm * j; }, 1,
+        prod(m, n, m, [&](int g) { return w.H + g; }, ldm, [&](int j) { return w.Lt + ldm * j; }, 1,
              [&](int g, int j, double c) { w.F[g + ldm * j] = w.G[g + ldm * j] + c; });                           // H L + G  (into F, dead by now)
         __syncthreads();
         // S = Symmetric(Q + A'(D S)A + L'(HL + G) + G'L)  (:390-391): the upper triangle rules
-        prod(n, n, n, [&](int i) { return w.At + (size_t)ldn * i; }, 1, [&](int j) { return w.T + (size_t)ldn * j; }, 1,
-             [&](int i, int j, double c) { if (i <= j) w.U[i + ldn * j] = Qk[i + n * j] + c; });
-        prod(n, n, m, [&](int i) { return w.Lt + (size_t)ldm * i; }, 1, [&](int j) { return w.F + (size_t)ldm * j; }, 1,
+        prod(n, n, n, [&](int i) { return w.At + ldn * i; }, 1, [&](int j) { return w.T + ldn * j; }, 1,
+             [&](int i, int j, double c) { if (i <= j) w.U[i + ldn * j] = w.Qs[i + ldn * j] + c; });
+        prod(n, n, m, [&](int i) { return w.Lt + ldm * i; }, 1, [&](int j) { return w.F + ldm * j; }, 1,
              [&](int i, int j, double c) { if (i <= j) w.U[i + ldn * j] += c; });
-        prod(n, n, m, [&](int i) { return w.G + (size_t)ldm * i; }, 1, [&](int j) { return w.Lt + (size_t)ldm * j; }, 1,
+        prod(n, n, m, [&](int i) { return w.G + ldm * i; }, 1, [&](int j) { return w.Lt + ldm * j; }, 1,
              [&](int i, int j, double c) { if (i <= j) { const double v = w.U[i + ldn * j] + c; w.U[i + ldn * j] = v; w.U[j + ldn * i] = v; } });
         if (lane < n) w.sv[lane] = w.sv0[lane];
         __syncthreads();
-        double *tmp = w.S; w.S = w.U; w.U = tmp;
+        ldsd *tmp = w.S; w.S = w.U; w.U = tmp; w.Z = tmp;
         s1 = s0;
         if (dump) {
             if (dump->s && lane == 0) dump->s[t] = s1;
@@ -394,13 +540,13 @@ __device__ double rollout_closed(const WideProblemDev &pb, Ws &w, const double *
     return best;
 }
 
-__device__ inline void carve(Ws &w, double *p, const int n, const int m) {                  // the workgroup's LDS area -> named matrices
+__device__ inline void carve(Ws &w, ldsd *p, const int n, const int m) {                  // the workgroup's LDS area -> named matrices
     const int ldn = n | 1, ldm = m | 1, sn = ldn * n, sb = ldn * m, sg = ldm * n, sf = sb > sg ? sb : sg, sh = ldm * m;
-    w.S = p; p += sn; w.U = p; p += sn; w.Z = p; p += sn; w.DS = p; p += sn; w.T = p; p += sn; w.At = p; p += sn;
-    w.Bm = p; p += sb; w.F = p; p += sf; w.G = p; p += sg; w.Lt = p; p += sg; w.H = p; p += sh; w.Hc = p; p += sh;
+    w.S = p; p += sn; w.U = p; w.Z = p; p += sn; w.DS = p; p += sn; w.T = p; p += sn; w.At = p; p += sn;      // (Z lives in U: see sweep)
+    w.Bm = p; p += sb; w.F = p; p += sf; w.G = p; p += sg; w.Lt = p; p += sg; w.H = p; p += sh;
     w.sv = p; p += n; w.z = p; p += n; w.dsv = p; p += n; w.qv = p; p += n; w.sv0 = p; p += n; w.xt = p; p += n; w.xb = p; p += n;
     w.g = p; p += m; w.dlv = p; p += m; w.rv = p; p += m; w.ut = p; p += m; w.hv = p; p += m;
-    w.idle = p;
+    w.Qs = p; p += sn; w.Ps = p; p += sg; w.Rs = p; p += sh; w.qvs = p; p += n; w.rvs = p; p += m; w.dA = p; p += n;
 }
 
 
@@ -410,7 +556,7 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     const OptsDev &op = a.op;
     const int n = pb.n, m = pb.m, N = pb.N, nm = n * m, lane = threadIdx.x, b = blockIdx.x;
     Ws w;
-    carve(w, lds, n, m);
+    carve(w, (ldsd *)lds, n, m);
     for (int e = lane; e < nm; e += 64) w.Bm[e % n + (n | 1) * (e / n)] = pb.B[e];
     const size_t xstr = (size_t)(N + 1) * n, ustr = (size_t)N * m;
     double *const xs = a.xs + (size_t)b * 2 * xstr, *const us = a.us + (size_t)b * 2 * ustr;
@@ -552,7 +698,7 @@ __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
     const int n = pb.n, m = pb.m, N = pb.N, n2 = n * n, nm = n * m, mm = m * m, lane = threadIdx.x, ldn = n | 1;
     const long b = blockIdx.x;
     Ws w;
-    carve(w, lds, n, m);
+    carve(w, (ldsd *)lds, n, m);
     for (int e = lane; e < nm; e += 64) w.Bm[e % n + ldn * (e / n)] = pb.B[e];
     __syncthreads();
     if (a.opcode == WOP_ROLL_OPEN) {                                  // simulate_dynamics(problem, x_0, u_array)  ileqg.jl:18-38
@@ -684,7 +830,7 @@ __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
 
 size_t wide_lds_bytes(int n, int m) {
     const size_t ldn = n | 1, ldm = m | 1, sb = ldn * m, sg = ldm * n;
-    return sizeof(double) * (6 * ldn * n + sb + (sb > sg ? sb : sg) + 2 * sg + 2 * ldm * m + (size_t)7 * n + (size_t)5 * m + 64);
+    return sizeof(double) * (6 * ldn * n + sb + (sb > sg ? sb : sg) + 3 * sg + 2 * ldm * m + (size_t)9 * n + (size_t)6 * m);
 }
 
 hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s) {
