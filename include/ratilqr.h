@@ -411,6 +411,9 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   fly_multi       0 / 1    ... and all candidates of a sample rolled out by one wavefront                               (1)
  *   dual            0 / 1    round-based path: candidate 0 paired with the next gain sweep in one wavefront              (E > 1)
  *   speculate       0 / 1    round-based path: speculative gain sweeps on a second stream                                (0)
+ *   nm_depth        0 .. 2   Nelder-Mead speculation: 0 the six vertices of the iteration per device call; 1 also the two current vertices (the
+ *                            final solve is read out of the last batch) and both initial vertices with the first iteration in one call; 2 also
+ *                            the vertices of the iteration after (two iterations per device call).  Results do not depend on it  (2)
  *   pets_wave16     0 .. 3   PETS rollouts: 0 four per wavefront; 1 sixteen per wavefront as MFMA columns, the noise drawn by three generator
  *                            wavefronts per workgroup while the launch is small (<= 1536 wavefronts), by the recursion's own beyond; 2 never
  *                            split; 3 always split.  1-3 are bit-identical, 0 agrees to rounding  (1)

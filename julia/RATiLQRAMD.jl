@@ -739,7 +739,7 @@ function NelderMeadBilevelOptimizationSolver(; μ_min_ileqg=1e-6, Δ_0_ileqg=2.0
     NelderMeadBilevelOptimizationSolver(o, c, device, nothing)
 end
 function handle!(s::NelderMeadBilevelOptimizationSolver, problem)
-    s.h === nothing && (s.h = Handle(s.opts, 6, 1, s.device))            # one step! asks for at most six vertices
+    s.h === nothing && (s.h = Handle(s.opts, 160, 1, s.device))          # both initial vertices + two iterations' vertices per device call
     bind!(s.h, problem)
 end
 "initialize!(nm_solver) -- :164-168 (c_high / c_low are left alone, as in the reference)"

@@ -109,6 +109,10 @@ struct rat_handle_s {
     size_t cap_pin = 0, cap_zn = 0, cap_zu = 0, cap_traj = 0, cap_cost = 0;
     double *h_pstage = nullptr; size_t cap_pstage = 0;      // pinned staging of x0 | padded controls (pets_stage_kernel reads it over the link)
     double *h_pcost = nullptr; size_t cap_hpcost = 0;       // pinned landing zone of the sample costs of the synchronous call (zero-copy)
+    // Nelder-Mead (rat_nm_solve): costs already evaluated for this (problem, x0, u0, kl_bound) by exact theta, and the thetas of the batch
+    // that ran last (its per-sample state is still on the device: the final solve is read out of it)
+    std::vector<double> nm_th, nm_c, nm_last;
+    int nm_depth = 2;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's)
     // CE randomness
     const double *z = nullptr;
     int64_t nz = 0, zpos = 0;
@@ -168,6 +172,7 @@ static const DebugSwitch debug_switches[] = {
     {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
     {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
     {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
+    {"nm_depth", [](rat_handle h, int64_t v) { h->nm_depth = (v < 0 || v > 2) ? 2 : (int)v; }, [](rat_handle h) -> int64_t { return h->nm_depth; }},
     {"pets_wave16", [](rat_handle h, int64_t v) { h->pets_wave16 = (v < 0 || v > 3) ? 1 : (int)v; }, [](rat_handle h) -> int64_t { return h->pets_wave16; }},
     {"ce_device", [](rat_handle h, int64_t v) { h->ce_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->ce_device; }},
 };
@@ -1158,7 +1163,7 @@ static rat_rc ileqg_solve_impl(rat_handle h, const double *x0, const double *u0,
         // ONE launch packs the accepted slot, the committed gain half and the scalars straight into the pinned staging area (the device
         // writes host memory in place), then ONE host wait: no copy commands behind the solve
         double *const s_s = reinterpret_cast<double *>(h->h_io) + 2;                 // 6 doubles of scalars (h_io holds >= 64 bytes)
-        launch_pack_solution(st, x ? s_x : nullptr, l ? s_u : nullptr, L ? s_L : nullptr, s_s, h->stream);
+        launch_pack_solution(st, 0, x ? s_x : nullptr, l ? s_u : nullptr, L ? s_L : nullptr, s_s, h->stream);
         if (hist_first) HIPCHK(hipMemcpyAsync(s_h, h->d_hist, hist_first * 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         p_d[1] = s_s[0]; st_h = (int)s_s[1]; it_h = (int)s_s[2]; hn = (int)s_s[3]; nom = 0; lsel = 0;      // (the packed copies ARE the selected slot / half)
@@ -2125,51 +2130,142 @@ extern "C" rat_rc rat_nm_compute_cost(rat_handle h, const double *x0, const doub
     return RAT_OK;
 }
 
-extern "C" rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound) {   // :174-252
-    if (!h || !s) return fail(RAT_ERR_ARG, "null");
+// ---- speculation ---------------------------------------------------------------------------------------------------------------
+// One Nelder-Mead iteration is a chain of up to three dependent evaluations, a solve! each, and a batch of up to two workgroup
+// generations takes one solve's time (solve_block_kernel: 0.28 ms for 1 ... 512 samples).  So every theta the sequential code CAN ask for
+// is evaluated ahead of time, with the sequential code's own expressions (bit-equal thetas), and the code then runs unchanged against a
+// table of (theta, cost): the six vertices of this iteration (round 2), the six of each of the twelve states the iteration can end in
+// (round 4: two iterations per device call), and -- in rat_nm_solve -- both initial vertices with the first two iterations under either
+// ordering.  The vertices that can become theta_low ride along, so the final solve (:346) is read out of the last batch's device state
+// instead of being run again.  What the sequential code evaluates, in what order, and every number it produces are unchanged
+// (n_solves counts its evaluations; n_batches the device calls: 3 instead of 6 for a solve of three iterations).
+static bool same_bits(double a, double b) { return memcmp(&a, &b, 8) == 0; }
+static bool nm_lookup(rat_handle h, double th, double *c) {
+    for (size_t i = 0; i < h->nm_th.size(); ++i) if (same_bits(h->nm_th[i], th)) { *c = h->nm_c[i]; return true; }
+    return false;
+}
+// the thetas one iteration from (theta_low = th_m, theta_high = th_h) can evaluate, as rat_nm_step_impl writes them
+static void nm_vertices(const rat_nm_solver *s, double th_m, double th_h, double *th) {
+    const double lo = s->theta_low_init;
+    const double th_r = std::max(lo, th_m + s->alpha * (th_m - th_h));                   // reflection      :195-196
+    th[0] = th_r;
+    th[1] = std::max(lo, th_m + s->beta * (th_r - th_m));                                // expansion       :204-205
+    th[2] = std::max(lo, th_m + s->gamma * (th_h - th_m));                               // contraction with theta_high kept  :232-233
+    th[3] = std::max(lo, th_m + s->gamma * (th_r - th_m));                               // contraction after theta_high <- theta_r
+    th[4] = (th_h + th_m) / 2;                                                           // shrink          :239
+    th[5] = (th_r + th_m) / 2;
+}
+// evaluates the thetas of `list` not yet in the table, in ONE batch (or several when the handle is smaller)
+static rat_rc nm_prefetch(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound, const std::vector<double> &list) {
+    std::vector<double> todo;
+    for (double th : list) {
+        double c;
+        if (nm_lookup(h, th, &c)) continue;
+        bool dup = false;
+        for (double t2 : todo) if (same_bits(t2, th)) { dup = true; break; }
+        if (!dup) todo.push_back(th);
+    }
+    for (size_t o = 0; o < todo.size(); o += (size_t)h->Bmax) {
+        const size_t nb = std::min(todo.size() - o, (size_t)h->Bmax);
+        std::vector<double> c(nb);
+        rat_rc rc = rat_ileqg_solve_batch(h, x0, u0, todo.data() + o, (int64_t)nb, c.data(), nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        s->n_batches += 1;
+        for (size_t i = 0; i < nb; ++i) { h->nm_th.push_back(todo[o + i]); h->nm_c.push_back(c[i] + kl_bound / todo[o + i]); }
+        h->nm_last.assign(todo.begin() + (std::ptrdiff_t)o, todo.begin() + (std::ptrdiff_t)(o + nb));
+    }
+    return RAT_OK;
+}
+static rat_rc nm_cost(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound, double th, double *c) {
+    s->n_solves += 1;
+    if (nm_lookup(h, th, c)) return RAT_OK;
+    rat_rc rc = nm_prefetch(h, s, x0, u0, kl_bound, std::vector<double>(1, th));
+    if (rc) return rc;
+    return nm_lookup(h, th, c) ? RAT_OK : fail(RAT_ERR_HIP, "Nelder-Mead: evaluated theta missing from the table");
+}
+// what to evaluate ahead of an iteration from (th_m, th_h): its vertices, the two current ones, and the next iteration's
+static void nm_plan(rat_handle h, const rat_nm_solver *s, double th_m, double th_h, std::vector<double> &list) {
+    double v[6];
+    nm_vertices(s, th_m, th_h, v);
+    list.insert(list.end(), v, v + 6);
+    if (h->nm_depth < 1) return;
+    list.push_back(th_m); list.push_back(th_h);
+    if (h->nm_depth < 2) return;
+    for (int k = 0; k < 6; ++k) {                                 // theta_high <- v[k]; the next iteration may swap the two (:184-187)
+        double w[6];
+        nm_vertices(s, th_m, v[k], w); list.insert(list.end(), w, w + 6);
+        nm_vertices(s, v[k], th_m, w); list.insert(list.end(), w, w + 6);
+    }
+}
+
+static rat_rc nm_step_impl(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound) {   // :174-252
     s->iter_current += 1;
     if (s->c_high < s->c_low) {                                                // :184-187
         std::swap(s->theta_low, s->theta_high);
         std::swap(s->c_low, s->c_high);
     }
-    const double th_m = s->theta_low, lo = s->theta_low_init;
-    // every vertex the sequential code can reach this iteration, computed with its own expressions
-    const double th_r = std::max(lo, th_m + s->alpha * (th_m - s->theta_high));          // reflection      :195-196
-    const double th_e = std::max(lo, th_m + s->beta * (th_r - th_m));                    // expansion       :204-205
-    const double th_c_old = std::max(lo, th_m + s->gamma * (s->theta_high - th_m));      // contraction with theta_high kept  :232-233
-    const double th_c_ref = std::max(lo, th_m + s->gamma * (th_r - th_m));               // contraction after theta_high <- theta_r
-    const double th_s_old = (s->theta_high + s->theta_low) / 2;                          // shrink          :239
-    const double th_s_ref = (th_r + s->theta_low) / 2;
-    double th[6] = {th_r, th_e, th_c_old, th_c_ref, th_s_old, th_s_ref}, c[6];
-    if (h->Bmax >= 6) {
-        rat_rc rc = rat_ileqg_solve_batch(h, x0, u0, th, 6, c, nullptr, nullptr, nullptr);
-        if (rc) return rc;
-        for (int i = 0; i < 6; ++i) c[i] = c[i] + kl_bound / th[i];
-        s->n_batches += 1;
-    } else {                                                                    // handle too small to speculate: evaluate on demand
-        for (int i = 0; i < 6; ++i) c[i] = NAN;
-    }
-    auto cost_of = [&](int i, double *out) -> rat_rc {
-        if (c[i] == c[i]) { *out = c[i]; s->n_solves += 1; return RAT_OK; }
-        s->n_solves += 1; s->n_batches += 1;
-        return rat_nm_compute_cost(h, x0, u0, th[i], kl_bound, out);
-    };
+    const double th_m = s->theta_low;
+    double th[6];
+    nm_vertices(s, th_m, s->theta_high, th);
+    const double th_r = th[0], th_e = th[1], th_c_old = th[2], th_c_ref = th[3], th_s_old = th[4], th_s_ref = th[5];
     rat_rc rc;
+    if (h->Bmax >= 6) {                                                         // (a smaller handle evaluates on demand)
+        bool all = true;
+        for (int i = 0; i < 6; ++i) { double c; all = all && nm_lookup(h, th[i], &c); }
+        if (!all) {
+            std::vector<double> list;
+            nm_plan(h, s, th_m, s->theta_high, list);
+            if ((int64_t)list.size() > h->Bmax) list.resize(h->Bmax >= 8 && h->nm_depth >= 1 ? 8 : 6);
+            if ((rc = nm_prefetch(h, s, x0, u0, kl_bound, list))) return rc;
+        }
+    }
     double c_r, c_e, c_c;
-    if ((rc = cost_of(0, &c_r))) return rc;
+    if ((rc = nm_cost(h, s, x0, u0, kl_bound, th_r, &c_r))) return rc;
     if (c_r < s->c_low) {                                                       // :202
-        if ((rc = cost_of(1, &c_e))) return rc;
+        if ((rc = nm_cost(h, s, x0, u0, kl_bound, th_e, &c_e))) return rc;
         if (c_e < c_r) { s->theta_high = th_e; s->c_high = c_e; }              // :209-220
         else { s->theta_high = th_r; s->c_high = c_r; }
     } else {
         bool took_r = false;
         if (c_r < s->c_high) { s->theta_high = th_r; s->c_high = c_r; took_r = true; }   // :227-230
-        if ((rc = cost_of(took_r ? 3 : 2, &c_c))) return rc;                    // :232-234
+        if ((rc = nm_cost(h, s, x0, u0, kl_bound, took_r ? th_c_ref : th_c_old, &c_c))) return rc;   // :232-234
         if (c_c > s->c_high) {                                                  // :238-240
             s->theta_high = took_r ? th_s_ref : th_s_old;
-            if ((rc = cost_of(took_r ? 5 : 4, &s->c_high))) return rc;
+            if ((rc = nm_cost(h, s, x0, u0, kl_bound, s->theta_high, &s->c_high))) return rc;
         } else { s->theta_high = took_r ? th_c_ref : th_c_old; s->c_high = c_c; }   // :245-250
     }
+    return RAT_OK;
+}
+
+extern "C" rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound) {   // :174-252
+    if (!h || !s) return fail(RAT_ERR_ARG, "null");
+    h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear();                     // (a stand-alone step: nothing is known about x0, u0, kl_bound)
+    return nm_step_impl(h, s, x0, u0, kl_bound);
+}
+
+// x, l, L, value, status of sample b of the batch that ran last, as rat_ileqg_solve returns them (tile-sized problems)
+static rat_rc fetch_batch_sample(rat_handle h, int b, double *x, double *l, double *L, double *value, int32_t *status) {
+    HIPCHK(hipSetDevice(h->device));
+    const size_t xs = (size_t)h->st.x_stride, us = (size_t)h->st.u_stride, Ls = (size_t)h->N * LSTR;
+    const size_t need = xs + us + Ls;
+    if (need > h->cap_sol) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->h_sol) (void)hipHostFree(h->h_sol);
+        h->h_sol = nullptr; h->cap_sol = 0;
+        HIPCHK(hipHostMalloc((void **)&h->h_sol, need * 8, hipHostMallocDefault));
+        h->cap_sol = need;
+    }
+    double *const s_x = h->h_sol, *const s_u = s_x + xs, *const s_L = s_u + us;
+    double *const s_s = reinterpret_cast<double *>(h->h_io) + 2;
+    launch_pack_solution(h->st, b, x ? s_x : nullptr, l ? s_u : nullptr, L ? s_L : nullptr, s_s, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int st_h = (int)s_s[1];
+    if (status) *status = st_h;
+    if (value) *value = (st_h == 0 || st_h == 3) ? s_s[0] : INFINITY;
+    if (x) { std::vector<double> xp(s_x, s_x + xs); unpad_x(h, xp, x); }
+    if (l) { std::vector<double> up(s_u, s_u + us); unpad_u(h, up, l); }
+    if (L) { std::vector<double> Lp(s_L, s_L + Ls); unpad_L(h, Lp, L); }
     return RAT_OK;
 }
 
@@ -2178,14 +2274,30 @@ extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0,
     if (!h || !s || !theta_opt || !value) return fail(RAT_ERR_ARG, "null");
     if (!(kl_bound >= 0)) return fail(RAT_ERR_ARG, "KL Divergence Bound must be non-negative (:279)");
     rat_nm_initialize(s);
+    h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear();
     double th_opt;
     rat_rc rc;
     if (kl_bound > 0) {
+        if (!s->has_c_high && !s->has_c_low && h->nm_depth >= 1 && h->Bmax >= 14) {
+            // both initial vertices and the first iteration(s) under either ordering, in one device call
+            std::vector<double> list{s->theta_high, s->theta_low}, a, b2;
+            nm_plan(h, s, s->theta_low, s->theta_high, a);
+            nm_plan(h, s, s->theta_high, s->theta_low, b2);
+            list.insert(list.end(), a.begin(), a.end());
+            list.insert(list.end(), b2.begin(), b2.end());
+            if ((int64_t)list.size() > h->Bmax) {                               // (without the second level)
+                double v[6];
+                list.assign({s->theta_high, s->theta_low});
+                nm_vertices(s, s->theta_low, s->theta_high, v); list.insert(list.end(), v, v + 6);
+                nm_vertices(s, s->theta_high, s->theta_low, v); list.insert(list.end(), v, v + 6);
+            }
+            if ((rc = nm_prefetch(h, s, x0, u0, kl_bound, list))) return rc;
+        }
         if (!s->has_c_high) {                                                   // :283-293
             for (int guard = 0;; ++guard) {
                 if (guard > 2000) return fail(RAT_ERR_DIVERGED, "theta_high halving loop cut");
-                if ((rc = rat_nm_compute_cost(h, x0, u0, s->theta_high, kl_bound, &s->c_high))) return rc;
-                s->has_c_high = 1; s->n_solves++; s->n_batches++;
+                if ((rc = nm_cost(h, s, x0, u0, kl_bound, s->theta_high, &s->c_high))) return rc;
+                s->has_c_high = 1;
                 if (!std::isinf(s->c_high)) break;
                 s->theta_high *= s->lambda; s->theta_high_init *= s->lambda;
             }
@@ -2193,14 +2305,14 @@ extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0,
         if (!s->has_c_low) {                                                    // :294-304
             for (int guard = 0;; ++guard) {
                 if (guard > 2000) return fail(RAT_ERR_DIVERGED, "theta_low halving loop cut");
-                if ((rc = rat_nm_compute_cost(h, x0, u0, s->theta_low, kl_bound, &s->c_low))) return rc;
-                s->has_c_low = 1; s->n_solves++; s->n_batches++;
+                if ((rc = nm_cost(h, s, x0, u0, kl_bound, s->theta_low, &s->c_low))) return rc;
+                s->has_c_low = 1;
                 if (!std::isinf(s->c_low)) break;
                 s->theta_low *= s->lambda; s->theta_low_init *= s->lambda;
             }
         }
         for (;;) {                                                              // :306-324
-            if ((rc = rat_nm_step(h, s, x0, u0, kl_bound))) return rc;
+            if ((rc = nm_step_impl(h, s, x0, u0, kl_bound))) return rc;
             const double c_mean = (s->c_low + s->c_high) / 2;
             const double stdev = std::sqrt(0.5 * ((s->c_high - c_mean) * (s->c_high - c_mean) + (s->c_low - c_mean) * (s->c_low - c_mean)));
             if (stdev < s->eps) break;
@@ -2211,7 +2323,10 @@ extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0,
         th_opt = 0.0;                                                           // :332
     }
     int32_t st = 0; double val = 0;
-    if ((rc = rat_ileqg_solve(h, x0, u0, th_opt, x, l, L, &val, &st, nullptr, nullptr, 0, nullptr))) return rc;   // :346 (not in a try)
+    int at = -1;                                                                // theta_opt among the samples of the batch that ran last?
+    if (!h->wide) for (size_t i = 0; i < h->nm_last.size(); ++i) if (same_bits(h->nm_last[i], th_opt)) { at = (int)i; break; }
+    if (at >= 0) { if ((rc = fetch_batch_sample(h, at, x, l, L, &val, &st))) return rc; }
+    else if ((rc = rat_ileqg_solve(h, x0, u0, th_opt, x, l, L, &val, &st, nullptr, nullptr, 0, nullptr))) return rc;   // :346 (not in a try)
     if (status) *status = st;
     *theta_opt = th_opt;
     *value = (kl_bound > 0) ? val + kl_bound / th_opt : val;                    // :347-351

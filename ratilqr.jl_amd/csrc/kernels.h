@@ -116,5 +116,5 @@ void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s);   // modes 6 (initialize! + first gain sweep), 7 (candidate 0 + next gain sweep)
 void launch_commit_init(const StateDev &st, hipStream_t s);
 bool rollin_notile_supported(const ProblemDev &pb, const StateDev &st);              // the speculative path can run without candidate tiles
-void launch_pack_solution(const StateDev &st, double *dst_x, double *dst_u, double *dst_L, double *dst_s, hipStream_t s);   // one solve's outputs, one launch
+void launch_pack_solution(const StateDev &st, int b, double *dst_x, double *dst_u, double *dst_L, double *dst_s, hipStream_t s);   // one solve's outputs, one launch
 void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, double *cost, double kl_bound, hipStream_t s);

@@ -2668,22 +2668,23 @@ __global__ void gather_kernel(StateDev st, double *value, int *status, int *iter
 // The result of ONE solve (sample 0 of the handle: rat_ileqg_solve, the final solve of rat_ce_solve) into one destination -- pinned host
 // memory the device writes in place: the accepted trajectory (slot slot_nom), the committed gains (half lsel) and the scalars.  Nine
 // device-to-host copies (each a copy kernel of ~5 us plus its gap in the stream) used to follow the solve; now one launch does.
-__global__ __launch_bounds__(256) void pack_solution_kernel(StateDev st, double *dst_x, double *dst_u, double *dst_L, double *dst_s) {
-    const int nom = st.slot_nom[0], lsel = st.lsel[0];
-    const double *__restrict__ xs = st.xs + (long)nom * st.x_stride, *__restrict__ us = st.us + (long)nom * st.u_stride;
-    const double *__restrict__ Ls = st.L + (long)lsel * st.l_half;
+__global__ __launch_bounds__(256) void pack_solution_kernel(StateDev st, int b, double *dst_x, double *dst_u, double *dst_L, double *dst_s) {
+    const int nom = st.slot_nom[b], lsel = st.lsel[b];
+    const long slot = (long)b * (st.E + 1) + nom;
+    const double *__restrict__ xs = st.xs + slot * st.x_stride, *__restrict__ us = st.us + slot * st.u_stride;
+    const double *__restrict__ Ls = st.L + (long)lsel * st.l_half + (long)b * st.N * LSTR;
     const int nx = (int)st.x_stride, nu = (int)st.u_stride, nL = st.N * LSTR;
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x, str = gridDim.x * blockDim.x;
     if (dst_x) for (int i = i0; i < nx; i += str) dst_x[i] = xs[i];
     if (dst_u) for (int i = i0; i < nu; i += str) dst_u[i] = us[i];
     if (dst_L) for (int i = i0; i < nL; i += str) dst_L[i] = Ls[i];
     if (i0 == 0) {
-        dst_s[0] = st.value[0]; dst_s[1] = (double)st.status[0]; dst_s[2] = (double)st.iter[0]; dst_s[3] = (double)st.hist_n[0];
+        dst_s[0] = st.value[b]; dst_s[1] = (double)st.status[b]; dst_s[2] = (double)st.iter[b]; dst_s[3] = (double)st.hist_n[b];
         dst_s[4] = (double)nom; dst_s[5] = (double)lsel;
     }
 }
-void launch_pack_solution(const StateDev &st, double *dst_x, double *dst_u, double *dst_L, double *dst_s, hipStream_t s) {
-    hipLaunchKernelGGL(pack_solution_kernel, dim3(4), dim3(256), 0, s, st, dst_x, dst_u, dst_L, dst_s);
+void launch_pack_solution(const StateDev &st, int b, double *dst_x, double *dst_u, double *dst_L, double *dst_s, hipStream_t s) {
+    hipLaunchKernelGGL(pack_solution_kernel, dim3(4), dim3(256), 0, s, st, b, dst_x, dst_u, dst_L, dst_s);
 }
 void launch_gather(const StateDev &st, double *value, int *status, int *iters, int *ls_evals, double *cost, double kl_bound, hipStream_t s) {
     hipLaunchKernelGGL(gather_kernel, dim3((st.B + 255) / 256), dim3(256), 0, s, st, value, status, iters, ls_evals, cost, kl_bound);

@@ -1,5 +1,6 @@
 """GPU restatement of /root/reference/test/nelder_mead_bilevel_optimization_test.jl (K16) and parity of the batched
-Nelder-Mead (one speculative batch of <= 6 iLEQG solves per iteration) against the sequential oracle."""
+Nelder-Mead (every theta the sequential code can ask for over the next two iterations evaluated ahead, in one batch) against the
+sequential oracle."""
 import numpy as np
 import pytest
 
@@ -75,3 +76,31 @@ def test_nm_kl_zero():
     s = rat.NelderMeadBilevelOptimizationSolver()
     th, x, l, L, val = nm.solve_(s, prob, x0, u, kl_bound=0.0)
     assert th == 0.0 and abs(val - 1.0029075497782471) < 1e-9 and s.c_high is None and s.c_low is None
+
+
+@pytest.mark.parametrize("case", ["lq", "nonlinear", "infeasible_start"])
+def test_speculation_depth_and_handle_size_do_not_change_anything(case):
+    """rat_nm_solve evaluates ahead of the sequential code -- the iteration's six vertices (nm_depth 0), also the current pair and the
+    initial pair with the first iteration (1), also the following iteration's vertices (2, default) -- as far as the handle's max_batch
+    allows, and reads the final solve out of the last batch.  theta_opt, objective, trajectory, gains, simplex, iteration and evaluation
+    counts are the same bits whatever was speculated; only the number of device calls drops."""
+    if case == "nonlinear":
+        prob, x0, u = nonlinear()
+        kw, kl = dict(iter_max=20, eps=1e-3, theta_high_init=10.0, theta_low_init=1e-8), 1.0
+    else:
+        prob, x0, u = rat.synthetic_lq_problem()
+        kw, kl = (dict(theta_high_init=40.0) if case == "infeasible_start" else {}), 0.1
+    got = {}
+    for depth, mb in ((0, 160), (1, 160), (2, 160), (2, 1), (2, 6), (2, 8), (2, 20), (2, 90)):
+        s = rat.NelderMeadBilevelOptimizationSolver(**kw)
+        s._ctx = rat.Context(prob, s.ileqg_opts, max_batch=mb, spec_eps=1)
+        s._ctx.debug_set("nm_depth", depth)
+        th, x, l, L, v = nm.solve_(s, prob, x0, u, kl_bound=kl)
+        got[(depth, mb)] = (th, v, x.tobytes(), l.tobytes(), L.tobytes(), s.c.theta_high, s.c.theta_low, s.c.c_high, s.c.c_low,
+                            s.c.iter_current, s.c.n_solves, s.c.theta_high_init), s.c.n_batches
+    ref = got[(0, 160)][0]
+    assert all(g[0] == ref for g in got.values())
+    nb = {k: g[1] for k, g in got.items()}
+    assert nb[(2, 160)] <= nb[(1, 160)] <= nb[(0, 160)] and nb[(2, 160)] < nb[(0, 160)] and nb[(2, 160)] < nb[(2, 1)] <= ref[10]
+    if case == "lq":
+        assert nb[(2, 160)] == 2 and nb[(0, 160)] == 5 and ref[9] == 3       # 3 iterations: 2 device calls instead of 2 + 3 (+ the final solve)
