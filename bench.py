@@ -768,7 +768,7 @@ def rank_main(args):
                     "path": c8s.get_path(128), "costs_identical_to_primary": bool(torch.equal(co8, w.cost[:128]))}
         del c8s
 
-    shard_lat = pets_sec = nm_sec = None
+    shard_lat = pets_sec = nm_sec = wide_sec = None
     if world == 1 and not args.no_second:
         # What each rank of an N-GPU run of the BASELINE metric executes: ONE launch over 1024 / N samples.  A strong-scaling shard costs
         # one solve's latency whatever its size, so these driver-timed figures are the scaling curve's proxy when no multi-GPU node is
@@ -840,7 +840,7 @@ def rank_main(args):
         pets_sec["unit"] = "trajectories/s (BASELINE config 5: 10k trajectories per call)"
 
         # BASELINE config 4: RAT iLQR++ (src/nelder_mead_bilevel_optimization.jl:276-352) on the headline problem: every Nelder-Mead
-        # iteration is one batched device call of the <= 6 vertices the sequential rule can ask for
+        # iteration's vertices -- and those of the iteration after -- are evaluated ahead in one batched device call (driver.cpp: nm_plan)
         from ratilqr.jl_amd import nelder_mead as nm
         nms = rat.NelderMeadBilevelOptimizationSolver(device=D.local_rank)
 
@@ -864,6 +864,25 @@ def rank_main(args):
                   "ms_per_solve": enm * 1e3, "nm_iterations": int(nms.c.iter_current), "batched_device_calls": n_bat,
                   "sequential_ileqg_solves_replaced": n_seq, "theta_opt": th_nm, "objective": val_nm,
                   "ms_per_sequential_solve": enm * 1e3 / max(n_seq, 1)}
+
+        # general sizes (wide.hip; ileqg.jl:229 takes the dimensions from the arrays): CE batch of 1024 at 16 x 4 and 32 x 32
+        wide_sec = {"workload": "rat_ileqg_solve_batch, LQ-plus-noise problems of the headline recipe beyond the 12 + 4 tile, N = 50, CE batch 1024, "
+                                "host arrays in and out", "runs": {}}
+        for n_, m_ in ((16, 4), (32, 32)):
+            wprob, wx0, wu = rat.synthetic_lq_problem(n=n_, m=m_, N=50)
+            wth = np.abs(1.0 + 2.0 * np.random.default_rng(1).standard_normal(1024)) * 0.2
+            wctx = rat.Context(wprob, max_batch=1024, device=D.local_rank)
+            wv, wst, wit, _ = wctx.solve_batch(wx0, wu, wth)
+            tw = []
+            for _ in range(3):
+                t0w = time.perf_counter()
+                wctx.solve_batch(wx0, wu, wth)
+                tw.append(time.perf_counter() - t0w)
+            wide_sec["runs"][f"{n_}x{m_}"] = {"ms_per_batch": min(tw) * 1e3, "solves_per_s": 1024 / min(tw), "feasible": int((wst == 0).sum()),
+                                              "iterations_max": int(wit.max())}
+            del wctx
+        wide_sec["value"] = wide_sec["runs"]["16x4"]["solves_per_s"]
+        wide_sec["unit"] = "solves/s (n = 16, m = 4)"
 
     if fused and world == 1 and not args.no_second:
         # per-phase breakdown of the same batch on the round-based path (one launch per phase; what the fused kernel replaces)
@@ -942,6 +961,8 @@ def rank_main(args):
             "ce_solve_ms": ce_sec["ms_per_solve"]["median"] if ce_sec else None,
             "compute_cost_host_ms": host_sec["ms_per_call"] if host_sec else None,
             "nm_ms_per_solve": nm_sec["ms_per_solve"] if nm_sec else None,
+            "wide_16x4_solves_per_s": wide_sec["runs"]["16x4"]["solves_per_s"] if wide_sec else None,
+            "wide_32x32_solves_per_s": wide_sec["runs"]["32x32"]["solves_per_s"] if wide_sec else None,
             "pets_traj_per_s": pets_sec["value"] if pets_sec else None,
             "pets_1m_traj_per_s": pets_sec["runs"]["1000x1000"]["trajectories_per_s"] if pets_sec else None,
             "steady_solves_per_s": steady["value"] if steady else None,
@@ -963,7 +984,7 @@ def rank_main(args):
             out["secondary_large_batch"] = large
         for key, val in (("secondary_contract", contract), ("secondary_compute_cost_host", host_sec), ("secondary_ce_solve", ce_sec),
                          ("secondary_spec_eps8_shard128", e8_shard),
-                         ("shard_latency_ms", shard_lat), ("secondary_pets", pets_sec), ("secondary_nm", nm_sec)):
+                         ("shard_latency_ms", shard_lat), ("secondary_pets", pets_sec), ("secondary_nm", nm_sec), ("secondary_wide", wide_sec)):
             if val is not None:
                 out[key] = val
         if cpu is not None:
