@@ -18,8 +18,9 @@
 // Round 4: the matrix products run on the matrix pipe (prod: 16 x 16 blocks, operands read from LDS straight into the MFMA's lanes), both
 // factorisations and their substitutions entirely in registers (chol_reg: a lane per column, rows broadcast by v_readlane, no LDS access
 // and no barrier per row), the step's tables are fetched once per sweep, and every LDS pointer carries its address space (ds_read /
-// ds_write instead of flat accesses).  A step is bound by the number of instructions ONE wavefront issues (~12 k at 16 x 4 for ~350
-// wave-instructions' worth of multiply-adds): masks, addressing and loops over matrices that do not fill the 64 lanes; see DESIGN.md.
+// ds_write instead of flat accesses).  A wave issues ~5 k instructions per backward step at 16 x 4 (a third of them scalar: loop control
+// and edge masks) for ~350 wave-instructions' worth of multiply-adds, and is parked half of its lifetime on the dependent chains of the
+// factorisation and on LDS round trips between phases; see DESIGN.md and profiles/r04_wide_sizes.md.
 #include <hip/hip_runtime.h>
 #include <math.h>
 

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ratilqr.jl_amd as rat
 out = []
-for n, m in ((16, 4), (32, 32)):
+sizes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(16, 4), (32, 32)]      # e.g. 16x4
+for n, m in sizes:
     prob, x0, u = rat.synthetic_lq_problem(n=n, m=m, N=50)
     theta = np.abs(1.0 + 2.0 * np.random.default_rng(1).standard_normal(1024)) * 0.2
     ctx = rat.Context(prob, max_batch=1024)
