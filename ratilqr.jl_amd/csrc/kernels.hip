@@ -35,6 +35,7 @@
 #include "kernels.h"
 
 #include "device_utils.h"
+#include "rat_normal.h"
 #include "rat_pow.h"
 #include "sweep_dual.h"
 
@@ -2758,10 +2759,7 @@ __global__ __launch_bounds__(64) void pets_rollout_kernel(PetsArgs a) {
                 const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
                 if (g.noise_kind == 1 && !need_sel) { z = u1; znext = u2; }
                 else {
-                    const double rad = sqrt(-2.0 * log(1.0 - u1));
-                    double sn, cs;
-                    sincospi(2.0 * u2, &sn, &cs);               // (argument in [0, 2): no range reduction by pi -- a third of the lane's time before)
-                    z = rad * cs; znext = rad * sn;
+                    ratn_box_muller(u1, u2, &z, &znext);     // (rat_normal.h: the transform written out for its argument ranges)
                 }
             } else z = znext;
             if (need_sel) {
@@ -2848,10 +2846,7 @@ __global__ __launch_bounds__(64) void noisy_rollout_kernel(NoisyArgs a) {
             if ((t & 1) == 0) {                                      // both outputs of one Box-Muller transform: steps t and t + 1
                 unsigned r[4];
                 philox4x32_10((unsigned)k, (unsigned)(k >> 32), (unsigned)(t >> 1), (unsigned)j, (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
-                const double rad = sqrt(-2.0 * log(1.0 - u01(r[0], r[1])));
-                double sn, cs;
-                sincospi(2.0 * u01(r[2], r[3]), &sn, &cs);
-                z = rad * cs; znext = rad * sn;
+                ratn_box_muller(u01(r[0], r[1]), u01(r[2], r[3]), &z, &znext);
             } else z = znext;
         }
         if (j < 12) shxu[row][j] = x;
@@ -2990,10 +2985,7 @@ __global__ __launch_bounds__(64) void pets_rollout16_kernel(PetsArgs a) {
                     const double u1 = u01(rr[0], rr[1]), u2 = u01(rr[2], rr[3]);
                     if (!gauss && !need_sel) { z[r] = u1; zn1[r] = u2; }
                     else {
-                        const double rad = sqrt(-2.0 * log(1.0 - u1));
-                        double sn, cs;
-                        sincospi(2.0 * u2, &sn, &cs);
-                        z[r] = rad * cs; zn1[r] = rad * sn;
+                        ratn_box_muller(u1, u2, &z[r], &zn1[r]);
                     }
                 }
             } else {
@@ -3100,10 +3092,7 @@ __global__ __launch_bounds__(256) void pets_rollout16s_kernel(PetsArgs a) {
                     const double u1 = u01(rr[0], rr[1]), u2 = u01(rr[2], rr[3]);
                     if (!gauss && !need_sel) { z0 = u1; z1 = u2; }
                     else {
-                        const double rad = sqrt(-2.0 * log(1.0 - u1));
-                        double sn, cs;
-                        sincospi(2.0 * u2, &sn, &cs);
-                        z0 = rad * cs; z1 = rad * sn;
+                        ratn_box_muller(u1, u2, &z0, &z1);
                     }
                     z0 *= cm; z1 *= cm;
                     if (r == 0 && need_sel) {

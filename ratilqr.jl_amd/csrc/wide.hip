@@ -26,6 +26,7 @@
 
 #include "wide.h"
 #include "device_utils.h"
+#include "rat_normal.h"
 
 namespace {
 
@@ -752,10 +753,7 @@ __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
                     unsigned r[4];
                     philox4x32_10((unsigned)b, (unsigned)((unsigned long long)b >> 32), (unsigned)(t >> 1), (unsigned)lane, (unsigned)a.seed,
                                   (unsigned)(a.seed >> 32), r);
-                    const double rad = sqrt(-2.0 * log(1.0 - u01(r[0], r[1])));
-                    double sn, cs;
-                    sincos(6.283185307179586476925286766559 * u01(r[2], r[3]), &sn, &cs);
-                    zt = rad * cs; znext = rad * sn;
+                    ratn_box_muller(u01(r[0], r[1]), u01(r[2], r[3]), &zt, &znext);
                 } else zt = znext;
                 w.z[lane] = zt;
             }

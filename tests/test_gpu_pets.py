@@ -144,6 +144,42 @@ def test_sixteen_per_wave_kernels_equal_four_per_wave(S, K, Nh, use_true):
     assert np.all(np.abs(gen[2] - gen[0]) <= 1e-12 * np.abs(gen[0]))
 
 
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al. 2011) on numpy arrays of 32-bit words held in uint64, as csrc/kernels.hip:philox4x32_10 writes it."""
+    M = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(v, np.uint64) & M for v in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0) & M, np.uint64(k1) & M
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & M, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & M
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return c0, c1, c2, c3
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 0])
+def test_device_generator_against_a_host_restatement(mode):
+    """The device noise itself, end to end: with x_{t+1} = w_t (A = B = 0), w ~ N(0, I) and cost 1/2 |x|^2 a trajectory's cost is half the sum
+    of the squares of its N x 12 standard normals.  The host draws them the way the kernels document -- Philox4x32-10 keyed by the seed,
+    counter (trajectory, step pair, component), two 53-bit uniforms per block, Box-Muller by csrc/rat_normal.h (oracle/normal_check.c) giving
+    the normals of steps 2p and 2p + 1 -- and must reproduce every sample cost.  An odd horizon leaves half a pair unused."""
+    import ctypes as C
+    from test_cpu_normal import parts
+    n, m, Nh, S, K, seed = 12, 4, 7, 5, 37, 0x1234567890ABCDEF
+    prob = rat.LQGenerativeProblem(np.zeros((n, n)), np.zeros((n, m)), Nh, ("gaussian", np.zeros(n), np.eye(n)), Q=np.eye(n), R=np.eye(m),
+                                   Qf=np.eye(n), kappa=0.0)
+    ds = rat.CrossEntropyDirectOptimizationSolver(np.zeros((Nh, m)), np.stack([np.eye(m)] * Nh), num_control_samples=S, num_trajectory_samples=K)
+    ds.context(prob).debug_set("pets_wave16", mode)
+    got = pets.compute_cost_serial(ds, prob, np.zeros(n), np.zeros((S, Nh, m)), None, seed=seed)
+    tj, p, c = np.meshgrid(np.arange(S * K), np.arange((Nh + 1) // 2), np.arange(n), indexing="ij")
+    r0, r1, r2, r3 = _philox4x32_10(tj, 0 * tj, p, c, seed & 0xFFFFFFFF, seed >> 32)
+    u1 = (((r0 << np.uint64(32)) | r1) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    u2 = (((r2 << np.uint64(32)) | r3) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    _, _, _, _, z0, z1 = parts(np.ascontiguousarray(u1.ravel()), np.ascontiguousarray(u2.ravel()))
+    z = np.stack([z0.reshape(u1.shape), z1.reshape(u1.shape)], axis=2).reshape(S * K, -1, n)[:, :Nh]      # [trajectory][step][component]
+    ref = (0.5 * (z ** 2).sum(axis=(1, 2))).reshape(S, K).mean(axis=1)
+    assert np.all(np.abs(got - ref) <= 1e-12 * ref)
+
+
 def test_device_generator_is_statistically_sane():
     """BASELINE config 5 shape: 10k trajectory samples, N = 30, device-generated noise (Philox): mean cost within a few
     standard errors of the injected-stream evaluation; reproducible for a fixed seed, different across seeds."""
