@@ -112,6 +112,7 @@ struct rat_handle_s {
     // Nelder-Mead (rat_nm_solve): costs already evaluated for this (problem, x0, u0, kl_bound) by exact theta, and the thetas of the batch
     // that ran last (its per-sample state is still on the device: the final solve is read out of it)
     std::vector<double> nm_th, nm_c, nm_last;
+    uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, x0, u0, kl_bound)
     int nm_depth = 2;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's)
     // CE randomness
     const double *z = nullptr;
@@ -444,7 +445,7 @@ static rat_rc problem_set_wide(rat_handle h, const rat_problem_desc *d) {
     memset(&h->pb, 0, sizeof(h->pb));
     h->pb.model = d->model; h->pb.n = n; h->pb.m = m; h->pb.N = N;
     h->wpb = wp; h->n = n; h->m = m; h->N = N;
-    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false;
+    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false; h->problem_serial++;
     if (realloc_state && (rc = alloc_state_wide(h))) return rc;
     return RAT_OK;
 }
@@ -551,7 +552,7 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
     // control step) keeps its buffers: every live lane is rewritten by the next solve.
     const bool realloc_state = !h->have_problem || h->wide || h->N != N || h->n != n || h->m != m;
     h->pb = pb; h->n = n; h->m = m; h->N = N;
-    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false;
+    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false; h->problem_serial++;
     if (realloc_state && (rc = alloc_state(h))) return rc;
     return RAT_OK;
 }
@@ -2237,9 +2238,22 @@ static rat_rc nm_step_impl(rat_handle h, rat_nm_solver *s, const double *x0, con
     return RAT_OK;
 }
 
+// the table of evaluated thetas is valid for one (problem, x0, u0, kl_bound, solver constants that shape the vertices do not matter: thetas are keys)
+static uint64_t nm_table_key(rat_handle h, const double *x0, const double *u0, double kl_bound) {
+    uint64_t k = 1469598103934665603ull ^ h->problem_serial;
+    auto mix = [&](const double *p, size_t cnt) {
+        for (size_t i = 0; i < cnt; ++i) { uint64_t b; memcpy(&b, p + i, 8); k = (k ^ b) * 1099511628211ull; k ^= k >> 29; }
+    };
+    if (x0) mix(x0, (size_t)h->n);
+    if (u0) mix(u0, (size_t)h->N * h->m);
+    mix(&kl_bound, 1);
+    return k | 1ull;
+}
 extern "C" rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound) {   // :174-252
     if (!h || !s) return fail(RAT_ERR_ARG, "null");
-    h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear();                     // (a stand-alone step: nothing is known about x0, u0, kl_bound)
+    // a caller's own loop over step! keeps what earlier steps evaluated ahead, as long as it is the same (problem, x0, u0, kl_bound)
+    const uint64_t key = nm_table_key(h, x0, u0, kl_bound);
+    if (key != h->nm_key) { h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear(); h->nm_key = key; }
     return nm_step_impl(h, s, x0, u0, kl_bound);
 }
 
@@ -2275,6 +2289,7 @@ extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0,
     if (!(kl_bound >= 0)) return fail(RAT_ERR_ARG, "KL Divergence Bound must be non-negative (:279)");
     rat_nm_initialize(s);
     h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear();
+    h->nm_key = nm_table_key(h, x0, u0, kl_bound);
     double th_opt;
     rat_rc rc;
     if (kl_bound > 0) {

@@ -104,3 +104,24 @@ def test_speculation_depth_and_handle_size_do_not_change_anything(case):
     assert nb[(2, 160)] <= nb[(1, 160)] <= nb[(0, 160)] and nb[(2, 160)] < nb[(0, 160)] and nb[(2, 160)] < nb[(2, 1)] <= ref[10]
     if case == "lq":
         assert nb[(2, 160)] == 2 and nb[(0, 160)] == 5 and ref[9] == 3       # 3 iterations: 2 device calls instead of 2 + 3 (+ the final solve)
+
+
+def test_a_callers_own_step_loop_keeps_what_was_evaluated_ahead():
+    """step! called in the caller's loop (the reference exposes it): the table of thetas evaluated ahead survives from one call to the next
+    while (problem, x0, u0, kl_bound) stay the same, so the loop needs a device call every other iteration; the simplex is the one
+    solve! reaches.  A different kl_bound (or x0) drops the table."""
+    prob, x0, u = rat.synthetic_lq_problem()
+    kl = 0.1
+    ref = rat.NelderMeadBilevelOptimizationSolver()
+    nm.solve_(ref, prob, x0, u, kl_bound=kl)
+    s = rat.NelderMeadBilevelOptimizationSolver()
+    s.c.c_high = rat.compute_cost_worker(s, prob, x0, u, s.theta_high, kl); s.c.has_c_high = 1
+    s.c.c_low = rat.compute_cost_worker(s, prob, x0, u, s.theta_low, kl); s.c.has_c_low = 1
+    nb0 = s.c.n_batches
+    for _ in range(ref.c.iter_current):
+        nm.step_(s, prob, x0, u, kl)
+    assert (s.c.theta_low, s.c.theta_high, s.c.c_low, s.c.c_high) == (ref.c.theta_low, ref.c.theta_high, ref.c.c_low, ref.c.c_high)
+    assert s.c.n_batches - nb0 == (ref.c.iter_current + 1) // 2
+    nb1 = s.c.n_batches
+    nm.step_(s, prob, x0, u, 0.2)                                  # another objective: nothing evaluated for kl = 0.1 may be reused
+    assert s.c.n_batches == nb1 + 1
