@@ -268,12 +268,17 @@ void   rat_nm_default(rat_nm_solver *s);                                     /* 
 void   rat_nm_initialize(rat_nm_solver *s);                                  /* initialize!   :164-168 */
 /* compute_cost_worker(nm_solver, problem, x, u_array, theta, kl_bound)        :134-158 */
 rat_rc rat_nm_compute_cost(rat_handle h, const double *x0, const double *u0, double theta, double kl_bound, double *cost);
-/* step! :174-252.  All vertices the sequential logic can ask for in one iteration (reflection, expansion, the two
- * possible contraction points and the two possible shrink points) are solved as ONE batch of <= 6 iLEQG solves; the
- * reflect/expand/contract/shrink decisions are then replayed on the host, so the outcome is the sequential one. */
+/* step! :174-252.  Every theta the sequential logic can ask for -- this iteration's reflection, expansion, two possible
+ * contraction and two possible shrink points and, as far as the handle's max_batch allows (80 samples), the six points of
+ * each state the iteration can end in -- is solved ahead in ONE batch (a batch of <= 512 samples takes one solve's time); the
+ * reflect / expand / contract / shrink decisions are then replayed on the host against the table of (theta, cost), so the
+ * outcome is the sequential one and the next call usually needs no device call.  The table is kept between calls while
+ * (problem, x0, u0, kl_bound) are unchanged.  Switch nm_depth (rat_debug_set) limits the speculation. */
 rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound);
 /* solve!(nm_solver, problem, x_0, u_array; kl_bound)                           :276-352 ; *status = final iLEQG status
- * (a failure there is an uncaught exception in the reference). */
+ * (a failure there is an uncaught exception in the reference).  Both initial vertices and the first two iterations under
+ * either ordering go into the first device call (158 samples), later calls cover two iterations each, and the final
+ * solve at theta_opt is read out of the last batch's device state instead of being run again. */
 rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound,
                     double *theta_opt, double *x, double *l, double *L, double *value, int32_t *status);
 
