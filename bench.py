@@ -840,7 +840,8 @@ def rank_main(args):
         pets_sec["unit"] = "trajectories/s (BASELINE config 5: 10k trajectories per call)"
 
         # BASELINE config 4: RAT iLQR++ (src/nelder_mead_bilevel_optimization.jl:276-352) on the headline problem: every Nelder-Mead
-        # iteration's vertices -- and those of the iteration after -- are evaluated ahead in one batched device call (driver.cpp: nm_plan)
+        # iteration's vertices -- and those of the iterations after (three deep in the first call, two afterwards) -- are evaluated ahead in
+        # one batched device call (driver.cpp: nm_tree / nm_plan)
         from ratilqr.jl_amd import nelder_mead as nm
         nms = rat.NelderMeadBilevelOptimizationSolver(device=D.local_rank)
 

@@ -277,7 +277,8 @@ rat_rc rat_nm_compute_cost(rat_handle h, const double *x0, const double *u0, dou
 rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound);
 /* solve!(nm_solver, problem, x_0, u_array; kl_bound)                           :276-352 ; *status = final iLEQG status
  * (a failure there is an uncaught exception in the reference).  Both initial vertices and the first two iterations under
- * either ordering go into the first device call (158 samples), later calls cover two iterations each, and the final
+ * either ordering go into the first device call (158 samples; three iterations, 1022 samples, on a handle that large), later calls
+ * cover two iterations each, and the final
  * solve at theta_opt is read out of the last batch's device state instead of being run again. */
 rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound,
                     double *theta_opt, double *x, double *l, double *L, double *value, int32_t *status);
@@ -416,9 +417,10 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   fly_multi       0 / 1    ... and all candidates of a sample rolled out by one wavefront                               (1)
  *   dual            0 / 1    round-based path: candidate 0 paired with the next gain sweep in one wavefront              (E > 1)
  *   speculate       0 / 1    round-based path: speculative gain sweeps on a second stream                                (0)
- *   nm_depth        0 .. 2   Nelder-Mead speculation: 0 the six vertices of the iteration per device call; 1 also the two current vertices (the
+ *   nm_depth        0 .. 3   Nelder-Mead speculation: 0 the six vertices of the iteration per device call; 1 also the two current vertices (the
  *                            final solve is read out of the last batch) and both initial vertices with the first iteration in one call; 2 also
- *                            the vertices of the iteration after (two iterations per device call).  Results do not depend on it  (2)
+ *                            the vertices of the iteration after (two iterations per device call); 3 also a third iteration in the first call
+ *                            of rat_nm_solve (handles of >= 1022 samples).  Results do not depend on it  (3)
  *   pets_wave16     0 .. 3   PETS rollouts: 0 four per wavefront; 1 sixteen per wavefront as MFMA columns, the noise drawn by three generator
  *                            wavefronts per workgroup while the launch is small (<= 1536 wavefronts), by the recursion's own beyond; 2 never
  *                            split; 3 always split.  1-3 are bit-identical, 0 agrees to rounding  (1)

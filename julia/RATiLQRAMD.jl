@@ -739,7 +739,7 @@ function NelderMeadBilevelOptimizationSolver(; μ_min_ileqg=1e-6, Δ_0_ileqg=2.0
     NelderMeadBilevelOptimizationSolver(o, c, device, nothing)
 end
 function handle!(s::NelderMeadBilevelOptimizationSolver, problem)
-    s.h === nothing && (s.h = Handle(s.opts, 160, 1, s.device))          # both initial vertices + two iterations' vertices per device call
+    s.h === nothing && (s.h = Handle(s.opts, 1024, 1, s.device))         # both initial vertices + three iterations' vertices in the first device call
     bind!(s.h, problem)
 end
 "initialize!(nm_solver) -- :164-168 (c_high / c_low are left alone, as in the reference)"

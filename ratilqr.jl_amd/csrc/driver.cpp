@@ -113,7 +113,8 @@ struct rat_handle_s {
     // that ran last (its per-sample state is still on the device: the final solve is read out of it)
     std::vector<double> nm_th, nm_c, nm_last;
     uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, x0, u0, kl_bound)
-    int nm_depth = 2;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's)
+    int nm_depth = 3;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's),
+                                     // 3 (+ a third iteration in rat_nm_solve's first call)
     // CE randomness
     const double *z = nullptr;
     int64_t nz = 0, zpos = 0;
@@ -173,7 +174,7 @@ static const DebugSwitch debug_switches[] = {
     {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
     {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
     {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
-    {"nm_depth", [](rat_handle h, int64_t v) { h->nm_depth = (v < 0 || v > 2) ? 2 : (int)v; }, [](rat_handle h) -> int64_t { return h->nm_depth; }},
+    {"nm_depth", [](rat_handle h, int64_t v) { h->nm_depth = (v < 0 || v > 3) ? 3 : (int)v; }, [](rat_handle h) -> int64_t { return h->nm_depth; }},
     {"pets_wave16", [](rat_handle h, int64_t v) { h->pets_wave16 = (v < 0 || v > 3) ? 1 : (int)v; }, [](rat_handle h) -> int64_t { return h->pets_wave16; }},
     {"ce_device", [](rat_handle h, int64_t v) { h->ce_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->ce_device; }},
 };
@@ -2157,15 +2158,21 @@ static void nm_vertices(const rat_nm_solver *s, double th_m, double th_h, double
     th[5] = (th_r + th_m) / 2;
 }
 // evaluates the thetas of `list` not yet in the table, in ONE batch (or several when the handle is smaller)
-static rat_rc nm_prefetch(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound, const std::vector<double> &list) {
+// `carry`: thetas that ride along even when their cost is known -- the current vertices, one of which may be the theta_low the solve ends
+// with: the final solve is read out of the LAST batch's device state, so they have to be in it (two more samples cost nothing)
+static rat_rc nm_prefetch(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound, const std::vector<double> &list,
+                          const std::vector<double> &carry = std::vector<double>()) {
     std::vector<double> todo;
+    auto add = [&](double th) {
+        for (double t2 : todo) if (same_bits(t2, th)) return;
+        todo.push_back(th);
+    };
     for (double th : list) {
         double c;
-        if (nm_lookup(h, th, &c)) continue;
-        bool dup = false;
-        for (double t2 : todo) if (same_bits(t2, th)) { dup = true; break; }
-        if (!dup) todo.push_back(th);
+        if (!nm_lookup(h, th, &c)) add(th);
     }
+    if (todo.empty()) return RAT_OK;
+    for (double th : carry) if ((int64_t)todo.size() < h->Bmax) add(th);
     for (size_t o = 0; o < todo.size(); o += (size_t)h->Bmax) {
         const size_t nb = std::min(todo.size() - o, (size_t)h->Bmax);
         std::vector<double> c(nb);
@@ -2184,19 +2191,30 @@ static rat_rc nm_cost(rat_handle h, rat_nm_solver *s, const double *x0, const do
     if (rc) return rc;
     return nm_lookup(h, th, c) ? RAT_OK : fail(RAT_ERR_HIP, "Nelder-Mead: evaluated theta missing from the table");
 }
-// what to evaluate ahead of an iteration from (th_m, th_h): its vertices, the two current ones, and the next iteration's
-static void nm_plan(rat_handle h, const rat_nm_solver *s, double th_m, double th_h, std::vector<double> &list) {
+// every theta the next `depth` iterations from (theta_low = th_m, theta_high = th_h) can evaluate: 6, 78, 942 for depth 1, 2, 3
+static void nm_tree(const rat_nm_solver *s, double th_m, double th_h, int depth, std::vector<double> &list) {
     double v[6];
     nm_vertices(s, th_m, th_h, v);
     list.insert(list.end(), v, v + 6);
-    if (h->nm_depth < 1) return;
-    list.push_back(th_m); list.push_back(th_h);
-    if (h->nm_depth < 2) return;
+    if (depth < 2) return;
     for (int k = 0; k < 6; ++k) {                                 // theta_high <- v[k]; the next iteration may swap the two (:184-187)
-        double w[6];
-        nm_vertices(s, th_m, v[k], w); list.insert(list.end(), w, w + 6);
-        nm_vertices(s, v[k], th_m, w); list.insert(list.end(), w, w + 6);
+        nm_tree(s, th_m, v[k], depth - 1, list);
+        nm_tree(s, v[k], th_m, depth - 1, list);
     }
+}
+// what to evaluate ahead of an iteration from (th_m, th_h): its vertices and the next iteration's
+static void nm_plan(rat_handle h, const rat_nm_solver *s, double th_m, double th_h, std::vector<double> &list) {
+    nm_tree(s, th_m, th_h, h->nm_depth >= 2 ? 2 : 1, list);
+}
+static size_t nm_unique(std::vector<double> &list) {               // drops bit-equal repeats, keeps the order
+    std::vector<double> u;
+    for (double th : list) {
+        bool dup = false;
+        for (double t2 : u) if (same_bits(t2, th)) { dup = true; break; }
+        if (!dup) u.push_back(th);
+    }
+    list.swap(u);
+    return list.size();
 }
 
 static rat_rc nm_step_impl(rat_handle h, rat_nm_solver *s, const double *x0, const double *u0, double kl_bound) {   // :174-252
@@ -2214,10 +2232,11 @@ static rat_rc nm_step_impl(rat_handle h, rat_nm_solver *s, const double *x0, con
         bool all = true;
         for (int i = 0; i < 6; ++i) { double c; all = all && nm_lookup(h, th[i], &c); }
         if (!all) {
-            std::vector<double> list;
+            std::vector<double> list, carry;
             nm_plan(h, s, th_m, s->theta_high, list);
-            if ((int64_t)list.size() > h->Bmax) list.resize(h->Bmax >= 8 && h->nm_depth >= 1 ? 8 : 6);
-            if ((rc = nm_prefetch(h, s, x0, u0, kl_bound, list))) return rc;
+            if ((int64_t)nm_unique(list) + 2 > h->Bmax) list.resize(6);          // (the first six are this iteration's vertices)
+            if (h->nm_depth >= 1) carry.assign({th_m, s->theta_high});
+            if ((rc = nm_prefetch(h, s, x0, u0, kl_bound, list, carry))) return rc;
         }
     }
     double c_r, c_e, c_c;
@@ -2294,18 +2313,18 @@ extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0,
     rat_rc rc;
     if (kl_bound > 0) {
         if (!s->has_c_high && !s->has_c_low && h->nm_depth >= 1 && h->Bmax >= 14) {
-            // both initial vertices and the first iteration(s) under either ordering, in one device call
-            std::vector<double> list{s->theta_high, s->theta_low}, a, b2;
-            nm_plan(h, s, s->theta_low, s->theta_high, a);
-            nm_plan(h, s, s->theta_high, s->theta_low, b2);
-            list.insert(list.end(), a.begin(), a.end());
-            list.insert(list.end(), b2.begin(), b2.end());
-            if ((int64_t)list.size() > h->Bmax) {                               // (without the second level)
-                double v[6];
+            // both initial vertices and the first iterations under either ordering, in one device call.  The ordering in which the vertex
+            // at theta_low_init turns out the worse one (its kl_bound / theta term is what makes it so: the swap of :184-187) is followed
+            // one level deeper when the handle is large enough -- 2 + 942 + 78 thetas: one batch on the one-wave-per-sample kernel covers
+            // the initial pair and THREE iterations (0.39 ms instead of two batches of 0.28 ms).  A wrong guess costs nothing but a miss.
+            std::vector<double> list;
+            for (int deep = std::min(h->nm_depth, 3); deep >= 1; --deep) {
                 list.assign({s->theta_high, s->theta_low});
-                nm_vertices(s, s->theta_low, s->theta_high, v); list.insert(list.end(), v, v + 6);
-                nm_vertices(s, s->theta_high, s->theta_low, v); list.insert(list.end(), v, v + 6);
+                nm_tree(s, s->theta_high, s->theta_low, deep, list);
+                nm_tree(s, s->theta_low, s->theta_high, std::min(deep, 2), list);
+                if ((int64_t)nm_unique(list) <= h->Bmax) break;
             }
+            if ((int64_t)list.size() > h->Bmax) list.resize((size_t)h->Bmax);
             if ((rc = nm_prefetch(h, s, x0, u0, kl_bound, list))) return rc;
         }
         if (!s->has_c_high) {                                                   // :283-293

@@ -45,8 +45,8 @@ class NelderMeadBilevelOptimizationSolver:
 
     def context(self, problem) -> Context:
         if self._ctx is None or self._ctx.problem is not problem:
-            # 160 samples: both initial vertices and two iterations' worth of vertices under either ordering in one device call (driver.cpp)
-            self._ctx = Context(problem, self.ileqg_opts, max_batch=160, spec_eps=1, device=self.device)
+            # 1024 samples: both initial vertices and three iterations' worth of vertices in the first device call (driver.cpp: rat_nm_solve)
+            self._ctx = Context(problem, self.ileqg_opts, max_batch=1024, spec_eps=1, device=self.device)
         return self._ctx
 
 

@@ -81,7 +81,8 @@ def test_nm_kl_zero():
 @pytest.mark.parametrize("case", ["lq", "nonlinear", "infeasible_start"])
 def test_speculation_depth_and_handle_size_do_not_change_anything(case):
     """rat_nm_solve evaluates ahead of the sequential code -- the iteration's six vertices (nm_depth 0), also the current pair and the
-    initial pair with the first iteration (1), also the following iteration's vertices (2, default) -- as far as the handle's max_batch
+    initial pair with the first iteration (1), also the following iteration's vertices (2), also a third iteration in the first call (3,
+    default) -- as far as the handle's max_batch
     allows, and reads the final solve out of the last batch.  theta_opt, objective, trajectory, gains, simplex, iteration and evaluation
     counts are the same bits whatever was speculated; only the number of device calls drops."""
     if case == "nonlinear":
@@ -91,7 +92,7 @@ def test_speculation_depth_and_handle_size_do_not_change_anything(case):
         prob, x0, u = rat.synthetic_lq_problem()
         kw, kl = (dict(theta_high_init=40.0) if case == "infeasible_start" else {}), 0.1
     got = {}
-    for depth, mb in ((0, 160), (1, 160), (2, 160), (2, 1), (2, 6), (2, 8), (2, 20), (2, 90)):
+    for depth, mb in ((0, 160), (1, 160), (2, 160), (2, 1), (2, 6), (2, 8), (2, 20), (2, 90), (3, 1024), (3, 500)):
         s = rat.NelderMeadBilevelOptimizationSolver(**kw)
         s._ctx = rat.Context(prob, s.ileqg_opts, max_batch=mb, spec_eps=1)
         s._ctx.debug_set("nm_depth", depth)
@@ -102,8 +103,10 @@ def test_speculation_depth_and_handle_size_do_not_change_anything(case):
     assert all(g[0] == ref for g in got.values())
     nb = {k: g[1] for k, g in got.items()}
     assert nb[(2, 160)] <= nb[(1, 160)] <= nb[(0, 160)] and nb[(2, 160)] < nb[(0, 160)] and nb[(2, 160)] < nb[(2, 1)] <= ref[10]
+    assert nb[(3, 1024)] <= nb[(2, 160)] and nb[(3, 500)] <= nb[(2, 160)]
     if case == "lq":
         assert nb[(2, 160)] == 2 and nb[(0, 160)] == 5 and ref[9] == 3       # 3 iterations: 2 device calls instead of 2 + 3 (+ the final solve)
+        assert nb[(3, 1024)] == 1                                            # ... and ONE when the first call reaches three iterations deep
 
 
 def test_a_callers_own_step_loop_keeps_what_was_evaluated_ahead():

@@ -6,7 +6,7 @@ import ratilqr.jl_amd as rat
 from ratilqr.jl_amd import nelder_mead as nm
 prob, x0, u0 = rat.synthetic_lq_problem()
 ref = None
-for depth in (2, 1, 0):
+for depth in (3, 2, 1, 0):
     nms = rat.NelderMeadBilevelOptimizationSolver()
     ctx = nms.context(prob)
     ctx.debug_set("nm_depth", depth)
@@ -25,4 +25,4 @@ for depth in (2, 1, 0):
     same = ref is None or key == ref
     ref = ref or key
     print(f"nm_depth {depth}: {dt * 1e3:.3f} ms per solve; iterations {nms.c.iter_current}, sequential evaluations {ns}, device calls {nb}; theta_opt {r[0]:.6g} "
-          f"objective {r[4]:.9g}; identical to depth 2: {same}")
+          f"objective {r[4]:.9g}; identical to depth 3: {same}")
