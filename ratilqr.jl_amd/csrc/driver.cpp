@@ -111,7 +111,8 @@ struct rat_handle_s {
     double *h_pcost = nullptr; size_t cap_hpcost = 0;       // pinned landing zone of the sample costs of the synchronous call (zero-copy)
     // Nelder-Mead (rat_nm_solve): costs already evaluated for this (problem, x0, u0, kl_bound) by exact theta, and the thetas of the batch
     // that ran last (its per-sample state is still on the device: the final solve is read out of it)
-    std::vector<double> nm_th, nm_c, nm_last;
+    std::vector<double> nm_th, nm_c, nm_last, nm_last_v;    // (nm_last_v / nm_last_st: value and status of the last batch's samples)
+    std::vector<int32_t> nm_last_st;
     uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, x0, u0, kl_bound)
     int nm_depth = 3;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's),
                                      // 3 (+ a third iteration in rat_nm_solve's first call)
@@ -2176,11 +2177,13 @@ static rat_rc nm_prefetch(rat_handle h, rat_nm_solver *s, const double *x0, cons
     for (size_t o = 0; o < todo.size(); o += (size_t)h->Bmax) {
         const size_t nb = std::min(todo.size() - o, (size_t)h->Bmax);
         std::vector<double> c(nb);
-        rat_rc rc = rat_ileqg_solve_batch(h, x0, u0, todo.data() + o, (int64_t)nb, c.data(), nullptr, nullptr, nullptr);
+        std::vector<int32_t> st(nb);
+        rat_rc rc = rat_ileqg_solve_batch(h, x0, u0, todo.data() + o, (int64_t)nb, c.data(), st.data(), nullptr, nullptr);
         if (rc) return rc;
         s->n_batches += 1;
         for (size_t i = 0; i < nb; ++i) { h->nm_th.push_back(todo[o + i]); h->nm_c.push_back(c[i] + kl_bound / todo[o + i]); }
         h->nm_last.assign(todo.begin() + (std::ptrdiff_t)o, todo.begin() + (std::ptrdiff_t)(o + nb));
+        h->nm_last_v.swap(c); h->nm_last_st.swap(st);
     }
     return RAT_OK;
 }
@@ -2272,8 +2275,25 @@ extern "C" rat_rc rat_nm_step(rat_handle h, rat_nm_solver *s, const double *x0, 
     if (!h || !s) return fail(RAT_ERR_ARG, "null");
     // a caller's own loop over step! keeps what earlier steps evaluated ahead, as long as it is the same (problem, x0, u0, kl_bound)
     const uint64_t key = nm_table_key(h, x0, u0, kl_bound);
-    if (key != h->nm_key) { h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear(); h->nm_key = key; }
+    if (key != h->nm_key) { h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear(); h->nm_last_v.clear(); h->nm_last_st.clear(); h->nm_key = key; }
     return nm_step_impl(h, s, x0, u0, kl_bound);
+}
+
+// general sizes: the trajectory, controls and gains of sample b of the batch that ran last (wide_solve_kernel keeps every sample's two
+// (x, u) slots, its gains and which slot holds the result); value and status are the batch's own outputs
+static rat_rc fetch_batch_sample_wide(rat_handle h, int b, double *x, double *l, double *L) {
+    HIPCHK(hipSetDevice(h->device));
+    const size_t xs = (size_t)(h->N + 1) * h->n, us = (size_t)h->N * h->m, Ls = us * h->n;
+    int32_t *p_i = reinterpret_cast<int32_t *>(h->h_io);
+    HIPCHK(hipMemcpyAsync(p_i, h->w_nom + b, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int nom = p_i[0];
+    if (nom < 0 || nom > 1) return fail(RAT_ERR_HIP, "general-size solve: slot index out of range");
+    if (x) HIPCHK(hipMemcpyAsync(x, h->w_xs + ((size_t)b * 2 + nom) * xs, xs * 8, hipMemcpyDeviceToHost, h->stream));
+    if (l) HIPCHK(hipMemcpyAsync(l, h->w_us + ((size_t)b * 2 + nom) * us, us * 8, hipMemcpyDeviceToHost, h->stream));
+    if (L) HIPCHK(hipMemcpyAsync(L, h->w_L + (size_t)b * Ls, Ls * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RAT_OK;
 }
 
 // x, l, L, value, status of sample b of the batch that ran last, as rat_ileqg_solve returns them (tile-sized problems)
@@ -2307,7 +2327,7 @@ extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0,
     if (!h || !s || !theta_opt || !value) return fail(RAT_ERR_ARG, "null");
     if (!(kl_bound >= 0)) return fail(RAT_ERR_ARG, "KL Divergence Bound must be non-negative (:279)");
     rat_nm_initialize(s);
-    h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear();
+    h->nm_th.clear(); h->nm_c.clear(); h->nm_last.clear(); h->nm_last_v.clear(); h->nm_last_st.clear();
     h->nm_key = nm_table_key(h, x0, u0, kl_bound);
     double th_opt;
     rat_rc rc;
@@ -2358,8 +2378,11 @@ extern "C" rat_rc rat_nm_solve(rat_handle h, rat_nm_solver *s, const double *x0,
     }
     int32_t st = 0; double val = 0;
     int at = -1;                                                                // theta_opt among the samples of the batch that ran last?
-    if (!h->wide) for (size_t i = 0; i < h->nm_last.size(); ++i) if (same_bits(h->nm_last[i], th_opt)) { at = (int)i; break; }
-    if (at >= 0) { if ((rc = fetch_batch_sample(h, at, x, l, L, &val, &st))) return rc; }
+    for (size_t i = 0; i < h->nm_last.size(); ++i) if (same_bits(h->nm_last[i], th_opt)) { at = (int)i; break; }
+    if (at >= 0 && h->wide) {
+        if ((rc = fetch_batch_sample_wide(h, at, x, l, L))) return rc;
+        st = h->nm_last_st[(size_t)at]; val = h->nm_last_v[(size_t)at];
+    } else if (at >= 0) { if ((rc = fetch_batch_sample(h, at, x, l, L, &val, &st))) return rc; }
     else if ((rc = rat_ileqg_solve(h, x0, u0, th_opt, x, l, L, &val, &st, nullptr, nullptr, 0, nullptr))) return rc;   // :346 (not in a try)
     if (status) *status = st;
     *theta_opt = th_opt;
