@@ -78,7 +78,7 @@ def test_nm_kl_zero():
     assert th == 0.0 and abs(val - 1.0029075497782471) < 1e-9 and s.c_high is None and s.c_low is None
 
 
-@pytest.mark.parametrize("case", ["lq", "nonlinear", "infeasible_start"])
+@pytest.mark.parametrize("case", ["lq", "nonlinear", "infeasible_start", "general_size"])
 def test_speculation_depth_and_handle_size_do_not_change_anything(case):
     """rat_nm_solve evaluates ahead of the sequential code -- the iteration's six vertices (nm_depth 0), also the current pair and the
     initial pair with the first iteration (1), also the following iteration's vertices (2), also a third iteration in the first call (3,
@@ -88,6 +88,9 @@ def test_speculation_depth_and_handle_size_do_not_change_anything(case):
     if case == "nonlinear":
         prob, x0, u = nonlinear()
         kw, kl = dict(iter_max=20, eps=1e-3, theta_high_init=10.0, theta_low_init=1e-8), 1.0
+    elif case == "general_size":                                  # wide.hip: the final solve is copied out of the last batch's slots
+        prob, x0, u = rat.synthetic_lq_problem(n=16, m=4, N=20)
+        kw, kl = dict(theta_high_init=1.0), 0.1
     else:
         prob, x0, u = rat.synthetic_lq_problem()
         kw, kl = (dict(theta_high_init=40.0) if case == "infeasible_start" else {}), 0.1
