@@ -2138,10 +2138,11 @@ extern "C" rat_rc rat_nm_compute_cost(rat_handle h, const double *x0, const doub
 // generations takes one solve's time (solve_block_kernel: 0.28 ms for 1 ... 512 samples).  So every theta the sequential code CAN ask for
 // is evaluated ahead of time, with the sequential code's own expressions (bit-equal thetas), and the code then runs unchanged against a
 // table of (theta, cost): the six vertices of this iteration (round 2), the six of each of the twelve states the iteration can end in
-// (round 4: two iterations per device call), and -- in rat_nm_solve -- both initial vertices with the first two iterations under either
-// ordering.  The vertices that can become theta_low ride along, so the final solve (:346) is read out of the last batch's device state
-// instead of being run again.  What the sequential code evaluates, in what order, and every number it produces are unchanged
-// (n_solves counts its evaluations; n_batches the device calls: 3 instead of 6 for a solve of three iterations).
+// (round 4: two iterations per device call), and -- in rat_nm_solve -- both initial vertices with the first THREE iterations (nm_tree:
+// 6, 78, 942 thetas for one, two, three iterations; bit-equal repeats are dropped).  The vertices that can become theta_low ride along,
+// so the final solve (:346) is read out of the last batch's device state instead of being run again.  What the sequential code
+// evaluates, in what order, and every number it produces are unchanged (n_solves counts its evaluations; n_batches the device calls:
+// 1 instead of 6 for a solve of three iterations).
 static bool same_bits(double a, double b) { return memcmp(&a, &b, 8) == 0; }
 static bool nm_lookup(rat_handle h, double th, double *c) {
     for (size_t i = 0; i < h->nm_th.size(); ++i) if (same_bits(h->nm_th[i], th)) { *c = h->nm_c[i]; return true; }
