@@ -236,6 +236,10 @@ rat_rc rat_ce_compute_cost_enqueue_ex(rat_handle h, const double *theta_dev, int
 rat_rc rat_ce_begin_step(rat_ce_solver *c);
 rat_rc rat_ce_draw(rat_handle h, const rat_ce_solver *c, double *theta);
 rat_rc rat_ce_update(rat_ce_solver *c, const double *theta, const double *cost, int32_t *redraw);
+/* rat_ce_update carried out by the update kernel of the device-resident loop (what rat_ce_solve runs between two batches) on
+ * host-supplied thetas / costs: same arithmetic, same elite order -- sort(by = cost) under Julia's isless (NaN last, -0.0 before
+ * +0.0, ties in input order; :326-328).  num_samples <= 1024. */
+rat_rc rat_ce_update_dev(rat_handle h, rat_ce_solver *c, const double *theta, const double *cost, int32_t *redraw);
 /* handle-free form of rat_ce_draw over an explicit stream (pure host code; usable before any device exists):
  * consumes z[*zpos..] and advances *zpos. */
 rat_rc rat_ce_draw_stream(const rat_ce_solver *c, const double *z, int64_t nz, int64_t *zpos, double *theta);

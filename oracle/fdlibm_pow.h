@@ -12,7 +12,18 @@
  *   1. Compute and return log2(x) in two pieces: log2(x) = w1 + w2, where w1 has 53-24 = 29 bit trailing zeros.
  *   2. Perform y*log2(x) = n+y' by simulating multi-precision arithmetic, where |y'| <= 0.5.
  *   3. Return x**y = 2**n*exp(y'*log2).
- * Only double operations in the stated order: compiled with -ffp-contract=off (oracle/Makefile). */
+ * Only double operations in the stated order: compiled with -ffp-contract=off (oracle/Makefile).
+ *
+ * fdlibm's notice, preserved as its licence asks (the algorithm, its step order and its published constants are fdlibm's):
+ * ====================================================
+ * Copyright (C) 1993, 2004 by Sun Microsystems, Inc. All rights reserved.
+ *
+ * Developed at SunSoft, a Sun Microsystems, Inc. business.
+ * Permission to use, copy, modify, and distribute this
+ * software is freely granted, provided that this notice
+ * is preserved.
+ * ====================================================
+ */
 #ifndef ORC_FDLIBM_POW_H
 #define ORC_FDLIBM_POW_H
 #include <math.h>

@@ -326,6 +326,12 @@ class CrossEntropyBilevelOptimizationSolver:
         rc = lib().orc_ce_get_positive_samples(C.byref(self.c), C.c_double(mu), C.c_double(sigma), C.c_int64(num), _p(th))
         return rc, th
 
+    def elite_update(self, theta, cost):
+        """the tail of step! (:314-334) on given thetas / costs"""
+        th, co = np.ascontiguousarray(theta, float), np.ascontiguousarray(cost, float)
+        assert th.size == co.size == self.c.num_samples
+        lib().orc_ce_elite_update(C.byref(self.c), _p(th), _p(co))
+
     def step(self, P: Problem, x0, u, kl_bound):
         B = self.c.num_samples
         th, cost = np.zeros(B), np.zeros(B)

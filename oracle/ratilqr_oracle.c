@@ -768,10 +768,10 @@ int orc_ce_get_positive_samples(orc_ce *c, double mu, double sigma, int64_t num,
 }
 
 typedef struct { double theta, cost; int64_t idx; } pair_t;
-static int pair_less(double a, double b) {            /* isless: NaN sorts last */
+static int pair_less(double a, double b) {            /* Base.isless on Float64: NaN sorts last, -0.0 before +0.0 */
     if (a != a) return 0;
     if (b != b) return 1;
-    return a < b;
+    return a < b || (a == b && signbit(a) && !signbit(b));
 }
 static void stable_sort_pairs(pair_t *v, int64_t n) { /* insertion sort: stable, like sort(by=...) */
     for (int64_t i = 1; i < n; ++i) {
@@ -779,6 +779,28 @@ static void stable_sort_pairs(pair_t *v, int64_t n) { /* insertion sort: stable,
         while (j >= 0 && pair_less(key.cost, v[j].cost)) { v[j + 1] = v[j]; --j; }
         v[j + 1] = key;
     }
+}
+
+/* tail of step! on given costs -- theta_min / theta_max (:314-324), elites by sort(by = cost) under isless, mean and population std (:326-334) */
+int orc_isless(double a, double b) { return pair_less(a, b); }
+void orc_ce_elite_update(orc_ce *c, const double *theta, const double *cost) {
+    int64_t B = c->num_samples;
+    for (int64_t i = 0; i < B; ++i) {                                           /* :314-324 */
+        if (isinf(cost[i])) continue;
+        if (theta[i] < c->theta_min) c->theta_min = theta[i];
+        else if (theta[i] > c->theta_max) c->theta_max = theta[i];
+    }
+    pair_t *pr = (pair_t *)malloc(sizeof(pair_t) * B);                          /* :326-330 */
+    for (int64_t i = 0; i < B; ++i) { pr[i].theta = theta[i]; pr[i].cost = cost[i]; pr[i].idx = i; }
+    stable_sort_pairs(pr, B);
+    double sum = 0;
+    for (int64_t i = 0; i < c->num_elite; ++i) sum += pr[i].theta;
+    double mu_new = sum / (double)c->num_elite;
+    double ss = 0;
+    for (int64_t i = 0; i < c->num_elite; ++i) ss += (pr[i].theta - mu_new) * (pr[i].theta - mu_new);
+    double sigma_new = sqrt(ss / (double)c->num_elite);
+    c->mu = mu_new; c->sigma = sigma_new;                                       /* :334 */
+    free(pr);
 }
 
 /* step!  -- :252-335 */
@@ -809,24 +831,7 @@ int orc_ce_step(orc_ce *c, const orc_problem *p, const double *x0, const double 
             break;
         }
     }
-    for (int64_t i = 0; i < B; ++i) {                                           /* :314-324 */
-        if (isinf(cost[i])) continue;
-        if (theta[i] < c->theta_min) c->theta_min = theta[i];
-        else if (theta[i] > c->theta_max) c->theta_max = theta[i];
-    }
-    {
-        pair_t *pr = (pair_t *)malloc(sizeof(pair_t) * B);                      /* :326-330 */
-        for (int64_t i = 0; i < B; ++i) { pr[i].theta = theta[i]; pr[i].cost = cost[i]; pr[i].idx = i; }
-        stable_sort_pairs(pr, B);
-        double sum = 0;
-        for (int64_t i = 0; i < c->num_elite; ++i) sum += pr[i].theta;
-        double mu_new = sum / (double)c->num_elite;
-        double ss = 0;
-        for (int64_t i = 0; i < c->num_elite; ++i) ss += (pr[i].theta - mu_new) * (pr[i].theta - mu_new);
-        double sigma_new = sqrt(ss / (double)c->num_elite);
-        c->mu = mu_new; c->sigma = sigma_new;                                   /* :334 */
-        free(pr);
-    }
+    orc_ce_elite_update(c, theta, cost);                                        /* :314-334 */
     if (theta_out) memcpy(theta_out, theta, sizeof(double) * B);
     if (cost_out) memcpy(cost_out, cost, sizeof(double) * B);
 done:

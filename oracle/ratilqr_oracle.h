@@ -164,6 +164,10 @@ void orc_ce_default(orc_ce *c);
 void orc_ce_initialize(orc_ce *c);                                   /* :133-138 */
 /* get_positive_samples :233-246 ; returns -1 if the z stream ran dry */
 int orc_ce_get_positive_samples(orc_ce *c, double mu, double sigma, int64_t num, double *theta);
+/* Base.isless on Float64 (the order of sort(by = cost), :326-328): NaN after everything, -0.0 before +0.0 */
+int orc_isless(double a, double b);
+/* the tail of step! on given thetas / costs: theta_min / theta_max (:314-324), elites, mu, sigma (:326-334) */
+void orc_ce_elite_update(orc_ce *c, const double *theta, const double *cost);
 /* step! :252-335 ; theta_out/cost_out (size num_samples) receive the last batch; -1 on dry stream */
 int orc_ce_step(orc_ce *c, const orc_problem *p, const double *x0, const double *u, double kl_bound,
                 double *theta_out, double *cost_out);

@@ -86,7 +86,7 @@ EXPORTS = [
     "rat_multi_allgathers", "rat_multi_problem_set", "rat_multi_set_initial", "rat_multi_ce_compute_cost", "rat_multi_ce_step",
     "rat_multi_ce_solve", "rat_multi_pets_problem_set", "rat_multi_pets_compute_cost",
     "rat_multi_ce_compute_cost_ex", "rat_multi_ileqg_solve_batch", "rat_multi_is_logical", "rat_set_path", "rat_get_path", "rat_ce_compute_cost_enqueue_ex",
-    "rat_debug_set", "rat_debug_get",
+    "rat_debug_set", "rat_debug_get", "rat_ce_update_dev",
 ]
 
 _lib = None

@@ -91,13 +91,13 @@ __device__ __forceinline__ void ce_draw(CeDev *const s, const double *__restrict
     __syncthreads();
 }
 
-// sort(by = cost) orders by isless on the costs -- NaN after everything, -0.0 == 0.0 -- with ties in input order (stable).  The cost is
-// mapped once to an unsigned key with the same order (sign-magnitude -> biased; every NaN -> the largest key; -0.0 -> +0.0), so that a
+// sort(by = cost) orders by isless on the costs -- Julia's total order on floats: NaN after everything, -0.0 BEFORE +0.0 (isless(-0.0, 0.0)
+// is true) -- with ties in input order (stable).  The cost is mapped once to an unsigned key with the same order (sign-magnitude -> biased:
+// the key of -0.0 is one below that of +0.0; every NaN -> the largest key), so that a
 // compare-exchange of the network is three integer comparisons and no branch (the comparator written on doubles, with its NaN cases,
 // compiled to nested divergent branches: 20 us per update instead of ~6).
 __device__ __forceinline__ unsigned long long elite_key(double c) {
     if (c != c) return ~0ull;
-    c = c + 0.0;                                               // -0.0 -> +0.0 (isless(-0.0, 0.0) is false)
     const unsigned long long b = (unsigned long long)__double_as_longlong(c);
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }

@@ -113,7 +113,9 @@ struct rat_handle_s {
     // that ran last (its per-sample state is still on the device: the final solve is read out of it)
     std::vector<double> nm_th, nm_c, nm_last, nm_last_v;    // (nm_last_v / nm_last_st: value and status of the last batch's samples)
     std::vector<int32_t> nm_last_st;
-    uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, x0, u0, kl_bound)
+    uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, options generation, x0, u0, kl_bound)
+    uint64_t opts_serial = 0;                     // bumped by everything that can change what a solve returns without a new problem: rat_set_ileqg_opts,
+                                                  // rat_debug_set, rat_set_path (the reference builds a fresh ILEQGSolver from the current options per evaluation)
     int nm_depth = 3;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's),
                                      // 3 (+ a third iteration in rat_nm_solve's first call)
     // CE randomness
@@ -280,6 +282,7 @@ extern "C" rat_rc rat_set_ileqg_opts(rat_handle h, const rat_ileqg_opts *opts) {
     if (!opts_ok(opts)) return fail(RAT_ERR_ARG, "ILEQGSolver option out of range (ileqg.jl:195-201)");
     h->opts = *opts;
     set_opd(h);
+    h->opts_serial++;
     return RAT_OK;
 }
 
@@ -782,6 +785,7 @@ extern "C" rat_rc rat_set_path(rat_handle h, int32_t path) {
     if (path == RAT_PATH_AUTO) finish_switches(h);
     else if (h->E == 1 && !h->speculate && !h->dual) h->fused = (path != RAT_PATH_ROUNDS);
     h->path_fixed = path;
+    h->opts_serial++;
     return relayout_if_needed(h, was_alias);
 }
 
@@ -792,6 +796,7 @@ extern "C" rat_rc rat_debug_set(rat_handle h, const char *key, int64_t value) {
         if (!strcmp(sw.key, key)) {
             const bool was_alias = h->st.tile_alias != 0;
             sw.set(h, value);
+            h->opts_serial++;
             finish_switches(h);
             if (h->path_fixed != RAT_PATH_AUTO) {            // a fixed path keeps what rat_set_path derived
                 if (h->E == 1 && !h->speculate && !h->dual) h->fused = (h->path_fixed != RAT_PATH_ROUNDS);
@@ -1895,6 +1900,8 @@ extern "C" rat_rc rat_ce_update(rat_ce_solver *c, const double *theta, const dou
         if (xn || yn) return xn ? (yn && a < b) : true;
         if (x < y) return true;
         if (y < x) return false;
+        const bool xs = std::signbit(x), ys = std::signbit(y);                       // isless(-0.0, 0.0) is true
+        if (xs != ys) return xs;
         return a < b;
     });
     double sum = 0;
@@ -1947,6 +1954,11 @@ static rat_rc ce_ensure_buffers(rat_handle h, size_t need_z) {
         HIPCHK(hipHostMalloc((void **)&h->h_ce, 2 * sizeof(CeDev), hipHostMallocDefault));       // [0] upload image, [1] read-back
         HIPCHK(hipMalloc((void **)&h->d_ce_theta, sizeof(double) * CE_DEV_MAX_B));
         HIPCHK(hipMalloc((void **)&h->d_ce_cost, sizeof(double) * CE_DEV_MAX_B));
+        // (a draw that runs dry writes nothing: the batches enqueued behind it then solve whatever the buffer holds before the host sees
+        //  CE_ERR_DRY and repeats the chain -- keep that a benign problem, theta = 1, not uninitialised bits)
+        std::vector<double> ones(CE_DEV_MAX_B, 1.0);
+        HIPCHK(hipMemcpy(h->d_ce_theta, ones.data(), sizeof(double) * CE_DEV_MAX_B, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(h->d_ce_cost, 0, sizeof(double) * CE_DEV_MAX_B));
     }
     if (need_z > h->cap_cez) {                       // (grown outside any chain: the caller has synchronised)
         // The standard normals live in pinned host memory that the draw kernel reads in place (a draw touches ~12 KB of it once): no copy
@@ -1963,18 +1975,60 @@ static rat_rc ce_ensure_buffers(rat_handle h, size_t need_z) {
     return RAT_OK;
 }
 
+// rat_ce_update on the device: the update kernel of the device-resident loop (ce_step_kernel, do_update only) applied to host-supplied
+// thetas / costs -- the same arithmetic and the same elite order as rat_ce_update (tests compare the two on costs that hold NaN, +-Inf,
+// ties and both signed zeros).  The solve counters are the caller's business, as with rat_ce_update.
+extern "C" rat_rc rat_ce_update_dev(rat_handle h, rat_ce_solver *c, const double *theta, const double *cost, int32_t *redraw) {
+    if (!h || !c || !theta || !cost || !redraw) return fail(RAT_ERR_ARG, "null");
+    const int64_t B = c->num_samples;
+    if (B < 1 || B > CE_DEV_MAX_B) return fail(RAT_ERR_UNSUPPORTED, "rat_ce_update_dev: 1 <= num_samples <= 1024");
+    if (c->num_elite < 1 || c->num_elite > B) return fail(RAT_ERR_ARG, "num_elite must be in [1, num_samples]");
+    HIPCHK(hipSetDevice(h->device));
+    rat_rc rc = ce_ensure_buffers(h, 1);
+    if (rc) return rc;
+    CeDev &up = h->h_ce[0];
+    CeDev &back = h->h_ce[1];
+    memset(&up, 0, sizeof(up));
+    up.mu_init = c->mu_init; up.sigma_init = c->sigma_init; up.mu = c->mu; up.sigma = c->sigma; up.theta_max = c->theta_max; up.theta_min = c->theta_min;
+    up.lambda = c->lambda; up.iter_current = c->iter_current; up.iter_max = c->iter_max; up.num_samples = B; up.num_elite = c->num_elite;
+    up.use_theta_max = c->use_theta_max;
+    HIPCHK(hipMemcpyAsync(h->d_ce, &up, sizeof(CeDev), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_ce_theta, theta, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_ce_cost, cost, sizeof(double) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    launch_ce_step(h->d_ce, h->d_cez, 0, h->d_ce_theta, h->d_ce_cost, 1, 0, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&back, h->d_ce, sizeof(CeDev), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    c->mu_init = back.mu_init; c->sigma_init = back.sigma_init; c->mu = back.mu; c->sigma = back.sigma;
+    c->theta_max = back.theta_max; c->theta_min = back.theta_min;
+    *redraw = back.redraw_pending;
+    return RAT_OK;
+}
+
 static rat_rc ce_solve_device(rat_handle h, rat_ce_solver *c, const double *x0, const double *u0, double kl_bound,
                               double *theta_opt, double *x, double *l, double *L, double *value, double *theta_min, double *theta_max) {
     const int64_t B = c->num_samples;
     rat_rc rc = rat_set_initial(h, x0, u0);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
-    const size_t per_slot = (size_t)(2 * B + 64);               // normals provisioned per draw (a draw keeps P(theta > 0) of them: >= 1/2 unless sigma >> mu)
+    const size_t per_slot = (size_t)(3 * B + 128);              // normals provisioned per draw (a draw keeps P(theta > 0) of them: >= 1/2 unless sigma >> mu)
+    const size_t slots_upfront = (size_t)std::min<int64_t>(std::max<int64_t>(c->iter_max, 0) + 2, 16);   // pinned up front; stage_to() grows it for longer chains
     // what the host holds of the stream: injected -> z[zpos..nz); built-in -> the FIFO of normals drawn ahead + the generator
     const bool internal = h->internal_rng;
     const size_t inj_avail = internal ? 0 : (size_t)std::max<int64_t>(0, (h->z ? h->nz - h->zpos : 0));
-    if ((rc = ce_ensure_buffers(h, internal ? per_slot * (size_t)(c->iter_max + 2) : std::min(inj_avail, per_slot * (size_t)(c->iter_max + 2)) + 1))) return rc;
+    if ((rc = ce_ensure_buffers(h, internal ? per_slot * slots_upfront : std::min(inj_avail, per_slot * slots_upfront) + 1))) return rc;
     size_t filled = 0, uploaded = 0;                            // h_cez[0..filled) generated / staged, [0..uploaded) on the device
+    // Normals the built-in generator produced for this chain but the chain did not consume go back to the FIFO, in order, on EVERY way
+    // out (an error return used to drop them: the next call then saw a different sequence than the host loop would have).
+    struct GiveBack {
+        rat_handle h; const bool on; size_t &filled; size_t consumed = 0;
+        ~GiveBack() {
+            if (!on || consumed >= filled) return;
+            std::vector<double> rest(h->h_cez + consumed, h->h_cez + filled);
+            rest.insert(rest.end(), h->zfifo.begin() + (std::ptrdiff_t)h->zfifo_pos, h->zfifo.end());
+            h->zfifo.swap(rest); h->zfifo_pos = 0;
+        }
+    } give_back{h, internal, filled};
     auto stage_to = [&](size_t want) -> rat_rc {                // make h_cez hold `want` normals (or all the injected stream has)
         if (!internal) want = std::min(want, inj_avail);
         if (want > h->cap_cez) {
@@ -2055,11 +2109,7 @@ static rat_rc ce_solve_device(rat_handle h, rat_ce_solver *c, const double *x0, 
         c->n_solves = back.n_solves; c->n_redraws = back.n_redraws;
         const size_t consumed = (size_t)back.zpos;
         h->zpos += (int64_t)consumed;
-        if (internal) {                                         // normals generated but not consumed go back to the FIFO, in order
-            std::vector<double> rest(h->h_cez + consumed, h->h_cez + filled);
-            rest.insert(rest.end(), h->zfifo.begin() + (std::ptrdiff_t)h->zfifo_pos, h->zfifo.end());
-            h->zfifo.swap(rest); h->zfifo_pos = 0;
-        }
+        give_back.consumed = consumed;                          // (the rest returns to the FIFO when this function leaves)
         double th_opt = back.theta_opt;
         const double tmin = c->theta_min, tmax = c->theta_max;
         for (int tries = 0;; ++tries) {                         // :390-414 (the first attempt ran behind the chain)
@@ -2238,7 +2288,10 @@ static rat_rc nm_step_impl(rat_handle h, rat_nm_solver *s, const double *x0, con
         if (!all) {
             std::vector<double> list, carry;
             nm_plan(h, s, th_m, s->theta_high, list);
-            if ((int64_t)nm_unique(list) + 2 > h->Bmax) list.resize(6);          // (the first six are this iteration's vertices)
+            if ((int64_t)nm_unique(list) + 2 > h->Bmax) {                        // too many for this handle: this iteration's six vertices only
+                list.assign(th, th + 6);                                         // (built explicitly: after de-duplication the list's first six
+                nm_unique(list);                                                 //  entries need not be them, and it may hold fewer than six)
+            }
             if (h->nm_depth >= 1) carry.assign({th_m, s->theta_high});
             if ((rc = nm_prefetch(h, s, x0, u0, kl_bound, list, carry))) return rc;
         }
@@ -2261,9 +2314,10 @@ static rat_rc nm_step_impl(rat_handle h, rat_nm_solver *s, const double *x0, con
     return RAT_OK;
 }
 
-// the table of evaluated thetas is valid for one (problem, x0, u0, kl_bound, solver constants that shape the vertices do not matter: thetas are keys)
+// the table of evaluated thetas is valid for one (problem, iLEQG options / execution switches, x0, u0, kl_bound); the Nelder-Mead constants that
+// shape the vertices do not matter: thetas are keys
 static uint64_t nm_table_key(rat_handle h, const double *x0, const double *u0, double kl_bound) {
-    uint64_t k = 1469598103934665603ull ^ h->problem_serial;
+    uint64_t k = (1469598103934665603ull ^ h->problem_serial) * 1099511628211ull ^ (h->opts_serial << 32);
     auto mix = [&](const double *p, size_t cnt) {
         for (size_t i = 0; i < cnt; ++i) { uint64_t b; memcpy(&b, p + i, 8); k = (k ^ b) * 1099511628211ull; k ^= k >> 29; }
     };
@@ -2598,7 +2652,7 @@ extern "C" rat_rc rat_pets_update(rat_pets_solver *s, const double *controls, co
         const double x = cost[a], y = cost[b];
         if (x != x) return false;
         if (y != y) return true;
-        return x < y;
+        return x < y || (x == y && std::signbit(x) && !std::signbit(y));        // isless(-0.0, 0.0) is true
     });
     for (int64_t e = 0; e < E; ++e) if (elite_idx) elite_idx[e] = idx[e];
     const double sf = s->smoothing_factor;

@@ -10,6 +10,16 @@
 // results within 2 ulp of the library's (tests/test_cpu_normal.py holds the header against libm on the CPU through oracle/normal_check.c;
 // tests/test_gpu_pets.py holds the device's costs against a host restatement of Philox + this transform).
 // Plain C: the CPU check includes this very file.
+//
+// fdlibm's notice, preserved as its licence asks (ratn_log: e_log.c's reduction, polynomial and constants):
+// ====================================================
+// Copyright (C) 1993, 2004 by Sun Microsystems, Inc. All rights reserved.
+//
+// Developed at SunSoft, a Sun Microsystems, Inc. business.
+// Permission to use, copy, modify, and distribute this
+// software is freely granted, provided that this notice
+// is preserved.
+// ====================================================
 #pragma once
 #include <math.h>
 #include <stdint.h>

@@ -16,11 +16,21 @@
 //   2. y * log2(x) = (y1 + y2)(t1 + t2) with y1 = y truncated: p_h + p_l, overflow / underflow decided here.
 //   3. 2^(p_h + p_l): n = round(p), 2^r by exp(r ln 2) = 1 - ((r t1') / (t1' - 2) - (w + r w)) - r with the degree-5 Remez P1..P5.
 //   Special cases (y = 0, +-1, 2, 0.5, +-inf; x = 0, +-1, +-inf, x < 0 with integer / non-integer y, NaNs) exactly as fdlibm.
+//
+// fdlibm's notice, preserved as its licence asks (the algorithm, its step order and its published constants are fdlibm's):
+// ====================================================
+// Copyright (C) 1993, 2004 by Sun Microsystems, Inc. All rights reserved.
+//
+// Developed at SunSoft, a Sun Microsystems, Inc. business.
+// Permission to use, copy, modify, and distribute this
+// software is freely granted, provided that this notice
+// is preserved.
+// ====================================================
 #pragma once
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RAT_POW_FN __host__ __device__ inline
 #else
 #define RAT_POW_FN static inline

@@ -128,6 +128,30 @@ def test_ce_elite_selection_equals_a_stable_sort_with_ties_inf_and_nan():
         assert c.sigma == float(np.sqrt(sum(((t - mu) * (t - mu)) for t in el.tolist()) / k))
 
 
+def test_elite_order_is_julias_isless_on_signed_zeros():
+    """sort(by = cost) orders by Base.isless, and isless(-0.0, 0.0) is TRUE (cross_entropy...jl:326-328): with costs
+    [0.0, -0.0, 0.0, -0.0] the stable sort puts samples 1, 3 before 0, 2.  Host update and oracle; the device update kernel is held to the
+    same in tests/test_gpu_ce_device.py."""
+    L = nv.lib()
+    lo = orc.lib()
+    lo.orc_isless.argtypes = [C.c_double, C.c_double]
+    assert lo.orc_isless(-0.0, 0.0) == 1 and lo.orc_isless(0.0, -0.0) == 0 and lo.orc_isless(0.0, 0.0) == 0
+    assert lo.orc_isless(1.0, float("nan")) == 1 and lo.orc_isless(float("nan"), float("inf")) == 0 and lo.orc_isless(-1.0, -0.0) == 1
+    theta = np.array([5.0, 1.0, 7.0, 2.0])
+    cost = np.array([0.0, -0.0, 0.0, -0.0])
+    for k, want in ((1, [1.0]), (2, [1.0, 2.0]), (3, [1.0, 2.0, 5.0])):
+        c = nv.CeSolver()
+        L.rat_ce_default(C.byref(c))
+        c.num_samples, c.num_elite, c.iter_current, c.lam = 4, k, 2, 0.0
+        redraw = C.c_int32()
+        nv.check(L.rat_ce_update(C.byref(c), nv.P(theta), nv.P(cost), C.byref(redraw)))
+        mu = sum(want) / k
+        assert redraw.value == 0 and c.mu == mu and c.sigma == float(np.sqrt(sum((t - mu) * (t - mu) for t in want) / k))
+        oc = orc.CrossEntropyBilevelOptimizationSolver(np.zeros(1), num_samples=4, num_elite=k)
+        oc.elite_update(theta, cost)
+        assert oc.c.mu == c.mu and oc.c.sigma == c.sigma
+
+
 def test_stream_exhaustion_is_an_error():
     L = nv.lib()
     c = nv.CeSolver()

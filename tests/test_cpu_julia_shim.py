@@ -210,7 +210,8 @@ def test_bound_surface():
     not_bound = set(PROTOS) - bound
     allowed = {"rat_default_ileqg_opts", "rat_set_ileqg_opts", "rat_ileqg_solve_batch_dev", "rat_ce_default", "rat_ce_seed",
                "rat_ce_get_positive_samples", "rat_ce_draw", "rat_ce_draw_stream", "rat_pets_initialize",
-               "rat_pets_sample_controls", "rat_pets_update", "rat_profile_enable", "rat_profile_reset", "rat_profile_get", "rat_layout_info"}
+               "rat_pets_sample_controls", "rat_pets_update", "rat_profile_enable", "rat_profile_reset", "rat_profile_get", "rat_layout_info",
+               "rat_ce_update_dev"}
     assert not_bound <= allowed, sorted(not_bound - allowed)
     # the reference's exported names (src/RATiLQR.jl:20-53) exist under their own names
     for name in ("simulate_dynamics", "integrate_cost", "ILEQGSolver", "initialize!", "ApproximationResult", "approximate_model",

@@ -114,3 +114,48 @@ def test_a_short_upload_is_topped_up():
     kw = dict(num_samples=512, num_elite=50, mu_init=-2.0, sigma_init=1.0)               # P(theta > 0) ~ 2 %: a draw needs ~ 22,000 normals, a slot provisions 1,088
     dev, host = run(prob, x0, u, z, True, **kw), run(prob, x0, u, z, False, **kw)
     same(dev[0], host[0])
+
+
+def test_update_kernel_equals_the_host_update_on_ties_inf_nan_and_signed_zeros():
+    """rat_ce_update_dev (the update kernel of the device-resident loop on injected costs) against rat_ce_update (host) and the oracle's
+    elite update: every field bit for bit on costs with exact ties, +-Inf, NaN and both signed zeros -- sort(by = cost) orders by isless,
+    and isless(-0.0, 0.0) is true (cross_entropy...jl:326-328)."""
+    import ctypes as C
+    nv = rat.native
+    L = nv.lib()
+    prob, x0, u = rat.synthetic_lq_problem()
+    ctx = rat.Context(prob, max_batch=16)
+    rng = np.random.default_rng(7)
+    cases = [(np.array([5.0, 1.0, 7.0, 2.0]), np.array([0.0, -0.0, 0.0, -0.0]), k) for k in (1, 2, 3)]
+    for trial in range(60):
+        B = int(rng.integers(4, 1025 if trial % 10 == 0 else 80))
+        k = int(rng.integers(1, B // 2 + 1))
+        theta = rng.uniform(0.1, 5.0, B)
+        cost = rng.integers(-2, 3, B).astype(float)
+        cost[rng.random(B) < 0.3] *= -0.0                                   # signed zeros of both kinds (x * -0.0 = -+0.0)
+        cost[rng.random(B) < 0.10] = np.inf
+        cost[rng.random(B) < 0.03] = -np.inf
+        if trial % 3 == 0:
+            cost[rng.random(B) < 0.1] = np.nan
+        cases.append((theta, cost, k))
+    for theta, cost, k in cases:
+        B = theta.size
+        for it in (1, 2):
+            cs = []
+            for dev in (False, True):
+                c = nv.CeSolver()
+                L.rat_ce_default(C.byref(c))
+                c.num_samples, c.num_elite, c.iter_current, c.lam = B, k, it, 0.5
+                c.theta_min, c.theta_max = 1.5, 2.5
+                redraw = C.c_int32()
+                if dev:
+                    nv.check(L.rat_ce_update_dev(ctx.h, C.byref(c), nv.P(theta), nv.P(cost), C.byref(redraw)))
+                else:
+                    nv.check(L.rat_ce_update(C.byref(c), nv.P(theta), nv.P(cost), C.byref(redraw)))
+                cs.append((redraw.value, c.mu, c.sigma, c.mu_init, c.sigma_init, c.theta_min, c.theta_max))
+            assert cs[0] == cs[1], (B, k, it, cs)
+            if cs[0][0] == 0:
+                oc = orc.CrossEntropyBilevelOptimizationSolver(np.zeros(1), num_samples=B, num_elite=k)
+                oc.c.theta_min, oc.c.theta_max = 1.5, 2.5
+                oc.elite_update(theta, cost)
+                assert (oc.c.mu, oc.c.sigma, oc.c.theta_min, oc.c.theta_max) == (cs[0][1], cs[0][2], cs[0][5], cs[0][6])

@@ -131,3 +131,32 @@ def test_a_callers_own_step_loop_keeps_what_was_evaluated_ahead():
     nb1 = s.c.n_batches
     nm.step_(s, prob, x0, u, 0.2)                                  # another objective: nothing evaluated for kl = 0.1 may be reused
     assert s.c.n_batches == nb1 + 1
+
+
+def test_changed_ileqg_options_drop_the_table_of_costs_evaluated_ahead():
+    """ADVICE r04: the (theta -> cost) table that survives between stand-alone step! calls was keyed on (problem, x0, u0, kl_bound) only;
+    rat_set_ileqg_opts changes what a solve returns (the reference builds a fresh ILEQGSolver from the current options for every
+    evaluation, nelder_mead...jl:148-156).  step, set_opts(iter_max = 1), step: the second step's costs are those of one-iteration
+    solves, as the sequential oracle computes them with the same change."""
+    prob, x0, u = rat.synthetic_lq_problem(kappa=0.05)             # (cubic drift: the value after one iteration differs from the converged one)
+    P = orc.Problem(prob)
+    kl = 0.1
+    so = orc.NelderMeadBilevelOptimizationSolver()
+    sg = rat.NelderMeadBilevelOptimizationSolver()
+    for s_ in (so.c, sg.c):
+        s_.has_c_high = s_.has_c_low = 1
+    ctx = sg.context(prob)
+    sg.c.c_high = so.c.c_high = rat.compute_cost_worker(sg, prob, x0, u, sg.theta_high, kl)
+    sg.c.c_low = so.c.c_low = rat.compute_cost_worker(sg, prob, x0, u, sg.theta_low, kl)
+    so.step(P, x0, u, kl)
+    nm.step_(sg, prob, x0, u, kl)
+    assert abs(sg.c.c_high - so.c.c_high) <= 1e-9 * abs(so.c.c_high) and abs(sg.c.theta_high - so.c.theta_high) <= 1e-9 * so.c.theta_high
+    nb = sg.c.n_batches
+    so.c.ileqg.iter_max = 1
+    sg.ileqg_opts.iter_max = 1
+    ctx.set_opts(sg.ileqg_opts)
+    so.step(P, x0, u, kl)
+    nm.step_(sg, prob, x0, u, kl)
+    assert sg.c.n_batches > nb                                     # nothing evaluated under the old options was reused
+    assert abs(sg.c.c_high - so.c.c_high) <= 1e-9 * abs(so.c.c_high) and abs(sg.c.c_low - so.c.c_low) <= 1e-9 * abs(so.c.c_low)
+    assert abs(sg.c.theta_high - so.c.theta_high) <= 1e-9 * so.c.theta_high and abs(sg.c.theta_low - so.c.theta_low) <= 1e-9 * so.c.theta_low
