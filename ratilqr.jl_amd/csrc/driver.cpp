@@ -114,6 +114,8 @@ struct rat_handle_s {
     std::vector<double> nm_th, nm_c, nm_last, nm_last_v;    // (nm_last_v / nm_last_st: value and status of the last batch's samples)
     std::vector<int32_t> nm_last_st;
     uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, options generation, x0, u0, kl_bound)
+    int psweep = 0;                               // > 2: the batched sweep operators run the segment-parallel kernel with this many waves per trajectory
+    int psw_hop = 130, psw_comp = 125;            // its cost model (x 100, in steps): one hop, one element step -- places the cuts
     uint64_t opts_serial = 0;                     // bumped by everything that can change what a solve returns without a new problem: rat_set_ileqg_opts,
                                                   // rat_debug_set, rat_set_path (the reference builds a fresh ILEQGSolver from the current options per evaluation)
     int nm_depth = 3;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's),
@@ -180,6 +182,9 @@ static const DebugSwitch debug_switches[] = {
     {"nm_depth", [](rat_handle h, int64_t v) { h->nm_depth = (v < 0 || v > 3) ? 3 : (int)v; }, [](rat_handle h) -> int64_t { return h->nm_depth; }},
     {"pets_wave16", [](rat_handle h, int64_t v) { h->pets_wave16 = (v < 0 || v > 3) ? 1 : (int)v; }, [](rat_handle h) -> int64_t { return h->pets_wave16; }},
     {"ce_device", [](rat_handle h, int64_t v) { h->ce_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->ce_device; }},
+    {"psweep", [](rat_handle h, int64_t v) { h->psweep = (v < 3 || v > PSW_MAXP) ? 0 : (int)v; }, [](rat_handle h) -> int64_t { return h->psweep; }},
+    {"psw_hop", [](rat_handle h, int64_t v) { h->psw_hop = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop; }},
+    {"psw_comp", [](rat_handle h, int64_t v) { h->psw_comp = (int)std::max<int64_t>(100, v); }, [](rat_handle h) -> int64_t { return h->psw_comp; }},
 };
 // what the requests amount to on this handle (speculation width, forced pairings)
 static void finish_switches(rat_handle h) {
@@ -642,6 +647,46 @@ static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     a.dump = h->d_dump;
 #endif
     return a;
+}
+
+// Segment boundaries of the time-parallel sweep (psweep.h; tests/psweep_model.py: boundaries()).  The last segment runs the recursion itself
+// while the others build their elements, so it is the longest; every wave should end its ordinary pass (phase 3) at the same time:
+//   end_s = a + (P - 1 - s) hop + b_s (s >= 1),  end_0 = a + (P - 2) hop + b_0,  element ready in time: comp b_s <= a + (P - 2 - s) hop.
+static PswCuts psweep_cuts(int N, int P, double hop, double comp) {
+    PswCuts pc;
+    memset(&pc, 0, sizeof(pc));
+    P = std::max(1, std::min(P, std::min(PSW_MAXP, N)));
+    pc.P = P;
+    pc.cut[P] = N;
+    if (P == 1) return pc;
+    double best = 1e300;
+    std::vector<double> bs_best;
+    for (int a = 1; a < N; ++a) {
+        double extra = 0;
+        for (int s = 1; s < P - 1; ++s) extra += (s - 1) * hop;
+        const double b0 = ((double)(N - a) - extra) / (P - 1);
+        if (b0 < 1) continue;
+        std::vector<double> bs(P - 1);
+        bs[0] = b0;
+        bool ok = true;
+        for (int s = 1; s < P - 1; ++s) { bs[s] = b0 + (s - 1) * hop; ok = ok && comp * bs[s] <= a + (P - 2 - s) * hop + 1e-9; }
+        const double end = a + (P - 2) * hop + b0;
+        if (ok && end < best) { best = end; bs_best = bs; }
+    }
+    if (bs_best.empty()) { for (int s = 1; s < P; ++s) pc.cut[s] = (int)((long)N * s / P); return pc; }
+    double t = 0;
+    for (int s = 0; s < P - 1; ++s) { t += bs_best[s]; pc.cut[s + 1] = (int)(t + 0.5); }
+    pc.cut[P] = N;
+    for (int s = 1; s <= P; ++s) pc.cut[s] = std::max(pc.cut[s], pc.cut[s - 1] + 1);
+    for (int s = P - 1; s >= 1; --s) pc.cut[s] = std::min(pc.cut[s], pc.cut[s + 1] - 1);
+    return pc;
+}
+// sweep launches of the batched operators: the segment-parallel kernel when the handle asks for it (switch psweep) and it covers the case
+static void launch_sweep_or_psweep(rat_handle h, const SweepArgs &a, int ntraj, bool gain) {
+    if (h->psweep >= 3 && psweep_supported(a, gain) && a.st.N >= 2 * h->psweep)
+        launch_psweep(a, ntraj, gain, psweep_cuts(a.st.N, h->psweep, h->psw_hop / 100.0, h->psw_comp / 100.0), h->stream);
+    else
+        launch_sweep(a, ntraj, gain, false, h->stream);
 }
 
 // One ROUND advances every sample by one stage of its own solve!/step!/line_search! sequence (ileqg.jl:494-659):
@@ -1707,7 +1752,7 @@ extern "C" rat_rc rat_dp_gain_sweep_batch(rat_handle h, int64_t B, const double 
     rat_rc rc = batch_state(h, B, theta, mu, delta, &st);
     if (rc) return rc;
     if ((rc = upload_tiles_batch(h, st, B, false, q, qv, Q, r, R, P, A, Bm))) return rc;
-    launch_sweep(sweep_args(h, st, 0), (int)B, true, false, h->stream);                  // solve_approximate_dp! per sample, mu restarts inside
+    prof_begin(h, RAT_K_SWEEP_GAIN, (long)B); launch_sweep_or_psweep(h, sweep_args(h, st, 0), (int)B, true); prof_end(h);   // solve_approximate_dp! per sample, mu restarts inside
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<int> sth((size_t)B);
     HIPCHK(hipMemcpy(mu, st.mu, B * 8, hipMemcpyDeviceToHost));
@@ -1748,7 +1793,7 @@ extern "C" rat_rc rat_dp_policy_eval_batch(rat_handle h, int64_t B, const double
     std::vector<int> ones((size_t)B, 1);
     HIPCHK(hipMemcpyAsync(st.ls_active, ones.data(), B * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(st.flag_c, 0, B * 4, h->stream));
-    launch_sweep(sweep_args(h, st, 1), (int)B, false, false, h->stream);                 // solve_approximate_dp (dl = nothing) per sample
+    prof_begin(h, RAT_K_SWEEP_EVAL, (long)B); launch_sweep_or_psweep(h, sweep_args(h, st, 1), (int)B, false); prof_end(h);   // solve_approximate_dp (dl = nothing) per sample
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<int> fl((size_t)B);
     HIPCHK(hipMemcpy(value, st.value_c, B * 8, hipMemcpyDeviceToHost));

@@ -104,6 +104,11 @@ struct NoisyArgs {              // Monte-Carlo rollouts under process noise (sim
 void launch_noisy_rollout(const NoisyArgs &a, hipStream_t s);
 
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s);
+// the segment-parallel sweep (psweep.h): one workgroup of pc.P wavefronts per trajectory
+#define PSW_MAXP 8
+struct PswCuts { int P; int cut[PSW_MAXP + 1]; };
+bool psweep_supported(const SweepArgs &a, bool gain);
+void launch_psweep(const SweepArgs &a, int ntraj, bool gain, const PswCuts &pc, hipStream_t s);
 void launch_rollout(const RolloutArgs &a, hipStream_t s);
 void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout + linearise (solver hot loop)
 void launch_linearize(const LinArgs &a, hipStream_t s);

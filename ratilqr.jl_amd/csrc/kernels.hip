@@ -49,8 +49,9 @@
 #define PART_BLOCK5 32    /* E = 4 */
 #define PART_BLOCK8 64    /* E = 8 */
 #define PART_MISC 128     /* PETS and noisy Monte-Carlo rollouts */
+#define PART_PSW 256      /* psweep_kernel: the segment-parallel sweep (psweep.h) */
 #ifndef RAT_PART
-#define RAT_PART 255
+#define RAT_PART 511
 #endif
 
 #ifndef OCC2_PREFETCH
@@ -492,6 +493,43 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
 #undef FBUF
 #undef SVB
 }
+
+#include "psweep.h"
+
+#if RAT_PART & PART_PSW
+// One workgroup of pc.P wavefronts per trajectory (psweep.h).  The modes are sweep_kernel's (0 gain sweep, 1 policy evaluation of candidates,
+// 2 initialize!'s evaluation, 4 / 5 speculative gain sweeps); results agree with sweep_kernel's to rounding (tests/test_gpu_psweep.py).
+// MAXP = 4: one wavefront per SIMD, each may hold 512 registers (256 + 256 accumulation registers as spill space of the gain element's
+// 4 x 4 factors); MAXP = 8: two per SIMD, 256 each.
+template <bool GAIN, int WM, bool HASL, int FLY, int MAXP>
+__global__ __launch_bounds__(64 * MAXP) void psweep_kernel(SweepArgs a, PswCuts pc) {
+    __shared__ double wls[MAXP][WLS_PSW];
+    __shared__ PswShared sh;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    psweep_body<GAIN, WM, HASL, FLY>(a, blockIdx.x, wls[wave], &sh, pc, wave);
+}
+
+bool psweep_supported(const SweepArgs &a, bool gain) {
+    if (a.pb.W_tv) return false;                                  // (time-varying W: the sequential kernels)
+    if (a.fly && a.pb.cost_tv) return false;
+    if (gain) return a.mode == 0 || a.mode == 4 || a.mode == 5;
+    return a.mode == 1 || a.mode == 2;
+}
+
+void launch_psweep(const SweepArgs &a, int ntraj, bool gain, const PswCuts &pc, hipStream_t s) {
+    if (ntraj <= 0) return;
+    const dim3 grid(ntraj), block(64 * pc.P);
+    const bool diag = a.pb.W_diag != 0;
+#define PSW_LAUNCH(G, H, F) do { if (pc.P <= 4) { if (diag) hipLaunchKernelGGL((psweep_kernel<G, 2, H, F, 4>), grid, block, 0, s, a, pc); \
+                                                   else hipLaunchKernelGGL((psweep_kernel<G, 0, H, F, 4>), grid, block, 0, s, a, pc); } \
+                                 else { if (diag) hipLaunchKernelGGL((psweep_kernel<G, 2, H, F, 8>), grid, block, 0, s, a, pc); \
+                                        else hipLaunchKernelGGL((psweep_kernel<G, 0, H, F, 8>), grid, block, 0, s, a, pc); } } while (0)
+    if (gain) { if (a.fly) PSW_LAUNCH(true, false, 1); else PSW_LAUNCH(true, false, 0); }
+    else if (a.mode == 2) { if (a.fly) PSW_LAUNCH(false, false, 1); else PSW_LAUNCH(false, false, 0); }
+    else { if (a.fly) PSW_LAUNCH(false, true, 1); else PSW_LAUNCH(false, true, 0); }
+#undef PSW_LAUNCH
+}
+#endif  // PART_PSW
 
 #if RAT_PART & PART_SWEEP
 // SWZ: the elimination's row exchange through the LDS crossbar (fewer vector instructions, longer latency; identical values): for launches
