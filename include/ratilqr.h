@@ -429,8 +429,8 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *                            wavefronts per workgroup while the launch is small (<= 1536 wavefronts), by the recursion's own beyond; 2 never
  *                            split; 3 always split.  1-3 are bit-identical, 0 agrees to rounding  (1)
  *   ce_device       0 / 1    rat_ce_solve keeps the CE loop on the device: draw / update kernels, one host wait per solve!        (1)
- *   psweep          0, 3..8  the batched sweep operators (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch) run the TIME-PARALLEL sweep:
- *                            that many wavefronts per trajectory, one per horizon segment (csrc/psweep.h); results agree with the
+ *   psweep          0, 2..8  the batched sweep operators (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch) run the TIME-PARALLEL sweep:
+ *                            that many wavefronts per trajectory over that many + 1 horizon segments (csrc/psweep.h); results agree with the
  *                            sequential sweep to rounding (not bit for bit)                                                        (0)
  *   psw_hop, psw_comp        its cost model in hundredths of a step (one hop; one element step): where the segment cuts go   (130, 125)
  *   wdiag           0 / 1    diagonal time-invariant W: inv(W) folded into M^-1's operand (takes effect at the next rat_problem_set) (1) */

@@ -115,7 +115,8 @@ struct rat_handle_s {
     std::vector<int32_t> nm_last_st;
     uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, options generation, x0, u0, kl_bound)
     int psweep = 0;                               // > 2: the batched sweep operators run the segment-parallel kernel with this many waves per trajectory
-    int psw_hop = 130, psw_comp = 125;            // its cost model (x 100, in steps): one hop, one element step -- places the cuts
+    int psw_hop = 120, psw_hop_e = 140, psw_comp = 125;   // its cost model (x 100, in ordinary steps): one hop (gain sweep / evaluation), one element step -- places the cuts
+    bool block_psw = false;                       // the workgroup-per-sample solve with time-parallel sweeps for batches of <= one sample per CU (solve_block_psw_kernel)
     uint64_t opts_serial = 0;                     // bumped by everything that can change what a solve returns without a new problem: rat_set_ileqg_opts,
                                                   // rat_debug_set, rat_set_path (the reference builds a fresh ILEQGSolver from the current options per evaluation)
     int nm_depth = 3;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's),
@@ -182,8 +183,10 @@ static const DebugSwitch debug_switches[] = {
     {"nm_depth", [](rat_handle h, int64_t v) { h->nm_depth = (v < 0 || v > 3) ? 3 : (int)v; }, [](rat_handle h) -> int64_t { return h->nm_depth; }},
     {"pets_wave16", [](rat_handle h, int64_t v) { h->pets_wave16 = (v < 0 || v > 3) ? 1 : (int)v; }, [](rat_handle h) -> int64_t { return h->pets_wave16; }},
     {"ce_device", [](rat_handle h, int64_t v) { h->ce_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->ce_device; }},
-    {"psweep", [](rat_handle h, int64_t v) { h->psweep = (v < 3 || v > PSW_MAXP) ? 0 : (int)v; }, [](rat_handle h) -> int64_t { return h->psweep; }},
+    {"psweep", [](rat_handle h, int64_t v) { h->psweep = (v < 2 || v > PSW_MAXP) ? 0 : (int)v; }, [](rat_handle h) -> int64_t { return h->psweep; }},
     {"psw_hop", [](rat_handle h, int64_t v) { h->psw_hop = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop; }},
+    {"psw_hop_e", [](rat_handle h, int64_t v) { h->psw_hop_e = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop_e; }},
+    {"block_psw", [](rat_handle h, int64_t v) { h->block_psw = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_psw; }},
     {"psw_comp", [](rat_handle h, int64_t v) { h->psw_comp = (int)std::max<int64_t>(100, v); }, [](rat_handle h) -> int64_t { return h->psw_comp; }},
 };
 // what the requests amount to on this handle (speculation width, forced pairings)
@@ -649,44 +652,37 @@ static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     return a;
 }
 
-// Segment boundaries of the time-parallel sweep (psweep.h; tests/psweep_model.py: boundaries()).  The last segment runs the recursion itself
-// while the others build their elements, so it is the longest; every wave should end its ordinary pass (phase 3) at the same time:
-//   end_s = a + (P - 1 - s) hop + b_s (s >= 1),  end_0 = a + (P - 2) hop + b_0,  element ready in time: comp b_s <= a + (P - 2 - s) hop.
+// Segment boundaries of the time-parallel sweep (psweep.h; tests/psweep_model.py: boundaries()).  P waves, P + 1 segments: wave P-1 runs the
+// recursion over the last segment (a steps), posts, and carries on through segment P-1; wave w <= P-2 builds the element of segment w+1
+// meanwhile (comp ordinary steps per step), hops when the boundary value arrives (hop steps) and runs the ordinary recursion over segment w.
+// Every wave should finish together:  b_w = b_0 + w hop (wave w ends at a + (P-1-w) hop + b_w; wave P-1 at a + b_{P-1}), and the first
+// element needed must be ready when the last segment is done:  a = comp b_{P-1}.
 static PswCuts psweep_cuts(int N, int P, double hop, double comp) {
     PswCuts pc;
     memset(&pc, 0, sizeof(pc));
-    P = std::max(1, std::min(P, std::min(PSW_MAXP, N)));
-    pc.P = P;
-    pc.cut[P] = N;
-    if (P == 1) return pc;
-    double best = 1e300;
-    std::vector<double> bs_best;
-    for (int a = 1; a < N; ++a) {
-        double extra = 0;
-        for (int s = 1; s < P - 1; ++s) extra += (s - 1) * hop;
-        const double b0 = ((double)(N - a) - extra) / (P - 1);
-        if (b0 < 1) continue;
-        std::vector<double> bs(P - 1);
-        bs[0] = b0;
-        bool ok = true;
-        for (int s = 1; s < P - 1; ++s) { bs[s] = b0 + (s - 1) * hop; ok = ok && comp * bs[s] <= a + (P - 2 - s) * hop + 1e-9; }
-        const double end = a + (P - 2) * hop + b0;
-        if (ok && end < best) { best = end; bs_best = bs; }
+    P = std::max(1, std::min(P, PSW_MAXP));
+    double b0 = 0;
+    for (; P >= 2; --P) {
+        b0 = ((double)N - comp * (P - 1) * hop - hop * P * (P - 1) / 2.0) / (P + comp);
+        if (b0 >= 1.0 && N >= 2 * (P + 1)) break;
     }
-    if (bs_best.empty()) { for (int s = 1; s < P; ++s) pc.cut[s] = (int)((long)N * s / P); return pc; }
+    pc.P = P;
+    if (P < 2) { pc.P = 1; pc.cut[1] = N; pc.cut[2] = N; return pc; }
     double t = 0;
-    for (int s = 0; s < P - 1; ++s) { t += bs_best[s]; pc.cut[s + 1] = (int)(t + 0.5); }
-    pc.cut[P] = N;
-    for (int s = 1; s <= P; ++s) pc.cut[s] = std::max(pc.cut[s], pc.cut[s - 1] + 1);
-    for (int s = P - 1; s >= 1; --s) pc.cut[s] = std::min(pc.cut[s], pc.cut[s + 1] - 1);
+    for (int w = 0; w < P; ++w) { t += b0 + w * hop; pc.cut[w + 1] = (int)(t + 0.5); }
+    pc.cut[P + 1] = N;
+    for (int s = 1; s <= P + 1; ++s) pc.cut[s] = std::max(pc.cut[s], pc.cut[s - 1] + 1);
+    pc.cut[P + 1] = N;
+    for (int s = P; s >= 1; --s) pc.cut[s] = std::min(pc.cut[s], pc.cut[s + 1] - 1);
     return pc;
 }
 // sweep launches of the batched operators: the segment-parallel kernel when the handle asks for it (switch psweep) and it covers the case
 static void launch_sweep_or_psweep(rat_handle h, const SweepArgs &a, int ntraj, bool gain) {
-    if (h->psweep >= 3 && psweep_supported(a, gain) && a.st.N >= 2 * h->psweep)
-        launch_psweep(a, ntraj, gain, psweep_cuts(a.st.N, h->psweep, h->psw_hop / 100.0, h->psw_comp / 100.0), h->stream);
-    else
-        launch_sweep(a, ntraj, gain, false, h->stream);
+    if (h->psweep >= 2 && psweep_supported(a, gain)) {
+        const PswCuts pc = psweep_cuts(a.st.N, h->psweep, (gain ? h->psw_hop : h->psw_hop_e) / 100.0, h->psw_comp / 100.0);
+        if (pc.P >= 2) { launch_psweep(a, ntraj, gain, pc, h->stream); return; }
+    }
+    launch_sweep(a, ntraj, gain, false, h->stream);
 }
 
 // One ROUND advances every sample by one stage of its own solve!/step!/line_search! sequence (ileqg.jl:494-659):
@@ -920,8 +916,17 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.census = (h->block_shape && h->E == 1 && B <= 2 * h->n_cu) ? h->d_census : nullptr;
         fa.helpers = (fa.census && B <= h->n_cu && h->block_helpers) ? 1 : 0;
         fa.acl = h->block_acl ? 1 : 0;
+        // one sample per compute unit, LQ family: the same solve with every sweep time-parallel over the sample's four SIMDs (psweep.h)
+        const bool psw = path == PATH_BLOCK && h->block_psw && fa.helpers && !fa.acl && !h->materialize && solve_block_psw_supported(fa);
+        if (psw) {
+            fa.psw2e = psweep_cuts(st.N, 2, h->psw_hop_e / 100.0, h->psw_comp / 100.0);
+            fa.psw2g = psweep_cuts(st.N, 2, h->psw_hop / 100.0, h->psw_comp / 100.0);
+            fa.psw4e = psweep_cuts(st.N, 4, h->psw_hop_e / 100.0, h->psw_comp / 100.0);
+            fa.psw4g = psweep_cuts(st.N, 4, h->psw_hop / 100.0, h->psw_comp / 100.0);
+        }
         prof_begin(h, path == PATH_BLOCK ? RAT_K_SOLVE_BLOCK : RAT_K_SOLVE_FUSED, B);
-        if (path == PATH_BLOCK) launch_solve_block(fa, h->stream); else launch_solve_fused(fa, h->stream);
+        if (psw) launch_solve_block_psw(fa, h->stream);
+        else if (path == PATH_BLOCK) launch_solve_block(fa, h->stream); else launch_solve_fused(fa, h->stream);
         prof_end(h);
         return RAT_OK;
     }

@@ -21,6 +21,10 @@ struct SweepArgs {
                            // Hessian of a step are formed in the sweep from x_t and the problem tables
 };
 
+// the time-parallel sweep (psweep.h): P waves over P + 1 horizon segments
+#define PSW_MAXP 8
+struct PswCuts { int P; int cut[PSW_MAXP + 2]; };     // cut[0] = 0 < cut[1] < ... < cut[P + 1] = N
+
 struct RolloutArgs {
     StateDev st;
     ProblemDev pb;
@@ -56,6 +60,9 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     // the code the samples would run themselves) and the tile-free kernels copy what they read of it: x, u, the [c_x | c_u | c] rows and
     // the terminal tile.  Null: every sample rolls out for itself.
     const double *init_x, *init_u, *init_t;
+    // solve_block_psw_kernel only: segment cuts of its time-parallel sweeps -- two-wave teams (evaluation / gain sweep side by side) and the
+    // four-wave team (a sweep that has the compute unit to itself)
+    PswCuts psw2e, psw2g, psw4e, psw4g;
 };
 #define CENSUS_SLOTS 4096              /* (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID / HW_REG_XCC_ID: 4 + 3 + 1 + 4 bits */
 
@@ -105,8 +112,6 @@ void launch_noisy_rollout(const NoisyArgs &a, hipStream_t s);
 
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s);
 // the segment-parallel sweep (psweep.h): one workgroup of pc.P wavefronts per trajectory
-#define PSW_MAXP 8
-struct PswCuts { int P; int cut[PSW_MAXP + 1]; };
 bool psweep_supported(const SweepArgs &a, bool gain);
 void launch_psweep(const SweepArgs &a, int ntraj, bool gain, const PswCuts &pc, hipStream_t s);
 void launch_rollout(const RolloutArgs &a, hipStream_t s);
@@ -114,6 +119,8 @@ void launch_rollin(const RolloutArgs &a, hipStream_t s);      // fused rollout +
 void launch_linearize(const LinArgs &a, hipStream_t s);
 void launch_solve_fused(const FusedArgs &a, hipStream_t s);   // complete solve! per sample in one launch (E = 1)
 void launch_solve_block(const FusedArgs &a, hipStream_t s);   // complete solve! per sample by a workgroup of wavefronts (E = 1, 2, 4, 8)
+bool solve_block_psw_supported(const FusedArgs &a);
+void launch_solve_block_psw(const FusedArgs &a, hipStream_t s);   // ... with time-parallel sweeps: four wavefronts per sample, one sample per CU (E = 1)
 bool solve_block_supported(int E);
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
 void launch_copy_initial(const StateDev &st, const double *init_x, const double *init_u, const double *init_t, hipStream_t s);   // round-based path: FusedArgs.init_* per sample

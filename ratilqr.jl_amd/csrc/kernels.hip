@@ -50,8 +50,9 @@
 #define PART_BLOCK8 64    /* E = 8 */
 #define PART_MISC 128     /* PETS and noisy Monte-Carlo rollouts */
 #define PART_PSW 256      /* psweep_kernel: the segment-parallel sweep (psweep.h) */
+#define PART_BPSW 512     /* solve_block_psw_kernel: the workgroup-per-sample solve with segment-parallel sweeps */
 #ifndef RAT_PART
-#define RAT_PART 511
+#define RAT_PART 1023
 #endif
 
 #ifndef OCC2_PREFETCH
@@ -506,6 +507,9 @@ __global__ __launch_bounds__(64 * MAXP) void psweep_kernel(SweepArgs a, PswCuts 
     __shared__ double wls[MAXP][WLS_PSW];
     __shared__ PswShared sh;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < PSW_MAXP) sh.flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { sh.bar = 0; sh.last_rc = 0; }
+    __syncthreads();
     psweep_body<GAIN, WM, HASL, FLY>(a, blockIdx.x, wls[wave], &sh, pc, wave);
 }
 
@@ -2614,6 +2618,115 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
 }
 
 #undef BLK_MARK
+
+// =====================================================================================================
+// solve_block_psw_kernel: the whole solve! of one theta-sample by a workgroup of FOUR wavefronts on a compute unit of its own (E = 1, LQ
+// family, batches of at most one sample per CU: strong-scaling shards, Nelder-Mead batches, the final solve), every Riccati sweep
+// TIME-PARALLEL (psweep.h).  solve_block_kernel walks each sweep's 50 dependent steps with one wavefront while the sample's other SIMDs
+// idle; here
+//   [initialize!'s evaluation || first gain sweep]          two teams of two waves each (waves {0, 2} / {1, 3}), side by side
+//   rollout                                                  recursion wave + three linearising waves (rollrec_body / rolllin_body, unchanged)
+//   [candidate's evaluation || next step!'s gain sweep]     the two teams again
+//   the evaluation that ends the solve, a plain gain sweep   one team of all four waves
+// Same control flow and the same device functions for everything but the sweeps as solve_block_kernel; the sweeps agree with the
+// sequential ones to rounding (boundary values handed along the chain differ by ~1e-15), so values are NOT bit-identical to the other
+// paths -- identical status / iteration / line-search counts (tests/test_gpu_psweep.py), values to 1e-10.
+// =====================================================================================================
+template <bool CTV, int WM>
+__global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
+    constexpr int FLYB = CTV ? 2 : 1;
+    const int b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const StateDev &st = fa.sw.st;
+    __shared__ double wls_all[4][WLS_PSW];
+    __shared__ double shxu_all[4][16];
+    __shared__ double stg[STG_DOUBLES];
+    __shared__ double xu[XU_DOUBLES];
+    __shared__ int prog;
+    __shared__ unsigned long long d_acc[2];
+    __shared__ PswShared psh[3];                 // [0] the evaluation team, [1] the gain team, [2] the four-wave team (a team's barrier counter
+                                                 // stays a multiple of ITS size)
+    int epoch = 0;
+    if (threadIdx.x == 0) prog = 0;
+    if (threadIdx.x < 3 * PSW_MAXP) psh[threadIdx.x / PSW_MAXP].flag[threadIdx.x % PSW_MAXP] = 0;
+    if (threadIdx.x < 3) { psh[threadIdx.x].bar = 0; psh[threadIdx.x].last_rc = 0; }
+    double *const wls = wls_all[wave], *const shxu = shxu_all[wave];
+    const bool leader = (wave == 0) && ((threadIdx.x & 63) == 0);
+    const int team = wave & 1, tw = wave >> 1;          // evaluations: waves {0, 2}; gain sweeps: waves {1, 3}
+    if (leader) init_state_body(st, fa.sw.op, fa.theta_in, b);
+    __syncthreads();
+    if (fa.init_x) {                             // initialize!'s rollout was run once for the whole batch (FusedArgs.init_*)
+        if (wave == 0) copy_initial(st, fa.init_x, fa.init_u, fa.init_t, b);
+    } else {                                     // initialize!: open-loop rollout (wave 0) + linearise (the other waves)   (ileqg.jl:214-233)
+        RolloutArgs ra = fa.ro; ra.mode = 0;
+        if (wave == 0) rollrec_body<0, true>(ra, b, stg, xu, &prog, epoch, d_acc);
+        else rolllin_body<0, CTV, true, true>(ra, b, shxu, xu, &prog, epoch, wave - 1, 3, d_acc);
+        epoch += st.N + 2;
+    }
+    __syncthreads();
+    {                                            // open-loop policy evaluation (:234) || the first step!'s gain sweep on the same trajectory
+        SweepArgs sa = fa.sw;
+        if (team == 0) { sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
+        else { sa.mode = 5; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[1], fa.psw2g, tw); }
+    }
+    __syncthreads();
+    if (leader) commit_init_body(st, b);
+    __syncthreads();
+    for (int guard = 0; guard < fa.max_rounds; ++guard) {
+        const int v_stat = __atomic_load_n(&st.status[b], __ATOMIC_RELAXED), v_act = __atomic_load_n(&st.ls_active[b], __ATOMIC_RELAXED);
+        if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
+        if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp! with no valid speculative sweep  (ileqg.jl:598-613)
+            SweepArgs sa = fa.sw; sa.mode = 0;
+            psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
+            __syncthreads();
+            continue;
+        }
+        {                                                    // the candidate of this line-search round  (ileqg.jl:504-521)
+            RolloutArgs ra = fa.ro; ra.mode = 1;
+            if (wave == 0) rollrec_body<1, true>(ra, b, stg, xu, &prog, epoch, d_acc);
+            else rolllin_body<1, CTV, true, true>(ra, b, shxu, xu, &prog, epoch, wave - 1, 3, d_acc);
+            epoch += st.N + 2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 64) {                             // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
+            st.d_c[b] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
+            st.flag_c[b] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
+        // would accepting this candidate end solve! (:642-653)?  Then nothing consumes a speculative gain sweep: all four waves evaluate.
+        const double v_dc = *(const volatile double *)&st.d_c[b], v_mu = *(const volatile double *)&st.mu[b];
+        const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
+        const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
+        const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
+        {
+            SweepArgs sa = fa.sw;
+            if (ends) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave); }
+            else if (team == 0) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
+            else { sa.mode = 4; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[1], fa.psw2g, tw); }
+        }
+        __syncthreads();
+        if (leader) ls_select_body(st, fa.sw.op, b, nullptr);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (leader) gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
+}
+
+#if RAT_PART & PART_BPSW
+bool solve_block_psw_supported(const FusedArgs &fa) {
+    return fa.sw.st.E == 1 && fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST && !fa.sw.pb.W_tv && fa.sw.st.N >= 8;
+}
+void launch_solve_block_psw(const FusedArgs &fa, hipStream_t s) {
+    if (fa.sw.st.B <= 0) return;
+    const dim3 grid(fa.sw.st.B), block(256);
+#define BPSW_LAUNCH(C) do { if (fa.sw.pb.W_diag) hipLaunchKernelGGL((solve_block_psw_kernel<C, 2>), grid, block, 0, s, fa); \
+                            else hipLaunchKernelGGL((solve_block_psw_kernel<C, 0>), grid, block, 0, s, fa); } while (0)
+    if (fa.sw.pb.cost_tv) BPSW_LAUNCH(true); else BPSW_LAUNCH(false);
+#undef BPSW_LAUNCH
+}
+#endif  // PART_BPSW
+
 template <int NW, bool GW>
 static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {
     const dim3 grid(fa.sw.st.B), block(64 * NW);

@@ -3,8 +3,8 @@
 //
 // The backward recursion is a chain of N dependent steps (~3,000-3,600 cycles each) that one in-order wavefront walks alone while the
 // sample's other SIMDs idle.  Here the horizon is cut into P segments [cut_s, cut_s+1):
-//   wave P-1          runs the recursion itself on the last segment, from the terminal condition;
-//   waves 1 .. P-2    meanwhile build the ELEMENT of their segment -- the map (S, s_vec) at its end -> (S, s_vec) at its start, in the
+//   wave P-1          runs the recursion itself on the last segment, from the terminal condition (and carries on through the segment before);
+//   the other waves   meanwhile build the ELEMENT of a segment each -- the map (S, s_vec) at its end -> (S, s_vec) at its start, in the
 //                     conditional-value-function form of the associative LQ scan (Sarkka & Garcia-Fernandez) -- with no knowledge of the
 //                     value function at the segment's end: the recursion from a ZERO terminal value (Jv), the transpose K of the
 //                     segment's closed-loop transition in homogeneous coordinates, the accumulated noise covariance (-Sigbar) and, for
@@ -15,7 +15,9 @@
 //   phase 3           with its true boundary value every wave re-runs the ORDINARY step over its own segment: gains, isposdef tests,
 //                     logdet(W M), theta s'M^-1 s and the additive scalar come from the sequential sweep's own arithmetic; only the
 //                     boundary values differ from the sequential sweep's, by rounding (measured <= 2e-15 relative).
-// Critical path: a + (P - 2) hops + b steps instead of N (a: last segment, b: first).  Anything the element form cannot decide -- theta
+// P waves cover P + 1 segments: wave w <= P-2 builds the element of segment w+1, hops, and runs phase 3 of segment w; wave P-1 runs the
+// recursion over segments P and P-1.  Critical path: a + (P - 1) hops + b steps instead of N (a: last segment, b: first) -- measured
+// (N = 50, P = 4): an element step costs 1.23 ordinary steps, a hop 1.1 - 1.4.  Anything the element form cannot decide -- theta
 // == 0 (its own recursion), a non-positive pivot while building an element or inside a hop (S_b singular: no state cost), NaNs -- makes
 // wave 0 run the sequential sweep_body instead: results never depend on the shortcut being available.
 #pragma once
@@ -28,7 +30,8 @@
 struct PswShared {
     double vbox[PSW_MAXP][256];            // vbox[s]: the true value at cut[s+1] (accumulator-layout image), written by wave s+1
     double part[PSW_MAXP][4];              // per wave: 0.5 V[12][12], sum of racc, log term, -
-    int flag[PSW_MAXP];                    // flag[s] = attempt number once vbox[s] is valid
+    int flag[PSW_MAXP];                    // flag[s] = epoch of the attempt once vbox[s] is valid
+    int bar;                               // team barrier: arrivals so far (a multiple of P between calls); zero before the first call
     int fail_def;                          // a definite M-not-PD (the ordinary step on true values)
     int uncertain;                         // the element form could not decide: sequential fallback
     int hnotpd;                            // gain sweeps: H not PD in an ordinary step (mu restart)
@@ -48,6 +51,14 @@ __device__ __forceinline__ double rows_sum4(double x) {
     return ((r[0] + r[1]) + r[2]) + r[3];
 }
 
+// phase-timeline build only (make diagp; tools/psweep_phases.py): cycle stamps per wave at the phase boundaries
+#ifdef RAT_DIAG_PHASES
+#define PSW_MARK(slot_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8 && a.dump) \
+        a.dump[4096 + blockIdx.x * 128 + wave * 16 + (slot_)] = (double)__builtin_readcyclecounter(); } while (0)
+#else
+#define PSW_MARK(slot_) do {} while (0)
+#endif
+
 template <bool GAIN, int WM, bool HASL, int FLY>
 __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, double *const wls, PswShared *const sh, const PswCuts &pc, const int wave) {
     int lane_ = threadIdx.x & 63;
@@ -57,6 +68,7 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     const StateDev &st = a.st;
     const ProblemDev &pb = a.pb;
     const int P = pc.P;
+    if (wave >= P && wave > 0) return;             // (a horizon too short for the team: the spare waves sit the sweep out)
     int b, k = 0, slot, cidx = -1;
     if (a.mode == 1) { const int Ek = st.E - a.k_first; b = tid / Ek; k = a.k_first + (tid - b * Ek); } else b = tid;
     const int fidx = b * st.E + k;
@@ -83,7 +95,7 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     }
     // what the element form does not cover runs sequentially on wave 0 (sweep_body writes every output itself)
     const bool theta0 = wave_uniform((theta == 0.0 || !(theta == theta)) ? 1 : 0) != 0;
-    if (theta0 || P < 3) {
+    if (theta0 || P < 2) {
         if (wave == 0) sweep_body<GAIN, false, WM, HASL, 0, FLY>(a, tid, wls);
         return;
     }
@@ -145,10 +157,11 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
         epall = ((((pb.epiv[0] * pb.epiv[2]) * pb.epiv[4]) * pb.epiv[6]) * pb.epiv[8]) * pb.epiv[10];
     }
     const double coef = -1.0 / (2.0 * theta);
-    // padded coordinates (n < 12): 1 on their diagonal for the hop's inversions
-    double padd[3];
+    // padded coordinates (n < 12): 1 on their diagonal for the hop's inversions; the padding's unit "noise" (inv(W) is padded with 1) is
+    // cleared from Cbar there
+    double padd[3], mnn[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) padd[r] = (4 * r + g == j && j >= pb.n) ? 1.0 : 0.0;
+    for (int r = 0; r < 3; ++r) { padd[r] = (4 * r + g == j && j >= pb.n) ? 1.0 : 0.0; mnn[r] = (4 * r + g < pb.n && j < pb.n) ? 1.0 : 0.0; }
     const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
 
     int restarts = 0;
@@ -158,7 +171,6 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     double racc = 0.0, rprod = 1.0;
     int rexp = 0;
     bool h_not_pd = false;
-    int attempt = 0;
 
     // one backward step on the tile registers `cur`.  COMP: the step also prepends itself to the element (kk, nsig, ub).
     // returns 0, 1 (M not PD), 2 (H not PD)
@@ -342,16 +354,34 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     using TrueTag = std::integral_constant<bool, true>;
     using FalseTag = std::integral_constant<bool, false>;
 
-    const int seg_lo = pc.cut[wave], seg_hi = pc.cut[wave + 1];
-    if (threadIdx.x < PSW_MAXP) sh->flag[threadIdx.x] = 0;
-    if (threadIdx.x == 0) sh->last_rc = 0;
+    // Team barrier of the P waves (LDS counter; no s_barrier: inside solve_block_kernel two teams run different sweeps side by side).
+    // sh->bar is a multiple of P whenever no wave of the team is inside this body: a PswShared serves teams of ONE size.
+    int gen = wave_uniform(__hip_atomic_load(&sh->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) / P;
+    auto team_barrier = [&]() {
+        WAVE_SYNC();
+        ++gen;
+        if (l_ == 0) __hip_atomic_fetch_add(&sh->bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        psw_spin(&sh->bar, gen * P);
+    };
+    auto post = [&](const d4 &val, const int box, const int epoch) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sh->vbox[box][64 * q + l] = val[q];
+        WAVE_SYNC();
+        if (l == 0) __hip_atomic_store(&sh->flag[box], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // P waves, P + 1 segments [cut[s], cut[s+1]):
+    //   wave P-1   the recursion itself over segment P from the terminal condition, posts the value at cut[P], and carries on through
+    //              segment P-1;
+    //   wave w     (w <= P-2) builds the element of segment w+1 meanwhile, takes the true value at cut[w+2] from wave w+1, hops to
+    //              cut[w+1], posts that for wave w-1, and runs the ordinary recursion over segment w from it.
     while (true) {
-        ++attempt;
-        if (threadIdx.x == 0) { sh->fail_def = 0; sh->uncertain = 0; sh->hnotpd = 0; }
-        __syncthreads();
+        if (wave == 0 && l == 0) { sh->fail_def = 0; sh->uncertain = 0; sh->hnotpd = 0; }
+        team_barrier();
+        const int epoch = gen;                       // unique per attempt and per call: what the flags of this attempt carry
         int my_fail = 0, my_unc = 0, my_h = 0;
+        PSW_MARK(0);
         if (wave == P - 1) {
-            // ---- last segment: the recursion itself, from the terminal condition (ileqg.jl:352-354 / 429-431) ----------------------------
+            // terminal condition (ileqg.jl:352-354 / 429-431)
             const double *__restrict__ tt = tile0 + (long)N * TSTRIDE;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -362,45 +392,45 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
             const double t3 = tt[(j < 12) ? TT_QV + j : TT_q];
             v[3] = (g == 0 && j <= 12) ? (j < 12 ? t3 : 2.0 * t3) : 0.0;
             racc = 0.0; rprod = 1.0; rexp = 0;
-            const int r = run(FalseTag(), seg_hi, seg_lo);
+            int r = run(FalseTag(), N, pc.cut[P]);
+            if (r && l == 0) __hip_atomic_store(&sh->last_rc, (epoch << 2) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            PSW_MARK(1);
+            if (P >= 2) post(v, P - 2, epoch);
+            PSW_MARK(3);
+            if (!r) {
+                r = run(FalseTag(), pc.cut[P], pc.cut[P - 1]);
+                if (r && l == 0) __hip_atomic_store(&sh->last_rc, (epoch << 2) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             if (r == 1) my_fail = 1;
             if (r == 2) my_h = 1;
-            if (r && l == 0) __hip_atomic_store(&sh->last_rc, (attempt << 2) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sh->vbox[wave - 1][64 * q + l] = v[q];
-            WAVE_SYNC();
-            if (l == 0) __hip_atomic_store(&sh->flag[wave - 1], attempt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
+            // ---- phase 1: the element of segment wave + 1 ---------------------------------------------------------------------------------------
             d4 ac = zero4;
-            if (wave >= 1) {
-                // ---- phase 1: the element of this segment ---------------------------------------------------------------------------------
-                v = zero4;
-                kk = (d4){(g == 0 && j == 0) || (g == 1 && j == 1) || (g == 2 && j == 2) || (g == 3 && j == 3) ? 1.0 : 0.0,
-                          (j == 4 + g) ? 1.0 : 0.0, (j == 8 + g) ? 1.0 : 0.0, (g == 0 && j == 12) ? 1.0 : 0.0};
-                nsig = zero4; ub = zero4;
-                racc = 0.0; rprod = 1.0; rexp = 0;
-                const int r = run(TrueTag(), seg_hi, seg_lo);
+            v = zero4;
+            kk = (d4){(j == g) ? 1.0 : 0.0, (j == 4 + g) ? 1.0 : 0.0, (j == 8 + g) ? 1.0 : 0.0, (g == 0 && j == 12) ? 1.0 : 0.0};
+            nsig = zero4; ub = zero4;
+            racc = 0.0; rprod = 1.0; rexp = 0;
+            {
+                const int r = run(TrueTag(), pc.cut[wave + 2], pc.cut[wave + 1]);
                 if (r) my_unc = 1;
-                // A_c = K' through the pad (once per segment, off the chain)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) tpad[(4 * q + g) * 16 + j] = kk[q];
-                WAVE_SYNC();
-#pragma unroll
-                for (int q = 0; q < 3; ++q) ac[q] = tpad[j * 16 + 4 * q + g];
-                WAVE_SYNC();
             }
-            // ---- the true value at this segment's end -------------------------------------------------------------------------------------
-            psw_spin(&sh->flag[wave], attempt);
-            const bool dead = (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->last_rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) == attempt;
+            // A_c = K' through the pad (once per segment, off the chain)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tpad[(4 * q + g) * 16 + j] = kk[q];
+            WAVE_SYNC();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ac[q] = tpad[j * 16 + 4 * q + g];
+            WAVE_SYNC();
+            PSW_MARK(1);
+            // ---- the true value at the end of that segment ------------------------------------------------------------------------------------
+            psw_spin(&sh->flag[wave], epoch);
+            PSW_MARK(2);
+            const bool dead = (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->last_rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) == epoch;
             d4 vb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) vb[q] = sh->vbox[wave][64 * q + l];
-            if (dead) {                                  // the last segment ended the sweep: pass the word on, nothing else to do
-                if (wave >= 1) {
-                    WAVE_SYNC();
-                    if (l == 0) __hip_atomic_store(&sh->flag[wave - 1], attempt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            } else if (wave >= 1) {
+            d4 vt = zero4;
+            if (!dead) {
                 // ---- hop: V at the segment's start = Jv + Aa' (S_b^-1 + Ubar - theta Sigbar)^-1 Aa,  Aa = [Abar | bbar + S_b^-1 s_b] ----------
                 const double s0 = sh->vbox[wave][192 + g], s1 = sh->vbox[wave][192 + 4 + g], s2 = sh->vbox[wave][192 + 8 + g];   // s_b by row index
                 d4 sb;
@@ -418,7 +448,7 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
                 if (!(pd > 0) || !(rp * 0.0 == 0.0)) my_unc = 1;
                 d4 y;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) y[r] = fma(theta, nsig[r], ub[r]) - sb[r];      // S_b^-1 + Ubar - theta Sigbar
+                for (int r = 0; r < 3; ++r) y[r] = fma(fma(theta, nsig[r], ub[r]), mnn[r], -sb[r]);      // S_b^-1 + Ubar - theta Sigbar
                 y[3] = 0.0;
                 // w = S_b^-1 s_b by column, then by component on the lanes of column 12
                 const double wpart = -((sb[0] * s0 + sb[1] * s1) + sb[2] * s2);
@@ -438,23 +468,22 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
                 for (int r = 0; r < 3; ++r) { aa[r] = fma(wpad[4 * r + g], mcol12, ac[r]); aan[r] = -aa[r]; }
                 aa[3] = 0.0; aan[3] = 0.0;
                 const d4 tgn = mm3(y, aa, zero4);                                  // -Xt Aa
-                d4 vt = mm3(aan, tgn, v);                                          // Jv + Aa' Xt Aa   (v = Jv after phase 1)
-                vt[3] *= mrow12 * m12;                                             // row 12: s_vec'; the additive scalar [12][12] is not propagated
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sh->vbox[wave - 1][64 * q + l] = vt[q];
-                WAVE_SYNC();
-                if (l == 0) __hip_atomic_store(&sh->flag[wave - 1], attempt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                vt = mm3(aan, tgn, v);                                             // Jv + Aa' Xt Aa   (v = Jv after phase 1)
+                vt[3] *= mrow12 * m12;                                             // row 12: s_vec'; the additive scalar [12][12] is summed over the
+                                                                                   // segments at the end, not propagated
             }
-            // ---- phase 3: the ordinary recursion over this segment from its true boundary value --------------------------------------------
-            v = vb;
-            v[3] *= mrow12 * m12;                                                  // the additive scalar is summed over the segments at the end
+            if (wave >= 1) post(vt, wave - 1, epoch);                              // (always: nobody downstream may hang)
+            PSW_MARK(3);
+            // ---- phase 3: the ordinary recursion over segment `wave` from the value the hop produced -----------------------------------------
+            v = vt;
             racc = 0.0; rprod = 1.0; rexp = 0;
             if (!my_unc && !dead) {
-                const int r = run(FalseTag(), seg_hi, seg_lo);
+                const int r = run(FalseTag(), pc.cut[wave + 1], pc.cut[wave]);
                 if (r == 1) my_fail = 1;
                 if (r == 2) my_h = 1;
             }
         }
+        PSW_MARK(4);
         // ---- per-wave partials; one decision for the workgroup ----------------------------------------------------------------------------
         {
             const double rsum = wave_sum(racc);
@@ -466,12 +495,13 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
                 if (my_h) __hip_atomic_store(&sh->hnotpd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        __syncthreads();
+        team_barrier();
+        PSW_MARK(5);
         const int any_fail = wave_uniform(sh->fail_def), any_h = wave_uniform(sh->hnotpd), v_last = wave_uniform(sh->last_rc);
-        const bool last_ended = (v_last >> 2) == attempt;
+        const bool last_ended = (v_last >> 2) == epoch;
         const int any_unc = last_ended ? 0 : wave_uniform(sh->uncertain);       // (what ended the last segment is definite whatever the others saw)
         if (any_unc) {                                   // the element form could not decide: the sequential sweep, on wave 0
-            __syncthreads();
+            team_barrier();                              // (everyone has read the words of this attempt)
             if (wave == 0) sweep_body<GAIN, false, WM, HASL, 0, FLY>(a, tid, wls);
             return;
         }
@@ -482,7 +512,7 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
             delta = fmax(a.op.delta_0, delta * a.op.delta_0);
             mu = fmax(a.op.mu_min, mu * delta);
             if (++restarts > 400 || !isfinite(mu)) { fail = 5; break; }
-            __syncthreads();
+            team_barrier();                              // (everyone has read the words of this attempt before wave 0 clears them)
             continue;
         }
         break;

@@ -87,9 +87,10 @@ class Composite:
 def hop(comp, Vb, theta, n=NP):
     """(S, s_vec) at the segment's start from the true value at its end; the [12][12] entry (the additive scalar) is not propagated.
     Problems with n < 12 are embedded with zero padding: the padded diagonal of S_b is set to 1 for the inversions (the padded rows of
-    the transition are zero, so nothing of it reaches the result)."""
+    the transition are zero, so nothing of it reaches the result) and the padded rows / columns of Cbar are cleared."""
     U, Sig = comp.Cbar
     Cb = U - theta * Sig
+    Cb[n:, :] = 0.0; Cb[:, n:] = 0.0            # (the padding's unit "noise" -- inv(W) is padded with 1 -- is not part of the problem)
     Sb, sb = Vb[:NP, :NP].copy(), Vb[:NP, AUG]
     Sb[n:, n:] += np.eye(NP - n)
     Sinv = np.linalg.inv(Sb)                                                       # SPD inversion 1 (six 2 x 2 block-pivot rounds)
@@ -123,76 +124,78 @@ def hop_noise_form(comp, Vb, theta):
 
 
 def boundaries(N, P_, hop_cost=1.3, comp_cost=1.25):
-    """segment boundaries t_0 = 0 < t_1 < ... < t_P = N balancing the critical path: the last segment (true recursion while the others
-    build their elements) is longer, composite segments shrink towards the end of the chain of hops"""
-    if P_ == 1:
-        return [0, N]
-    # lengths: a (last), b_s (middle, s = P-2 .. 1), b_0 (first).  All phase-3 passes should end together:
-    #   end_s = a + (P-1-s) h + b_s  (s >= 1),  end_0 = a + (P-2) h + b_0;  composite ready: comp_cost b_s <= a + (P-2-s) h
-    best = None
-    for a in range(2, N):
-        rest = N - a
-        # b_s = b_0 + (s-1) h for s >= 1 ... solve b_0 from the sum
-        extra = sum((s - 1) * hop_cost for s in range(1, P_ - 1))
-        b0 = (rest - extra) / (P_ - 1)
-        if b0 < 1:
-            continue
-        bs = [b0] + [b0 + (s - 1) * hop_cost for s in range(1, P_ - 1)]
-        ok = all(comp_cost * bs[s] <= a + (P_ - 2 - s) * hop_cost + 1e-9 for s in range(1, P_ - 1))
-        end = a + (P_ - 2) * hop_cost + b0
-        if ok and (best is None or end < best[0]):
-            best = (end, a, bs)
-    _, a, bs = best
+    """cuts of P waves' P + 1 segments, 0 = cut[0] < ... < cut[P + 1] = N (driver.cpp: psweep_cuts).  Wave P-1 runs the recursion over the
+    last segment (a steps), posts its value and carries on through segment P-1; wave w <= P-2 meanwhile builds the element of segment
+    w+1, hops when the boundary value arrives and runs the ordinary recursion over segment w.  All waves end together when
+    b_w = b_0 + w hop, and the first element must be ready when the last segment is done: a = comp b_{P-1}."""
+    P = P_
+    while P >= 2:
+        b0 = (N - comp_cost * (P - 1) * hop_cost - hop_cost * P * (P - 1) / 2.0) / (P + comp_cost)
+        if b0 >= 1.0 and N >= 2 * (P + 1):
+            break
+        P -= 1
+    if P < 2:
+        return [0, N, N]
     cuts, t = [0], 0.0
-    for s in range(P_ - 1):
-        t += bs[s]
-        cuts.append(int(round(t)))
+    for w in range(P):
+        t += b0 + w * hop_cost
+        cuts.append(int(t + 0.5))
     cuts.append(N)
     for i in range(1, len(cuts)):
         cuts[i] = max(cuts[i], cuts[i - 1] + 1)
     cuts[-1] = N
+    for i in range(len(cuts) - 2, 0, -1):
+        cuts[i] = min(cuts[i], cuts[i + 1] - 1)
     return cuts
 
 
 def psweep(a, n, m, N, W, theta, mu, cuts, L=None, dl=None, noise_form=False):
-    """segment-parallel sweep; L given: policy evaluation, else gain sweep.  Returns (Ls, dls, V_0 with V[12][12] = the summed additive
-    scalar, boundary values, ok)."""
+    """segment-parallel sweep over the segments [cuts[s], cuts[s+1]) (P = len(cuts) - 2 waves); L given: policy evaluation, else gain
+    sweep.  Returns (Ls, dls, V_0 with V[12][12] = the summed additive scalar, the values handed along the chain, ok)."""
     gain = L is None
     Winv = np.eye(NP); Winv[:n, :n] = np.linalg.inv(W)
     Wp = np.zeros((NP, NP)); Wp[:n, :n] = W
     logdetW = np.linalg.slogdet(W)[1]
-    P_ = len(cuts) - 1
+    S_ = len(cuts) - 1                         # segments 0 .. S_-1; the last TWO are the last wave's own recursion
     tiles = [pad_tiles(a, t, n, m) for t in range(N)]
-    # phase 1: elements of segments 1 .. P-2 (segment 0 needs none: nobody is upstream of it); the last segment runs the recursion
+    # phase 1: the elements of segments 1 .. S_-2 (built by waves 0 .. P-2 while the last wave runs segment S_-1)
     comps = {}
-    for s in range(1, P_ - 1):
+    for s in range(1, S_ - 1):
         c = Composite()
         for t in reversed(range(cuts[s], cuts[s + 1])):
             c.prepend(tiles[t], Winv, Wp, logdetW, theta, mu, n, m, None if gain else L[t],
                       None if (gain or dl is None) else dl[t], gain=gain)
         comps[s] = c
     ok = all(c.ok for c in comps.values())
-    # phase 2: true boundary values down the chain; phase 3: the ordinary recursion inside every segment
-    Vb = {P_: terminal(a, n, N)}
     Ls = np.zeros((N, m, n)); dls = np.zeros((N, m))
-    scal = 0.0
-    for s in reversed(range(P_)):
-        V = Vb[s + 1].copy()
-        if s < P_ - 1:
-            V[AUG, AUG] = 0.0                  # the additive scalar is summed over the segments at the end
-        if 1 <= s < P_ - 1:
-            Vh, okh = (hop_noise_form(comps[s], Vb[s + 1], theta), True) if (noise_form and not gain) else hop(comps[s], Vb[s + 1], theta, n)
-            ok = ok and okh
+
+    def recurse(V, s):
+        nonlocal ok
         for t in reversed(range(cuts[s], cuts[s + 1])):
             Z, C, qr, q = tiles[t]
             V, Laug, ok1, ok2 = step(V, Z, C, qr, q, Winv, Wp, logdetW, theta, mu, n, m, None if gain else L[t],
                                      None if (gain or dl is None) else dl[t])
             ok = ok and ok1 and ok2
             Ls[t] = Laug[:m, :n]; dls[t] = Laug[:m, AUG]
+        return V
+
+    # the last wave: segment S_-1 from the terminal condition, posts, carries on through segment S_-2
+    Vb = {}
+    V = recurse(terminal(a, n, N), S_ - 1)
+    Vb[S_ - 1] = V.copy()                       # the value at cuts[S_-1]: handed to the wave that owns the element of segment S_-2
+    scal = 0.0
+    if S_ >= 2:
+        V = recurse(V, S_ - 2)
+    scal += V[AUG, AUG]
+    V_first = V
+    # the chain: wave w hops over segment w+1 and runs the ordinary recursion over segment w
+    for s in reversed(range(1, S_ - 1)):
+        Vh, okh = (hop_noise_form(comps[s], Vb[s + 1], theta), True) if (noise_form and not gain) else hop(comps[s], Vb[s + 1], theta, n)
+        ok = ok and okh
+        Vb[s] = Vh
+        V = recurse(Vh.copy(), s - 1)
         scal += V[AUG, AUG]
-        if 1 <= s < P_ - 1:
-            Vb[s] = Vh                         # what the chain hands upstream (phase 3 recomputes the same value sequentially)
-        else:
-            Vb[s] = V
-    V0 = V.copy(); V0[AUG, AUG] = scal
+        if s == 1:
+            V_first = V
+    V0 = V_first.copy(); V0[AUG, AUG] = scal
     return Ls, dls, V0, Vb, ok

@@ -1,0 +1,149 @@
+"""The TIME-PARALLEL Riccati sweep (csrc/psweep.h: P wavefronts per trajectory over P + 1 horizon segments -- segment elements of the
+associative LQ scan, information-form hops, the ordinary step from the true boundary values) through the batched sweep operators
+(rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch, switch psweep = P) against the SAME calls on the sequential sweep kernels
+(psweep = 0) and against the oracle (solve_approximate_dp!, ileqg.jl:341-406; solve_approximate_dp, :412-465):
+identical status / mu / Delta, gains and values to 1e-10 (measured ~1e-15)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import ratilqr.jl_amd as rat
+from oracle import oracle as orc
+from psweep_time import Harness, approx_of, rel
+
+pytestmark = pytest.mark.gpu
+WAVES = (2, 3, 4, 6, 8)
+
+
+def check(prob, x0, u, theta, waves=WAVES, mu0=None, expect_status=None, tol=1e-10):
+    B = len(theta)
+    Pp, ap_o, ap = approx_of(prob, x0, u)
+    hs = Harness(prob, B)
+    ref = hs.gain(ap, theta, mu=mu0)
+    if expect_status is not None:
+        assert list(ref["st"]) == list(expect_status), ref["st"]
+    okb = ref["st"] == 0
+    for b in np.nonzero(okb)[0][:4]:                                           # the sequential kernel against the oracle (a few samples)
+        rc, Lo, dlo, dpo, muo, deo = orc.dp_gain(Pp, ap_o, float(theta[b]), mu=0.0 if mu0 is None else float(mu0[b]))
+        assert rc == 0 and rel(ref["L"][b], Lo) < tol and ref["mu"][b] == muo and ref["delta"][b] == deo
+    Ls = np.where(okb[:, None, None, None], 0.9 * ref["L"], 0.0)
+    mu_e = np.where(okb, np.maximum(ref["mu"], 1e-6), 1e-6)
+    refe = hs.evalp(ap, Ls, theta, mu_e)
+    for P in waves:
+        g = hs.gain(ap, theta, mu=mu0, P=P)
+        assert np.array_equal(g["st"], ref["st"]) and np.array_equal(g["mu"], ref["mu"]) and np.array_equal(g["delta"], ref["delta"]), (P, g["st"], ref["st"])
+        if okb.any():
+            assert rel(g["L"][okb], ref["L"][okb]) < tol and rel(g["dl"][okb], ref["dl"][okb]) < tol, P
+        e = hs.evalp(ap, Ls, theta, mu_e, P=P)
+        assert np.array_equal(e["st"], refe["st"]), (P, e["st"], refe["st"])
+        fin = np.isfinite(refe["val"])
+        assert np.array_equal(fin, np.isfinite(e["val"])) and (not fin.any() or rel(e["val"][fin], refe["val"][fin]) < tol), P
+    return ref, refe
+
+
+def test_headline_problem_feasible_infeasible_and_theta_zero():
+    prob, x0, _ = rat.synthetic_lq_problem()
+    u = 0.1 * np.random.default_rng(1).standard_normal((prob.N, prob.m))
+    theta = np.array([0.0, 0.05, 0.5, 2.0, 6.0, 11.0, 12.5, 13.5, 20.0, 60.0, 1e4])          # theta = 0: the sequential body; the last ones: M not PD
+    ref, refe = check(prob, x0, u, theta)
+    assert np.all(ref["st"][:6] == 0) and ref["st"][-1] == 2 and np.isposinf(refe["val"][-1])
+
+
+@pytest.mark.parametrize("n,m,N,kappa", [(12, 4, 50, 0.05), (4, 2, 20, 0.0), (7, 3, 33, 0.02), (12, 4, 13, 0.0), (12, 4, 5, 0.0), (3, 1, 52, 0.0)])
+def test_sizes_horizons_and_cubic_drift(n, m, N, kappa):
+    prob, x0, _ = rat.synthetic_lq_problem(n=n, m=m, N=N, seed=5, kappa=kappa)
+    u = 0.1 * np.random.default_rng(2).standard_normal((N, m))
+    check(prob, x0, u, np.array([0.3, 1.0, 4.0, 9.0]))
+
+
+def test_general_noise_covariance_and_time_varying_cost():
+    """W full (not diagonal): the element step takes inv(W) G as a product instead of a row scaling; time-varying cost tables."""
+    rng = np.random.default_rng(11)
+    n, m, N = 12, 4, 40
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A, B, x0 = 0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), rng.standard_normal(n)
+    G = rng.standard_normal((n, n))
+    W = 1e-3 * (np.eye(n) + 0.2 * (G @ G.T) / n)
+    Qt = np.stack([(1.0 + 0.02 * k) * np.eye(n) for k in range(N)])
+    Rt = np.stack([(0.1 + 0.005 * k) * np.eye(m) for k in range(N)])
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=Qt, R=Rt, N=N, W=W, Qf=2.0 * np.eye(n))
+    u = 0.1 * rng.standard_normal((N, m))
+    check(prob, x0, u, np.array([0.2, 1.0, 3.0, 5.0]))
+
+
+def test_mu_regularisation_restarts():
+    """Indefinite stage cost: H not PD in the ordinary pass -> increase_mu_and_delta!, the whole sweep again (ileqg.jl:372-378):
+    the same mu / Delta as the sequential kernel and the oracle; an element whose own recursion meets H not PD falls back."""
+    rng = np.random.default_rng(1)
+    n, m, N = 12, 4, 50
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A, B, x0 = 0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), rng.standard_normal(n)
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=-0.2 * np.eye(n), R=0.1 * np.eye(m), N=N, W=1e-3 * np.eye(n), Qf=np.eye(n))
+    ref, _ = check(prob, x0, np.zeros((N, m)), np.array([0.0, 1.0, 4.0]))
+    assert np.all(ref["mu"] > 1e-6)
+
+
+def test_no_state_cost_falls_back_to_the_sequential_sweep():
+    """S = 0 along the whole horizon (the reference's own c = k, h = 1 test cost has no state term): the hop cannot invert S_b -- the
+    workgroup's wave 0 runs the sequential body, results are its bits."""
+    rng = np.random.default_rng(3)
+    n, m, N = 6, 2, 30
+    A, B = 0.8 * np.eye(n), rng.standard_normal((n, m))
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=np.zeros((n, n)), R=np.eye(m), N=N, W=1e-2 * np.eye(n), Qf=np.zeros((n, n)))
+    x0, u = rng.standard_normal(n), 0.1 * rng.standard_normal((N, m))
+    theta = np.array([0.5, 2.0])
+    Pp, ap_o, ap = approx_of(prob, x0, u)
+    hs = Harness(prob, 2)
+    ref = hs.gain(ap, theta)
+    for P in (2, 4):
+        g = hs.gain(ap, theta, P=P)
+        assert np.array_equal(g["st"], ref["st"]) and np.array_equal(g["L"], ref["L"]) and np.array_equal(g["dl"], ref["dl"])
+
+
+def _solve_both(prob, x0, u, theta, opts=None, **kw):
+    out = []
+    for psw in (0, 1):
+        ctx = rat.Context(prob, opts, max_batch=len(theta), spec_eps=1, **kw)
+        ctx.debug_set("block_psw", psw)
+        ctx.profile(True)
+        val, st, it, ls = ctx.solve_batch(x0, u, theta)
+        kinds = [k for k, v in ctx.profile_get().items() if v["launches"]]
+        assert kinds == ["solve_block"], kinds
+        out.append((val, st, it, ls))
+    return out
+
+
+@pytest.mark.parametrize("case", ["lq", "cubic", "small", "indefinite", "short"])
+def test_block_solve_with_time_parallel_sweeps_equals_the_block_solve_and_the_oracle(case):
+    """solve_block_psw_kernel (switch block_psw: four waves per sample, every sweep time-parallel) against solve_block_kernel and the
+    oracle: identical status, iteration and line-search counts, values to 1e-9 (measured ~1e-14)."""
+    opts = None
+    if case == "lq":
+        prob, x0, u = rat.synthetic_lq_problem()
+        theta = np.concatenate([[0.0], np.linspace(0.05, 12.0, 29), [13.2, 60.0]])
+    elif case == "cubic":                                                     # line searches that backtrack, > 2 iterations
+        prob, x0, u = rat.synthetic_lq_problem(kappa=0.05)
+        theta = np.linspace(0.0, 9.0, 24)
+    elif case == "small":
+        prob, x0, u = rat.synthetic_lq_problem(n=4, m=2, N=20, seed=2, kappa=0.02)
+        theta = np.linspace(0.0, 3.0, 16)
+    elif case == "short":                                                     # N = 9: two-wave teams at most
+        prob, x0, u = rat.synthetic_lq_problem(n=6, m=2, N=9, seed=4)
+        theta = np.linspace(0.0, 3.0, 8)
+    else:                                                                     # mu restarts, runs to iter_max
+        rng = np.random.default_rng(1)
+        n, m, N = 12, 4, 50
+        Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        A, B, x0 = 0.9 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), rng.standard_normal(n)
+        prob = rat.LQRiskSensitiveProblem(A, B, Q=-0.2 * np.eye(n), R=0.1 * np.eye(m), N=N, W=1e-3 * np.eye(n), Qf=np.eye(n))
+        u, theta, opts = np.zeros((N, m)), np.array([0.0, 1.0, 4.0]), rat.ileqg.make_opts(iter_max=6)
+    (v0, s0, i0, l0), (v1, s1, i1, l1) = _solve_both(prob, x0, u, theta, opts)
+    assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1), (s0, s1, i0, i1, l0, l1)
+    fin = np.isfinite(v0)
+    assert np.array_equal(fin, np.isfinite(v1)) and rel(v1[fin], v0[fin]) < 1e-9
+    vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=8, **({} if opts is None else dict(iter_max=6)))
+    assert np.array_equal(so, s1) and np.array_equal(io, i1) and np.array_equal(lo, l1)
+    assert rel(v1[fin], vo[fin]) < 1e-9

@@ -95,8 +95,9 @@ def main():
             assert rel(ref["L"][b], Lo) < 1e-10 and abs(refe["val"][b] - dpe["s"][0]) < 1e-10 * abs(dpe["s"][0])
         row = {"seq": {"gain_ms": ref["ms"], "eval_ms": refe["ms"]}}
         print(f"B={B}: sequential gain {ref['ms']:.4f} ms, eval {refe['ms']:.4f} ms", flush=True)
-        for P in (3, 4, 5, 6, 8):
-            for hop, comp in ((130, 125),):
+        grid = [(int(h), int(c)) for h, c in (g.split(":") for g in os.environ.get("PSW_GRID", "130:125").split(","))]
+        for P in [int(p) for p in os.environ.get("PSW_P", "2,3,4,5,6,8").split(",")]:
+            for hop, comp in grid:
                 g = hs.gain(ap, theta, P=P, psw_hop=hop, psw_comp=comp)
                 g = hs.gain(ap, theta, P=P, psw_hop=hop, psw_comp=comp)
                 e = hs.evalp(ap, Ls, theta, mu, P=P)
@@ -104,7 +105,7 @@ def main():
                 okg = np.array_equal(g["st"], ref["st"]) and np.array_equal(g["mu"], ref["mu"])
                 eL, edl, ev = rel(g["L"], ref["L"]), rel(g["dl"], ref["dl"]), rel(e["val"], refe["val"])
                 oke = np.array_equal(e["st"], refe["st"])
-                row[f"P{P}"] = {"gain_ms": g["ms"], "eval_ms": e["ms"], "err_L": eL, "err_dl": edl, "err_val": ev, "status_equal": bool(okg and oke)}
+                row[f"P{P}_h{hop}_c{comp}"] = {"gain_ms": g["ms"], "eval_ms": e["ms"], "err_L": eL, "err_dl": edl, "err_val": ev, "status_equal": bool(okg and oke)}
                 print(f"   P={P} (hop {hop}, comp {comp}): gain {g['ms']:.4f} ms  eval {e['ms']:.4f} ms | err L {eL:.1e} dl {edl:.1e} val {ev:.1e} status_equal {okg and oke}",
                       flush=True)
         out[str(B)] = row
