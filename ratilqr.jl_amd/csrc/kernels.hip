@@ -2653,8 +2653,18 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     double *const wls = wls_all[wave], *const shxu = shxu_all[wave];
     const bool leader = (wave == 0) && ((threadIdx.x & 63) == 0);
     const int team = wave & 1, tw = wave >> 1;          // evaluations: waves {0, 2}; gain sweeps: waves {1, 3}
+#ifdef RAT_DIAG_PHASES
+    const unsigned long long dg_t0 = __builtin_readcyclecounter();
+    int dg_pi = 0;
+#define BPSW_MARK() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8 && fa.sw.dump && dg_pi < 40 && wave < 2) \
+        fa.sw.dump[1024 + blockIdx.x * 80 + (wave ? 40 : 0) + dg_pi] = (double)(__builtin_readcyclecounter() - dg_t0); ++dg_pi; } while (0)
+#else
+#define BPSW_MARK() do {} while (0)
+#endif
     if (leader) init_state_body(st, fa.sw.op, fa.theta_in, b);
+    BPSW_MARK();
     __syncthreads();
+    BPSW_MARK();
     if (fa.init_x) {                             // initialize!'s rollout was run once for the whole batch (FusedArgs.init_*)
         if (wave == 0) copy_initial(st, fa.init_x, fa.init_u, fa.init_t, b);
     } else {                                     // initialize!: open-loop rollout (wave 0) + linearise (the other waves)   (ileqg.jl:214-233)
@@ -2663,22 +2673,30 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         else rolllin_body<0, CTV, true, true>(ra, b, shxu, xu, &prog, epoch, wave - 1, 3, d_acc);
         epoch += st.N + 2;
     }
+    BPSW_MARK();
     __syncthreads();
+    BPSW_MARK();
     {                                            // open-loop policy evaluation (:234) || the first step!'s gain sweep on the same trajectory
         SweepArgs sa = fa.sw;
         if (team == 0) { sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
         else { sa.mode = 5; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[1], fa.psw2g, tw); }
     }
+    BPSW_MARK();
     __syncthreads();
+    BPSW_MARK();
     if (leader) commit_init_body(st, b);
+    BPSW_MARK();
     __syncthreads();
+    BPSW_MARK();
     for (int guard = 0; guard < fa.max_rounds; ++guard) {
         const int v_stat = __atomic_load_n(&st.status[b], __ATOMIC_RELAXED), v_act = __atomic_load_n(&st.ls_active[b], __ATOMIC_RELAXED);
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp! with no valid speculative sweep  (ileqg.jl:598-613)
             SweepArgs sa = fa.sw; sa.mode = 0;
             psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
-            __syncthreads();
+            BPSW_MARK();
+    __syncthreads();
+    BPSW_MARK();
             continue;
         }
         {                                                    // the candidate of this line-search round  (ileqg.jl:504-521)
@@ -2687,13 +2705,17 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
             else rolllin_body<1, CTV, true, true>(ra, b, shxu, xu, &prog, epoch, wave - 1, 3, d_acc);
             epoch += st.N + 2;
         }
-        __syncthreads();
+        BPSW_MARK();
+    __syncthreads();
+    BPSW_MARK();
         if (threadIdx.x == 64) {                             // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
             st.d_c[b] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
             st.flag_c[b] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __syncthreads();
+        BPSW_MARK();
+    __syncthreads();
+    BPSW_MARK();
         // would accepting this candidate end solve! (:642-653)?  Then nothing consumes a speculative gain sweep: all four waves evaluate.
         const double v_dc = *(const volatile double *)&st.d_c[b], v_mu = *(const volatile double *)&st.mu[b];
         const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
@@ -2705,14 +2727,21 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
             else if (team == 0) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
             else { sa.mode = 4; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[1], fa.psw2g, tw); }
         }
-        __syncthreads();
-        if (leader) ls_select_body(st, fa.sw.op, b, nullptr);
-        __syncthreads();
-    }
+        BPSW_MARK();
     __syncthreads();
+    BPSW_MARK();
+        if (leader) ls_select_body(st, fa.sw.op, b, nullptr);
+        BPSW_MARK();
+    __syncthreads();
+    BPSW_MARK();
+    }
+    BPSW_MARK();
+    __syncthreads();
+    BPSW_MARK();
     if (leader) gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
 }
 
+#undef BPSW_MARK
 #if RAT_PART & PART_BPSW
 bool solve_block_psw_supported(const FusedArgs &fa) {
     return fa.sw.st.E == 1 && fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST && !fa.sw.pb.W_tv && fa.sw.st.N >= 8;

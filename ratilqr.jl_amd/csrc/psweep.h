@@ -54,7 +54,7 @@ __device__ __forceinline__ double rows_sum4(double x) {
 // phase-timeline build only (make diagp; tools/psweep_phases.py): cycle stamps per wave at the phase boundaries
 #ifdef RAT_DIAG_PHASES
 #define PSW_MARK(slot_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8 && a.dump) \
-        a.dump[4096 + blockIdx.x * 128 + wave * 16 + (slot_)] = (double)__builtin_readcyclecounter(); } while (0)
+        a.dump[4096 + blockIdx.x * 512 + (a.mode & 7) * 64 + wave * 16 + (slot_)] = (double)__builtin_readcyclecounter(); } while (0)
 #else
 #define PSW_MARK(slot_) do {} while (0)
 #endif
@@ -122,8 +122,6 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     const double m12 = (j < 12) ? 1.0 : 0.0;
     const double nth12 = -theta * m12;
     const double mA = (g == 0 && j < 12) ? 1.0 : 0.0, mB = (g == 0 && j == 12) ? 1.0 : 0.0, mH = (j == 12 + g) ? 1.0 : 0.0;
-    const double mrow12 = (g == 0 && j <= 12) ? 1.0 : 0.0;          // row 12 of a 16 x 16 image (register 3, first 16-lane row)
-    const double mcol12 = (j == 12) ? 1.0 : 0.0;
     ElimMasks em;
     elim_masks(em, g, j);
     int hoff[4], foff[3], goff[4];
@@ -157,11 +155,6 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
         epall = ((((pb.epiv[0] * pb.epiv[2]) * pb.epiv[4]) * pb.epiv[6]) * pb.epiv[8]) * pb.epiv[10];
     }
     const double coef = -1.0 / (2.0 * theta);
-    // padded coordinates (n < 12): 1 on their diagonal for the hop's inversions; the padding's unit "noise" (inv(W) is padded with 1) is
-    // cleared from Cbar there
-    double padd[3], mnn[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { padd[r] = (4 * r + g == j && j >= pb.n) ? 1.0 : 0.0; mnn[r] = (4 * r + g < pb.n && j < pb.n) ? 1.0 : 0.0; }
     const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
 
     int restarts = 0;
@@ -224,7 +217,7 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
             gneg = mm3(m, kk, zero4);                                          // m = -M^-1 (symmetric)
             const double part = (SVB(g) * gneg[0] + SVB(4 + g) * gneg[1]) + SVB(8 + g) * gneg[2];      // -(s_vec' G), this row group's share
             const double ssum = rows_sum4(part);
-            tk3 = fma(-theta, ssum, kk[3]) * mrow12;
+            tk3 = fma(-theta, ssum, kk[3]) * (mA + mB);                 // (row 12 of the image: register 3, first 16-lane row, columns <= 12)
             if (WM == 2) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) tk[r] = gneg[r] * nwrow[r];      // (-G)(-inv(W)_ii): inv(W) G, W diagonal
@@ -335,6 +328,10 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     // steps thi-1 .. tlo over ping-pong tile registers (prefetch clamped at the segment's first step)
     auto run = [&](auto comp_tag, const int thi, const int tlo) -> int {
         TileRegs nx, rb;
+        // (every memory operation issued so far lands before the loop is entered: a load still in flight at the loop's entry makes the
+        //  compiler's wait at the loop HEADER a vmcnt(0) -- paid on every step, it drains the gain stores and the prefetch: +500 cycles a
+        //  step; so does any branch inside the loop, which is why the last wave's hand-over sits between two calls, not inside one)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         load_tile<HASL, false, FLY>(nx, tile0 + (long)(thi - 1) * TSTRIDE, l, lx, lq, Lb + (long)(thi - 1) * LSTR, nullptr, mL, g, j, &fc, thi - 1);
         for (int t = thi - 1; t >= tlo; t -= 2) {
             {
@@ -380,6 +377,8 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
         const int epoch = gen;                       // unique per attempt and per call: what the flags of this attempt carry
         int my_fail = 0, my_unc = 0, my_h = 0;
         PSW_MARK(0);
+        bool dead = false;
+        int thi, tlo, tmid;                          // the ordinary recursion runs over [tmid, thi) and then [tlo, tmid)
         if (wave == P - 1) {
             // terminal condition (ileqg.jl:352-354 / 429-431)
             const double *__restrict__ tt = tile0 + (long)N * TSTRIDE;
@@ -391,18 +390,7 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
             }
             const double t3 = tt[(j < 12) ? TT_QV + j : TT_q];
             v[3] = (g == 0 && j <= 12) ? (j < 12 ? t3 : 2.0 * t3) : 0.0;
-            racc = 0.0; rprod = 1.0; rexp = 0;
-            int r = run(FalseTag(), N, pc.cut[P]);
-            if (r && l == 0) __hip_atomic_store(&sh->last_rc, (epoch << 2) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            PSW_MARK(1);
-            if (P >= 2) post(v, P - 2, epoch);
-            PSW_MARK(3);
-            if (!r) {
-                r = run(FalseTag(), pc.cut[P], pc.cut[P - 1]);
-                if (r && l == 0) __hip_atomic_store(&sh->last_rc, (epoch << 2) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (r == 1) my_fail = 1;
-            if (r == 2) my_h = 1;
+            thi = N; tlo = pc.cut[P - 1]; tmid = pc.cut[P];
         } else {
             // ---- phase 1: the element of segment wave + 1 ---------------------------------------------------------------------------------------
             d4 ac = zero4;
@@ -425,17 +413,22 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
             // ---- the true value at the end of that segment ------------------------------------------------------------------------------------
             psw_spin(&sh->flag[wave], epoch);
             PSW_MARK(2);
-            const bool dead = (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->last_rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) == epoch;
-            d4 vb;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) vb[q] = sh->vbox[wave][64 * q + l];
+            dead = (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->last_rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) == epoch;
             d4 vt = zero4;
             if (!dead) {
                 // ---- hop: V at the segment's start = Jv + Aa' (S_b^-1 + Ubar - theta Sigbar)^-1 Aa,  Aa = [Abar | bbar + S_b^-1 s_b] ----------
+                int l = l_, g = g_, j = j_;
+                asm volatile("" : "+v"(l), "+v"(g), "+v"(j));      // (the hop's lane masks are formed here, not kept live across the time loops)
+                const double mcol12 = (j == 12) ? 1.0 : 0.0;
+                d4 vb;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) vb[q] = sh->vbox[wave][64 * q + l];
                 const double s0 = sh->vbox[wave][192 + g], s1 = sh->vbox[wave][192 + 4 + g], s2 = sh->vbox[wave][192 + 8 + g];   // s_b by row index
+                // padded coordinates (n < 12): 1 on their diagonal for the inversions; the padding's unit "noise" (inv(W) is padded with 1) is
+                // cleared from Cbar there
                 d4 sb;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) sb[r] = fma(vb[r], m12, padd[r]);
+                for (int r = 0; r < 3; ++r) sb[r] = fma(vb[r], m12, (4 * r + g == j && j >= pb.n) ? 1.0 : 0.0);
                 sb[3] = 0.0;
                 int pd = 1;
                 double rp = 1.0;
@@ -448,7 +441,7 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
                 if (!(pd > 0) || !(rp * 0.0 == 0.0)) my_unc = 1;
                 d4 y;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) y[r] = fma(fma(theta, nsig[r], ub[r]), mnn[r], -sb[r]);      // S_b^-1 + Ubar - theta Sigbar
+                for (int r = 0; r < 3; ++r) y[r] = fma(fma(theta, nsig[r], ub[r]), (4 * r + g < pb.n && j < pb.n) ? 1.0 : 0.0, -sb[r]);      // S_b^-1 + Ubar - theta Sigbar
                 y[3] = 0.0;
                 // w = S_b^-1 s_b by column, then by component on the lanes of column 12
                 const double wpart = -((sb[0] * s0 + sb[1] * s1) + sb[2] * s2);
@@ -469,19 +462,32 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
                 aa[3] = 0.0; aan[3] = 0.0;
                 const d4 tgn = mm3(y, aa, zero4);                                  // -Xt Aa
                 vt = mm3(aan, tgn, v);                                             // Jv + Aa' Xt Aa   (v = Jv after phase 1)
-                vt[3] *= mrow12 * m12;                                             // row 12: s_vec'; the additive scalar [12][12] is summed over the
+                vt[3] *= mA;                                                       // row 12: s_vec'; the additive scalar [12][12] is summed over the
                                                                                    // segments at the end, not propagated
             }
             if (wave >= 1) post(vt, wave - 1, epoch);                              // (always: nobody downstream may hang)
             PSW_MARK(3);
             // ---- phase 3: the ordinary recursion over segment `wave` from the value the hop produced -----------------------------------------
             v = vt;
-            racc = 0.0; rprod = 1.0; rexp = 0;
-            if (!my_unc && !dead) {
-                const int r = run(FalseTag(), pc.cut[wave + 1], pc.cut[wave]);
-                if (r == 1) my_fail = 1;
-                if (r == 2) my_h = 1;
+            thi = pc.cut[wave + 1]; tlo = pc.cut[wave]; tmid = tlo;
+        }
+        // ---- the ordinary recursion: the last wave over its two segments (posting at the cut between them), the others over their own --------
+        racc = 0.0; rprod = 1.0; rexp = 0;
+        if (!my_unc && !dead) {
+            int r = 0;
+            for (int part = 0; part < 2 && !r; ++part) {                           // (one call site: one copy of the loop)
+                const int hi = part ? tmid : thi, lo = part ? tlo : tmid;
+                if (hi > lo) r = run(FalseTag(), hi, lo);
+                if (part == 0 && wave == P - 1) {
+                    if (r && l == 0) __hip_atomic_store(&sh->last_rc, (epoch << 2) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    PSW_MARK(1);
+                    post(v, P - 2, epoch);                                         // (always: whatever it holds ends the others' wait)
+                    PSW_MARK(3);
+                }
             }
+            if (r && wave == P - 1 && l == 0) __hip_atomic_store(&sh->last_rc, (epoch << 2) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (r == 1) my_fail = 1;
+            if (r == 2) my_h = 1;
         }
         PSW_MARK(4);
         // ---- per-wave partials; one decision for the workgroup ----------------------------------------------------------------------------

@@ -25,9 +25,9 @@ for P in Ps:
     for kind in ("gain", "eval"):
         for _ in range(3):
             r = hs.gain(ap, theta, P=P, psw_hop=hop, psw_comp=comp) if kind == "gain" else hs.evalp(ap, Ls, theta, mu, P=P, psw_hop=hop, psw_comp=comp)
-        out = np.zeros(1024)
-        lib.rat_diag_read_n(hs.ctx.h, out.ctypes.data_as(C.POINTER(C.c_double)), 4096, 1024)
-        t = out.reshape(8, 8, 16)[:, :P, :6]
+        out = np.zeros(4096)
+        lib.rat_diag_read_n(hs.ctx.h, out.ctypes.data_as(C.POINTER(C.c_double)), 4096, 4096)
+        t = out.reshape(8, 8, 4, 16)[:, 0 if kind == "gain" else 1, :min(P, 4), :6]          # (mode 0: gain sweep, mode 1: evaluation; waves 0..3)
         t0 = t[:, :, 0].min(axis=1, keepdims=True)
         rel = (t - t0[:, :, None]).mean(axis=0)
         print(f"{kind} P={P} (model hop {hop} comp {comp}): kernel {r['ms'] * 1e3:.1f} us; cycles from the first wave's start, mean of 8 trajectories")
