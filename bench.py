@@ -564,6 +564,8 @@ def rank_main(args):
             e8 = D.timed(w8.step, K8, max(2, W))
             strong8 = {"value": G * K8 / e8, "unit": "solves/s", "ms_per_step": e8 / K8 * 1e3, "steps": K8, "global_batch": G,
                        "spec_eps": 8, "costs_identical_to_primary": bool(torch.equal(w8.cost[: w8.nloc], w.cost[: w.nloc])),
+                       # (shards of <= one sample per CU run time-parallel sweeps at E = 1: equal to rounding, not bit for bit)
+                       "costs_match_primary_1e-12": bool(torch.allclose(w8.cost[: w8.nloc], w.cost[: w.nloc], rtol=1e-12, atol=0.0, equal_nan=True)),
                        "mean_ls_evals": float(w8.gathered()[3].mean())}
             del w8
 
@@ -792,7 +794,10 @@ def rank_main(args):
             torch.cuda.synchronize()
             es = time.perf_counter() - ts
             shard_lat[str(Bs)] = {"ms_per_batch": es / Ks * 1e3, "steps": Ks, "path": cs.get_path(Bs),
-                                  "costs_identical_to_primary": bool(torch.equal(cst, w.cost[:Bs]))}
+                                  "time_parallel_sweeps": bool(cs.debug_get("block_psw")) and Bs <= 256,
+                                  "costs_identical_to_primary": bool(torch.equal(cst, w.cost[:Bs])),
+                                  # (shards of <= one sample per CU run time-parallel sweeps: equal to rounding, not bit for bit)
+                                  "costs_match_primary_1e-12": bool(torch.allclose(cst, w.cost[:Bs], rtol=1e-12, atol=0.0, equal_nan=True))}
             del cs
 
         # BASELINE config 5: PETS forward simulation (src/pets.jl:128-157), 100 control samples x 100 stochastic rollouts = 10k

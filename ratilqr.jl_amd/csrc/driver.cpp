@@ -116,7 +116,7 @@ struct rat_handle_s {
     uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, options generation, x0, u0, kl_bound)
     int psweep = 0;                               // > 2: the batched sweep operators run the segment-parallel kernel with this many waves per trajectory
     int psw_hop = 120, psw_hop_e = 140, psw_comp = 125;   // its cost model (x 100, in ordinary steps): one hop (gain sweep / evaluation), one element step -- places the cuts
-    bool block_psw = false;                       // the workgroup-per-sample solve with time-parallel sweeps for batches of <= one sample per CU (solve_block_psw_kernel)
+    bool block_psw = true;                        // the workgroup-per-sample solve with time-parallel sweeps for batches of <= one sample per CU (solve_block_psw_kernel)
     uint64_t opts_serial = 0;                     // bumped by everything that can change what a solve returns without a new problem: rat_set_ileqg_opts,
                                                   // rat_debug_set, rat_set_path (the reference builds a fresh ILEQGSolver from the current options per evaluation)
     int nm_depth = 3;                // switch nm_depth: 0 no speculation beyond the step's own vertices, 1 (+ carry), 2 (+ the next step's),

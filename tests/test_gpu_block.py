@@ -37,6 +37,8 @@ def _run_all(E):
 
 @pytest.mark.parametrize("E", [1, 2, 4, 8])
 def test_block_kernel_is_bit_identical_to_the_other_paths(E, monkeypatch):
+    monkeypatch.setenv("RATILQR_BLOCK_PSW", "0")               # bit-identity is a property of the sequential-sweep paths; the time-parallel
+                                                               # sweeps of small batches agree to rounding (tests/test_gpu_psweep.py)
     monkeypatch.setenv("RATILQR_BLOCK", "1")
     block = _run_all(E)
     monkeypatch.setenv("RATILQR_BLOCK", "0")
@@ -111,6 +113,8 @@ def test_eight_candidates_with_a_lazily_evaluated_last_one(lam, eps_min, monkeyp
 def test_block_geometries_are_bit_identical(monkeypatch):
     """E = 1 geometries of the block kernel: four-wave workgroups with ticketed SIMD pairs and linearise helper waves (one sample per CU),
     without the helpers, plain two-wave workgroups -- and rollouts split over the waves or not (N > 52: unsplit)."""
+    monkeypatch.setenv("RATILQR_BLOCK_PSW", "0")               # bit-identity is a property of the sequential-sweep paths; the time-parallel
+                                                               # sweeps of small batches agree to rounding (tests/test_gpu_psweep.py)
     prob, x0, u = rat.synthetic_lq_problem(kappa=0.04)
     theta = np.concatenate([[0.0], np.linspace(0.05, 9.0, 60), [40.0]])
     long_p, lx0, lu = rat.synthetic_lq_problem(N=60, seed=3, kappa=0.02)

@@ -136,8 +136,13 @@ def test_config3_full_size_ce_matches_the_oracle():
         assert solver.c.n_solves == 5 * 1024
         assert np.abs(x - x_o).max() < 1e-9 and np.abs(L - L_o).max() < 1e-9
         res.append((th, val, solver.c.mu, solver.c.sigma, x, l, L))
-    for a, b in zip(res[0], res[1]):                                               # speculation width does not change a bit
-        assert np.array_equal(np.asarray(a), np.asarray(b))
+    # speculation width does not change a bit of the batches (mu, sigma, theta_opt); the final solve at theta_opt is ONE sample, which
+    # the E = 1 handle runs with time-parallel sweeps (solve_block_psw_kernel): its outputs agree to rounding
+    for k, (a, b) in enumerate(zip(res[0], res[1])):
+        if k in (0, 2, 3):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        else:
+            assert np.allclose(np.asarray(a), np.asarray(b), rtol=1e-12, atol=1e-13)
 
 
 # ---- the two solve! branches the reference's own tests never reach (VERDICT r01 missing #5), GPU vs oracle ------------------------

@@ -138,7 +138,7 @@ def test_bench_self_launches_two_ranks():
     assert d["value"] == d["strong"]["value"] > 0 and abs(d["value"] - 256 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert d["config"]["feasible_fraction"] == 1.0 and d["roofline"]["launches"] == 3 and d["roofline"]["trajectories_per_launch"] == 128
     assert d["weak"]["global_batch"] == 512 and d["weak"]["value"] > 0
-    assert d["strong_spec_eps8"]["costs_identical_to_primary"] is True and d["strong_spec_eps8"]["value"] > 0
+    assert d["strong_spec_eps8"]["costs_match_primary_1e-12"] is True and d["strong_spec_eps8"]["value"] > 0
 
 
 def test_bench_runs_as_two_ranks_under_the_drivers_launcher():

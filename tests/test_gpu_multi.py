@@ -97,6 +97,8 @@ def test_logical_devices_run_the_multi_device_code(G, monkeypatch):
     """n_devices > 1 on a one-GPU box (logical devices): contiguous ragged shards (B = 10, 13 on 8 devices: empty and short blocks whose
     pad slots must never be read), one gather per batch, and the gathered status / iteration / line-search counts of every shard equal
     the single handle's, as do the costs, bit for bit; then the whole CE solve."""
+    monkeypatch.setenv("RATILQR_BLOCK_PSW", "0")               # bit-identity is a property of the sequential-sweep paths; the time-parallel
+                                                               # sweeps of small batches agree to rounding (tests/test_gpu_psweep.py)
     monkeypatch.setenv("RATILQR_MULTI_LOGICAL", "1")
     prob, x0, u = rat.synthetic_lq_problem(kappa=0.03)
     rng = np.random.default_rng(20 + G)
@@ -151,8 +153,10 @@ def test_logical_devices_with_polled_shards(monkeypatch):
     assert st[17] == 1 and it.max() >= 3 and mc.allgathers == 1
 
 
-def test_set_path_per_handle():
+def test_set_path_per_handle(monkeypatch):
     """rat_set_path: the execution path is a property of the handle, not of the process environment; results do not depend on it."""
+    monkeypatch.setenv("RATILQR_BLOCK_PSW", "0")               # bit-identity is a property of the sequential-sweep paths; the time-parallel
+                                                               # sweeps of small batches agree to rounding (tests/test_gpu_psweep.py)
     prob, x0, u = rat.synthetic_lq_problem(kappa=0.04)
     theta = np.abs(1.0 + 2.0 * np.random.default_rng(4).standard_normal(64)); theta[5] = 60.0
     ctx = rat.Context(prob, max_batch=64)

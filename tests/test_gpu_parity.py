@@ -265,6 +265,8 @@ def test_dp_failed_line_search_candidates(seed, theta):
 def test_speculative_gain_sweep_is_result_identical(monkeypatch):
     """Opt-in mode (RATILQR_SPECULATE=1): the next step!'s gain sweep runs on candidate 0 concurrently with its
     evaluation sweep and is committed by the select kernel.  Must not change a single bit of any result."""
+    monkeypatch.setenv("RATILQR_BLOCK_PSW", "0")               # bit-identity is a property of the sequential-sweep paths; the time-parallel
+                                                               # sweeps of small batches agree to rounding (tests/test_gpu_psweep.py)
     prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
     theta = np.array([0.0, 1.0, 4.0, 5.0, 5.9, 6.3, 6.6, 9.0])
     sprob, sx0, su = stress_problem(2, kappa=0.03)
@@ -287,6 +289,8 @@ def test_speculative_gain_sweep_is_result_identical(monkeypatch):
 def test_dual_sweep_wavefronts_are_result_identical(monkeypatch):
     """Opt-in mode (RATILQR_DUAL=1, E = 1): one wavefront runs candidate 0's policy evaluation and the next step!'s gain sweep
     over a single pass of the tiles.  Same expressions as the separate kernels: every output must be bit-identical."""
+    monkeypatch.setenv("RATILQR_BLOCK_PSW", "0")               # bit-identity is a property of the sequential-sweep paths; the time-parallel
+                                                               # sweeps of small batches agree to rounding (tests/test_gpu_psweep.py)
     prob, x0, u = rat.synthetic_lq_problem(seed=5, kappa=0.05)
     theta = np.array([0.0, 1.0, 4.0, 5.0, 5.9, 6.3, 6.6, 9.0, 30.0])
     sprob, sx0, su = stress_problem(2, kappa=0.03)
