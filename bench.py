@@ -845,6 +845,32 @@ def rank_main(args):
             del ds
         pets_sec["value"] = pets_sec["runs"]["100x100"]["trajectories_per_s"]
         pets_sec["unit"] = "trajectories/s (BASELINE config 5: 10k trajectories per call)"
+        # one PETS solve! (pets.jl:270-281): 5 CE iterations of 100 control samples x 100 rollouts, the loop over control sequences resident on
+        # the device (sampling, rollouts, elites and the smoothed update in one enqueue chain, one host wait); the library call alone
+        # (control normals drawn on the device: zc = NULL) and the kernel sum from HIP events
+        import ctypes as _C
+        from ratilqr.jl_amd import _native as _nv
+        dsv = rat.CrossEntropyDirectOptimizationSolver(np.zeros((30, 4)), np.stack([0.3 * np.eye(4)] * 30), num_control_samples=100,
+                                                       num_trajectory_samples=100, num_elite=10, iter_max=5, device=D.local_rank)
+        sctx = dsv.context(gprob)
+        xpp = _nv.f64(xp0)
+
+        def one_solve(seed):
+            _nv.check(_nv.lib().rat_pets_solve(sctx.h, _C.byref(dsv.c), _nv.P(xpp), 0, None, None, None, _C.c_uint64(seed)))
+
+        for i in range(5):
+            one_solve(20 + i)
+        tsv = []
+        for i in range(30):
+            t0 = time.perf_counter(); one_solve(40 + i); tsv.append(time.perf_counter() - t0)
+        sctx.profile(True); sctx.profile_reset()
+        one_solve(99)
+        pv = sctx.profile_get(); sctx.profile(False)
+        pets_sec["solve"] = {"what": "rat_pets_solve, 5 iterations x (100 control samples x 100 rollouts), device-resident loop, control normals and "
+                                     "rollout noise from the device generators", "ms_per_solve": float(np.median(tsv)) * 1e3,
+                             "kernel_sum_ms": float(sum(v["ms"] for v in pv.values())), "launches": int(sum(v["launches"] for v in pv.values())),
+                             "mu_finite": bool(np.all(np.isfinite(dsv.mu_array)))}
+        del dsv
 
         # BASELINE config 4: RAT iLQR++ (src/nelder_mead_bilevel_optimization.jl:276-352) on the headline problem: every Nelder-Mead
         # iteration's vertices -- and those of the iterations after (three deep in the first call, two afterwards) -- are evaluated ahead in
@@ -973,6 +999,7 @@ def rank_main(args):
             "wide_32x32_solves_per_s": wide_sec["runs"]["32x32"]["solves_per_s"] if wide_sec else None,
             "pets_traj_per_s": pets_sec["value"] if pets_sec else None,
             "pets_1m_traj_per_s": pets_sec["runs"]["1000x1000"]["trajectories_per_s"] if pets_sec else None,
+            "pets_solve_ms": pets_sec["solve"]["ms_per_solve"] if pets_sec else None,
             "steady_solves_per_s": steady["value"] if steady else None,
         }
         out.update({k: v for k, v in flat.items() if v is not None})

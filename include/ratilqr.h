@@ -333,7 +333,9 @@ rat_rc rat_pets_update(rat_pets_solver *s, const double *controls, const double 
 rat_rc rat_pets_step(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc,
                      const double *zn, const double *zu, uint64_t seed, double *controls_out, double *cost_out);
 /* solve! (pets.jl:270-281): iter_max steps from (mu_init, Sigma_init); streams hold iter_max consecutive step blocks
- * (zc may not be NULL; zn NULL -> device generator with seed + iteration). */
+ * (zn NULL -> device generator with seed + iteration).  With zn NULL and <= 1024 control samples the whole loop stays on the device
+ * (switch pets_device): sampling, rollouts, elite selection and the smoothed update are one enqueue chain, one host wait per solve!;
+ * mu / Sigma equal the host loop's bit for bit.  zc NULL (device-resident loop only): the control normals are drawn on the device too. */
 rat_rc rat_pets_solve(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc,
                       const double *zn, const double *zu, uint64_t seed);
 
@@ -429,6 +431,7 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *                            wavefronts per workgroup while the launch is small (<= 1536 wavefronts), by the recursion's own beyond; 2 never
  *                            split; 3 always split.  1-3 are bit-identical, 0 agrees to rounding  (1)
  *   ce_device       0 / 1    rat_ce_solve keeps the CE loop on the device: draw / update kernels, one host wait per solve!        (1)
+ *   pets_device     0 / 1    rat_pets_solve keeps the CE loop over control sequences on the device (one host wait per solve!)      (1)
  *   psweep          0, 2..8  the batched sweep operators (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch) run the TIME-PARALLEL sweep:
  *                            that many wavefronts per trajectory over that many + 1 horizon segments (csrc/psweep.h); results agree with the
  *                            sequential sweep to rounding (not bit for bit)                                                        (0)

@@ -20,3 +20,9 @@ struct CeDev {                  // mirrors rat_ce_solver (include/ratilqr.h) + t
 
 // one launch between two batches: update on the finished batch (do_update), draw of the next one (do_draw)
 void launch_ce_step(CeDev *s, const double *z, long long z_avail, double *theta, const double *cost, int do_update, int do_draw, hipStream_t st);
+
+// PETS step! bookkeeping on the device (ce_device.hip): control sequences from (mu_t, Sigma_t) and the elite / smoothed update
+#define PETS_DEV_MAX_S 1024     /* one workgroup sorts the sample costs */
+// one launch between two rollout launches: elites + smoothed update on the finished rollouts (do_update), the next control sequences (do_sample)
+void launch_pets_step(double *mu, double *Sigma, double *controls, const double *cost, long S, int ne, int N, int m, double sf, const double *zc,
+                      unsigned long long seed, int it, int do_update, int do_sample, int *err, hipStream_t st);

@@ -12,6 +12,7 @@
 #include <math.h>
 
 #include "ce_device.h"
+#include "rat_normal.h"
 
 #define CE_T 1024
 
@@ -223,4 +224,154 @@ __global__ __launch_bounds__(CE_T) void ce_step_kernel(CeDev *sg, const double *
 
 void launch_ce_step(CeDev *s, const double *z, long long z_avail, double *theta, const double *cost, int do_update, int do_draw, hipStream_t st) {
     hipLaunchKernelGGL(ce_step_kernel, dim3(1), dim3(CE_T), 0, st, s, z, z_avail, theta, cost, do_update, do_draw);
+}
+
+
+// =====================================================================================================================================
+// PETS (CrossEntropyDirectOptimizationSolver, pets.jl:159-245): the bookkeeping of step! on the device, so that solve! (:270-281) is ONE
+// enqueue chain  [sample control sequences -> rollouts -> elites + smoothed update] x iter_max -> one copy back, one host wait.
+// The arithmetic is the host code's (driver.cpp rat_pets_sample_controls / rat_pets_update) operation for operation, no contraction:
+// mu and Sigma come out bit-identical to the host loop on an injected stream of control normals (tests/test_gpu_pets.py).
+// =====================================================================================================================================
+// Philox4x32-10 (as in kernels.hip) for control normals drawn on the device (zc == nullptr)
+__device__ __forceinline__ void pd_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double pd_u01(unsigned hi, unsigned lo) { return (double)((((unsigned long long)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0); }
+
+// ONE bookkeeping launch between two rollout launches (one workgroup of 1024 threads; the sort runs over CT slots, CT = the power of two
+// >= S, at least 64 -- a batch of 100 control samples needs 28 of the 55 stages of the 1024-slot network, one of them through LDS):
+//   do_update: get_elite_samples + compute_new_distribution (pets.jl:159-191) on the sample costs of the finished rollouts -- elites by the
+//              bitonic network of ce_update under (isless(cost), index), over CT slots only; then a thread per (t, a): mean and unbiased
+//              variance over the elites in sorted order, smoothed update of mu_t and of the diagonal covariance;
+//   do_sample: the next iteration's control sequences, controls[ii][t][0..3] = mu_t + chol(Sigma_t) z  (rand(rng, MvNormal(mu_t, Sigma_t)),
+//              :206-216), padded to four controls: the N covariances are factorised by a thread per time step (m <= 4), then (ii, t) pairs
+//              in strides of CT.  zc: injected standard normals [S][N][m] of that iteration, or nullptr: Philox keyed by (seed, iteration).
+template <int CT>
+__global__ __launch_bounds__(CE_T) void pets_step_kernel(double *__restrict__ mu, double *__restrict__ Sigma, double *__restrict__ controls,
+                                                       const double *__restrict__ cost, long S, int ne, int N, int m, double sf,
+                                                       const double *__restrict__ zc, unsigned long long seed, int it, int do_update, int do_sample, int *err) {
+#pragma clang fp contract(off)
+    __shared__ unsigned long long k_sh[CT];
+    __shared__ int idx_sh[CT];
+    extern __shared__ double Lsh[];                          // [N][16]
+    const int tid = threadIdx.x;
+    if (do_update) {
+        const bool sorter = tid < CT;                        // (whole wavefronts: CT is a multiple of 64)
+        const double c = (tid < S) ? cost[tid] : NAN;        // (pad slots: NaN cost, index >= S: after every sample)
+        int id = tid;
+        unsigned long long key = elite_key(c);
+#pragma unroll
+        for (int k = 2; k <= CT; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                unsigned long long ok = key; int oi = id;
+                if (j >= 64) {
+                    __syncthreads();
+                    if (sorter) { k_sh[tid] = key; idx_sh[tid] = id; }
+                    __syncthreads();
+                    if (sorter) { ok = k_sh[tid ^ j]; oi = idx_sh[tid ^ j]; }
+                } else if (sorter) {
+                    ok = (unsigned long long)__shfl_xor((long long)key, j, 64); oi = __shfl_xor(id, j, 64);
+                }
+                const bool want_min = ((tid & j) == 0) == ((tid & k) == 0);
+                const bool mine_first = (key < ok) | ((key == ok) & (id < oi));
+                const bool take = sorter && (want_min != mine_first);
+                key = take ? ok : key;
+                id = take ? oi : id;
+            }
+        }
+        __syncthreads();
+        if (sorter) idx_sh[tid] = id;                        // position tid of the sorted sequence
+        __syncthreads();
+        for (int e_ = tid; e_ < N * m; e_ += CE_T) {
+            const int t = e_ / m, a = e_ - t * m;
+            // (the elites' loads are independent of the running sums: eight in flight at a time; the sums stay sequential, in sorted order)
+            double mean = 0.0;
+            for (int e0 = 0; e0 < ne; e0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = controls[((long)idx_sh[(e0 + q < ne) ? e0 + q : 0] * N + t) * 4 + a];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (e0 + q < ne) mean += v[q];
+            }
+            mean /= (double)ne;                                                    // :183
+            double var = 0.0;
+            for (int e0 = 0; e0 < ne; e0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = controls[((long)idx_sh[(e0 + q < ne) ? e0 + q : 0] * N + t) * 4 + a];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (e0 + q < ne) { const double d = v[q] - mean; var += d * d; }
+            }
+            var /= (double)(ne - 1);                                               // var = unbiased :184
+            mu[t * m + a] = (1.0 - sf) * mean + sf * mu[t * m + a];                 // :186
+            for (int b = 0; b < m; ++b) {                                          // Diagonal(var) :184, smoothing :187
+                double *Sg = &Sigma[(long)t * m * m + a + m * b];
+                *Sg = (1.0 - sf) * (a == b ? var : 0.0) + sf * *Sg;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();                                     // (the sampling below reads the mu / Sigma just written, and overwrites the controls)
+    }
+    if (!do_sample) return;
+    for (int t = tid; t < N; t += CE_T) {                    // host_chol_lower, column-major m x m
+        const double *A = Sigma + (long)t * m * m;
+        double *Lo = Lsh + t * 16;
+        for (int q = 0; q < 16; ++q) Lo[q] = 0.0;
+        bool ok = true;
+        for (int j = 0; j < m && ok; ++j) {
+            double d = A[j + m * j];
+            for (int k = 0; k < j; ++k) d -= Lo[j + m * k] * Lo[j + m * k];
+            if (!(d > 0.0)) { ok = false; break; }
+            Lo[j + m * j] = sqrt(d);
+            for (int i = j + 1; i < m; ++i) {
+                double v = A[i + m * j];
+                for (int k = 0; k < j; ++k) v -= Lo[i + m * k] * Lo[j + m * k];
+                Lo[i + m * j] = v / Lo[j + m * j];
+            }
+        }
+        if (!ok) atomicExch(err, 1);                         // Sigma_t is not positive definite (MvNormal would throw)
+    }
+    __syncthreads();
+    for (long e = tid; e < S * N; e += CE_T) {
+        const long ii = e / N;
+        const int t = (int)(e - ii * N);
+        double z[4] = {0.0, 0.0, 0.0, 0.0};
+        if (zc) {
+            for (int b = 0; b < m; ++b) z[b] = zc[(ii * N + t) * m + b];
+        } else {
+            unsigned r[4];
+            pd_philox((unsigned)ii, (unsigned)(ii >> 32), (unsigned)t, 0x50455453u, (unsigned)seed ^ 0xC0117201u, (unsigned)(seed >> 32) + (unsigned)it, r);
+            ratn_box_muller(pd_u01(r[0], r[1]), pd_u01(r[2], r[3]), &z[0], &z[1]);
+            if (m > 2) {
+                pd_philox((unsigned)ii, (unsigned)(ii >> 32), (unsigned)t, 0x50455454u, (unsigned)seed ^ 0xC0117201u, (unsigned)(seed >> 32) + (unsigned)it, r);
+                ratn_box_muller(pd_u01(r[0], r[1]), pd_u01(r[2], r[3]), &z[2], &z[3]);
+            }
+        }
+        const double *Lt = Lsh + t * 16;
+        double out[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int a = 0; a < m; ++a) {
+            double v = mu[t * m + a];
+            for (int b = 0; b <= a; ++b) v += Lt[a + m * b] * z[b];
+            out[a] = v;
+        }
+        double *c = controls + (ii * N + t) * 4;
+        c[0] = out[0]; c[1] = out[1]; c[2] = out[2]; c[3] = out[3];
+    }
+}
+
+void launch_pets_step(double *mu, double *Sigma, double *controls, const double *cost, long S, int ne, int N, int m, double sf, const double *zc,
+                      unsigned long long seed, int it, int do_update, int do_sample, int *err, hipStream_t st) {
+    const size_t lds = (size_t)N * 16 * sizeof(double);
+#define PSTEP(CT) hipLaunchKernelGGL((pets_step_kernel<CT>), dim3(1), dim3(CE_T), lds, st, mu, Sigma, controls, cost, S, ne, N, m, sf, zc, seed, it, do_update, do_sample, err)
+    if (S <= 64) PSTEP(64); else if (S <= 128) PSTEP(128); else if (S <= 256) PSTEP(256); else if (S <= 512) PSTEP(512); else PSTEP(1024);
+#undef PSTEP
 }

@@ -108,6 +108,10 @@ struct rat_handle_s {
     double *d_pin = nullptr, *d_pzn = nullptr, *d_pzu = nullptr, *d_ptraj = nullptr, *d_pcost = nullptr;   // d_pin: x0 | padded controls
     size_t cap_pin = 0, cap_zn = 0, cap_zu = 0, cap_traj = 0, cap_cost = 0;
     double *h_pstage = nullptr; size_t cap_pstage = 0;      // pinned staging of x0 | padded controls (pets_stage_kernel reads it over the link)
+    double *d_pmu = nullptr, *d_psig = nullptr; size_t cap_pmu = 0, cap_psig = 0;   // device-resident PETS loop: mu [N][m], Sigma [N][m*m]
+    int *d_perr = nullptr;                                  // ... its error word (a covariance that is not positive definite)
+    double *h_pzc = nullptr; size_t cap_pzc = 0;            // ... pinned: the injected control normals of a whole solve! | mu | Sigma | error word on the way back
+    bool pets_device = true;                                // switch pets_device
     double *h_pcost = nullptr; size_t cap_hpcost = 0;       // pinned landing zone of the sample costs of the synchronous call (zero-copy)
     // Nelder-Mead (rat_nm_solve): costs already evaluated for this (problem, x0, u0, kl_bound) by exact theta, and the thetas of the batch
     // that ran last (its per-sample state is still on the device: the final solve is read out of it)
@@ -183,6 +187,7 @@ static const DebugSwitch debug_switches[] = {
     {"nm_depth", [](rat_handle h, int64_t v) { h->nm_depth = (v < 0 || v > 3) ? 3 : (int)v; }, [](rat_handle h) -> int64_t { return h->nm_depth; }},
     {"pets_wave16", [](rat_handle h, int64_t v) { h->pets_wave16 = (v < 0 || v > 3) ? 1 : (int)v; }, [](rat_handle h) -> int64_t { return h->pets_wave16; }},
     {"ce_device", [](rat_handle h, int64_t v) { h->ce_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->ce_device; }},
+    {"pets_device", [](rat_handle h, int64_t v) { h->pets_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->pets_device; }},
     {"psweep", [](rat_handle h, int64_t v) { h->psweep = (v < 2 || v > PSW_MAXP) ? 0 : (int)v; }, [](rat_handle h) -> int64_t { return h->psweep; }},
     {"psw_hop", [](rat_handle h, int64_t v) { h->psw_hop = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop; }},
     {"psw_hop_e", [](rat_handle h, int64_t v) { h->psw_hop_e = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop_e; }},
@@ -265,7 +270,9 @@ extern "C" void rat_destroy(rat_handle h) {
     free_list(h->pb_allocs);
     free_list(h->st_allocs);
     free_list(h->gen_allocs);
-    for (double *q : {h->d_pin, h->d_pzn, h->d_pzu, h->d_ptraj, h->d_pcost}) if (q) (void)hipFree(q);
+    for (double *q : {h->d_pin, h->d_pzn, h->d_pzu, h->d_ptraj, h->d_pcost, h->d_pmu, h->d_psig}) if (q) (void)hipFree(q);
+    if (h->d_perr) (void)hipFree(h->d_perr);
+    if (h->h_pzc) (void)hipHostFree(h->h_pzc);
     if (h->h_pcost) (void)hipHostFree(h->h_pcost);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -2740,11 +2747,100 @@ extern "C" rat_rc rat_pets_step(rat_handle h, rat_pets_solver *s, const double *
     return RAT_OK;
 }
 
+// solve! with the Cross-Entropy loop over control sequences resident on the device (ce_device.hip: pets_sample_kernel / pets_update_kernel):
+//   [control sequences from (mu_t, Sigma_t) -> S x K stochastic rollouts + sample means -> elites, smoothed update] x iter_max
+// enqueued as ONE chain on the handle's stream; mu, Sigma and an error word come back through pinned memory behind ONE host wait.
+// Rollout noise comes from the device generator (seed + iteration, as the host loop keys it); the control normals are the injected
+// stream (read in place from pinned memory) or, zc == nullptr, drawn on the device.  Arithmetic = the host loop's: mu / Sigma bit for bit.
+static bool pets_device_usable(rat_handle h, const rat_pets_solver *s, const double *zn) {
+    return h->pets_device && !zn && s->num_control_samples >= 1 && s->num_control_samples <= PETS_DEV_MAX_S &&
+           s->m <= 4 && s->N <= 1024 && s->num_elite >= 2 && s->num_elite <= s->num_control_samples && s->iter_max >= 1;
+}
+static rat_rc pets_solve_device(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc, uint64_t seed) {
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->gn, m = h->gm, N = h->gN;
+    const int64_t S = s->num_control_samples, K = s->num_trajectory_samples, IT = s->iter_max;
+    const size_t ntraj = (size_t)S * K, nzc = (size_t)S * N * m, nmu = (size_t)N * m, nsg = (size_t)N * m * m;
+    rat_rc rc;
+    HIPCHK(hipStreamSynchronize(h->stream));                  // (a previous enqueue may still be reading the buffers)
+    if ((rc = grow(&h->d_pin, &h->cap_pin, XSTR + (size_t)S * N * USTR))) return rc;
+    if ((rc = grow(&h->d_ptraj, &h->cap_traj, ntraj))) return rc;
+    if ((rc = grow(&h->d_pcost, &h->cap_cost, (size_t)S))) return rc;
+    if ((rc = grow(&h->d_pmu, &h->cap_pmu, nmu))) return rc;
+    if ((rc = grow(&h->d_psig, &h->cap_psig, nsg))) return rc;
+    if (!h->d_perr) HIPCHK(hipMalloc((void **)&h->d_perr, sizeof(int)));
+    // pinned: [x0 (XSTR) | mu | Sigma | error word (as a double slot) | control normals of all iterations]
+    const size_t off_mu = XSTR, off_sg = off_mu + nmu, off_err = off_sg + nsg, off_zc = off_err + 2, need = off_zc + (zc ? nzc * (size_t)IT : 0);
+    if (need > h->cap_pzc) {
+        if (h->h_pzc) (void)hipHostFree(h->h_pzc);
+        h->h_pzc = nullptr; h->cap_pzc = 0;
+        HIPCHK(hipHostMalloc((void **)&h->h_pzc, need * sizeof(double), hipHostMallocDefault));
+        h->cap_pzc = need;
+    }
+    double *hp = h->h_pzc;
+    memset(hp, 0, XSTR * sizeof(double));
+    for (int i = 0; i < n; ++i) hp[i] = x0[i];
+    memcpy(hp + off_mu, s->mu, nmu * 8);
+    memcpy(hp + off_sg, s->Sigma, nsg * 8);
+    if (zc) memcpy(hp + off_zc, zc, nzc * (size_t)IT * 8);
+    const double *hp_dev = nullptr;
+    HIPCHK(hipHostGetDevicePointer((void **)&hp_dev, hp, 0));
+    HIPCHK(hipMemsetAsync(h->d_perr, 0, sizeof(int), h->stream));
+    const double *zc_dev = nullptr;
+    if (zc) {                                                                         // the injected control normals: pulled over the link by one parallel launch
+        if ((rc = grow(&h->d_pzu, &h->cap_zu, nzc * (size_t)IT))) return rc;          // (the rollouts draw their noise on the device: d_pzu is free)
+        launch_pets_stage(hp_dev + off_zc, h->d_pzu, (long)(nzc * (size_t)IT), h->stream);
+        zc_dev = h->d_pzu;
+    }
+    launch_pets_stage(hp_dev, h->d_pin, (long)XSTR, h->stream);                       // x0
+    launch_pets_stage(hp_dev + off_mu, h->d_pmu, (long)nmu, h->stream);
+    launch_pets_stage(hp_dev + off_sg, h->d_psig, (long)nsg, h->stream);
+    PetsArgs a;
+    a.g = h->gen; a.x0 = h->d_pin; a.controls = h->d_pin + XSTR; a.S = S; a.K = K; a.use_true = use_true_model ? 1 : 0;
+    a.zn = nullptr; a.zu = nullptr; a.traj0 = 0; a.traj_cost = h->d_ptraj; a.cost = h->d_pcost; a.wave16 = h->pets_wave16;
+    // sample_1 | rollouts_1 | update_1 + sample_2 | rollouts_2 | ... | update_n : one bookkeeping launch between two rollout launches
+    double *const ctrl = h->d_pin + XSTR;
+    prof_begin(h, RAT_K_CE, S);
+    launch_pets_step(h->d_pmu, h->d_psig, ctrl, h->d_pcost, (long)S, (int)s->num_elite, N, m, s->smoothing_factor, zc_dev, seed, 0, 0, 1,
+                     h->d_perr, h->stream);
+    prof_end(h);
+    for (int64_t it = 0; it < IT; ++it) {
+        a.seed = seed + (uint64_t)it;
+        prof_begin(h, RAT_K_PETS, (int64_t)ntraj);
+        launch_pets(a, h->stream);
+        prof_end(h);
+        const int more = (it + 1 < IT) ? 1 : 0;
+        prof_begin(h, RAT_K_CE, S);
+        launch_pets_step(h->d_pmu, h->d_psig, ctrl, h->d_pcost, (long)S, (int)s->num_elite, N, m, s->smoothing_factor,
+                         (zc_dev && more) ? zc_dev + (size_t)(it + 1) * nzc : nullptr, seed, (int)(it + 1), 1, more, h->d_perr, h->stream);
+        prof_end(h);
+    }
+    HIPCHK(hipGetLastError());
+    // results back into the pinned area by the same pull kernel, the other way (device -> pinned host)
+    double *hp_w = nullptr;
+    HIPCHK(hipHostGetDevicePointer((void **)&hp_w, hp, 0));
+    launch_pets_stage(h->d_pmu, hp_w + off_mu, (long)nmu, h->stream);
+    launch_pets_stage(h->d_psig, hp_w + off_sg, (long)nsg, h->stream);
+    HIPCHK(hipMemcpyAsync(hp + off_err, h->d_perr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int err = 0;
+    memcpy(&err, hp + off_err, sizeof(int));
+    if (err) return fail(RAT_ERR_ARG, "Sigma_t is not positive definite (MvNormal would throw)");
+    memcpy(s->mu, hp + off_mu, nmu * 8);
+    memcpy(s->Sigma, hp + off_sg, nsg * 8);
+    s->iter_current = IT;
+    return RAT_OK;
+}
+
 extern "C" rat_rc rat_pets_solve(rat_handle h, rat_pets_solver *s, const double *x0, int32_t use_true_model, const double *zc,
                                  const double *zn, const double *zu, uint64_t seed) {   // pets.jl:270-281
-    if (!h || !s || !zc) return fail(RAT_ERR_ARG, "null");
+    if (!h || !s || !x0) return fail(RAT_ERR_ARG, "null");
     if (!h->have_gen) return fail(RAT_ERR_NO_PROBLEM, "rat_pets_problem_set was not called");
+    if (s->N != h->gN || s->m != h->gm) return fail(RAT_ERR_ARG, "solver N / m do not match the problem");
     rat_pets_initialize(s);
+    if (pets_device_usable(h, s, zn)) return pets_solve_device(h, s, x0, use_true_model, zc, seed);
+    if (!zc) return fail(RAT_ERR_UNSUPPORTED, "rat_pets_solve: control normals are drawn on the device only by the device-resident loop (switch pets_device, "
+                                              "no injected rollout noise, <= 1024 control samples)");
     const size_t nzc = (size_t)s->num_control_samples * s->N * s->m;
     const size_t ntraj = (size_t)s->num_control_samples * s->num_trajectory_samples;
     const size_t nzn = ntraj * s->N * h->gn, nzu = ntraj * s->N;

@@ -172,7 +172,16 @@ def step_(direct_solver, problem, x, rng, use_true_model=False, verbose=False, s
 
 
 def solve_(direct_solver, problem, x_0, rng, use_true_model=False, verbose=False, serial=True, seed=None):   # solve!  pets.jl:270-281
-    """Returns (mu_array, Sigma_array)."""
+    """Returns (mu_array, Sigma_array).  With a `seed` (rollout noise from the device generator) the whole loop is one library call
+    (rat_pets_solve: sampling, rollouts, elites and the smoothed update stay on the device, one host wait); the control normals are the
+    ones step_ would draw from `rng`, iteration after iteration.  rng = None: they are drawn on the device as well."""
+    if seed is not None:
+        ctx = direct_solver.context(problem)
+        c = direct_solver.c
+        S, N, m = int(c.num_control_samples), direct_solver.N, direct_solver.m
+        zc = None if rng is None else nv.f64(rng.standard_normal(int(c.iter_max) * S * N * m))
+        nv.check(nv.lib().rat_pets_solve(ctx.h, C.byref(c), nv.P(nv.f64(x_0)), int(use_true_model), nv.P(zc), None, None, C.c_uint64(int(seed))))
+        return direct_solver.mu_array, direct_solver.Sigma_array
     initialize_(direct_solver)
     while direct_solver.c.iter_current < direct_solver.c.iter_max:
         step_(direct_solver, problem, x_0, rng, use_true_model, verbose, serial,

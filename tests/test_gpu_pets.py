@@ -215,3 +215,50 @@ def test_config5_ten_thousand_trajectories():
     dev2 = pets.compute_cost_serial(ds, prob, x0, ctrl, None, False, seed=11)
     assert np.all(np.isfinite(dev)) and np.array_equal(dev, dev2)
     assert np.median(np.abs(dev - got) / np.abs(got)) < 0.05          # two independent K = 100 estimates of the same means
+
+
+@pytest.mark.parametrize("S,K,Nh,n,m,ne,use_true", [(100, 100, 30, 12, 4, 10, False), (16, 20, 15, 6, 2, 4, False), (37, 33, 30, 12, 4, 5, True),
+                                                     (1024, 4, 9, 12, 3, 100, False), (2, 7, 30, 12, 4, 2, False)])
+def test_device_resident_solve_equals_the_host_loop(S, K, Nh, n, m, ne, use_true):
+    """rat_pets_solve with the loop over control sequences on the device (ce_device.hip: pets_sample_kernel / pets_update_kernel, ONE host
+    wait per solve!) against the same call with the switch pets_device = 0 (sample / update on the host between device calls,
+    pets.jl:159-245): mu and Sigma bit for bit on an injected stream of control normals, rollout noise from the device generator."""
+    prob, r = rich_problem(n=n, m=m, Nh=Nh, kappa=0.0)
+    mu0 = 0.05 * r.standard_normal((Nh, m))
+    Sig0 = np.stack([0.3 * np.eye(m) + 0.05 * np.ones((m, m))] * Nh)
+    x0 = r.standard_normal(n)
+    kw = dict(num_control_samples=S, num_trajectory_samples=K, num_elite=ne, iter_max=4, smoothing_factor=0.15)
+    out = []
+    for dev in (1, 0):
+        ds = rat.CrossEntropyDirectOptimizationSolver(mu0, Sig0, **kw)
+        ctx = ds.context(prob)
+        ctx.debug_set("pets_device", dev)
+        ctx.profile(True); ctx.profile_reset()
+        mu, Sig = pets.solve_(ds, prob, x0, np.random.default_rng(5), use_true_model=use_true, seed=1234)
+        kinds = {k: v["launches"] for k, v in ctx.profile_get().items() if v["launches"]}
+        ctx.profile(False)
+        assert ds.iter_current == 4
+        out.append((mu.copy(), Sig.copy(), kinds))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][2].get("ce_bookkeeping") == 5 and "ce_bookkeeping" not in out[1][2]          # sample | (update + sample) x 3 | update: on the device
+    assert np.all(np.isfinite(out[0][0])) and not np.array_equal(out[0][0], mu0)
+
+
+def test_device_resident_solve_draws_its_own_control_normals_and_reports_a_bad_covariance():
+    prob, r = rich_problem(kappa=0.0)
+    Nh, m = 30, 4
+    mu0, Sig0 = np.zeros((Nh, m)), np.stack([0.25 * np.eye(m)] * Nh)
+    x0 = r.standard_normal(12)
+    ds = rat.CrossEntropyDirectOptimizationSolver(mu0, Sig0, num_control_samples=64, num_trajectory_samples=32, num_elite=8, iter_max=3)
+    mu_a, Sig_a = pets.solve_(ds, prob, x0, None, seed=7)                   # rng = None: Philox on the device for the control normals too
+    mu_a, Sig_a = mu_a.copy(), Sig_a.copy()
+    mu_b, Sig_b = pets.solve_(ds, prob, x0, None, seed=7)
+    assert np.array_equal(mu_a, mu_b) and np.array_equal(Sig_a, Sig_b) and np.all(np.isfinite(mu_a))          # a seed names the draws
+    mu_c, _ = pets.solve_(ds, prob, x0, None, seed=8)
+    assert not np.array_equal(mu_a, mu_c)
+    dg = np.diagonal(Sig_a, axis1=1, axis2=2)
+    assert np.all(dg > 0) and np.all(np.isfinite(dg)) and np.count_nonzero(Sig_a) == dg.size               # Diagonal(var) + smoothing: stays diagonal
+    bad = Sig0.copy(); bad[3] = -np.eye(m)
+    ds_bad = rat.CrossEntropyDirectOptimizationSolver(mu0, bad, num_control_samples=8, num_trajectory_samples=4, num_elite=2, iter_max=2)
+    with pytest.raises(rat.RatError):
+        pets.solve_(ds_bad, prob, x0, np.random.default_rng(1), seed=3)
