@@ -432,6 +432,10 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *                            split; 3 always split.  1-3 are bit-identical, 0 agrees to rounding  (1)
  *   ce_device       0 / 1    rat_ce_solve keeps the CE loop on the device: draw / update kernels, one host wait per solve!        (1)
  *   pets_device     0 / 1    rat_pets_solve keeps the CE loop over control sequences on the device (one host wait per solve!)      (1)
+ *   block_psw       0 / 1    E = 1 batches of at most one sample per compute unit (LQ family): the workgroup-per-sample solve with every Riccati
+ *                            sweep TIME-PARALLEL over the sample's four SIMDs (solve_block_psw_kernel, csrc/psweep.h); status / iteration /
+ *                            line-search counts as on every other path, values equal to rounding (~1e-15), not bit for bit          (1)
+ *   psw_acl         0 / 1    ... its closed-loop rollouts in deviation form (3 MFMAs on the recursion's chain)                      (1)
  *   psweep          0, 2..8  the batched sweep operators (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch) run the TIME-PARALLEL sweep:
  *                            that many wavefronts per trajectory over that many + 1 horizon segments (csrc/psweep.h); results agree with the
  *                            sequential sweep to rounding (not bit for bit)                                                        (0)

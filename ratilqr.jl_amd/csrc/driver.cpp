@@ -120,6 +120,7 @@ struct rat_handle_s {
     uint64_t nm_key = 0, problem_serial = 0;      // what the table was filled for: hash of (problem generation, options generation, x0, u0, kl_bound)
     int psweep = 0;                               // > 2: the batched sweep operators run the segment-parallel kernel with this many waves per trajectory
     int psw_hop = 120, psw_hop_e = 140, psw_comp = 125;   // its cost model (x 100, in ordinary steps): one hop (gain sweep / evaluation), one element step -- places the cuts
+    bool psw_acl = true;                          // ... with its closed-loop rollouts in deviation form (rollacl_body: what block_acl is to solve_block_kernel)
     bool block_psw = true;                        // the workgroup-per-sample solve with time-parallel sweeps for batches of <= one sample per CU (solve_block_psw_kernel)
     uint64_t opts_serial = 0;                     // bumped by everything that can change what a solve returns without a new problem: rat_set_ileqg_opts,
                                                   // rat_debug_set, rat_set_path (the reference builds a fresh ILEQGSolver from the current options per evaluation)
@@ -192,6 +193,7 @@ static const DebugSwitch debug_switches[] = {
     {"psw_hop", [](rat_handle h, int64_t v) { h->psw_hop = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop; }},
     {"psw_hop_e", [](rat_handle h, int64_t v) { h->psw_hop_e = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop_e; }},
     {"block_psw", [](rat_handle h, int64_t v) { h->block_psw = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_psw; }},
+    {"psw_acl", [](rat_handle h, int64_t v) { h->psw_acl = (v != 0); }, [](rat_handle h) -> int64_t { return h->psw_acl; }},
     {"psw_comp", [](rat_handle h, int64_t v) { h->psw_comp = (int)std::max<int64_t>(100, v); }, [](rat_handle h) -> int64_t { return h->psw_comp; }},
 };
 // what the requests amount to on this handle (speculation width, forced pairings)
@@ -924,8 +926,9 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.helpers = (fa.census && B <= h->n_cu && h->block_helpers) ? 1 : 0;
         fa.acl = h->block_acl ? 1 : 0;
         // one sample per compute unit, LQ family: the same solve with every sweep time-parallel over the sample's four SIMDs (psweep.h)
-        const bool psw = path == PATH_BLOCK && h->block_psw && fa.helpers && !fa.acl && !h->materialize && solve_block_psw_supported(fa);
+        const bool psw = path == PATH_BLOCK && h->block_psw && fa.helpers && !h->materialize && solve_block_psw_supported(fa);
         if (psw) {
+            fa.acl = (h->psw_acl || h->block_acl) ? 1 : 0;       // (this kernel's values agree with the sequential paths to rounding anyway)
             fa.psw2e = psweep_cuts(st.N, 2, h->psw_hop_e / 100.0, h->psw_comp / 100.0);
             fa.psw2g = psweep_cuts(st.N, 2, h->psw_hop / 100.0, h->psw_comp / 100.0);
             fa.psw4e = psweep_cuts(st.N, 4, h->psw_hop_e / 100.0, h->psw_comp / 100.0);

@@ -2642,12 +2642,13 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     __shared__ double shxu_all[4][16];
     __shared__ double stg[STG_DOUBLES];
     __shared__ double xu[XU_DOUBLES];
-    __shared__ int prog;
+    __shared__ double aclring[ACL_DOUBLES];
+    __shared__ int prog, pprog, lpool;
     __shared__ unsigned long long d_acc[2];
     __shared__ PswShared psh[3];                 // [0] the evaluation team, [1] the gain team, [2] the four-wave team (a team's barrier counter
                                                  // stays a multiple of ITS size)
     int epoch = 0;
-    if (threadIdx.x == 0) prog = 0;
+    if (threadIdx.x == 0) { prog = 0; pprog = 0; }
     if (threadIdx.x < 3 * PSW_MAXP) psh[threadIdx.x / PSW_MAXP].flag[threadIdx.x % PSW_MAXP] = 0;
     if (threadIdx.x < 3) { psh[threadIdx.x].bar = 0; psh[threadIdx.x].last_rc = 0; }
     double *const wls = wls_all[wave], *const shxu = shxu_all[wave];
@@ -2699,15 +2700,33 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     BPSW_MARK();
             continue;
         }
-        {                                                    // the candidate of this line-search round  (ileqg.jl:504-521)
+        if (fa.acl) {                                        // the candidate of this line-search round in deviation form (rollacl_body; switch block_acl)
+            RolloutArgs ra = fa.ro; ra.mode = 1;
+            int nom_, lsel_;
+            double eps_;
+            const bool act = rollout_active<1>(st, b, nom_, lsel_, eps_);       // (every wave reads the same words)
+            if (act) {
+                if (leader) { d_acc[0] = 0ull; d_acc[1] = 0ull; lpool = 0; }
+                stage_shared<4>(ra, b, nom_, lsel_, stg, wave);
+            }
+            BPSW_MARK();
+            __syncthreads();
+            BPSW_MARK();
+            if (act) {
+                if (wave == 0) rollacl_body(ra, eps_, stg, aclring, xu, &pprog, &prog, epoch);
+                else if (wave == 1) rollprod_body(ra, stg, aclring, &pprog, &prog, epoch);
+                rolllin_body<1, CTV, true, true, true>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc, stg, eps_, &lpool, wave == 0 ? 1 : 0);
+            }
+            epoch += st.N + 2;
+        } else {                                             // the candidate of this line-search round  (ileqg.jl:504-521)
             RolloutArgs ra = fa.ro; ra.mode = 1;
             if (wave == 0) rollrec_body<1, true>(ra, b, stg, xu, &prog, epoch, d_acc);
             else rolllin_body<1, CTV, true, true>(ra, b, shxu, xu, &prog, epoch, wave - 1, 3, d_acc);
             epoch += st.N + 2;
         }
         BPSW_MARK();
-    __syncthreads();
-    BPSW_MARK();
+        __syncthreads();
+        BPSW_MARK();
         if (threadIdx.x == 64) {                             // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
             st.d_c[b] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
             st.flag_c[b] = 0;
