@@ -53,6 +53,8 @@ for seed in range(S0, S0 + NS):
             lo_, hi_ = grid[badi[0] - 1], grid[badi[0]]
             theta = np.concatenate([[0.0], np.linspace(lo_, hi_, 23)])
     E = int(rng.choice([1, 1, 2, 3, 4, 8, 11]))       # 1, 2, 4, 8: solve_block_kernel (default path for small batches); 3, 11: round-based path
+    if os.environ.get('SOAK_E'):                      # SOAK_E=1: every problem on the E = 1 default path (small batches: the time-parallel sweeps of
+        E = int(os.environ['SOAK_E'])                 # solve_block_psw_kernel)
     kw = {}
     if rng.integers(0, 2):
         kw = dict(lam=float(rng.uniform(0.3, 0.7)), iter_max=int(rng.integers(3, 40)), adaptive_eps_init=int(rng.integers(0, 2)))
@@ -60,7 +62,7 @@ for seed in range(S0, S0 + NS):
     gkw = dict(kw)
     if "adaptive_eps_init" in gkw: gkw["adaptive_eps_init"] = bool(gkw["adaptive_eps_init"])
     ctx = rat.Context(prob, rat.ileqg.make_opts(**gkw), max_batch=theta.size, spec_eps=E)
-    if os.environ.get('SOAK_WIDE') != '1' and seed % 2 == 1:
+    if os.environ.get('SOAK_WIDE') != '1' and seed % 2 == 1 and not os.environ.get('SOAK_E'):
         ctx.set_path("rounds")                 # E > 1: candidates without tile records (fly sweeps, all candidates of a sample in one rollout wave)
     vg, sg, ig, lg = ctx.solve_batch(x0, u, theta)
     fin = np.isfinite(vo)

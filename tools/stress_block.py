@@ -1,6 +1,9 @@
 """Race hunt for solve_block_kernel (waves of a workgroup hand data to each other through LDS: the trajectory buffer and progress word
 of the split rollouts, the helper waves' d_current reduction, the per-CU placement tickets): random batch sizes, thetas and problems,
 thousands of launches, every output compared bit for bit with solve_fused_kernel (one wave per sample: no intra-sample concurrency).
+STRESS_PSW=1: the same hunt for solve_block_psw_kernel (time-parallel sweeps: boundary values, flags and team barriers through LDS between the
+four waves of a sample) -- batches of at most one sample per CU, statuses / iteration / line-search counts equal, values to 1e-10 (a
+race shows as a wrong value or a hang, not as a rounding difference).
   STRESS_S=60 python tools/stress_block.py      (on an MI355X)"""
 import os
 import sys
@@ -30,10 +33,11 @@ def main():
         N = int(rng.choice([50, 50, 50, 7, 23, 52, 53, 60]))
         n, m = (12, 4) if rng.random() < 0.6 else (int(rng.integers(1, 13)), int(rng.integers(1, 5)))
         prob, x0, u = rat.synthetic_lq_problem(n=n, m=m, N=N, seed=int(rng.integers(0, 50)), kappa=kappa)
-        Bmax = int(rng.choice([1, 3, 17, 64, 128, 200, 256, 257, 400, 512, 700]))
-        E = int(rng.choice([1, 1, 1, 2, 4, 8]))
+        psw = os.environ.get("STRESS_PSW") == "1"
+        Bmax = int(rng.choice([1, 3, 17, 64, 128, 200, 256] if psw else [1, 3, 17, 64, 128, 200, 256, 257, 400, 512, 700]))
+        E = 1 if psw else int(rng.choice([1, 1, 1, 2, 4, 8]))
         ref = ctx_for(prob, Bmax, 1, {"RATILQR_BLOCK": "0"})
-        blk = ctx_for(prob, Bmax, E, {"RATILQR_BLOCK": "1"})
+        blk = ctx_for(prob, Bmax, E, {"RATILQR_BLOCK": "1", "RATILQR_BLOCK_PSW": "1" if psw else "0"})
         for _ in range(int(rng.integers(3, 12))):
             B = int(rng.integers(1, Bmax + 1))
             theta = np.abs(rng.normal(1.0, 2.0, B)) * float(rng.choice([0.05, 1.0, 1.0, 3.0]))
@@ -42,9 +46,28 @@ def main():
             a = ref.solve_batch(x0, u, theta)
             b = blk.solve_batch(x0, u, theta)
             launches += 1
-            if not all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a, b)):
+            if psw:
+                # (not compared: samples that run into iter_max -- chaotic cubic-drift iterations amplify one ulp into another path, as in
+                #  every soak since round 1; values at 0 < theta < 1e-4 to 1e-6 only: -1/(2 theta) logdet(W M) is a difference of O(1)
+                #  numbers divided by theta on every path, the reference's included)
+                keep = a[2] < 100
+                fin = np.isfinite(a[0]) & keep
+                tol = np.where((theta > 0) & (theta < 1e-4), 1e-6, 1e-10)
+                same = all(np.array_equal(p[keep], q[keep]) for p, q in zip(a[1:], b[1:])) and np.array_equal(fin, np.isfinite(b[0]) & keep) and \
+                    (not fin.any() or np.all(np.abs(b[0][fin] - a[0][fin]) <= tol[fin] * np.abs(a[0][fin])))
+            else:
+                same = all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a, b))
+            if not same:
                 bad += 1
                 print("MISMATCH", dict(n=n, m=m, N=N, kappa=kappa, Bmax=Bmax, B=B, E=E), flush=True)
+                if psw:                                  # what differs, and whether the same launch repeats it (a race would not)
+                    b2 = blk.solve_batch(x0, u, theta)
+                    rep = all(np.array_equal(p, q, equal_nan=True) for p, q in zip(b, b2))
+                    idx = [i for i in range(B) if a[2][i] < 100 and any(p[i] != q[i] for p, q in zip(a[1:], b[1:])) or
+                           (np.isfinite(a[0][i]) != np.isfinite(b[0][i])) or (np.isfinite(a[0][i]) and abs(b[0][i] - a[0][i]) > 1e-10 * abs(a[0][i]))]
+                    for i in idx[:4]:
+                        print("   sample", i, "theta", repr(float(theta[i])), "fused (value, status, iters, ls)", [float(x[i]) for x in a],
+                              "psw", [float(x[i]) for x in b], "repeatable", rep, flush=True)
     print(f"stress done: {launches} block-kernel launches compared with the fused kernel, {bad} mismatches, {time.time() - t0:.0f} s")
 
 

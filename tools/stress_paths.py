@@ -64,7 +64,7 @@ def main():
         # speculation widths too: the default path (block kernel within one generation of workgroups, beyond it rounds whose candidates
         # carry no tile records and roll out in one wavefront per sample) against rounds with materialised tiles and one wave per candidate
         E = int(rng.choice([1, 1, 1, 2, 4, 8, 3])) if B <= 1024 else 1
-        dflt, ref = ctx_for(prob, B, {}, E), ctx_for(prob, B, {"RATILQR_FUSED": "0", "RATILQR_FLY": "0"}, E)
+        dflt, ref = ctx_for(prob, B, {"RATILQR_BLOCK_PSW": "0"}, E), ctx_for(prob, B, {"RATILQR_FUSED": "0", "RATILQR_FLY": "0"}, E)   # (bit-identity: the sequential-sweep paths)
         dflt.profile(True)
         a, b = dflt.solve_batch(x0, u, theta), ref.solve_batch(x0, u, theta)
         for k, p in dflt.profile_get().items():
