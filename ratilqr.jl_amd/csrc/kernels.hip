@@ -2663,20 +2663,21 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
 #define BPSW_MARK() do {} while (0)
 #endif
     if (leader) init_state_body(st, fa.sw.op, fa.theta_in, b);
-    BPSW_MARK();
-    __syncthreads();
-    BPSW_MARK();
-    if (fa.init_x) {                             // initialize!'s rollout was run once for the whole batch (FusedArgs.init_*)
-        if (wave == 0) copy_initial(st, fa.init_x, fa.init_u, fa.init_t, b);
-    } else {                                     // initialize!: open-loop rollout (wave 0) + linearise (the other waves)   (ileqg.jl:214-233)
-        RolloutArgs ra = fa.ro; ra.mode = 0;
-        if (wave == 0) rollrec_body<0, true>(ra, b, stg, xu, &prog, epoch, d_acc);
-        else rolllin_body<0, CTV, true, true>(ra, b, shxu, xu, &prog, epoch, wave - 1, 3, d_acc);
-        epoch += st.N + 2;
+    if (fa.init_x) {                             // initialize!'s rollout was run once for the whole batch (FusedArgs.init_*): copied by another
+        if (wave == 1) copy_initial(st, fa.init_x, fa.init_u, fa.init_t, b);          // wave while the leader writes the sample's control words
     }
     BPSW_MARK();
     __syncthreads();
     BPSW_MARK();
+    if (!fa.init_x) {                            // initialize!: open-loop rollout (wave 0) + linearise (the other waves)   (ileqg.jl:214-233)
+        RolloutArgs ra = fa.ro; ra.mode = 0;
+        if (wave == 0) rollrec_body<0, true>(ra, b, stg, xu, &prog, epoch, d_acc);
+        else rolllin_body<0, CTV, true, true>(ra, b, shxu, xu, &prog, epoch, wave - 1, 3, d_acc);
+        epoch += st.N + 2;
+        BPSW_MARK();
+        __syncthreads();
+        BPSW_MARK();
+    }
     {                                            // open-loop policy evaluation (:234) || the first step!'s gain sweep on the same trajectory
         SweepArgs sa = fa.sw;
         if (team == 0) { sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
@@ -2727,16 +2728,13 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         BPSW_MARK();
         __syncthreads();
         BPSW_MARK();
-        if (threadIdx.x == 64) {                             // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
-            st.d_c[b] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
-            st.flag_c[b] = 0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        BPSW_MARK();
-    __syncthreads();
-    BPSW_MARK();
+        // d of the candidate, gathered by the linearise waves in LDS (d_acc): to where the accept rule reads it (ordered before select by the
+        // barrier behind the sweeps); every wave forms it for the test below
+        const unsigned long long da0 = d_acc[0], da1 = d_acc[1];
+        const double v_dc = da1 ? NAN : sqrt(__longlong_as_double((long long)da0));
+        if (threadIdx.x == 64) { st.d_c[b] = v_dc; st.flag_c[b] = 0; }
         // would accepting this candidate end solve! (:642-653)?  Then nothing consumes a speculative gain sweep: all four waves evaluate.
-        const double v_dc = *(const volatile double *)&st.d_c[b], v_mu = *(const volatile double *)&st.mu[b];
+        const double v_mu = *(const volatile double *)&st.mu[b];
         const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
         const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
         const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
