@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-5 profiles on an MI355X (run through gpurun): kernel-trace stats, HBM traffic (separate --pmc passes, no trace domains in the
+# same run) and SQ counters of
+#   fused      B = 1024, E = 1  solve_fused_kernel: the headline
+#   block128   B = 128,  E = 1  solve_block_psw_kernel (time-parallel sweeps): the per-GPU shard of the headline at 8 GPUs
+#   block256   B = 256,  E = 1  solve_block_psw_kernel: the shard at 4 GPUs
+#   seq128     B = 128,  E = 1  solve_block_kernel (switch block_psw = 0): the same shard with sequential sweeps
+#   e8_1024    B = 1024, E = 8  round-based path without candidate tiles: BASELINE config 3 on one GPU (rollin_multi_kernel, fly sweeps)
+#   e8_128     B = 128,  E = 8  solve_block_kernel: config 3's shard at 8 GPUs
+#   fused_4096 B = 4096, E = 1  the paired kernel in four generations
+#   contract   B = 1024, E = 1  the headline kernel with tile records materialised and no shared initialize! (SURVEY 8d to the letter)
+#   block512   B = 512,  E = 1  solve_block_kernel: the per-GPU shard at 2 GPUs
+# Outputs under gpurun_out/r05/prof/; summarised into profiles/ by tools/profile_report.py r05.   usage: profile_r05.sh [config ...]
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05/prof; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+cd $R
+B="--steps 10 --warmup 2 --no-cpu --no-second --condition-seconds 0.05"
+run() {  # name, bench args
+  local name=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_$name -o runc --output-format csv -- python3 bench.py $B "$@" > $O/bench_${name}_under_rocprof.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch_$name -o runc --output-format csv -- python3 bench.py $B "$@" > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/write_$name -o runc --output-format csv -- python3 bench.py $B "$@" > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU -d $O/sq1_$name -o runc --output-format csv -- python3 bench.py $B "$@" > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $O/sq2_$name -o runc --output-format csv -- python3 bench.py $B "$@" > /dev/null 2>&1
+}
+want() { [ $# -eq 0 ] && return 0; for c in "$@"; do [ "$c" = "$CUR" ] && return 0; done; return 1; }
+CUR=fused;     want "$@" && run fused --batch 1024
+CUR=contract;  want "$@" && run contract --batch 1024 --debug materialize=1 --debug init_share=0
+CUR=block512;  want "$@" && run block512 --batch 512
+CUR=block128;  want "$@" && run block128 --batch 128
+CUR=block256;  want "$@" && run block256 --batch 256
+CUR=seq128;    want "$@" && run seq128 --batch 128 --debug block_psw=0
+CUR=e8_1024;   want "$@" && run e8_1024 --batch 1024 --spec-eps 8
+CUR=e8_128;    want "$@" && run e8_128 --batch 128 --spec-eps 8
+CUR=fused_4096; want "$@" && run fused_4096 --batch 4096
+find $O -name "*.csv" | wc -l

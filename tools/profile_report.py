@@ -8,11 +8,12 @@ sys.path.insert(0, ROOT)
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 O = os.path.join(ROOT, "gpurun_out", RND, "prof")
-CFG = {"fused": (1, 1024), "contract": (1, 1024), "block128": (1, 128), "block512": (1, 512), "e8_1024": (8, 1024), "e8_128": (8, 128), "fused_4096": (1, 4096)}
+CFG = {"fused": (1, 1024), "contract": (1, 1024), "seq128": (1, 128), "block128": (1, 128), "block256": (1, 256), "block512": (1, 512),   # (seq128 before block128: the default kernel keeps the key) "e8_1024": (8, 1024), "e8_128": (8, 128),
+       "fused_4096": (1, 4096)}
 # kernel-name pattern -> the key bench.py uses (traffic_for(f"{kind}_E{E}_B{B}")); first match wins
-KINDS = [("solve_fused_kernel", "solve_fused"), ("solve_block_kernel", "solve_block"), ("sweep_dual_kernel", "sweep_dual"),
+KINDS = [("solve_fused_kernel", "solve_fused"), ("solve_block_psw_kernel", "solve_block"), ("solve_block_kernel", "solve_block"), ("sweep_dual_kernel", "sweep_dual"),
          ("rollin_multi_kernel", "rollout_multi"), ("rollin_stage_kernel", "rollout"), ("rollin_kernel", "rollout_init"),
          ("copy_initial_kernel", "copy_initial"),
          ("sweep_kernel<false", "sweep_eval"), ("sweep_kernel<true", "sweep_gain"), ("materialize_kernel", "materialize"),
@@ -49,7 +50,7 @@ def by_kind(per, counter, how=max):
 
 
 traffic = {"kernels_sha": bench.kernel_source_hash(), "round": RND, "sq": {}}
-md = [f"# {RND} rocprofv3 summaries (tools/profile_r04.sh; one MI355X, ROCm 7.2)\n",
+md = [f"# {RND} rocprofv3 summaries (tools/profile_{RND}.sh; one MI355X, ROCm 7.2)\n",
       "Commands: `rocprofv3 --kernel-trace --stats` / `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / two `--pmc SQ_*` passes (each its own run, no trace",
       "domains with counters) around `python3 bench.py --steps 10 --warmup 2 --no-cpu --no-second [--batch B] [--spec-eps E]`.\n",
       "## Kernel duration (kernel-trace stats) and HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE: gfx950 tallies 128-B read requests at 64 B)\n",
