@@ -163,7 +163,6 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     d4 kk = zero4, nsig = zero4, ub = zero4;      // the element: K, -Sigbar, Ubar
     double racc = 0.0, rprod = 1.0;
     int rexp = 0;
-    bool h_not_pd = false;
 
     // one backward step on the tile registers `cur`.  COMP: the step also prepends itself to the element (kk, nsig, ub).
     // returns 0, 1 (M not PD), 2 (H not PD)
@@ -511,7 +510,6 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
             if (wave == 0) sweep_body<GAIN, false, WM, HASL, 0, FLY>(a, tid, wls);
             return;
         }
-        h_not_pd = false;
         fail = any_fail ? 1 : 0;
         if (GAIN && !fail && any_h) {
             // increase_mu_and_delta!  (ileqg.jl:471-474), then the whole sweep again (:373-378); every wave keeps the same mu, delta
