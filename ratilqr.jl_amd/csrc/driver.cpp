@@ -934,6 +934,9 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
             fa.psw4e = psweep_cuts(st.N, 4, h->psw_hop_e / 100.0, h->psw_comp / 100.0);
             fa.psw4g = psweep_cuts(st.N, 4, h->psw_hop / 100.0, h->psw_comp / 100.0);
         }
+        // two waves per sample (up to two samples per CU): only the evaluation that ends the solve has an idle partner -- the two run it time-parallel
+        fa.psw_last = (!psw && path == PATH_BLOCK && h->block_psw && h->E == 1 && fa.census && !fa.helpers && !h->materialize && st.N >= 8) ? 1 : 0;
+        if (fa.psw_last) fa.psw2e = psweep_cuts(st.N, 2, h->psw_hop_e / 100.0, h->psw_comp / 100.0);
         prof_begin(h, path == PATH_BLOCK ? RAT_K_SOLVE_BLOCK : RAT_K_SOLVE_FUSED, B);
         if (psw) launch_solve_block_psw(fa, h->stream);
         else if (path == PATH_BLOCK) launch_solve_block(fa, h->stream); else launch_solve_fused(fa, h->stream);

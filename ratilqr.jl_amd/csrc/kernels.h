@@ -63,6 +63,7 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     // solve_block_psw_kernel only: segment cuts of its time-parallel sweeps -- two-wave teams (evaluation / gain sweep side by side) and the
     // four-wave team (a sweep that has the compute unit to itself)
     PswCuts psw2e, psw2g, psw4e, psw4g;
+    int psw_last;                      // solve_block_kernel, two-wave geometry: the evaluation that ends the solve by both waves, time-parallel (psw2e)
 };
 #define CENSUS_SLOTS 4096              /* (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID / HW_REG_XCC_ID: 4 + 3 + 1 + 4 bits */
 

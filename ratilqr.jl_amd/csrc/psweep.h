@@ -27,10 +27,11 @@
 
 // (PswCuts: kernels.h -- cut[0] = 0 < cut[1] < ... < cut[P] = N)
 
-struct PswShared {
-    double vbox[PSW_MAXP][256];            // vbox[s]: the true value at cut[s+1] (accumulator-layout image), written by wave s+1
-    double part[PSW_MAXP][4];              // per wave: 0.5 V[12][12], sum of racc, log term, -
-    int flag[PSW_MAXP];                    // flag[s] = epoch of the attempt once vbox[s] is valid
+template <int MP>                          // MP: the largest team this area serves
+struct PswSharedT {
+    double vbox[MP][256];                  // vbox[s]: the true value at cut[s+1] (accumulator-layout image), written by wave s+1
+    double part[MP][4];                    // per wave: 0.5 V[12][12], sum of racc, log term, -
+    int flag[MP];                          // flag[s] = epoch of the attempt once vbox[s] is valid
     int bar;                               // team barrier: arrivals so far (a multiple of P between calls); zero before the first call
     int fail_def;                          // a definite M-not-PD (the ordinary step on true values)
     int uncertain;                         // the element form could not decide: sequential fallback
@@ -38,6 +39,7 @@ struct PswShared {
     int last_rc;                           // (attempt << 2) | what ended the LAST segment's recursion early (1 M not PD, 2 H not PD): definite,
                                            // the sequential sweep meets it first; the other waves skip the rest of the attempt
 };
+using PswShared = PswSharedT<PSW_MAXP>;
 
 __device__ __forceinline__ void psw_spin(int *const word, const int want) {
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - want < 0) __builtin_amdgcn_s_sleep(1);
@@ -59,8 +61,8 @@ __device__ __forceinline__ double rows_sum4(double x) {
 #define PSW_MARK(slot_) do {} while (0)
 #endif
 
-template <bool GAIN, int WM, bool HASL, int FLY>
-__device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, double *const wls, PswShared *const sh, const PswCuts &pc, const int wave) {
+template <bool GAIN, int WM, bool HASL, int FLY, class SH>
+__device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, double *const wls, SH *const sh, const PswCuts &pc, const int wave) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));
     const int l_ = lane_, g_ = l_ >> 4, j_ = l_ & 15;

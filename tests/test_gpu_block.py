@@ -142,6 +142,8 @@ def test_block_geometries_are_bit_identical(monkeypatch):
 def test_block_kernel_default_policy_and_several_generations(monkeypatch):
     """E = 1: batches up to 512 samples run on the block kernel (two SIMDs per sample), larger ones on the fused kernel; forced, a batch
     larger than the chip runs its workgroups in several generations with unchanged results."""
+    monkeypatch.setenv("RATILQR_BLOCK_PSW", "0")               # bit-identity is a property of the sequential-sweep paths (the two-wave kernel runs the
+                                                               # evaluation that ends a solve time-parallel under block_psw: equal to rounding)
     prob, x0, u = rat.synthetic_lq_problem()
     theta = np.abs(1.0 + 2.0 * np.random.default_rng(9).standard_normal(2500))
     ctx = rat.Context(prob, max_batch=2500)

@@ -74,6 +74,28 @@ def test_general_noise_covariance_and_time_varying_cost():
     check(prob, x0, u, np.array([0.2, 1.0, 3.0, 5.0]))
 
 
+def test_time_varying_noise_covariance():
+    """W(k) time-varying: every step loads its own inv(W), W and pivots; the element step and the hop are the same formulas (sweep
+    operators).  The whole solve keeps the sequential-sweep kernel for such problems: same results whatever the switch says."""
+    rng = np.random.default_rng(12)
+    n, m, N = 9, 3, 41
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A, B, x0 = 0.85 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), rng.standard_normal(n)
+
+    def spd(k, scale):
+        G = rng.standard_normal((k, k))
+        return scale * (np.eye(k) + 0.2 * G @ G.T / k)
+
+    W = np.stack([spd(n, 1e-3 * (0.5 + rng.random())) for _ in range(N)])
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=spd(n, 1.0), R=spd(m, 0.2), N=N, W=W, Qf=spd(n, 1.0), kappa=0.02)
+    u = 0.1 * rng.standard_normal((N, m))
+    check(prob, x0, u, np.array([0.2, 1.0, 3.0, 8.0]))
+    (v0, s0, i0, l0), (v1, s1, i1, l1) = _solve_both(prob, x0, u, np.array([0.0, 0.5, 2.0, 6.0, 400.0]))
+    assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1)
+    fin = np.isfinite(v0)
+    assert np.array_equal(fin, np.isfinite(v1)) and rel(v1[fin], v0[fin]) < 1e-9
+
+
 def test_mu_regularisation_restarts():
     """Indefinite stage cost: H not PD in the ordinary pass -> increase_mu_and_delta!, the whole sweep again (ileqg.jl:372-378):
     the same mu / Delta as the sequential kernel and the oracle; an element whose own recursion meets H not PD falls back."""
@@ -147,3 +169,17 @@ def test_block_solve_with_time_parallel_sweeps_equals_the_block_solve_and_the_or
     vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=8, **({} if opts is None else dict(iter_max=6)))
     assert np.array_equal(so, s1) and np.array_equal(io, i1) and np.array_equal(lo, l1)
     assert rel(v1[fin], vo[fin]) < 1e-9
+
+
+def test_two_wave_kernel_runs_the_last_evaluation_time_parallel():
+    """257 ... 512 samples: two waves per sample (solve_block_kernel) -- the evaluation that ends the solve has the gain wave idle beside it
+    and the two run it as a two-wave team (switch block_psw): identical counts, values to rounding, against block_psw = 0 and the oracle."""
+    prob, x0, u = rat.synthetic_lq_problem(kappa=0.03)
+    rng = np.random.default_rng(21)
+    theta = np.abs(1.0 + 2.0 * rng.standard_normal(300)); theta[::41] = 0.0; theta[7] = 70.0
+    (v0, s0, i0, l0), (v1, s1, i1, l1) = _solve_both(prob, x0, u, theta)
+    assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1)
+    fin = np.isfinite(v0)
+    assert np.array_equal(fin, np.isfinite(v1)) and rel(v1[fin], v0[fin]) < 1e-10 and not np.array_equal(v0[fin], v1[fin])
+    vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=8)
+    assert np.array_equal(so, s1) and np.array_equal(io, i1) and np.array_equal(lo, l1) and rel(v1[fin], vo[fin]) < 1e-9

@@ -2,7 +2,7 @@
 of the split rollouts, the helper waves' d_current reduction, the per-CU placement tickets): random batch sizes, thetas and problems,
 thousands of launches, every output compared bit for bit with solve_fused_kernel (one wave per sample: no intra-sample concurrency).
 STRESS_PSW=1: the same hunt for solve_block_psw_kernel (time-parallel sweeps: boundary values, flags and team barriers through LDS between the
-four waves of a sample) -- batches of at most one sample per CU, statuses / iteration / line-search counts equal, values to 1e-10 (a
+four waves of a sample) and the two-wave kernel's time-parallel last evaluation (257 ... 512 samples) -- statuses / iteration / line-search counts equal, values to 1e-10 (a
 race shows as a wrong value or a hang, not as a rounding difference).
   STRESS_S=60 python tools/stress_block.py      (on an MI355X)"""
 import os
@@ -34,7 +34,7 @@ def main():
         n, m = (12, 4) if rng.random() < 0.6 else (int(rng.integers(1, 13)), int(rng.integers(1, 5)))
         prob, x0, u = rat.synthetic_lq_problem(n=n, m=m, N=N, seed=int(rng.integers(0, 50)), kappa=kappa)
         psw = os.environ.get("STRESS_PSW") == "1"
-        Bmax = int(rng.choice([1, 3, 17, 64, 128, 200, 256] if psw else [1, 3, 17, 64, 128, 200, 256, 257, 400, 512, 700]))
+        Bmax = int(rng.choice([1, 3, 17, 64, 128, 200, 256, 300, 400, 512] if psw else [1, 3, 17, 64, 128, 200, 256, 257, 400, 512, 700]))
         E = 1 if psw else int(rng.choice([1, 1, 1, 2, 4, 8]))
         ref = ctx_for(prob, Bmax, 1, {"RATILQR_BLOCK": "0"})
         blk = ctx_for(prob, Bmax, E, {"RATILQR_BLOCK": "1", "RATILQR_BLOCK_PSW": "1" if psw else "0"})
