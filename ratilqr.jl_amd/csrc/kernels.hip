@@ -2787,8 +2787,9 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
 #undef BPSW_MARK
 #if RAT_PART & PART_BPSW
 bool solve_block_psw_supported(const FusedArgs &fa) {
-    // (a time-varying W(k) runs solve_block_kernel: the whole solve with W_tv tables came out wrong in the candidates' evaluations -- every one
-    //  flagged failed -- while the sweep operators with W_tv pass their parity tests; not understood yet, so not enabled)
+    // (a time-varying W(k) runs solve_block_kernel.  Tried: with W_tv tables -- even constant ones -- the elements / hops of this kernel's
+    //  fly sweeps come out wrong (negative pivots in the ordinary pass behind a hop), while the sweep operators with W_tv on materialised
+    //  tiles pass their parity tests for 2 ... 8 waves; the instantiation <fly, W_tv> is not understood yet, so not enabled)
     return fa.sw.st.E == 1 && fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST && !fa.sw.pb.W_tv && fa.sw.st.N >= 8;
 }
 void launch_solve_block_psw(const FusedArgs &fa, hipStream_t s) {
