@@ -483,13 +483,15 @@ mutable struct CrossEntropyBilevelOptimizationSolver
     spec_eps::Int; devices::Vector{Int32}
     h::Union{Nothing,Handle,MultiHandle}
     z::Vector{Float64}                      # the N(0,1) stream currently registered with the handle (kept alive)
+    carrier::Any                            # closure problems: the carrier ILEQGSolver whose device handle runs the batched sweeps ...
+    carrier_key::Any                        # ... and the (n, m, N, batch, W identity) it was built for: one handle per solver, not one per compute_cost
 end
 function CrossEntropyBilevelOptimizationSolver(; μ_min_ileqg=1e-6, Δ_0_ileqg=2.0, λ_ileqg=0.5, d_ileqg=1e-2, iter_max_ileqg=100,
         adaptive_ϵ_init_ileqg=false, ϵ_init_ileqg=1.0, ϵ_min_ileqg=1e-6, μ_init=1.0, σ_init=2.0, num_samples=10, num_elite=3,
         iter_max=5, λ=0.5, f_returns_jacobian=false, use_θ_max=false, spec_eps=1, device=0, devices=[device])
     o = IleqgOpts(μ_min_ileqg, Δ_0_ileqg, λ_ileqg, d_ileqg, iter_max_ileqg, ϵ_init_ileqg, ϵ_min_ileqg, adaptive_ϵ_init_ileqg)
     c = CeState(num_samples, num_elite, iter_max, λ, use_θ_max, μ_init, σ_init, μ_init, σ_init, 0.0, Inf, 0, 0, 0, 0)
-    CrossEntropyBilevelOptimizationSolver(o, c, spec_eps, collect(Int32, devices), nothing, Float64[])
+    CrossEntropyBilevelOptimizationSolver(o, c, spec_eps, collect(Int32, devices), nothing, Float64[], nothing, nothing)
 end
 
 "The solver's device context for `problem`: created on first use, re-bound when the problem object changes (receding-horizon callers
@@ -1012,10 +1014,24 @@ function solve_closure_batch(o::IleqgOpts, problem, x_0::Vector{Float64}, u_arra
     [(status[b] == 0 || status[b] == 3) ? value[b] : Inf for b in 1:B], status, iters, ls_evals
 end
 
+"The carrier solver of a closure problem (its device handle: stream, events, pinned buffers, B-sample state), kept on the CE solver and
+rebuilt only when the sizes, the batch or the problem object change -- not once per compute_cost call (ADVICE r04)."
+function closure_carrier!(s::CrossEntropyBilevelOptimizationSolver, problem, n::Integer, m::Integer, B::Integer)
+    key = (n, m, problem.N, B, objectid(problem))
+    if s.carrier === nothing || s.carrier_key != key
+        o = s.opts
+        s.carrier = ILEQGSolver(carrier_problem(problem, n, m); μ_min=o.mu_min, Δ_0=o.delta_0, λ=o.lambda, d=o.d, iter_max=o.iter_max, ϵ_init=o.eps_init,
+                                ϵ_min=o.eps_min, adaptive_ϵ_init=o.adaptive_eps_init != 0, max_batch=B, device=s.devices[1])
+        s.carrier_key = key
+    end
+    s.carrier
+end
+
 "compute_cost (:173-195) of a closure problem: the B solves of the batch share their device sweeps"
 function compute_cost(s::CrossEntropyBilevelOptimizationSolver, problem, x::Vector{Float64}, u_array::Vector{Vector{Float64}},
                       θ_array::Vector{Float64}, kl_bound::Float64; f_returns_jacobian::Bool=false)
-    value, _, _, _ = solve_closure_batch(s.opts, problem, x, u_array, θ_array; f_returns_jacobian=f_returns_jacobian, device=s.devices[1])
+    cs = closure_carrier!(s, problem, length(x), length(u_array[1]), length(θ_array))
+    value, _, _, _ = solve_closure_batch(s.opts, problem, x, u_array, θ_array; f_returns_jacobian=f_returns_jacobian, device=s.devices[1], carrier=cs)
     value .+ kl_bound ./ θ_array                                                         # :193
 end
 
@@ -1048,13 +1064,23 @@ function solve!(s::CrossEntropyBilevelOptimizationSolver, problem, x_0::Vector{F
         end
         θ_opt = c.use_theta_max != 0 ? c.theta_max : c.mu                                # :375-382
     end
+    cs1 = closure_carrier!(s, problem, length(x_0), length(u_array[1]), max(1, Int(c.num_samples)))     # (a batch of one fits the batch's carrier)
     while true                                                                           # :390-414: final solve with the retry on failure
-        value, st, _, _ = solve_closure_batch(o, problem, x_0, u_array, [θ_opt]; f_returns_jacobian=f_returns_jacobian, device=s.devices[1])
+        value, st, _, _ = solve_closure_batch(o, problem, x_0, u_array, [θ_opt]; f_returns_jacobian=f_returns_jacobian, device=s.devices[1], carrier=cs1)
         if st[1] == 0 || st[1] == 3
             ref = R.ILEQGSolver(problem; μ_min=o.mu_min, Δ_0=o.delta_0, λ=o.lambda, d=o.d, iter_max=o.iter_max, ϵ_init=o.eps_init,
                                 adaptive_ϵ_init=o.adaptive_eps_init != 0, ϵ_min=o.eps_min, f_returns_jacobian=f_returns_jacobian)
-            xa, la, La, val, _ = R.solve!(ref, problem, x_0, u_array; θ=θ_opt, verbose=false)      # the trajectory and gains of the accepted θ
-            return kl_bound > 0 ? (θ_opt, xa, la, La, val + kl_bound / θ_opt, c.theta_min, c.theta_max) : (θ_opt, xa, la, La, val, 0.0, 0.0)
+            # the trajectory and gains of the accepted θ: the reference's own solve!.  An exception there (a borderline isposdef on which device
+            # and CPU differ) feeds the same retry as a failed device solve (:410-413) instead of escaping the loop (ADVICE r04)
+            out = try
+                R.solve!(ref, problem, x_0, u_array; θ=θ_opt, verbose=false)
+            catch
+                nothing
+            end
+            if out !== nothing
+                xa, la, La, val, _ = out
+                return kl_bound > 0 ? (θ_opt, xa, la, La, val + kl_bound / θ_opt, c.theta_min, c.theta_max) : (θ_opt, xa, la, La, val, 0.0, 0.0)
+            end
         end
         θ_opt = max(0.0, θ_opt - c.sigma)                                                # :412
     end
