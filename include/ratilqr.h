@@ -415,7 +415,8 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   block_acl       0 / 1    E = 1 workgroup-per-sample kernel: closed-loop rollouts in deviation form (3 MFMAs on the recursion's
  *                            chain; values agree with the other paths to rounding, ~1e-15, not bit for bit; opt-in)      (0)
  *   fused_dual      0 / 1    policy evaluation + following gain sweep as two recursions of one wavefront                 (1)
- *   fused_occ2      B0       batches of >= B0 samples: the 256-register one-recursion kernel, two samples per SIMD       (0 = never)
+ *   fused_occ2      B0       batches of >= B0 samples: the 256-register one-recursion kernel, two samples per SIMD       (0 = never;
+ *                            -1, the default: LQ-family batches of more samples than the device has SIMDs)
  *   init_share      0 / 1    initialize!'s rollout (independent of theta) rolled out once per (x_0, u_array) and copied   (1)
  *   materialize     0 / 1    one-wavefront-per-sample kernel, LQ family, time-invariant cost: tile records written by the
  *                            rollouts and loaded by the sweeps (SURVEY 8d's wording) instead of formed in registers      (0)

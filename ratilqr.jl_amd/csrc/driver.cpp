@@ -50,7 +50,8 @@ struct rat_handle_s {
     bool wdiag = true;               // switch wdiag = 0: diagonal time-invariant W still runs the general-W arithmetic (applied by rat_problem_set)
     bool materialize = false;        // switch materialize = 1: the one-wavefront-per-sample kernel writes and reads tile records (SURVEY 8d's wording)
     std::vector<double> x0_host, u0_host;   // padded copies of what d_x0 / d_u0 hold (rat_set_initial skips identical uploads)
-    int fused_occ2 = 0;              // RATILQR_FUSED_OCC2=B0: batches of at least B0 samples run the 256-register one-recursion-per-pass variant, two samples per SIMD (0: never, the default)
+    int fused_occ2 = -1;             // RATILQR_FUSED_OCC2=B0: batches of at least B0 samples run the 256-register one-recursion-per-pass variant, two samples per
+                                     // SIMD (0: never; -1, the default: LQ-family batches of more samples than the device has SIMDs)
     bool fused_dual = true;          // ... with policy evaluation + following gain sweep paired in one pass (RATILQR_FUSED_DUAL=0: separate)
     int block_mode = -1;             // workgroup-per-sample solve kernel (solve_block_kernel): -1 auto, 0 never, 1 whenever it is supported (RATILQR_BLOCK)
     int block_max_b = 512;           // auto, E = 1: used for batches up to this size (RATILQR_BLOCK_MAX_B)
@@ -239,11 +240,11 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming | hipEventDisableSystemFence));
     h->dual = spec_eps > 1;          // E > 1: candidate 0 in paired wavefronts beside the other candidates' evaluation (+3.5 % at E = 8)
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
-    // E = 1 batches beyond one sample per SIMD run the paired kernel in generations.  (Rounds 2-3: two samples per SIMD in 256 registers each,
-    // one recursion per pass, beat two generations of the paired kernel by 6..10 % -- until that kernel stopped writing tile records: the
-    // 256-register variant cannot stage its rollouts in LDS, so it keeps its tiles, and now loses 1..3 % at 2048..8192 samples.
-    // The debug switch fused_occ2 = B0 still selects it for batches of at least B0 samples.)
-    h->fused_occ2 = 0;
+    // E = 1 batches beyond one sample per SIMD: two samples per SIMD in 256 registers each, one recursion per pass (solve_fused_kernel<.., OCC2>).
+    // Tile-free like the paired kernel since round 5 (its rollouts fetch their operands step by step, the sweeps form their tiles from x_t): no
+    // scratch, and the second wave fills the first one's dependency stalls -- 4096 samples 3.25 M solves/s against 2.74 M for the paired kernel
+    // run in generations (profiles/r05_occ2.md).  The power-law family keeps its tile records and the paired kernel (-1..3 % otherwise).
+    h->fused_occ2 = -1;
     h->block_max_b = 2 * h->n_cu;    // E = 1: a workgroup per sample while every sample can have two SIMDs
     // execution switches (tests, A/B tools, bench.py's contract secondary): ONE table (debug_switches), reachable through rat_debug_set and,
     // at creation, through the environment variable RATILQR_<KEY> of each entry -- the only place this library reads the environment
@@ -907,7 +908,8 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.ro = ra;
         fa.max_rounds = (int)std::min<int64_t>(((int64_t)h->opd.iter_max + 1) * 4002, 2000000000);
         fa.dual = h->fused_dual ? 1 : 0;
-        fa.occ2 = (path == PATH_FUSED && h->fused_dual && h->fused_occ2 > 0 && B >= h->fused_occ2) ? 1 : 0;
+        fa.occ2 = (path == PATH_FUSED && h->fused_dual &&
+                   (h->fused_occ2 > 0 ? B >= h->fused_occ2 : (h->fused_occ2 < 0 && h->pb.model == 1 && !h->materialize && B > 4 * (int64_t)h->n_cu))) ? 1 : 0;
         fa.mat = h->materialize ? 1 : 0;
         fa.theta_in = theta_dev;
         fa.out_value = out.value; fa.out_status = out.status; fa.out_iters = out.iters; fa.out_ls = out.ls;

@@ -2274,7 +2274,9 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
     // and the cost Hessian of step t from x_t and the problem tables (FLY sweeps, as on the speculative path), so the rollouts store per
     // step only [x_t; u_t] and the [c_x | c_u | c] row -- 0.3 KB instead of 3.4 KB; the registers of a sweep hold the bits a record
     // would have delivered (fx_diag), so results are identical to the tile-materialising paths.
-    constexpr int FLYF = (MODEL == 1 && DUALF && STG && !OCC2 && !MAT) ? (CTV ? 2 : 1) : 0;
+    // (OCC2: tile-free as well -- its rollouts fetch their operands from HBM step by step instead of staging them, the second wave of the
+    //  SIMD covers the latency; 2 KB of LDS per wave)
+    constexpr int FLYF = (MODEL == 1 && ((DUALF && STG && !OCC2) || (OCC2 && !DUALF && !STG)) && !MAT) ? (CTV ? 2 : 1) : 0;
     constexpr bool NT = FLYF != 0;
     // the sample's own wave initialises its state and, at the end, writes its outputs: a batch is ONE launch
     if (threadIdx.x == 0) init_state_body(st, fa.sw.op, fa.theta_in, b);
@@ -2299,7 +2301,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
             PHASE_MARK();
         } else {
             SweepArgs sa = fa.sw; sa.mode = 2;
-            sweep_body<false, false, WM, false, OCC2>(sa, b, wls);
+            sweep_body<false, false, WM, false, OCC2, FLYF>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();

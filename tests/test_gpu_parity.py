@@ -387,6 +387,39 @@ def test_fused_solve_kernel_equals_round_based_path(monkeypatch):
         assert np.array_equal(np.asarray(a), np.asarray(d), equal_nan=True)
 
 
+def test_batches_beyond_one_sample_per_simd_take_the_two_per_simd_kernel(monkeypatch):
+    """More samples than the device has SIMDs (LQ family, E = 1): by default the 256-register, tile-free variant of the fused kernel runs two
+    samples per SIMD (switch fused_occ2 = -1); the paired kernel run in generations (fused_occ2 = 0) must give the same bits -- also beyond
+    the staging horizon, with time-varying cost and noise tables (n = 6, m = 3), with an indefinite stage cost (mu restarts) and cubic drift."""
+    import torch
+    nsimd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    B = nsimd + 77
+    rng = np.random.default_rng(8)
+    n, m, N = 6, 3, 25
+    k = np.arange(N, dtype=float)[:, None, None]
+    Wk = np.stack([(1e-3 * (1 + 0.5 * np.sin(t))) * np.eye(n) + 1e-4 * np.outer(v, v) for t, v in zip(range(N), rng.standard_normal((N, n)))])
+    tv = rat.LQRiskSensitiveProblem(0.95 * np.linalg.qr(rng.standard_normal((n, n)))[0], rng.standard_normal((n, m)) / np.sqrt(n),
+                                    Q=(0.5 + 0.1 * k) * np.eye(n), R=(0.2 + 0.05 * k) * np.eye(m), P=0.05 * rng.standard_normal((N, m, n)),
+                                    qv=0.1 * rng.standard_normal((N, n)), rv=0.1 * rng.standard_normal((N, m)), q0=k.ravel(), N=N, W=Wk,
+                                    Qf=2 * np.eye(n), qvf=0.3 * rng.standard_normal(n), q0f=1.5, kappa=0.01)
+    cases = [rat.synthetic_lq_problem(seed=5, kappa=0.05), rat.synthetic_lq_problem(n=12, m=4, N=60, seed=4, kappa=0.02), stress_problem(1, kappa=0.03),
+             (tv, rng.standard_normal(n), 0.1 * rng.standard_normal((N, m)))]
+    for prob, x0, u in cases:
+        theta = np.abs(1.0 + 2.0 * rng.standard_normal(B))
+        theta[:3] = [0.0, 30.0, 5.9]
+        ctx = rat.Context(prob, rat.ileqg.make_opts(iter_max=6), max_batch=B)
+        assert ctx.debug_get("fused_occ2") == -1
+        got = ctx.solve_batch(x0, u, theta)
+        del ctx
+        monkeypatch.setenv("RATILQR_FUSED_OCC2", "0")
+        ctx = rat.Context(prob, rat.ileqg.make_opts(iter_max=6), max_batch=B)
+        ref = ctx.solve_batch(x0, u, theta)
+        monkeypatch.delenv("RATILQR_FUSED_OCC2")
+        del ctx
+        for a, b in zip(got, ref):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
 @pytest.mark.parametrize("Nh", [1, 3, 7, 13, 60])
 def test_horizon_lengths_around_the_unroll_and_staging_limits(Nh):
     """The closed-loop rollout unrolls its time loop by 5 (tail of N mod 5 steps) and, inside the fused solve, stages its operands in
