@@ -56,7 +56,10 @@
 #endif
 
 #ifndef OCC2_PREFETCH
-#define OCC2_PREFETCH 3            /* the same for the two-samples-per-SIMD solve: the other wave covers the latency, registers are scarce */
+#define OCC2_PREFETCH 5            /* the same for the two-samples-per-SIMD solve: the other wave covers the latency, registers are scarce */
+#endif
+#ifndef OCC2_SWZ
+#define OCC2_SWZ 1                 /* ... and the elimination's row exchange through the LDS crossbar (fewer vector instructions) */
 #endif
 #ifndef ROLLIN_PREFETCH
 #define ROLLIN_PREFETCH 5          /* rotating operand sets of rollin_body: prefetch distance ROLLIN_PREFETCH - 1 steps */
@@ -2301,7 +2304,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
             PHASE_MARK();
         } else {
             SweepArgs sa = fa.sw; sa.mode = 2;
-            sweep_body<false, false, WM, false, OCC2, FLYF>(sa, b, wls);
+            sweep_body<false, false, WM, false, OCC2 ? OCC2_SWZ : 0, FLYF>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -2313,7 +2316,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp!  (ileqg.jl:598-613)
             SweepArgs sa = fa.sw; sa.mode = 0;
-            sweep_body<true, false, WM, false, OCC2, FLYF>(sa, b, wls);
+            sweep_body<true, false, WM, false, OCC2 ? OCC2_SWZ : 0, FLYF>(sa, b, wls);
             PHASE_MARK();
             PHASE_FENCE();
             PHASE_MARK();
@@ -2338,7 +2341,7 @@ __global__ __launch_bounds__(64, OCC2 ? 2 : 1) void solve_fused_kernel(FusedArgs
                 sweep_dual_body<WM, true, FLYF>(sa, b, wls);
             } else {
                 SweepArgs sa = fa.sw; sa.mode = 1;
-                sweep_body<false, false, WM, true, OCC2, FLYF>(sa, b, wls);
+                sweep_body<false, false, WM, true, OCC2 ? OCC2_SWZ : 0, FLYF>(sa, b, wls);
             }
             PHASE_MARK();
             PHASE_FENCE();
