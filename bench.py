@@ -671,7 +671,8 @@ def rank_main(args):
                   "algorithmic_GBps": algo_bytes_of_solves(itn.cpu().numpy(), lsn.cpu().numpy()) * Kn / en / 1e9}
         del ctxn
 
-        # CE batches larger than the chip's 1024 SIMDs: two samples per SIMD (the 256-register variant of the fused kernel)
+        # CE batches larger than the chip's 1024 SIMDs: two samples per SIMD (the 256-register, tile-free variant of the fused kernel: the default
+        # there since round 5, switch fused_occ2 = -1)
         large = {}
         for Bl in (2048, 4096, 8192):
             ctxl = rat.Context(prob, max_batch=Bl, spec_eps=E, device=D.local_rank)
@@ -1001,6 +1002,9 @@ def rank_main(args):
             "pets_1m_traj_per_s": pets_sec["runs"]["1000x1000"]["trajectories_per_s"] if pets_sec else None,
             "pets_solve_ms": pets_sec["solve"]["ms_per_solve"] if pets_sec else None,
             "steady_solves_per_s": steady["value"] if steady else None,
+            "batch2048_solves_per_s": large["2048"]["value"] if large else None,
+            "batch4096_solves_per_s": large["4096"]["value"] if large else None,
+            "batch8192_solves_per_s": large["8192"]["value"] if large else None,
         }
         out.update({k: v for k, v in flat.items() if v is not None})
         # ... and inside `roofline`, which the driver's record keeps whole: the SURVEY 8(d)-to-the-letter contract figure
