@@ -112,6 +112,7 @@ struct rat_handle_s {
     double *d_pmu = nullptr, *d_psig = nullptr; size_t cap_pmu = 0, cap_psig = 0;   // device-resident PETS loop: mu [N][m], Sigma [N][m*m]
     int *d_perr = nullptr;                                  // ... its error word (a covariance that is not positive definite)
     double *h_pzc = nullptr; size_t cap_pzc = 0;            // ... pinned: the injected control normals of a whole solve! | mu | Sigma | error word on the way back
+    bool wide16 = true;              // general sizes with n <= 16, m <= 4: the sweeps of the solve kernel in registers on the matrix pipe (wide16.h)
     bool pets_device = true;                                // switch pets_device
     double *h_pcost = nullptr; size_t cap_hpcost = 0;       // pinned landing zone of the sample costs of the synchronous call (zero-copy)
     // Nelder-Mead (rat_nm_solve): costs already evaluated for this (problem, x0, u0, kl_bound) by exact theta, and the thetas of the batch
@@ -184,6 +185,7 @@ static const DebugSwitch debug_switches[] = {
     {"fly", [](rat_handle h, int64_t v) { h->fly = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly; }},
     {"fly_multi", [](rat_handle h, int64_t v) { h->fly_multi = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly_multi; }},
     {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
+    {"wide16", [](rat_handle h, int64_t v) { h->wide16 = v != 0; }, [](rat_handle h) -> int64_t { return h->wide16; }},
     {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
     {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
     {"nm_depth", [](rat_handle h, int64_t v) { h->nm_depth = (v < 0 || v > 3) ? 3 : (int)v; }, [](rat_handle h) -> int64_t { return h->nm_depth; }},
@@ -887,7 +889,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
     const Path path = pick_path(h, B);
     if (path == PATH_WIDE) {
         WideArgs wa;
-        wa.pb = h->wpb; wa.op = h->opd; wa.B = B;
+        wa.pb = h->wpb; wa.op = h->opd; wa.B = B; wa.fast16 = h->wide16 ? 1 : 0;
         wa.x0 = h->d_x0; wa.u0 = h->d_u0; wa.theta = theta_dev;
         wa.xs = h->w_xs; wa.us = h->w_us; wa.L = h->w_L; wa.dl = h->w_dl; wa.nom = h->w_nom;
         wa.out_value = out.value; wa.out_status = out.status; wa.out_iters = out.iters; wa.out_ls = out.ls;

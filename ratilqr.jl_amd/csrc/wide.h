@@ -23,6 +23,7 @@ struct WideArgs {
     WideProblemDev pb;
     OptsDev op;
     int B;
+    int fast16;                      // n <= 16, m <= 4: sweeps in registers on the matrix pipe (wide16.h); 0 = the general sweep (A/B, tests)
     const double *x0, *u0, *theta;   // [n], [N*m] column-major (time slowest), [B]
     // per-sample scratch (the solver object of one theta-sample: x_array, l_array and their candidates, L_array, dl)
     double *xs, *us;                 // [B][2][(N+1)*n], [B][2][N*m]

@@ -23,6 +23,7 @@
 // factorisation and on LDS round trips between phases; see DESIGN.md and profiles/r04_wide_sizes.md.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 
 #include "wide.h"
 #include "device_utils.h"
@@ -468,6 +469,8 @@ __device__ int sweep(const WideProblemDev &pb_in, const Ws &w_in, const Tiles &t
     return 0;
 }
 
+#include "wide16.h"
+
 // simulate_dynamics(problem, x_0, u_array)  (ileqg.jl:18-38) into (xo, uo)
 __device__ void rollout_open(const WideProblemDev &pb, Ws &w, const double *x0, const double *u0, double *xo, double *uo) {
     const int n = pb.n, m = pb.m, N = pb.N, lane = threadIdx.x;
@@ -542,6 +545,10 @@ __device__ double rollout_closed(const WideProblemDev &pb, Ws &w, const double *
     return best;
 }
 
+__host__ __device__ inline size_t wide_lds_doubles(const int n, const int m) {            // what carve() hands out
+    const size_t ldn = n | 1, ldm = m | 1, sb = ldn * m, sg = ldm * n;
+    return 6 * ldn * n + sb + (sb > sg ? sb : sg) + 3 * sg + 2 * ldm * m + (size_t)9 * n + (size_t)6 * m;
+}
 __device__ inline void carve(Ws &w, ldsd *p, const int n, const int m) {                  // the workgroup's LDS area -> named matrices
     const int ldn = n | 1, ldm = m | 1, sn = ldn * n, sb = ldn * m, sg = ldm * n, sf = sb > sg ? sb : sg, sh = ldm * m;
     w.S = p; p += sn; w.U = p; w.Z = p; p += sn; w.DS = p; p += sn; w.T = p; p += sn; w.At = p; p += sn;      // (Z lives in U: see sweep)
@@ -569,11 +576,23 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     double mu = 0.0, delta = op.delta_0, d_cur = INFINITY, value_cur = INFINITY, eps_init = op.eps_init;
     int iter = 0, n_ls = 0, hn = 0, nom = 0, status = ST_RUNNING;
     for (size_t e = lane; e < (size_t)N * nm; e += 64) Lg[e] = 0.0;                         // :230-232
-    rollout_open(pb, w, a.x0, a.u0, xs, us);                                                // :225, :228
     Tiles tl = {};
+    // n <= 16, m <= 4: the sweeps run in registers on the matrix pipe (wide16.h); the exchange area of its gain solve is T's place in LDS
+    const bool s16 = a.fast16 && n >= 12 && n <= 16 && m <= 4;
+    ldsd *const tab16 = (ldsd *)lds + wide_lds_doubles(n, m);                             // (its tables: behind the general kernel's area)
+    if (s16) setup16(pb, tab16);
+    if (s16) rollout16<false>(pb, a.x0, a.u0, nullptr, nullptr, 0.0, xs, us);               // :225, :228
+    else rollout_open(pb, w, a.x0, a.u0, xs, us);
+    auto run_sweep = [&](const double *xt, const double *ut, const double mu_, auto gain_c, auto zero_c, double &val) -> int {
+        constexpr bool gain = decltype(gain_c)::value, zeroL = decltype(zero_c)::value;
+        if (s16) return sweep16<gain, zeroL>(pb, w.T, tab16, xt, ut, theta, mu_, Lg, dlg, val);
+        tl.x = xt; tl.u = ut;
+        return sweep(pb, w, tl, theta, mu_, gain, zeroL, Lg, dlg, nullptr, nullptr, val);
+    };
+    const std::integral_constant<bool, true> yes;
+    const std::integral_constant<bool, false> no;
     {
-        tl.x = xs; tl.u = us;
-        const int rc = sweep(pb, w, tl, theta, mu, false, true, Lg, dlg, nullptr, nullptr, value_cur);     // :233-235
+        const int rc = run_sweep(xs, us, mu, no, yes, value_cur);                          // :233-235
         if (rc) status = 1;
     }
     // ---- while true: step!  (:640-654)
@@ -584,8 +603,7 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
         int restarts = 0;
         for (;;) {                                                                          // solve_approximate_dp!  (:359-403)
             double dummy;
-            tl.x = xn; tl.u = un;
-            const int rc = sweep(pb, w, tl, theta, mu, true, false, Lg, dlg, nullptr, nullptr, dummy);
+            const int rc = run_sweep(xn, un, mu, yes, no, dummy);
             if (rc == 0) break;
             if (rc == 2) { status = 2; break; }
             delta = fmax(op.delta_0, delta * op.delta_0);                                   // increase_mu_and_delta!  (:471-474)
@@ -601,10 +619,9 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
             count++;                                                                        // :505
             if (count > 4000) { status = 7; break; }                                        // (App. B.5)
             n_ls++;
-            const double d_new = rollout_closed(pb, w, xn, un, dlg, Lg, eps, xc, uc);       // :509-517
+            const double d_new = s16 ? rollout16<true>(pb, xn, un, dlg, Lg, eps, xc, uc) : rollout_closed(pb, w, xn, un, dlg, Lg, eps, xc, uc);       // :509-517
             double newv;
-            tl.x = xc; tl.u = uc;
-            const int rc = sweep(pb, w, tl, theta, mu, false, false, Lg, dlg, nullptr, nullptr, newv);     // :520-528
+            const int rc = run_sweep(xc, uc, mu, no, no, newv);                      // :520-528
             if (rc) { eps *= op.lambda; continue; }                                         // :529-535
             if (hist_on) {                                                                  // :537
                 if (hn < a.hist_cap && lane == 0) { a.hist[2 * (size_t)hn] = eps; a.hist[2 * (size_t)hn + 1] = newv - cur; }
@@ -827,13 +844,12 @@ __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
 
 }  // namespace
 
-size_t wide_lds_bytes(int n, int m) {
-    const size_t ldn = n | 1, ldm = m | 1, sb = ldn * m, sg = ldm * n;
-    return sizeof(double) * (6 * ldn * n + sb + (sb > sg ? sb : sg) + 3 * sg + 2 * ldm * m + (size_t)9 * n + (size_t)6 * m);
-}
+size_t wide_lds_bytes(int n, int m) { return sizeof(double) * wide_lds_doubles(n, m); }
+
 
 hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s) {
-    const size_t lds = wide_lds_bytes(a.pb.n, a.pb.m);
+    const bool s16 = a.fast16 && a.pb.n >= 12 && a.pb.n <= 16 && a.pb.m <= 4;
+    const size_t lds = wide_lds_bytes(a.pb.n, a.pb.m) + (s16 ? sizeof(double) * W16_LDS : 0);
     if (lds > 64 * 1024) {               // (per device: set on every launch that needs it, the call is cheap)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -89,6 +89,62 @@ def test_batched_solves_match_the_oracle(n, m, N, seed, kappa, tv):
     assert kinds == ["solve_wide"], kinds
 
 
+@pytest.mark.parametrize("n,m,N,seed,kappa,tv", [
+    (16, 4, 30, 21, 0.0, False),       # the full tile of the register sweep (wide16.h)
+    (16, 4, 20, 22, 0.03, True),       # cubic drift, time-varying cost tables and W(k)
+    (13, 1, 25, 23, 0.0, False),       # odd n: the last pivot block pairs a state with a padded unit row; one control
+    (15, 3, 20, 24, 0.02, False),
+    (14, 2, 12, 25, 0.0, True),
+    (16, 4, 1, 26, 0.0, False),        # a single step
+])
+def test_register_sweep_sizes_match_the_oracle_and_the_general_sweep(n, m, N, seed, kappa, tv, monkeypatch):
+    """n <= 16, m <= 4 beyond the 12 + 4 tile: the solve kernel's sweeps run in registers on the matrix pipe (wide16.h: two-tile form of the
+    tile kernels' recursion, elimination with 2 x 2 block pivots instead of Cholesky factors).  Same bar against the oracle as every wide size,
+    and the general LDS sweep (switch wide16 = 0) must agree on every count and to 1e-10 on the values."""
+    prob, x0, u = wide_problem(n, m, N, seed, kappa, tv)
+    P = orc.Problem(prob)
+    theta = theta_grid(P, x0, u)
+    ctx = rat.Context(prob, max_batch=theta.size)
+    assert ctx.debug_get("wide16") == 1
+    vg, sg = check_batch(ctx, P, x0, u, theta)
+    assert sg[0] == 0 and (sg[-2:] != 0).all() and (sg[1:-2] == 0).sum() >= 5
+    _, _, ig, lg = ctx.solve_batch(x0, u, theta)
+    monkeypatch.setenv("RATILQR_WIDE16", "0")
+    ref = rat.Context(prob, max_batch=theta.size)
+    monkeypatch.delenv("RATILQR_WIDE16")
+    assert ref.debug_get("wide16") == 0
+    vr, sr, ir, lr = ref.solve_batch(x0, u, theta)
+    assert np.array_equal(sg, sr) and np.array_equal(ig, ir) and np.array_equal(lg, lr)
+    fin = np.isfinite(vr)
+    assert np.all(np.abs(vg[fin] - vr[fin]) <= 1e-10 * np.abs(vr[fin]))
+    # single solve: trajectory, controls and gains
+    th = float(theta[3])
+    r1, r0 = ctx.solve(x0, u, th), ref.solve(x0, u, th)
+    assert rel(r1["x"], r0["x"]) < 1e-10 and rel(r1["l"], r0["l"]) < 1e-10 and rel(r1["L"], r0["L"]) < 1e-9
+    so = orc.ILEQGSolver(P)
+    assert so.solve(x0, u, th) == 0 and r1["status"] == 0 and r1["iters"] == so.s.iter_current
+    for k, o in (("x", so.x_array), ("l", so.l_array), ("L", so.L_array)):
+        assert np.abs(r1[k] - o).max() <= VT * (1 + np.abs(o).max()), k
+
+
+def test_register_sweep_regularisation_restarts_and_backtracking():
+    """wide16.h: an indefinite c_uu (H loses positive definiteness: mu, Delta raised, the sweep restarts, ileqg.jl:372-378) and cubic drift
+    with rejected step sizes"""
+    prob, x0, u = wide_problem(14, 4, 10, 91)
+    prob.R = prob.R - 0.9 * np.eye(4) * np.linalg.eigvalsh(prob.R).max()
+    P = orc.Problem(prob)
+    ctx = rat.Context(prob, max_batch=3)
+    vo, so, io, lo = orc.compute_value_batch(P, x0, u, np.array([0.0, 0.1, 0.3]), nthreads=3)
+    check_batch(ctx, P, x0, u, np.array([0.0, 0.1, 0.3]))
+    for n, m, N, seed, kappa in ((16, 4, 20, 3, 0.05), (14, 3, 30, 2, 0.05), (13, 2, 30, 0, 0.05)):
+        prob, x0, u = rat.synthetic_lq_problem(n=n, m=m, N=N, seed=seed, kappa=kappa)
+        theta = np.array([0.0, 1.0, 3.0, 6.0])
+        ctx = rat.Context(prob, max_batch=4)
+        vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=4)
+        assert (lo > io).any()
+        check_batch(ctx, orc.Problem(prob), x0, u, theta)
+
+
 def test_backtracking_line_searches():
     """cubic drift: rejected step sizes (more evaluations than iterations)"""
     for n, m, N, seed, kappa in ((14, 6, 30, 0, 0.05), (16, 5, 20, 1, 0.05), (14, 6, 30, 6, 0.04)):
