@@ -3,6 +3,7 @@ time-varying tables, cubic drift, random solver options and speculation widths, 
 boundary).  Round 1: 3000 problems, 2 mismatches, both on trajectories that overflow to 1e57+ and run into iter_max (chaotic
 line-search paths / an LU singularity in 1e120-scale arithmetic): no mismatch on a well-posed problem.
   SOAK_N=3000 python tools/soak_parity.py   (on an MI355X; ~40 s)
+  SOAK_WIDE=16: n 13..16 with m 1..4 (the register sweeps and rollouts of wide16.h).
   SOAK_WIDE=1: shapes beyond the tile instead -- n 13..32 with m 1..32, or n 1..12 with m 5..32; N 1..30 (the general-size kernels of wide.hip)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +23,8 @@ for seed in range(S0, S0 + NS):
             n, m = int(rng.integers(1, 13)), int(rng.integers(5, 33))
         elif seed % 3 == 2:
             m = int(rng.integers(1, 33))
+    if os.environ.get('SOAK_WIDE') == '16':   # the register sweep of wide16.h: n 13..16, m 1..4, N 1..40
+        n, m, N = int(rng.integers(13, 17)), int(rng.integers(1, 5)), int(rng.integers(1, 41))
     tv = bool(rng.integers(0, 2))
     A = (0.7 + 0.3 * rng.random()) * np.linalg.qr(rng.standard_normal((n, n)))[0]
     B = rng.standard_normal((n, m)) / np.sqrt(n)
@@ -62,7 +65,7 @@ for seed in range(S0, S0 + NS):
     gkw = dict(kw)
     if "adaptive_eps_init" in gkw: gkw["adaptive_eps_init"] = bool(gkw["adaptive_eps_init"])
     ctx = rat.Context(prob, rat.ileqg.make_opts(**gkw), max_batch=theta.size, spec_eps=E)
-    if os.environ.get('SOAK_WIDE') != '1' and seed % 2 == 1 and not os.environ.get('SOAK_E'):
+    if not os.environ.get('SOAK_WIDE') and seed % 2 == 1 and not os.environ.get('SOAK_E'):
         ctx.set_path("rounds")                 # E > 1: candidates without tile records (fly sweeps, all candidates of a sample in one rollout wave)
     vg, sg, ig, lg = ctx.solve_batch(x0, u, theta)
     fin = np.isfinite(vo)
