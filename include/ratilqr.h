@@ -417,6 +417,8 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   fused_dual      0 / 1    policy evaluation + following gain sweep as two recursions of one wavefront                 (1)
  *   fused_occ2      B0       batches of >= B0 samples: the 256-register one-recursion kernel, two samples per SIMD       (0 = never;
  *                            -1, the default: LQ-family batches of more samples than the device has SIMDs)
+ *   wide16          0 / 1    general sizes with n <= 16, m <= 4: sweeps and rollouts of the solve kernel in registers on the
+ *                            matrix pipe (wide16.h); 0 = the general LDS sweep                                           (1)
  *   init_share      0 / 1    initialize!'s rollout (independent of theta) rolled out once per (x_0, u_array) and copied   (1)
  *   materialize     0 / 1    one-wavefront-per-sample kernel, LQ family, time-invariant cost: tile records written by the
  *                            rollouts and loaded by the sweeps (SURVEY 8d's wording) instead of formed in registers      (0)
