@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak (one datapath, profiles/r01_ubench_fp64_pipe.md)
 # every file a counter figure of profiles/traffic.json depends on (tile / general-size / PETS / CE kernels and what they include)
-KERNEL_SOURCES = ("kernels.hip", "sweep_dual.h", "sweep_dual.hip", "device_utils.h", "layout.h", "kernels.h", "wide.hip", "wide.h",
+KERNEL_SOURCES = ("kernels.hip", "psweep.h", "sweep_dual.h", "sweep_dual.hip", "device_utils.h", "layout.h", "kernels.h", "wide.hip", "wide.h", "wide16.h",
                   "ce_device.hip", "ce_device.h", "rat_pow.h", "rat_normal.h")
 
 

@@ -9,11 +9,11 @@
 //   M = inv(W) - theta S                  -M^-1 by the symmetric sweep with 2 x 2 block pivots (8 rounds, one MFMA each; isposdef(M) <=> all
 //                                         leading minors > 0; logdet from the running product of the block determinants)      ileqg.jl:365-366
 //   X1 = S A, X2 = S [B | 0] + [0 | s_vec]      Y = theta M^-1 X      T = X + S Y = (D S)[A | B | S^-1 s_vec]: column 4 of T2 = D s_vec  :367
-//   F11 = Q + A'T1   F12 = [. | q_vec + A'D s_vec]   F21 = P + B'T1 = G   F22 = [R + mu I + B'T2 | r + B'D s_vec] = [H | g]     :368-371
+//   F11 = Q + A'T1   F12 = A'T2 = [(G - P)' | q_vec + A'D s_vec]   F22 = [R + mu I + B'T2 | r + B'D s_vec] = [H | g]               :368-371
 //   H [L | dl] = -[G | g] by LDL' in every lane for its own column (pivots > 0 <=> isposdef(H))                                :372-382
 //   S' = F11 + L'(H L + G) + G'L,  s_vec' = F12 + L'(H dl + g) + G'dl  (two rank-4 MFMAs each);  scalars accumulate per lane    :383-391
 // The step's cost gradients (approximate_model, :294-313) are five + five MFMAs on [x_t; u_t] held in column 4.
-// 62 MFMAs + ~0.5 k vector instructions per step against ~5 k instructions and a dozen LDS round trips in the general sweep().
+// 58 MFMAs + ~0.5 k vector instructions per step against ~5 k instructions and a dozen LDS round trips in the general sweep().
 #pragma once
 
 // Per-lane 0 / 1 tables of the elimination rounds (tm, wa, cm, crm of ElimMasks, device_utils.h, for eight rounds), the one-hot diagonal
@@ -83,7 +83,7 @@ __device__ __forceinline__ void setup16(const WideProblemDev &pb, ldsd *const ta
 
 // solve_approximate_dp (gain = false, :412-465) / one pass of solve_approximate_dp! (gain = true, :341-406) over the trajectory (x, u) of an
 // LQ-family problem with n <= 16, m <= 4.  Returns 0, 2 (M not positive definite) or -1 (H not positive definite: the caller raises mu and
-// restarts).  ex: 128 doubles of the workgroup's LDS (the [H | g] and G rows of a step, for the per-lane gain solve).
+// restarts).  ex: 192 doubles of the workgroup's LDS (the [H | g] and G rows of a step, for the per-lane gain solve).
 // (GAIN / ZEROL are template parameters and the function is inlined at its three call sites: the kernel's pointers keep their address space
 //  -- through a real call every one of them is generic, each load a FLAT instruction that holds vmcnt AND lgkmcnt -- and the prefetch of the
 //  next step's operands sits in straight-line code.)
@@ -145,7 +145,9 @@ __device__ __forceinline__ int sweep16(const WideProblemDev &pb_in, ldsd *const 
     };
     if (!pb.cost_tv) load_cost(0);
     if (!pb.W_tv) load_noise(0);
-    int hoff[4];
+    int hoff[4], gtoff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gtoff[r] = (j < 4) ? 64 + j * 16 + 4 * r + g : 128 + l;   // (the lanes of columns >= 4 write to slots nobody reads)
 #pragma unroll
     for (int c = 0; c < 4; ++c) hoff[c] = (g <= c) ? g * 16 + c : c * 16 + g;      // Symmetric(H): the upper triangle rules (:371)
     const double mH = (j == g) ? mu : 0.0;
@@ -221,23 +223,24 @@ __device__ __forceinline__ int sweep16(const WideProblemDev &pb_in, ldsd *const 
         for (int r = 0; r < 4; ++r) { qvt[r] += qvc[r]; acc += xv[r] * (0.5 * qx[r] + qvc[r]); }
         const double rvt = c4 * (ru + px) + rvc;              // (column 4, rows < m; the padded rows of R contribute u = 0)
         acc += uv * (0.5 * ru + px + rvc);
-        // T = (D S)[A | B | S^-1 s_vec]
-        const d4 X1 = mm4(S, Ad, zero4);
-        const d4 X2 = mm4(S, Z2, sv2);
+        // T = (D S)[A | B | S^-1 s_vec].  X = S [A | B] + [0 | s_vec] does not depend on the inverse: its eight MFMAs are issued one behind each
+        // elimination round's own -- the round's result needs ~20 wait states before the next round may read it anyway, so they are free there
+        d4 X1 = zero4, X2 = sv2;
         d4 T1, T2;
         if (theta != 0.0) {
             d4 M;
 #pragma unroll
             for (int r = 0; r < 4; ++r) M[r] = fma(nth, S[r], Winv[r]);                 // M = Symmetric(inv(W) - theta S)   (:365)
             int pdmin = 1;
-            elim16_round<0>(M, mk, es, odd, pdmin, rprod);
-            elim16_round<1>(M, mk, es, odd, pdmin, rprod);
-            elim16_round<2>(M, mk, es, odd, pdmin, rprod);
-            elim16_round<3>(M, mk, es, odd, pdmin, rprod);
-            elim16_round<4>(M, mk, es, odd, pdmin, rprod);
-            elim16_round<5>(M, mk, es, odd, pdmin, rprod);
-            elim16_round<6>(M, mk, es, odd, pdmin, rprod);
-            elim16_round<7>(M, mk, es, odd, pdmin, rprod);
+            __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise clumps the X products behind two of the rounds)
+            elim16_round<0>(M, mk, es, odd, pdmin, rprod); X1 = MFMA(S[0], Ad[0], X1); __builtin_amdgcn_sched_barrier(0);
+            elim16_round<1>(M, mk, es, odd, pdmin, rprod); X1 = MFMA(S[1], Ad[1], X1); __builtin_amdgcn_sched_barrier(0);
+            elim16_round<2>(M, mk, es, odd, pdmin, rprod); X1 = MFMA(S[2], Ad[2], X1); __builtin_amdgcn_sched_barrier(0);
+            elim16_round<3>(M, mk, es, odd, pdmin, rprod); X1 = MFMA(S[3], Ad[3], X1); __builtin_amdgcn_sched_barrier(0);
+            elim16_round<4>(M, mk, es, odd, pdmin, rprod); X2 = MFMA(S[0], Z2[0], X2); __builtin_amdgcn_sched_barrier(0);
+            elim16_round<5>(M, mk, es, odd, pdmin, rprod); X2 = MFMA(S[1], Z2[1], X2); __builtin_amdgcn_sched_barrier(0);
+            elim16_round<6>(M, mk, es, odd, pdmin, rprod); X2 = MFMA(S[2], Z2[2], X2); __builtin_amdgcn_sched_barrier(0);
+            elim16_round<7>(M, mk, es, odd, pdmin, rprod); X2 = MFMA(S[3], Z2[3], X2); __builtin_amdgcn_sched_barrier(0);
             if (!(pdmin > 0) || !(rprod * 0.0 == 0.0)) return 2;                        // @assert isposdef(M)  (:366 / :440)
             rexp += __builtin_amdgcn_frexp_exp(rprod);
             rprod = __builtin_amdgcn_frexp_mant(rprod);
@@ -250,6 +253,8 @@ __device__ __forceinline__ int sweep16(const WideProblemDev &pb_in, ldsd *const 
             // theta == 0: D = I; 0.5 tr(W S)  (:385).  The reference still asserts isposdef(inv(W) - 0 S): a non-finite S fails it.
             const double nf = fma(S[3], 0.0, fma(S[2], 0.0, fma(S[1], 0.0, S[0] * 0.0)));
             if (__ballot(nf != nf) != 0ull) return 2;
+            X1 = mm4(S, Ad, X1);
+            X2 = mm4(S, Z2, X2);
             if (pb.W_tv) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) racc = fma(((const gbld *)pb.W)[(size_t)kw * n2 + rc[r] + n * jn] * (in_nn[r] ? 1.0 : 0.0), S[r], racc);
@@ -262,12 +267,15 @@ __device__ __forceinline__ int sweep16(const WideProblemDev &pb_in, ldsd *const 
         // F = [A | B]'T + the step's cost model
         const d4 F11 = mm4(Ad, T1, Q);                                                  // Q + A'(D S)A   (:390)
         d4 F12 = mm4(Ad, T2, qvt);                                                      // column 4: q_vec + A'D s_vec   (:389)
-        const d4 C21 = {Pn, 0.0, 0.0, 0.0}, C22 = {Rn + mH + rvt, 0.0, 0.0, 0.0};
-        const double gq = mm4(Z2, T1, C21)[0];                                          // G = P + B'(D S)A   (:369), natural rows
+        const d4 C22 = {Rn + mH + rvt, 0.0, 0.0, 0.0};
         const double hq = mm4(Z2, T2, C22)[0];                                          // [H | g] = [R + B'(D S)B + mu I | r + B'D s_vec]  (:368, :370)
+        // G = P + B'(D S)A (:369) is the transpose of columns 0..3 of F12 = A'(D S)[B | .] (D S is symmetric): it goes through the exchange
+        // the gain solve needs anyway -- written as (state, control), read back in natural rows -- instead of four MFMAs of its own
         ex[g * 16 + j] = hq;
-        ex[64 + g * 16 + j] = gq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ex[gtoff[r]] = F12[r] + PT[r];
         WAVE_SYNC();
+        const double gq = ex[64 + g * 16 + j];
         const double hg0 = ex[hoff[0]], hg1 = ex[hoff[1]], hg2 = ex[hoff[2]], hg3 = ex[hoff[3]];       // row g of Symmetric(H)
         const double gvg = ex[g * 16 + 4];                                              // g_g
         double x0, x1, x2, x3, d0v, d1v, d2v, d3v;                                      // column j of L, and dl

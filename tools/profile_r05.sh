@@ -7,7 +7,8 @@
 #   seq128     B = 128,  E = 1  solve_block_kernel (switch block_psw = 0): the same shard with sequential sweeps
 #   e8_1024    B = 1024, E = 8  round-based path without candidate tiles: BASELINE config 3 on one GPU (rollin_multi_kernel, fly sweeps)
 #   e8_128     B = 128,  E = 8  solve_block_kernel: config 3's shard at 8 GPUs
-#   fused_4096 B = 4096, E = 1  the paired kernel in four generations
+#   fused_4096 B = 4096, E = 1  two samples per SIMD: the 256-register tile-free kernel (default beyond one sample per SIMD)
+#   paired_4096 B = 4096, E = 1 the paired kernel in four generations (switch fused_occ2 = 0: the round-4 default)
 #   contract   B = 1024, E = 1  the headline kernel with tile records materialised and no shared initialize! (SURVEY 8d to the letter)
 #   block512   B = 512,  E = 1  solve_block_kernel: the per-GPU shard at 2 GPUs
 # Outputs under gpurun_out/r05/prof/; summarised into profiles/ by tools/profile_report.py r05.   usage: profile_r05.sh [config ...]
@@ -33,4 +34,5 @@ CUR=seq128;    want "$@" && run seq128 --batch 128 --debug block_psw=0
 CUR=e8_1024;   want "$@" && run e8_1024 --batch 1024 --spec-eps 8
 CUR=e8_128;    want "$@" && run e8_128 --batch 128 --spec-eps 8
 CUR=fused_4096; want "$@" && run fused_4096 --batch 4096
+CUR=paired_4096; want "$@" && run paired_4096 --batch 4096 --debug fused_occ2=0
 find $O -name "*.csv" | wc -l

@@ -10,9 +10,9 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 O = os.path.join(ROOT, "gpurun_out", RND, "prof")
-# (seq128 before block128: both map to the key solve_block_E1_B128 of profiles/traffic.json, the default kernel keeps it)
+# (seq128 before block128, paired_4096 before fused_4096: both map to one key of profiles/traffic.json, the default kernel keeps it)
 CFG = {"fused": (1, 1024), "contract": (1, 1024), "seq128": (1, 128), "block128": (1, 128), "block256": (1, 256), "block512": (1, 512),
-       "e8_1024": (8, 1024), "e8_128": (8, 128), "fused_4096": (1, 4096)}
+       "e8_1024": (8, 1024), "e8_128": (8, 128), "paired_4096": (1, 4096), "fused_4096": (1, 4096)}
 # kernel-name pattern -> the key bench.py uses (traffic_for(f"{kind}_E{E}_B{B}")); first match wins
 KINDS = [("solve_fused_kernel", "solve_fused"), ("solve_block_psw_kernel", "solve_block"), ("solve_block_kernel", "solve_block"), ("sweep_dual_kernel", "sweep_dual"),
          ("rollin_multi_kernel", "rollout_multi"), ("rollin_stage_kernel", "rollout"), ("rollin_kernel", "rollout_init"),

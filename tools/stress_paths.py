@@ -1,6 +1,6 @@
 """Every single-launch solve kernel against the round-based path, bit for bit, over random problems the fixed tests do not combine:
-time-varying cost and noise tables, cubic drift, the power-law family, horizons around the staging limit, batch sizes from 1 to 1500
-(block kernel up to 512, paired fused kernel up to 1024, two-samples-per-SIMD fused kernel beyond).
+time-varying cost and noise tables, cubic drift, the power-law family, horizons around the staging limit, batch sizes from 1 to 3000
+(block kernel up to 512, paired fused kernel up to 1024, beyond it the two-samples-per-SIMD tile-free fused kernel for the LQ family).
   STRESS_S=120 python tools/stress_paths.py      (on an MI355X)"""
 import os
 import sys
@@ -59,7 +59,7 @@ def main():
     t0, launches, bad, kinds = time.time(), 0, 0, {}
     while time.time() - t0 < budget:
         prob, x0, u, scale = powerlaw(rng) if rng.random() < 0.2 else lq(rng)
-        B = int(rng.choice([1, 5, 100, 300, 512, 513, 800, 1024, 1025, 1500]))
+        B = int(rng.choice([1, 5, 100, 300, 512, 513, 800, 1024, 1025, 1500, 2100, 3000]))
         theta = np.concatenate([[0.0], np.abs(rng.normal(0.0, scale, B - 1))]) if B > 1 else np.array([scale])
         # speculation widths too: the default path (block kernel within one generation of workgroups, beyond it rounds whose candidates
         # carry no tile records and roll out in one wavefront per sample) against rounds with materialised tiles and one wave per candidate
