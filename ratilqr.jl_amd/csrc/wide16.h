@@ -36,14 +36,20 @@ __device__ __forceinline__ d4 mm4(const d4 &a, const d4 &b, d4 acc) {       // a
     return acc;
 }
 
+struct RoundMasks { double tm, wa, cm, crm; };
+__device__ __forceinline__ RoundMasks round_masks(const ldsd *const mk, const int kb) {
+    RoundMasks r;
+    r.tm = mk[64 * W16_TM(kb)]; r.wa = mk[64 * W16_WA(kb)]; r.cm = mk[64 * W16_CM(kb)]; r.crm = mk[64 * W16_CRM(kb)];
+    return r;
+}
 template <int KB>
-__device__ __forceinline__ void elim16_round(d4 &m, const ldsd *const mk, const double (&es)[4], const bool odd, int &pdmin, double &rprod) {
+__device__ __forceinline__ void elim16_round(d4 &m, const RoundMasks &rm, const double (&es)[4], const bool odd, int &pdmin, double &rprod) {
     constexpr int k = 2 * KB, kr = k >> 2, kg = k & 3;          // rows k, k+1 live in register kr, quad-rows kg, kg+1
     const double p11 = readlane_f64(m[kr], kg * 16 + k);
     const double p12 = readlane_f64(m[kr], kg * 16 + k + 1);
     const double p22 = readlane_f64(m[kr], (kg + 1) * 16 + k + 1);
-    const double cm = mk[64 * W16_CM(KB)], crm = mk[64 * W16_CRM(KB)];
-    const double t = fma(m[kr], mk[64 * W16_TM(KB)], mk[64 * W16_WA(KB)]);          // pivot rows, -I in the pivot block, zero elsewhere
+    const double cm = rm.cm, crm = rm.crm;
+    const double t = fma(m[kr], rm.tm, rm.wa);          // pivot rows, -I in the pivot block, zero elsewhere
     const double other = row_partner<0>(t, odd);
     const double det = fma(p11, p22, -(p12 * p12));
     const double idet = fast_rcp1(det);
@@ -232,15 +238,18 @@ __device__ __forceinline__ int sweep16(const WideProblemDev &pb_in, ldsd *const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) M[r] = fma(nth, S[r], Winv[r]);                 // M = Symmetric(inv(W) - theta S)   (:365)
             int pdmin = 1;
-            __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise clumps the X products behind two of the rounds)
-            elim16_round<0>(M, mk, es, odd, pdmin, rprod); X1 = MFMA(S[0], Ad[0], X1); __builtin_amdgcn_sched_barrier(0);
-            elim16_round<1>(M, mk, es, odd, pdmin, rprod); X1 = MFMA(S[1], Ad[1], X1); __builtin_amdgcn_sched_barrier(0);
-            elim16_round<2>(M, mk, es, odd, pdmin, rprod); X1 = MFMA(S[2], Ad[2], X1); __builtin_amdgcn_sched_barrier(0);
-            elim16_round<3>(M, mk, es, odd, pdmin, rprod); X1 = MFMA(S[3], Ad[3], X1); __builtin_amdgcn_sched_barrier(0);
-            elim16_round<4>(M, mk, es, odd, pdmin, rprod); X2 = MFMA(S[0], Z2[0], X2); __builtin_amdgcn_sched_barrier(0);
-            elim16_round<5>(M, mk, es, odd, pdmin, rprod); X2 = MFMA(S[1], Z2[1], X2); __builtin_amdgcn_sched_barrier(0);
-            elim16_round<6>(M, mk, es, odd, pdmin, rprod); X2 = MFMA(S[2], Z2[2], X2); __builtin_amdgcn_sched_barrier(0);
-            elim16_round<7>(M, mk, es, odd, pdmin, rprod); X2 = MFMA(S[3], Z2[3], X2); __builtin_amdgcn_sched_barrier(0);
+            // (the scheduler otherwise clumps the X products behind two of the rounds; with the rounds fenced, each round's 0 / 1 tables are
+            //  fetched from LDS at the top of the round before it)
+            RoundMasks ra = round_masks(mk, 0), rb;
+            __builtin_amdgcn_sched_barrier(0);
+            rb = round_masks(mk, 1); elim16_round<0>(M, ra, es, odd, pdmin, rprod); X1 = MFMA(S[0], Ad[0], X1); __builtin_amdgcn_sched_barrier(0);
+            ra = round_masks(mk, 2); elim16_round<1>(M, rb, es, odd, pdmin, rprod); X1 = MFMA(S[1], Ad[1], X1); __builtin_amdgcn_sched_barrier(0);
+            rb = round_masks(mk, 3); elim16_round<2>(M, ra, es, odd, pdmin, rprod); X1 = MFMA(S[2], Ad[2], X1); __builtin_amdgcn_sched_barrier(0);
+            ra = round_masks(mk, 4); elim16_round<3>(M, rb, es, odd, pdmin, rprod); X1 = MFMA(S[3], Ad[3], X1); __builtin_amdgcn_sched_barrier(0);
+            rb = round_masks(mk, 5); elim16_round<4>(M, ra, es, odd, pdmin, rprod); X2 = MFMA(S[0], Z2[0], X2); __builtin_amdgcn_sched_barrier(0);
+            ra = round_masks(mk, 6); elim16_round<5>(M, rb, es, odd, pdmin, rprod); X2 = MFMA(S[1], Z2[1], X2); __builtin_amdgcn_sched_barrier(0);
+            rb = round_masks(mk, 7); elim16_round<6>(M, ra, es, odd, pdmin, rprod); X2 = MFMA(S[2], Z2[2], X2); __builtin_amdgcn_sched_barrier(0);
+            elim16_round<7>(M, rb, es, odd, pdmin, rprod); X2 = MFMA(S[3], Z2[3], X2); __builtin_amdgcn_sched_barrier(0);
             if (!(pdmin > 0) || !(rprod * 0.0 == 0.0)) return 2;                        // @assert isposdef(M)  (:366 / :440)
             rexp += __builtin_amdgcn_frexp_exp(rprod);
             rprod = __builtin_amdgcn_frexp_mant(rprod);

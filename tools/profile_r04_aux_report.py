@@ -1,8 +1,9 @@
-"""profiles/r04_aux_kernels.md from the passes of tools/profile_r04_aux.sh (gpurun_out/r04/aux): duration, HBM traffic and SQ counters of
+"""profiles/<round>_aux_kernels.md from the passes of tools/profile_<round>_aux.sh (gpurun_out/<round>/aux; usage: profile_r04_aux_report.py [round], default r04): duration, HBM traffic and SQ counters of
 the kernels outside the headline configuration."""
 import collections, csv, glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, "gpurun_out", "r04", "aux")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+O = os.path.join(ROOT, "gpurun_out", RND, "aux")
 HBM_PEAK, CLK = 8.0e12, 2.4e9
 
 
@@ -14,7 +15,7 @@ def counters(d):
     return per
 
 
-md = ["# r04: counter evidence for the kernels outside the headline (tools/profile_r04_aux.sh; one MI355X, ROCm 7.2)\n",
+md = [f"# {RND}: counter evidence for the kernels outside the headline (tools/profile_{RND}_aux.sh; one MI355X, ROCm 7.2)\n",
       "Runs: `tools/pets_bench.py` (BASELINE config 5: 100 x 100, 1000 x 100 and 1000 x 1000 control samples x noisy rollouts, N = 30),",
       "`tools/aux_wide_run.py` (general sizes: CE batch 1024 at n x m = 16 x 4 and 32 x 32, N = 50) and `tools/aux_nm_run.py` (BASELINE config 4:",
       "fresh Nelder-Mead solves: two iterations' worth of vertices per batch, the final solve read out of the last batch).  Each counter set is its own rocprofv3 run.",
@@ -27,7 +28,7 @@ for name in ("pets", "wide", "nm"):
     if not st:
         continue
     import shutil
-    shutil.copy(st[0], os.path.join(ROOT, "profiles", f"r04_kernel_stats_aux_{name}.csv"))
+    shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{RND}_kernel_stats_aux_{name}.csv"))
     f, w = counters(f"fetch_{name}"), counters(f"write_{name}")
     s = collections.defaultdict(dict)
     for d in ("sq1", "sq2", "sq3"):
@@ -58,5 +59,5 @@ for name in ("pets", "wide", "nm"):
         ln = [l.strip() for l in open(log) if l.startswith("{") or l.startswith("[")]
         if ln:
             md.append(f"| {name}: the run's own line | `{ln[-1][:600]}` |")
-open(os.path.join(ROOT, "profiles", "r04_aux_kernels.md"), "w").write("\n".join(md) + "\n")
+open(os.path.join(ROOT, "profiles", f"{RND}_aux_kernels.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md))
