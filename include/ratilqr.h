@@ -417,6 +417,8 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   fused_dual      0 / 1    policy evaluation + following gain sweep as two recursions of one wavefront                 (1)
  *   fused_occ2      B0       batches of >= B0 samples: the 256-register one-recursion kernel, two samples per SIMD       (0 = never;
  *                            -1, the default: LQ-family batches of more samples than the device has SIMDs)
+ *   prune           0 / 1    round-based path, E > 1, tile-free candidates: the evaluations of candidates 1 .. E-1 of a sample stop once
+ *                            candidate 0 is known to be the line search's choice (identical outputs)                      (1)
  *   wide16          0 / 1    general sizes with n <= 16, m <= 4: sweeps and rollouts of the solve kernel in registers on the
  *                            matrix pipe (wide16.h); 0 = the general LDS sweep                                           (1)
  *   init_share      0 / 1    initialize!'s rollout (independent of theta) rolled out once per (x_0, u_array) and copied   (1)

@@ -217,6 +217,19 @@ __device__ __forceinline__ void elim_round_pair(d4 &mA, d4 &mB, const ElimMasks 
     mB = MFMA(tB, nuB, mB);
 }
 
+// The scalars of a sweep that never feed back, folded once at its end: 0.5 sum(racc) - logdet(W M) / (2 theta) with the running product of the
+// block determinants renormalised to mantissa x 2^rexp.  ONE rounding order in every kernel whose results must agree bit for bit (the
+// compiler's own choice between a fused and a separate multiply-add depends on the code around the expression: it changed in one of the two
+// compilations of the paired sweep when an unrelated statement was added behind it, on the samples whose exponent sum is not zero).
+__device__ __forceinline__ double sweep_scalars(double racc_sum, double coef, double rprod, int rexp, bool risk) {
+#pragma clang fp contract(off)
+    const double half = 0.5 * racc_sum;
+    if (!risk) return half;
+    const double ld = __builtin_fma((double)rexp, 0.6931471805599453094, log(rprod));
+    const double t = coef * ld;
+    return half + t;
+}
+
 __device__ __forceinline__ bool isapprox_default(double x, double y) {   // Base.isapprox, rtol = sqrt(eps), atol = 0
     if (x == y) return true;
     if (!isfinite(x) || !isfinite(y)) return false;

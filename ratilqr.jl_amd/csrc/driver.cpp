@@ -112,6 +112,8 @@ struct rat_handle_s {
     double *d_pmu = nullptr, *d_psig = nullptr; size_t cap_pmu = 0, cap_psig = 0;   // device-resident PETS loop: mu [N][m], Sigma [N][m*m]
     int *d_perr = nullptr;                                  // ... its error word (a covariance that is not positive definite)
     double *h_pzc = nullptr; size_t cap_pzc = 0;            // ... pinned: the injected control normals of a whole solve! | mu | Sigma | error word on the way back
+    bool prune = true;               // round-based path, E > 1, tile-free candidates: evaluations of candidates 1 .. E-1 stop once candidate 0 is the line search's choice
+    hipStream_t stream_lo = nullptr; // ... their stream: the lowest priority the device offers
     bool wide16 = true;              // general sizes with n <= 16, m <= 4: the sweeps of the solve kernel in registers on the matrix pipe (wide16.h)
     bool pets_device = true;                                // switch pets_device
     double *h_pcost = nullptr; size_t cap_hpcost = 0;       // pinned landing zone of the sample costs of the synchronous call (zero-copy)
@@ -186,6 +188,7 @@ static const DebugSwitch debug_switches[] = {
     {"fly_multi", [](rat_handle h, int64_t v) { h->fly_multi = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly_multi; }},
     {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
     {"wide16", [](rat_handle h, int64_t v) { h->wide16 = v != 0; }, [](rat_handle h) -> int64_t { return h->wide16; }},
+    {"prune", [](rat_handle h, int64_t v) { h->prune = v != 0; }, [](rat_handle h) -> int64_t { return h->prune; }},
     {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
     {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
     {"nm_depth", [](rat_handle h, int64_t v) { h->nm_depth = (v < 0 || v > 3) ? 3 : (int)v; }, [](rat_handle h) -> int64_t { return h->nm_depth; }},
@@ -237,6 +240,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
         return fail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     CREATECHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATECHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    { int lo = 0, hi = 0; CREATECHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); CREATECHK(hipStreamCreateWithPriority(&h->stream_lo, hipStreamNonBlocking, lo)); }
     // (ev_a / ev_b order the handle's two streams on ONE device: no system-scope fence)
     CREATECHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming | hipEventDisableSystemFence));
     CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -292,6 +296,7 @@ extern "C" void rat_destroy(rat_handle h) {
     for (int i = 0; i < CTR_RING; ++i) if (h->round_ev[i]) (void)hipEventDestroy(h->round_ev[i]);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->stream_lo) (void)hipStreamDestroy(h->stream_lo);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -374,7 +379,7 @@ static rat_rc alloc_state(rat_handle h) {
     AL(st.lsel, B); AL(st.mu_spec, B); AL(st.delta_spec, B); AL(st.spec_st, B);
     AL(st.theta, B); AL(st.mu, B); AL(st.delta, B); AL(st.value, B); AL(st.d_cur, B); AL(st.eps_init, B); AL(st.ls_eps, B);
     AL(st.status, B); AL(st.iter, B); AL(st.ls_active, B); AL(st.ls_count, B); AL(st.slot_nom, B); AL(st.n_ls, B); AL(st.hist_n, B);
-    AL(st.value_c, (size_t)B * E); AL(st.d_c, (size_t)B * E); AL(st.flag_c, (size_t)B * E);
+    AL(st.value_c, (size_t)B * E); AL(st.d_c, (size_t)B * E); AL(st.flag_c, (size_t)B * E); AL(st.acc0, B);
     AL(st.counters, 2 * CTR_RING); AL(st.sink, (size_t)SINK_SLOTS * 64);
     st.hist = nullptr; st.hist_cap = 0;
     AL(h->d_x0, XSTR); AL(h->d_u0, (size_t)N * USTR); AL(h->d_theta, B); AL(h->d_val, B);
@@ -393,6 +398,7 @@ static rat_rc alloc_state(rat_handle h) {
     HIPCHK(hipMemsetAsync(st.lsel, 0, (size_t)B * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(st.spec_st, 0, (size_t)B * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(st.flag_c, 0, (size_t)B * E * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(st.acc0, 0, (size_t)B * sizeof(int), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return RAT_OK;
 }
@@ -606,6 +612,7 @@ static void prof_flush(rat_handle h) {
     if (!h->ev_used) return;
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamSynchronize(h->stream2);
+    if (h->stream_lo) (void)hipStreamSynchronize(h->stream_lo);
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, h->evs[i].a, h->evs[i].b);
@@ -657,7 +664,7 @@ extern "C" rat_rc rat_layout_info(rat_handle h, int64_t *tile_bytes, int64_t *L_
 static SweepArgs sweep_args(rat_handle h, const StateDev &st, int mode) {
     SweepArgs a;
     a.st = st; a.pb = h->pb; a.op = h->opd; a.mode = mode; a.k_first = 0; a.dl_in = nullptr; a.mu_op = 0.0; a.op_out = nullptr; a.dump = nullptr;
-    a.fly = 0;
+    a.fly = 0; a.prune = 0;
 #if defined(RAT_DIAG) || defined(RAT_DIAG_PHASES)
     a.dump = h->d_dump;
 #endif
@@ -735,18 +742,36 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
         { SweepArgs sg0 = sweep_args(h, st, 0); sg0.fly = fly;       // (tile-free path: the plain gain sweep forms its tiles too -- nothing to materialise)
           prof_begin(h, RAT_K_SWEEP_GAIN, st.B); launch_sweep(sg0, st.B, true, false, h->stream); prof_end(h); }
         prof_begin(h, RAT_K_ROLLOUT, nc); launch_rollin(ra, h->stream); prof_end(h);
-        if (st.E > 1) {              // candidates 1 .. E-1: plain policy evaluation, beside candidate 0's paired wavefronts (second stream)
+        // Speculation pruned (switch prune, tile-free candidates): candidate 0's paired wavefronts go first and say whether the line search
+        // will settle on it (StateDev.acc0); the evaluations of candidates 1 .. E-1 -- on a stream of the lowest priority, so that the paired
+        // launch, which holds a SIMD's register file alone, is dispatched ahead of them -- poll that word and stop: the sequential rule never
+        // reads a candidate behind the one it accepts.  Identical outputs; the evaluations cost what the rejected candidate 0s need.
+        const bool prune = h->prune && fly && st.E > 1 && h->stream_lo;
+        auto launch_evals = [&](hipStream_t s2) -> rat_rc {   // candidates 1 .. E-1: plain policy evaluation, beside candidate 0's paired wavefronts
             HIPCHK(hipEventRecord(h->ev_a, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_a, 0));
+            HIPCHK(hipStreamWaitEvent(s2, h->ev_a, 0));
             SweepArgs se = sweep_args(h, st, 1);
             se.k_first = 1;
             se.fly = fly;
+            se.prune = prune ? 1 : 0;
             const int64_t n1 = (int64_t)st.B * (st.E - 1);
-            prof_begin(h, RAT_K_SWEEP_EVAL, n1, h->stream2); launch_sweep(se, (int)n1, false, false, h->stream2); prof_end(h, h->stream2);
-            HIPCHK(hipEventRecord(h->ev_b, h->stream2));
-        }
-        { SweepArgs sd = sweep_args(h, st, 7); sd.fly = fly;
+            prof_begin(h, RAT_K_SWEEP_EVAL, n1, s2); launch_sweep(se, (int)n1, false, false, s2); prof_end(h, s2);
+            HIPCHK(hipEventRecord(h->ev_b, s2));
+            return RAT_OK;
+        };
+        rat_rc rce;
+        if (st.E > 1 && !prune && (rce = launch_evals(h->stream2))) return rce;
+        if (prune) HIPCHK(hipEventRecord(h->ev_a, h->stream));               // (the rollouts' end, before the paired launch is enqueued behind it)
+        { SweepArgs sd = sweep_args(h, st, 7); sd.fly = fly; sd.prune = prune ? 1 : 0;
           prof_begin(h, RAT_K_SWEEP_DUAL, st.B); launch_sweep_dual(sd, st.B, h->stream); prof_end(h); }
+        if (prune) {
+            HIPCHK(hipStreamWaitEvent(h->stream_lo, h->ev_a, 0));
+            SweepArgs se = sweep_args(h, st, 1);
+            se.k_first = 1; se.fly = fly; se.prune = 1;
+            const int64_t n1 = (int64_t)st.B * (st.E - 1);
+            prof_begin(h, RAT_K_SWEEP_EVAL, n1, h->stream_lo); launch_sweep(se, (int)n1, false, false, h->stream_lo); prof_end(h, h->stream_lo);
+            HIPCHK(hipEventRecord(h->ev_b, h->stream_lo));
+        }
         if (st.E > 1) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_b, 0));
         prof_begin(h, RAT_K_SELECT, st.B); launch_ls_select(st, h->opd, slot, h->stream); prof_end(h);
         HIPCHK(hipMemcpyAsync(h->h_counters + 2 * slot, st.counters + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -19,6 +19,8 @@ struct SweepArgs {
     double *dump;          // DUMP instantiations: [N+1][DUMP_STRIDE]
     int fly;               // modes 1 / 7: the candidates' records hold only [c_x | c_u | c] (RolloutArgs.notile): f_x | f_u and the cost
                            // Hessian of a step are formed in the sweep from x_t and the problem tables
+    int prune;             // round-based path, E > 1: mode 7 publishes whether candidate 0 is the line search's choice (StateDev.acc0); mode 1
+                           // launches of candidates 1 .. E-1 poll it and stop (sweep_kernel<.., PRUNE>)
 };
 
 // the time-parallel sweep (psweep.h): P waves over P + 1 horizon segments

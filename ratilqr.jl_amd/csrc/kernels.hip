@@ -113,7 +113,7 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
 // wls: this wavefront's LDS scratch (WLS_SWEEP doubles).
 // SWZ: the elimination's row exchange through the LDS crossbar (ds_swizzle) instead of vector-ALU lane swaps: identical values, fewer
 // vector instructions, longer latency -- for the kernel that runs two samples per SIMD, which is short of issue slots, not of latency.
-template <bool GAIN, bool DUMP, int WM, bool HASL, int SWZ = 0, int FLY = 0>
+template <bool GAIN, bool DUMP, int WM, bool HASL, int SWZ = 0, int FLY = 0, bool PRUNE = false>
 __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, double *const wls) {
     int lane_ = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_));      // opaque per phase: keeps the per-lane constants of one phase from being shared with
@@ -137,6 +137,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
         if (!s_act) return;
         cidx = fidx;
         if (s_flag == 2) return;
+        // PRUNE (candidates 1 .. E-1 of the round-based path): candidate 0 is already known to be the line search's choice -- the sequential
+        // rule will not read this candidate's value (ls_select_body stops at the first it accepts)
+        if (PRUNE && __builtin_amdgcn_readfirstlane(__atomic_load_n(&st.acc0[b], __ATOMIC_RELAXED))) return;
         slot = cand_slot(b, k, s_nom, st.E);
     } else if (a.mode == 4) {          // speculative gain sweep of the NEXT iteration on line-search candidate 0
         if (!s_act) return;
@@ -412,7 +415,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
             DIAG_STAMP(5, v[0]);
             if (DUMP) {
                 double *dp = a.dump + (long)t * DUMP_STRIDE;
-                const double tot = 0.5 * wave_sum(racc) + ((theta != 0.0) ? coef * (log(rprod) + (double)rexp * 0.6931471805599453094) : 0.0);
+                const double tot = sweep_scalars(wave_sum(racc), coef, rprod, rexp, theta != 0.0);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int i = 4 * r + g;
@@ -434,6 +437,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
         TileRegs rb;
         BODY_MARK(a.dump, dgs + 1);
         for (int t = N - 1; t >= 0; t -= 2) {
+            // (PRUNE: the word is requested ahead of the pair's tile loads and looked at behind its two steps -- the oldest load in flight by
+            //  then, so the counted wait leaves every younger one alone)
+            int polled = 0;
+            if (PRUNE) polled = __atomic_load_n(&st.acc0[b], __ATOMIC_RELAXED);
             {
                 const int tn = (t > 0) ? t - 1 : 0;
                 load_tile<HASL, DUMP, FLY>(rb, tile0 + (long)tn * TSTRIDE, l, lx, lq, Lb + (long)tn * LSTR,
@@ -447,6 +454,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
                                 a.dl_in ? a.dl_in + (long)tn * USTR : nullptr, mL, g, j, &fc, tn);
             }
             if (step(t - 1, rb)) break;
+            if (PRUNE && __builtin_amdgcn_readfirstlane(polled)) return;        // nobody will read this candidate: no outputs
         }
         BODY_MARK(a.dump, dgs + 2);
         if (GAIN && h_not_pd) {
@@ -463,7 +471,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
     if (l_ == 0 && blockIdx.x < 8 && a.dump)
         for (int q = 0; q < 6; ++q) a.dump[blockIdx.x * 8 + q] = (double)dg_acc[q];
 #endif
-    const double tot = 0.5 * wave_sum(racc) + ((theta != 0.0) ? coef * (log(rprod) + (double)rexp * 0.6931471805599453094) : 0.0);
+    const double tot = sweep_scalars(wave_sum(racc), coef, rprod, rexp, theta != 0.0);
     if (l == 12) {
         const double s0 = 0.5 * v[3] + tot;
         if (a.mode == 1) {
@@ -543,10 +551,10 @@ void launch_psweep(const SweepArgs &a, int ntraj, bool gain, const PswCuts &pc, 
 // SWZ: the elimination's row exchange through the LDS crossbar (fewer vector instructions, longer latency; identical values): for launches
 // that put several waves on a SIMD, where the datapath is saturated (profiles/r03_rocprof_summary.md: two evaluation waves per SIMD issue
 // 50 % each) and only the instruction count matters
-template <bool GAIN, bool DUMP, int WM, bool HASL, int FLY = 0, int SWZ = 0>
+template <bool GAIN, bool DUMP, int WM, bool HASL, int FLY = 0, int SWZ = 0, bool PRUNE = false>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs a) {
     __shared__ double wls[WLS_SWEEP];
-    sweep_body<GAIN, DUMP, WM, HASL, SWZ, FLY>(a, blockIdx.x, wls);
+    sweep_body<GAIN, DUMP, WM, HASL, SWZ, FLY, PRUNE>(a, blockIdx.x, wls);
 }
 
 template <bool GAIN, bool DUMP, bool HASL>
@@ -572,7 +580,9 @@ void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream
         launch_sweep_w<false, false, false>(a, grid, s);
     } else if (a.fly && a.mode == 1 && !dump) {    // candidates whose records hold only [c_x | c_u | c]: tiles formed in the sweep
         const bool many = ntraj > 2048;            // more than two waves per SIMD on an MI355X: the datapath is saturated
-#define FLY_LAUNCH(W) do { if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 2>), grid, dim3(64), 0, s, a); \
+#define FLY_LAUNCH(W) do { if (a.prune && a.pb.cost_tv) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 2, 0, true>), grid, dim3(64), 0, s, a); \
+                           else if (a.prune) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1, 1, true>), grid, dim3(64), 0, s, a); \
+                           else if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 2>), grid, dim3(64), 0, s, a); \
                            else if (many) hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1, 1>), grid, dim3(64), 0, s, a); \
                            else hipLaunchKernelGGL((sweep_kernel<false, false, W, true, 1>), grid, dim3(64), 0, s, a); } while (0)
         if (a.pb.W_tv) FLY_LAUNCH(1); else if (a.pb.W_diag) FLY_LAUNCH(2); else FLY_LAUNCH(0);
@@ -2042,6 +2052,7 @@ __device__ __forceinline__ void init_state_body(const StateDev &st, const OptsDe
     st.hist_n[b] = 0;
     st.lsel[b] = 0;
     st.spec_st[b] = 0;
+    st.acc0[b] = 0;
 }
 
 // Start of the next step! (ileqg.jl:598-613) for a sample whose gain sweep has already been run speculatively:
@@ -2116,6 +2127,7 @@ __device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev
     const int hn_in = st.hist ? st.hist_n[b] : 0;
     const int fl0 = st.flag_c[c0];
     const double nv0 = st.value_c[c0], dc0 = st.d_c[c0];
+    st.acc0[b] = 0;                                            // (the next round's candidates start unpruned)
     if (!active) return;
     double eps = eps_in;
     int count = count_in, hn = hn_in;

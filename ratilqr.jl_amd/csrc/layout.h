@@ -117,6 +117,9 @@ struct StateDev {
     int *status, *iter, *ls_active, *ls_count, *slot_nom, *n_ls, *hist_n;
     double *value_c, *d_c;                     // [B*E]
     int *flag_c;                               // [B*E] 0 ok, 1 DP failed (M not PD), 2 domain failure
+    int *acc0;                                 // [B] round-based path, E > 1: 1 once candidate 0 of this round is known to be the line search's choice
+                                               // (the paired sweep that evaluates it says so): the evaluations of candidates 1 .. E-1 of the
+                                               // sample, whose results the sequential rule would then never read, stop where they are
     double *hist; int hist_cap;                // [B][2*hist_cap] or null
     int *counters;                             // [CTR_RING][2]: per round {samples still in line search, samples running}
     double *sink;                              // [SINK_SLOTS][64] write-only: idle lanes of unconditional stores (a lane-conditional store

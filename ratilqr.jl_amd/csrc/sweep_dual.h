@@ -336,13 +336,20 @@ __device__ __forceinline__ void sweep_dual_body(const SweepArgs &a, const int b,
     if (l_ == 0 && blockIdx.x < 8 && a.dump)
         for (int q = 0; q < 6; ++q) a.dump[128 + blockIdx.x * 8 + q] = (double)dg_acc[q];
 #endif
-    const double totA = 0.5 * wave_sum(raccA) + ((theta != 0.0) ? coef * (log(rprodA) + (double)rexpA * 0.6931471805599453094) : 0.0);
+    const double totA = sweep_scalars(wave_sum(raccA), coef, rprodA, rexpA, theta != 0.0);
     (void)raccB; (void)rprodB; (void)rexpB;          // B's value s_1 is not used by step! (only L, dl, mu, Delta are)
     if (l == 12) {
         const double s0 = 0.5 * vA[3] + totA;
         if (a.mode == 7) {
             st.value_c[cidx] = s0;
             st.flag_c[cidx] = failA ? 1 : 0;
+            if (a.prune) {
+                // Will line_search! settle on this candidate (ileqg.jl:538, or the forced accept of :557-558)?  Then the sequential rule never
+                // reads candidates 1 .. E-1 of this round: their evaluation waves poll this word and stop (sweep_body<.., PRUNE>).
+                const double cur = st.value[b], eps = st.ls_eps[b];
+                const bool take = !failA && (isapprox_default(s0, cur) || s0 < cur || eps * a.op.lambda < a.op.eps_min);
+                __atomic_store_n(&st.acc0[b], take ? 1 : 0, __ATOMIC_RELAXED);
+            }
         } else {
             st.value[b] = failA ? INFINITY : s0;
             if (failA) st.status[b] = 1;                      // RAT_ST_M_NOT_PD_INIT

@@ -230,6 +230,32 @@ def test_full_size_batch_properties():
     assert np.array_equal(v1, v) and np.array_equal(st1, st) and np.array_equal(ls1, ls)
 
 
+def test_pruned_speculation_gives_the_same_batch(monkeypatch):
+    """Round-based path, E > 1, tile-free candidates: candidate 0's paired wavefronts publish whether the line search will settle on it and the
+    evaluations of candidates 1 .. E-1 stop (switch prune).  The sequential rule never reads a candidate behind the one it accepts, so every
+    output is the same with the switch off, and the same as E = 1 -- on a workload whose line search backtracks (cubic drift: candidate 0 is
+    rejected for part of the samples, which then need the other candidates' values) as on the headline's."""
+    for kappa in (0.06, 0.0):
+        prob, x0, u = rat.synthetic_lq_problem(kappa=kappa)
+        B = 1024
+        theta = np.where(np.arange(B) % 2 == 0, 2.0, 5.0).astype(float) if kappa else np.abs(1.0 + 2.0 * np.random.default_rng(3).standard_normal(B))
+        theta[:3] = [0.0, 30.0, 5.9]
+        ref = rat.Context(prob, max_batch=B, spec_eps=1).solve_batch(x0, u, theta)
+        if kappa:
+            assert (ref[3] > ref[2]).any()                       # some line search really backtracked
+        for E in (8, 2):
+            ctx = rat.Context(prob, max_batch=B, spec_eps=E)
+            assert ctx.get_path(B) == "rounds" and ctx.debug_get("prune") == 1
+            got = ctx.solve_batch(x0, u, theta)
+            monkeypatch.setenv("RATILQR_PRUNE", "0")
+            off = rat.Context(prob, max_batch=B, spec_eps=E)
+            monkeypatch.delenv("RATILQR_PRUNE")
+            assert off.debug_get("prune") == 0
+            plain = off.solve_batch(x0, u, theta)
+            for a, b, c in zip(got, plain, ref):
+                assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
+
+
 def test_api_misuse_is_reported():
     prob, x0, u = rat.synthetic_lq_problem()
     ctx = rat.Context(prob, max_batch=4)
