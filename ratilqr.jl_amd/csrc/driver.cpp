@@ -932,6 +932,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
     if (path != PATH_ROUNDS) {       // the whole state machine below, per sample, inside one launch
         FusedArgs fa;
         fa.sw = sweep_args(h, st, 0);
+        fa.sw.prune = (h->prune && st.E > 1) ? 1 : 0;       // workgroup-per-sample kernel, E > 1: candidates 1 .. E-1 stop once candidate 0 is the choice
         fa.ro = ra;
         fa.max_rounds = (int)std::min<int64_t>(((int64_t)h->opd.iter_max + 1) * 4002, 2000000000);
         fa.dual = h->fused_dual ? 1 : 0;

@@ -477,6 +477,11 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
         if (a.mode == 1) {
             st.value_c[cidx] = s0;
             st.flag_c[cidx] = fail ? 1 : 0;
+            if (a.prune && k == 0) {         // (workgroup-per-sample kernel, E > 1: see sweep_dual_body, mode 7)
+                const double cur = st.value[b], eps = st.ls_eps[b];
+                const bool take = !fail && (isapprox_default(s0, cur) || s0 < cur || eps * a.op.lambda < a.op.eps_min);
+                __atomic_store_n(&st.acc0[b], take ? 1 : 0, __ATOMIC_RELAXED);
+            }
         } else if (a.mode == 2) {
             st.value[b] = fail ? INFINITY : s0;
             if (fail) st.status[b] = 1;                      // RAT_ST_M_NOT_PD_INIT
@@ -2592,6 +2597,9 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
             }
             epoch += st.N + 2;
         } else if (wave < E) {                                // candidates of this line-search round  (ileqg.jl:504-521)
+            // E > 1, speculation pruned (FusedArgs.sw.prune): candidate 0 runs ahead of the wave it shares a SIMD with; when its evaluation
+            // shows that the line search settles on it, the other candidates' evaluations stop (their results would never be read)
+            if (E > 1 && FLYB && fa.sw.prune && wave == 0) __builtin_amdgcn_s_setprio(2);
             RolloutArgs ra = fa.ro; ra.mode = 1;
             rollin_body<MODEL, 1, CTV, STG, false, ROLLIN_PREFETCH, NTB>(ra, b * E + wave, shxu, stg);
         }
@@ -2619,7 +2627,9 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         if (psw_done) {
         } else if (wave < E && !(LAZY && wave == WG)) {       // their policy evaluations  (:522-536)
             SweepArgs sa = fa.sw; sa.mode = 1;
-            sweep_body<false, false, WM, true, 0, FLYB>(sa, b * E + wave, wls);
+            if (E > 1 && FLYB && sa.prune && wave > 0) sweep_body<false, false, WM, true, 0, FLYB, (E > 1 && FLYB != 0)>(sa, b * E + wave, wls);
+            else sweep_body<false, false, WM, true, 0, FLYB>(sa, b * E + wave, wls);
+            if (E > 1 && FLYB && sa.prune && wave == 0) __builtin_amdgcn_s_setprio(0);
         } else if (wave == WG) {                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
             if ((helpers || (SPLIT && fa.acl)) && (threadIdx.x & 63) == 0) {      // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
                 st.d_c[b * E] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
