@@ -2454,8 +2454,10 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     __shared__ double stg[STG ? STG_DOUBLES : 1];
     __shared__ double xu[SPLIT ? XU_DOUBLES : 1];
     __shared__ double aclring[SPLIT ? ACL_DOUBLES : 1];
-    __shared__ int prog, pprog, lpool;
+    __shared__ int prog, pprog, lpool, rdone;
     __shared__ unsigned long long d_acc[2];
+    constexpr bool PRUNEB = (E > 1) && (FLYB != 0) && !SPLIT;      // speculation pruned (FusedArgs.sw.prune): see the line-search round below
+    int rnd = 0;                                                  // line-search rounds so far (every wave counts alike)
     // PSW2 (the two-wave geometry, LQ family, staged): the evaluation that ENDS the solve has the sample's gain wave idle beside it -- the two
     // run it time-parallel (psweep.h, P = 2: 19 + 15 ordinary steps and a hop instead of 50 steps).  Equal to rounding, switch block_psw.
     constexpr bool PSW2 = SPLIT && !CTV && (WM != 1);
@@ -2464,7 +2466,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     if (PSW2 && threadIdx.x == 0) { psh2.flag[0] = 0; psh2.flag[PSW2 ? 1 : 0] = 0; psh2.bar = 0; psh2.last_rc = 0; }
     constexpr bool HELP = SPLIT && PAD4;         // fa.helpers: the two waves a padded workgroup does not need stay as linearise helpers
     int epoch = 0;
-    if (threadIdx.x == 0) { prog = 0; pprog = 0; }
+    if (threadIdx.x == 0) { prog = 0; pprog = 0; rdone = 0; }
     double *const wls = wls_all[hwave], *const shxu = shxu_all[hwave];
     int wave = hwave;                            // role: 0 .. E-1 candidates, WG gain sweeps
     if (PAD4) {
@@ -2597,14 +2599,24 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
             }
             epoch += st.N + 2;
         } else if (wave < E) {                                // candidates of this line-search round  (ileqg.jl:504-521)
-            // E > 1, speculation pruned (FusedArgs.sw.prune): candidate 0 runs ahead of the wave it shares a SIMD with; when its evaluation
-            // shows that the line search settles on it, the other candidates' evaluations stop (their results would never be read)
-            if (E > 1 && FLYB && fa.sw.prune && wave == 0) __builtin_amdgcn_s_setprio(2);
+            // E > 1, speculation pruned (FusedArgs.sw.prune): candidate 0 runs ahead of the wave it shares a SIMD with -- no workgroup barrier
+            // between the rollouts and the evaluations: every candidate's evaluation follows its own rollout, the gain wave waits for candidate
+            // 0's alone (a word in LDS) -- and when its evaluation shows that the line search settles on it, the other candidates' evaluations
+            // stop (their results would never be read).  The last candidate (LAZY: the gain wave's) is rolled out only if the rule gets that far.
             RolloutArgs ra = fa.ro; ra.mode = 1;
-            rollin_body<MODEL, 1, CTV, STG, false, ROLLIN_PREFETCH, NTB>(ra, b * E + wave, shxu, stg);
+            if (PRUNEB && fa.sw.prune) {
+                if (wave == 0) __builtin_amdgcn_s_setprio(2);
+                if (!(LAZY && wave == WG)) rollin_body<MODEL, 1, CTV, STG, false, ROLLIN_PREFETCH, NTB>(ra, b * E + wave, shxu, stg);
+                PHASE_FENCE();                                // (the wave's own evaluation reads what it has just stored)
+                if (leader) __hip_atomic_store(&rdone, rnd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                rollin_body<MODEL, 1, CTV, STG, false, ROLLIN_PREFETCH, NTB>(ra, b * E + wave, shxu, stg);
+            }
         }
         BLK_MARK();
+        if (!(PRUNEB && fa.sw.prune))
     __syncthreads();
+        ++rnd;
     BLK_MARK();
         bool psw_done = false;
         if constexpr (PSW2) if (fa.psw_last && !helpers && wave <= 1) {
@@ -2627,10 +2639,11 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         if (psw_done) {
         } else if (wave < E && !(LAZY && wave == WG)) {       // their policy evaluations  (:522-536)
             SweepArgs sa = fa.sw; sa.mode = 1;
-            if (E > 1 && FLYB && sa.prune && wave > 0) sweep_body<false, false, WM, true, 0, FLYB, (E > 1 && FLYB != 0)>(sa, b * E + wave, wls);
+            if (PRUNEB && sa.prune && wave > 0) sweep_body<false, false, WM, true, 0, FLYB, PRUNEB>(sa, b * E + wave, wls);
             else sweep_body<false, false, WM, true, 0, FLYB>(sa, b * E + wave, wls);
-            if (E > 1 && FLYB && sa.prune && wave == 0) __builtin_amdgcn_s_setprio(0);
+            if (PRUNEB && sa.prune && wave == 0) __builtin_amdgcn_s_setprio(0);
         } else if (wave == WG) {                              // the gain wave: next step!'s sweep on candidate 0's tiles, unless accepting
+            if (PRUNEB && fa.sw.prune) { spin_until(&rdone, rnd); PHASE_FENCE(); }          // candidate 0 has been rolled out
             if ((helpers || (SPLIT && fa.acl)) && (threadIdx.x & 63) == 0) {      // d of the candidate, gathered by the linearise waves: to where the accept rule reads it
                 st.d_c[b * E] = d_acc[1] ? NAN : sqrt(__longlong_as_double((long long)d_acc[0]));
                 st.flag_c[b * E] = 0;
@@ -2651,6 +2664,11 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
         if (LAZY) {                                           // the last candidate, only if the rule gets that far (every wave reads the same words)
             if (!ls_settled_within(st, fa.sw.op, b, E - 1)) {
                 if (wave == WG) {
+                    if (PRUNEB && fa.sw.prune) {
+                        RolloutArgs ra = fa.ro; ra.mode = 1;
+                        rollin_body<MODEL, 1, CTV, STG, false, ROLLIN_PREFETCH, NTB>(ra, b * E + wave, shxu, stg);
+                        PHASE_FENCE();
+                    }
                     SweepArgs sa = fa.sw; sa.mode = 1;
                     sweep_body<false, false, WM, true, 0, FLYB>(sa, b * E + wave, wls);
                 }
