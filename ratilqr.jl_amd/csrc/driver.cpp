@@ -763,7 +763,9 @@ static rat_rc enqueue_round(rat_handle h, const StateDev &st, int round) {
         if (st.E > 1 && !prune && (rce = launch_evals(h->stream2))) return rce;
         if (prune) HIPCHK(hipEventRecord(h->ev_a, h->stream));               // (the rollouts' end, before the paired launch is enqueued behind it)
         { SweepArgs sd = sweep_args(h, st, 7); sd.fly = fly; sd.prune = prune ? 1 : 0;
-          prof_begin(h, RAT_K_SWEEP_DUAL, st.B); launch_sweep_dual(sd, st.B, h->stream); prof_end(h); }
+          prof_begin(h, RAT_K_SWEEP_DUAL, st.B);
+          if (prune) launch_sweep_cand0(sd, st.B, h->stream); else launch_sweep_dual(sd, st.B, h->stream);
+          prof_end(h); }
         if (prune) {
             HIPCHK(hipStreamWaitEvent(h->stream_lo, h->ev_a, 0));
             SweepArgs se = sweep_args(h, st, 1);

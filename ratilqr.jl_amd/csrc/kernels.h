@@ -128,6 +128,7 @@ bool solve_block_supported(int E);
 void launch_init_state(const StateDev &st, const OptsDev &op, const double *theta_dev, hipStream_t s);
 void launch_copy_initial(const StateDev &st, const double *init_x, const double *init_u, const double *init_t, hipStream_t s);   // round-based path: FusedArgs.init_* per sample
 void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream_t s);
+void launch_sweep_cand0(const SweepArgs &a, int nsamples, hipStream_t s);  // mode 7 on tile-free candidates: the paired pass, or the plain evaluation where accepting would end solve!
 void launch_sweep_dual(const SweepArgs &a, int nsamples, hipStream_t s);   // modes 6 (initialize! + first gain sweep), 7 (candidate 0 + next gain sweep)
 void launch_commit_init(const StateDev &st, hipStream_t s);
 bool rollin_notile_supported(const ProblemDev &pb, const StateDev &st);              // the speculative path can run without candidate tiles

@@ -569,6 +569,37 @@ static void launch_sweep_w(const SweepArgs &a, dim3 grid, hipStream_t s) {
     else hipLaunchKernelGGL((sweep_kernel<GAIN, DUMP, 0, HASL>), grid, dim3(64), 0, s, a);
 }
 
+// Round-based path, candidate 0 of a line-search round (tile-free candidates): the paired pass (its evaluation + the NEXT step!'s gain sweep,
+// sweep_dual_body mode 7) -- unless accepting the candidate would end solve! (d < d_tol with mu at its floor, or iter_max: ileqg.jl:642-653):
+// nothing would consume the gains, and the plain evaluation (half the instructions) runs instead, as in solve_fused_kernel.  Same values either
+// way (the recursions are independent); spec_st = 0 tells the accept rule that no gain sweep rides along.
+template <int WM, int FLY>
+__global__ __launch_bounds__(64) void sweep_cand0_kernel(SweepArgs a) {
+    __shared__ double wls[WLS_DUAL];
+    const StateDev &st = a.st;
+    const int b = blockIdx.x;
+    const int v_act = __atomic_load_n(&st.ls_active[b], __ATOMIC_RELAXED), v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
+    const double v_dc = *(const volatile double *)&st.d_c[b * st.E], v_mu = *(const volatile double *)&st.mu[b];
+    if (!__builtin_amdgcn_readfirstlane(v_act)) return;
+    const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
+    const bool ends = (a.op.d > dc && mu <= a.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == a.op.iter_max;
+    if (ends) {
+        if (threadIdx.x == 0) st.spec_st[b] = 0;
+        SweepArgs sa = a; sa.mode = 1; sa.k_first = 0;
+        sweep_body<false, false, WM, true, 1, FLY>(sa, b * st.E, wls);        // (tid = b E: candidate 0 of sample b when k_first = 0 and the launch covers E candidates)
+    } else {
+        sweep_dual_body<WM, true, FLY>(a, b, wls);
+    }
+}
+void launch_sweep_cand0(const SweepArgs &a, int nsamples, hipStream_t s) {
+    if (nsamples <= 0) return;
+    const dim3 grid(nsamples), block(64);
+#define C0_LAUNCH(W) do { if (a.pb.cost_tv) hipLaunchKernelGGL((sweep_cand0_kernel<W, 2>), grid, block, 0, s, a); \
+                          else hipLaunchKernelGGL((sweep_cand0_kernel<W, 1>), grid, block, 0, s, a); } while (0)
+    if (a.pb.W_tv) C0_LAUNCH(1); else if (a.pb.W_diag) C0_LAUNCH(2); else C0_LAUNCH(0);
+#undef C0_LAUNCH
+}
+
 void launch_sweep(const SweepArgs &a, int ntraj, bool gain, bool dump, hipStream_t s) {
     if (ntraj <= 0) return;
     dim3 grid(ntraj);
