@@ -240,7 +240,11 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
         return fail(RAT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     CREATECHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATECHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    { int lo = 0, hi = 0; CREATECHK(hipDeviceGetStreamPriorityRange(&lo, &hi)); CREATECHK(hipStreamCreateWithPriority(&h->stream_lo, hipStreamNonBlocking, lo)); }
+    // (the pruned evaluations' stream: the lowest priority the device offers; without it the switch prune stays off)
+    { int lo = 0, hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->stream_lo, hipStreamNonBlocking, lo) != hipSuccess) {
+          (void)hipGetLastError(); h->stream_lo = nullptr;
+      } }
     // (ev_a / ev_b order the handle's two streams on ONE device: no system-scope fence)
     CREATECHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming | hipEventDisableSystemFence));
     CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming | hipEventDisableSystemFence));
