@@ -14,7 +14,7 @@ O = os.path.join(ROOT, "gpurun_out", RND, "prof")
 CFG = {"fused": (1, 1024), "contract": (1, 1024), "seq128": (1, 128), "block128": (1, 128), "block256": (1, 256), "block512": (1, 512),
        "e8_1024": (8, 1024), "e8_128": (8, 128), "paired_4096": (1, 4096), "fused_4096": (1, 4096)}
 # kernel-name pattern -> the key bench.py uses (traffic_for(f"{kind}_E{E}_B{B}")); first match wins
-KINDS = [("solve_fused_kernel", "solve_fused"), ("solve_block_psw_kernel", "solve_block"), ("solve_block_kernel", "solve_block"), ("sweep_dual_kernel", "sweep_dual"),
+KINDS = [("solve_fused_kernel", "solve_fused"), ("solve_block_psw_kernel", "solve_block"), ("solve_block_kernel", "solve_block"), ("sweep_dual_kernel", "sweep_dual"), ("sweep_cand0_kernel", "sweep_cand0"),
          ("rollin_multi_kernel", "rollout_multi"), ("rollin_stage_kernel", "rollout"), ("rollin_kernel", "rollout_init"),
          ("copy_initial_kernel", "copy_initial"),
          ("sweep_kernel<false", "sweep_eval"), ("sweep_kernel<true", "sweep_gain"), ("materialize_kernel", "materialize"),
@@ -85,8 +85,8 @@ for name, (E, B) in CFG.items():
         if k in ("solve_fused", "solve_block", "solve_fused_mat"):
             alg = B * (1537256 if E == 1 else 368312 + 2 * 188864 + 2 * E * 395608)
         elif k == "sweep_eval":
-            alg = a["sweep_eval"] * B * (E - 1 if "sweep_dual" in rows else E)
-        elif k == "sweep_dual":
+            alg = a["sweep_eval"] * B * (E - 1 if ("sweep_dual" in rows or "sweep_cand0" in rows) else E)
+        elif k in ("sweep_dual", "sweep_cand0"):
             alg = (a["sweep_eval"] + a["sweep_gain"]) * B
         elif k in ("rollout", "rollout_multi"):
             alg = (a["rollout_candidate"] + a["linearise"]) * B * E
