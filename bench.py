@@ -1017,6 +1017,15 @@ def rank_main(args):
             rf["contract_frac"] = contract["frac_of_hbm_peak_on_algorithmic_bytes"]
             rf["contract_hbm_real_frac"] = contract["hbm_real_frac"]
         rf.update({k: v for k, v in flat.items() if v is not None})
+        # key ORDER: the driver's record keeps the first 24 keys of `roofline` -- the contract's six, then the scalars a
+        # reader of BENCH_rNN.json needs; the prose (`bound_is`, `traffic_source`, `frac_is`, `kernel`) goes last
+        front = ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_of_bound", "contract_solves_per_s", "contract_frac",
+                 "shard128_ms", "shard256_ms", "shard512_ms", "ce_solve_ms", "e8_solves_per_s", "e8_shard128_ms", "nm_ms_per_solve",
+                 "fp64_frac", "issue_frac", "hbm_real_frac", "avg_launch_ms", "batch4096_solves_per_s", "wide_32x32_solves_per_s",
+                 "pets_solve_ms", "contract_hbm_real_frac")
+        prose = ("kernel", "bound_is", "frac_is", "traffic_source")
+        out["roofline"] = rf = {**{k: rf[k] for k in front if k in rf}, **{k: v for k, v in rf.items() if k not in front and k not in prose},
+                                **{k: rf[k] for k in prose if k in rf}}
         if weak is not None:
             out["weak"] = weak
         if strong8 is not None:

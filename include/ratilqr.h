@@ -419,8 +419,9 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *                            -1, the default: LQ-family batches of more samples than the device has SIMDs)
  *   prune           0 / 1    round-based path, E > 1, tile-free candidates: the evaluations of candidates 1 .. E-1 of a sample stop once
  *                            candidate 0 is known to be the line search's choice (identical outputs)                      (1)
- *   wide16          0 / 1    general sizes with n <= 16, m <= 4: sweeps and rollouts of the solve kernel in registers on the
- *                            matrix pipe (wide16.h); 0 = the general LDS sweep                                           (1)
+ *   wide16          0 / 1    general sizes with 12 <= n <= 16, m <= 4 (beyond the 12 + 4 tile): sweeps and rollouts of the solve kernel in
+ *                            registers on the matrix pipe (wide16.h); 0 = the general LDS sweep.  rat_debug_get: 1 only where the
+ *                            problem set on the handle really runs that form                                              (1)
  *   init_share      0 / 1    initialize!'s rollout (independent of theta) rolled out once per (x_0, u_array) and copied   (1)
  *   materialize     0 / 1    one-wavefront-per-sample kernel, LQ family, time-invariant cost: tile records written by the
  *                            rollouts and loaded by the sweeps (SURVEY 8d's wording) instead of formed in registers      (0)
@@ -444,7 +445,8 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   psweep          0, 2..8  the batched sweep operators (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch) run the TIME-PARALLEL sweep:
  *                            that many wavefronts per trajectory over that many + 1 horizon segments (csrc/psweep.h); results agree with the
  *                            sequential sweep to rounding (not bit for bit)                                                        (0)
- *   psw_hop, psw_comp        its cost model in hundredths of a step (one hop; one element step): where the segment cuts go   (130, 125)
+ *   psw_hop, psw_hop_e, psw_comp   its cost model in hundredths of an ordinary step -- one hop of a gain sweep, one hop of an evaluation, one
+ *                            element step: where the segment cuts go                                                      (120, 140, 125)
  *   wdiag           0 / 1    diagonal time-invariant W: inv(W) folded into M^-1's operand (takes effect at the next rat_problem_set) (1) */
 rat_rc  rat_debug_set(rat_handle h, const char *key, int64_t value);
 rat_rc  rat_debug_get(rat_handle h, const char *key, int64_t *value);      /* the EFFECTIVE value on this handle */

@@ -484,7 +484,7 @@ mutable struct CrossEntropyBilevelOptimizationSolver
     h::Union{Nothing,Handle,MultiHandle}
     z::Vector{Float64}                      # the N(0,1) stream currently registered with the handle (kept alive)
     carrier::Any                            # closure problems: the carrier ILEQGSolver whose device handle runs the batched sweeps ...
-    carrier_key::Any                        # ... and the (n, m, N, batch, W identity) it was built for: one handle per solver, not one per compute_cost
+    carrier_key::Any                        # ... and the (n, m, N, batch, problem, hash of W(k), opts) it was built for: one handle per solver, not one per compute_cost
 end
 function CrossEntropyBilevelOptimizationSolver(; μ_min_ileqg=1e-6, Δ_0_ileqg=2.0, λ_ileqg=0.5, d_ileqg=1e-2, iter_max_ileqg=100,
         adaptive_ϵ_init_ileqg=false, ϵ_init_ileqg=1.0, ϵ_min_ileqg=1e-6, μ_init=1.0, σ_init=2.0, num_samples=10, num_elite=3,
@@ -1017,7 +1017,12 @@ end
 "The carrier solver of a closure problem (its device handle: stream, events, pinned buffers, B-sample state), kept on the CE solver and
 rebuilt only when the sizes, the batch or the problem object change -- not once per compute_cost call (ADVICE r04)."
 function closure_carrier!(s::CrossEntropyBilevelOptimizationSolver, problem, n::Integer, m::Integer, B::Integer)
-    key = (n, m, problem.N, B, objectid(problem))
+    # the carrier bakes in W(k) as evaluated now and s.opts (its device gain sweeps restart with mu_min / delta_0): both are part of the key,
+    # so a reassigned s.opts or a W closure that reads mutable state rebuilds it instead of running stale sweeps (ADVICE r05)
+    o = s.opts
+    wh = hash([Matrix{Float64}(problem.W(k)) for k in 0:problem.N-1])
+    key = (n, m, problem.N, B, objectid(problem), wh,
+           (o.mu_min, o.delta_0, o.lambda, o.d, o.iter_max, o.eps_init, o.eps_min, o.adaptive_eps_init))
     if s.carrier === nothing || s.carrier_key != key
         o = s.opts
         s.carrier = ILEQGSolver(carrier_problem(problem, n, m); μ_min=o.mu_min, Δ_0=o.delta_0, λ=o.lambda, d=o.d, iter_max=o.iter_max, ϵ_init=o.eps_init,

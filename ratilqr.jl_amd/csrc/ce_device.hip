@@ -371,7 +371,11 @@ __global__ __launch_bounds__(CE_T) void pets_step_kernel(double *__restrict__ mu
 void launch_pets_step(double *mu, double *Sigma, double *controls, const double *cost, long S, int ne, int N, int m, double sf, const double *zc,
                       unsigned long long seed, int it, int do_update, int do_sample, int *err, hipStream_t st) {
     const size_t lds = (size_t)N * 16 * sizeof(double);
-#define PSTEP(CT) hipLaunchKernelGGL((pets_step_kernel<CT>), dim3(1), dim3(CE_T), lds, st, mu, Sigma, controls, cost, S, ne, N, m, sf, zc, seed, it, do_update, do_sample, err)
+    // beyond 64 KB of LDS (static ~12 KB + 128 B per time step: horizons above ~400) a launch needs the attribute raised first, as
+    // launch_wide_solve does; a failure here surfaces through hipGetLastError at the caller's check like a failed launch
+#define PSTEP(CT) do { if (lds + 16 * 1024 > 64 * 1024) \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pets_step_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((pets_step_kernel<CT>), dim3(1), dim3(CE_T), lds, st, mu, Sigma, controls, cost, S, ne, N, m, sf, zc, seed, it, do_update, do_sample, err); } while (0)
     if (S <= 64) PSTEP(64); else if (S <= 128) PSTEP(128); else if (S <= 256) PSTEP(256); else if (S <= 512) PSTEP(512); else PSTEP(1024);
 #undef PSTEP
 }

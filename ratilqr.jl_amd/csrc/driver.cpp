@@ -187,7 +187,10 @@ static const DebugSwitch debug_switches[] = {
     {"fly", [](rat_handle h, int64_t v) { h->fly = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly; }},
     {"fly_multi", [](rat_handle h, int64_t v) { h->fly_multi = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly_multi; }},
     {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
-    {"wide16", [](rat_handle h, int64_t v) { h->wide16 = v != 0; }, [](rat_handle h) -> int64_t { return h->wide16; }},
+    {"wide16", [](rat_handle h, int64_t v) { h->wide16 = v != 0; }, [](rat_handle h) -> int64_t {
+         // EFFECTIVE: with a problem set, whether its solves run the register form (launch_wide_solve's own gate: 12 <= n <= 16, m <= 4)
+         if (!h->have_problem) return h->wide16;
+         return h->wide16 && h->wide && h->wpb.n >= 12 && h->wpb.n <= 16 && h->wpb.m <= 4; }},
     {"prune", [](rat_handle h, int64_t v) { h->prune = v != 0; }, [](rat_handle h) -> int64_t { return h->prune; }},
     {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
     {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
@@ -969,6 +972,14 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
             fa.psw2g = psweep_cuts(st.N, 2, h->psw_hop / 100.0, h->psw_comp / 100.0);
             fa.psw4e = psweep_cuts(st.N, 4, h->psw_hop_e / 100.0, h->psw_comp / 100.0);
             fa.psw4g = psweep_cuts(st.N, 4, h->psw_hop / 100.0, h->psw_comp / 100.0);
+            // the four-wave gain sweep and the four-wave evaluation share one PswShared (psh[2]), whose barrier counter serves teams of ONE
+            // size: the two cost models (hop 1.2 / 1.4) may settle on different team sizes at short horizons (N = 11: 3 / 2; 17, 18: 4 / 3)
+            for (int it = 0; it < PSW_MAXP && fa.psw4e.P != fa.psw4g.P; ++it) {
+                const int p = std::min(fa.psw4e.P, fa.psw4g.P);
+                fa.psw4e = psweep_cuts(st.N, p, h->psw_hop_e / 100.0, h->psw_comp / 100.0);
+                fa.psw4g = psweep_cuts(st.N, p, h->psw_hop / 100.0, h->psw_comp / 100.0);
+            }
+            if (fa.psw4e.P != fa.psw4g.P) fa.psw4e = fa.psw4g = psweep_cuts(st.N, 1, 1.0, 1.0);
         }
         // two waves per sample (up to two samples per CU): only the evaluation that ends the solve has an idle partner -- the two run it time-parallel
         fa.psw_last = (!psw && path == PATH_BLOCK && h->block_psw && h->E == 1 && fa.census && !fa.helpers && !h->materialize && st.N >= 8) ? 1 : 0;

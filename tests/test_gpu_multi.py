@@ -182,3 +182,61 @@ def test_set_path_per_handle(monkeypatch):
         assert np.array_equal(a, b)
     with pytest.raises(rat.RatError):
         rat.Context(prob, max_batch=4, spec_eps=3).set_path("block")
+
+
+def test_default_switch_shards_of_the_baseline_batch_against_the_oracle(monkeypatch):
+    """What an 8-GPU run of the BASELINE batch runs: B = 1024 over G = 8 logical devices with DEFAULT switches, so
+    every shard is a 128-sample launch of the time-parallel workgroup-per-sample kernel (block_psw on) -- through
+    rat_multi_ce_compute_cost_ex against the ORACLE (compute_cost, cross_entropy_bilevel_optimization.jl:173-195: identical status /
+    iteration / line-search counts, costs to 1e-9), and the whole rat_multi_ce_solve against the one-device run and the oracle's CE
+    solve on the same injected stream (theta_opt, mu, sigma to 1e-9; SURVEY App. B.16: a result must not depend on the sharding)."""
+    import os
+    from oracle import oracle as orc
+    monkeypatch.delenv("RATILQR_BLOCK_PSW", raising=False)
+    monkeypatch.setenv("RATILQR_MULTI_LOGICAL", "1")
+    G, B = 8, 1024
+    prob, x0, u = rat.synthetic_lq_problem()
+    mc = rat.MultiContext(prob, max_batch=B, devices=tuple(range(G)))
+    assert mc.n_devices == G and mc.is_logical
+    for i in range(G):                                                      # every shard: the time-parallel kernel, by the handle's own word
+        v = C.c_int64()
+        nv.check(nv.lib().rat_debug_get(mc.handle(i), b"block_psw", C.byref(v)))
+        assert v.value == 1
+    rng = np.random.default_rng(77)
+    theta = np.abs(1.0 + 2.0 * rng.standard_normal(B))
+    theta[5], theta[300], theta[1023] = 0.0, 70.0, 13.4                    # theta = 0, infeasible in initialize!, near the breakdown
+    cost, st, it, ls = mc.compute_cost_ex(x0, u, theta, 0.1)
+    vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=os.cpu_count() or 8)
+    assert np.array_equal(st, so) and np.array_equal(it, io) and np.array_equal(ls, lo)
+    with np.errstate(divide="ignore"):
+        co = vo + 0.1 / theta
+    fin = np.isfinite(co)
+    assert np.array_equal(fin, np.isfinite(cost)) and fin.sum() > 1000
+    assert (np.abs(cost[fin] - co[fin]) <= 1e-9 * np.abs(co[fin])).all()
+    # the same batch on ONE device (1024 samples: the one-wavefront kernel, another rounding order): to rounding
+    ctx = rat.Context(prob, max_batch=B)
+    v1, s1, i1, l1 = ctx.solve_batch(x0, u, theta)
+    assert np.array_equal(s1, st) and np.array_equal(i1, it) and np.array_equal(l1, ls)
+    with np.errstate(divide="ignore"):
+        assert (np.abs(cost[fin] - (v1 + 0.1 / theta)[fin]) <= 1e-12 * np.abs(co[fin])).all()
+    # the whole RAT iLQR solve: 8 shards vs one device vs the oracle, same injected stream
+    z = np.random.default_rng(31).standard_normal(40000)
+    kw = dict(num_samples=B, num_elite=100)
+    oc = orc.CrossEntropyBilevelOptimizationSolver(z, nthreads=os.cpu_count() or 8, **kw)
+    rc, th_o, x_o, l_o, L_o, val_o, tmin_o, tmax_o = oc.solve(orc.Problem(prob), x0, u, 0.1)
+    assert rc == 0
+    one = rat.CrossEntropyBilevelOptimizationSolver(**kw)
+    th1, x1, l1_, L1, val1, tmin1, tmax1 = ce.solve_(one, prob, x0, u, z, kl_bound=0.1)
+    c = nv.CeSolver()
+    nv.lib().rat_ce_default(C.byref(c))
+    c.num_samples, c.num_elite = B, 100
+    mc.set_stream(z)
+    n_g = mc.allgathers
+    th, x, l, L, val, tmin, tmax = mc.ce_solve(c, x0, u, 0.1)
+    assert mc.allgathers == n_g + c.n_solves // B and c.n_solves == one.c.n_solves == 5 * B
+    for a, b in ((th, th_o), (val, val_o), (c.mu, oc.c.mu), (th, th1), (val, val1), (c.mu, one.c.mu)):
+        assert abs(a - b) <= 1e-9 * abs(b)
+    assert abs(c.sigma - oc.c.sigma) <= 1e-6 * oc.c.sigma + 1e-12 and abs(c.sigma - one.c.sigma) <= 1e-6 * one.c.sigma + 1e-12
+    assert tmin == tmin_o == tmin1 and tmax == tmax_o == tmax1             # extreme samples: identical draws
+    assert c.mu_init == oc.c.mu_init == one.c.mu_init and c.sigma_init == oc.c.sigma_init
+    assert np.abs(x - x_o).max() < 1e-9 and np.abs(L - L_o).max() < 1e-9 and np.abs(l - l_o).max() < 1e-9

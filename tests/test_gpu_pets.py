@@ -218,7 +218,8 @@ def test_config5_ten_thousand_trajectories():
 
 
 @pytest.mark.parametrize("S,K,Nh,n,m,ne,use_true", [(100, 100, 30, 12, 4, 10, False), (16, 20, 15, 6, 2, 4, False), (37, 33, 30, 12, 4, 5, True),
-                                                     (1024, 4, 9, 12, 3, 100, False), (2, 7, 30, 12, 4, 2, False)])
+                                                     (1024, 4, 9, 12, 3, 100, False), (2, 7, 30, 12, 4, 2, False),
+                                                     (12, 6, 600, 6, 2, 3, False)])       # N = 600: > 64 KB of LDS in the bookkeeping launch
 def test_device_resident_solve_equals_the_host_loop(S, K, Nh, n, m, ne, use_true):
     """rat_pets_solve with the loop over control sequences on the device (ce_device.hip: pets_sample_kernel / pets_update_kernel, ONE host
     wait per solve!) against the same call with the switch pets_device = 0 (sample / update on the host between device calls,

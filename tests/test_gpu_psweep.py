@@ -19,6 +19,8 @@ WAVES = (2, 3, 4, 6, 8)
 
 
 def check(prob, x0, u, theta, waves=WAVES, mu0=None, expect_status=None, tol=1e-10):
+    """Sequential kernel and every P-wave kernel against the ORACLE on every sample (gain sweep: feasibility, mu, Delta identical, L and dl
+    to `tol`; policy evaluation: feasibility identical, value to `tol`), and the P-wave kernels against the sequential one."""
     B = len(theta)
     Pp, ap_o, ap = approx_of(prob, x0, u)
     hs = Harness(prob, B)
@@ -26,21 +28,39 @@ def check(prob, x0, u, theta, waves=WAVES, mu0=None, expect_status=None, tol=1e-
     if expect_status is not None:
         assert list(ref["st"]) == list(expect_status), ref["st"]
     okb = ref["st"] == 0
-    for b in np.nonzero(okb)[0][:4]:                                           # the sequential kernel against the oracle (a few samples)
-        rc, Lo, dlo, dpo, muo, deo = orc.dp_gain(Pp, ap_o, float(theta[b]), mu=0.0 if mu0 is None else float(mu0[b]))
-        assert rc == 0 and rel(ref["L"][b], Lo) < tol and ref["mu"][b] == muo and ref["delta"][b] == deo
+    orc_gain = [orc.dp_gain(Pp, ap_o, float(theta[b]), mu=0.0 if mu0 is None else float(mu0[b])) for b in range(B)]
+
+    def gain_vs_oracle(g, who):
+        for b, (rc, Lo, dlo, dpo, muo, deo) in enumerate(orc_gain):
+            assert (rc == 0) == bool(g["st"][b] == 0), (who, b, rc, g["st"][b])
+            if rc == 0:
+                assert g["mu"][b] == muo and g["delta"][b] == deo, (who, b)
+                assert rel(g["L"][b], Lo) < tol and rel(g["dl"][b], dlo) < tol, (who, b, rel(g["L"][b], Lo), rel(g["dl"][b], dlo))
+
+    gain_vs_oracle(ref, "seq")
     Ls = np.where(okb[:, None, None, None], 0.9 * ref["L"], 0.0)
     mu_e = np.where(okb, np.maximum(ref["mu"], 1e-6), 1e-6)
     refe = hs.evalp(ap, Ls, theta, mu_e)
+    orc_eval = [orc.dp_eval(Pp, ap_o, Ls[b], None, float(theta[b]), float(mu_e[b])) for b in range(B)]
+
+    def eval_vs_oracle(e, who):
+        for b, (rc, dpe) in enumerate(orc_eval):
+            assert (rc == 0) == bool(np.isfinite(e["val"][b])), (who, b, rc, e["val"][b])
+            if rc == 0:
+                assert abs(e["val"][b] - dpe["s"][0]) <= tol * abs(dpe["s"][0]), (who, b, e["val"][b], dpe["s"][0])
+
+    eval_vs_oracle(refe, "seq")
     for P in waves:
         g = hs.gain(ap, theta, mu=mu0, P=P)
         assert np.array_equal(g["st"], ref["st"]) and np.array_equal(g["mu"], ref["mu"]) and np.array_equal(g["delta"], ref["delta"]), (P, g["st"], ref["st"])
         if okb.any():
             assert rel(g["L"][okb], ref["L"][okb]) < tol and rel(g["dl"][okb], ref["dl"][okb]) < tol, P
+        gain_vs_oracle(g, P)
         e = hs.evalp(ap, Ls, theta, mu_e, P=P)
         assert np.array_equal(e["st"], refe["st"]), (P, e["st"], refe["st"])
         fin = np.isfinite(refe["val"])
         assert np.array_equal(fin, np.isfinite(e["val"])) and (not fin.any() or rel(e["val"][fin], refe["val"][fin]) < tol), P
+        eval_vs_oracle(e, P)
     return ref, refe
 
 
@@ -169,6 +189,21 @@ def test_block_solve_with_time_parallel_sweeps_equals_the_block_solve_and_the_or
     vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=8, **({} if opts is None else dict(iter_max=6)))
     assert np.array_equal(so, s1) and np.array_equal(io, i1) and np.array_equal(lo, l1)
     assert rel(v1[fin], vo[fin]) < 1e-9
+
+
+@pytest.mark.parametrize("N", [8, 11, 17, 18, 23])
+def test_short_horizons_where_the_cost_models_disagree_on_the_team_size(N):
+    """N = 11 (3 / 2 waves), 17 and 18 (4 / 3): the gain-sweep and the evaluation cost models of psweep_cuts settle on different team
+    sizes; the four-wave gain sweep and the four-wave evaluation share one barrier area, so the host holds them to one size (ADVICE
+    r05).  Cubic drift: four iterations per solve; every solve ends in the four-wave evaluation."""
+    prob, x0, u = rat.synthetic_lq_problem(n=6, m=2, N=N, seed=1, kappa=0.15)
+    theta = np.linspace(0.0, 4.0, 12)
+    (v0, s0, i0, l0), (v1, s1, i1, l1) = _solve_both(prob, x0, u, theta)
+    assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1), (s0, s1, i0, i1, l0, l1)
+    fin = np.isfinite(v0)
+    assert fin.sum() >= 10 and i1.max() >= 3 and np.array_equal(fin, np.isfinite(v1)) and rel(v1[fin], v0[fin]) < 1e-9
+    vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=8)
+    assert np.array_equal(so, s1) and np.array_equal(io, i1) and np.array_equal(lo, l1) and rel(v1[fin], vo[fin]) < 1e-9
 
 
 def test_two_wave_kernel_runs_the_last_evaluation_time_parallel():
