@@ -52,6 +52,8 @@ typedef int32_t rat_rc;
 #define RAT_ST_MU_DIVERGED        5  /* mu-restart loop cut                                         -> Inf */
 #define RAT_ST_SINGULAR           6  /* reserved (SingularException)                                 -> Inf */
 #define RAT_ST_LS_DIVERGED        7  /* line search cut after 4000 DP-failed candidates (App. B.5)  -> Inf */
+#define RAT_ST_INTERNAL           8  /* a hand-over between the two workgroups of a sample timed out (never
+                                        expected; reported instead of a device hang)                 -> Inf */
 
 /* ---- model families --------------------------------------------------------------------------- */
 #define RAT_MODEL_LQ        1  /* f = A x + B u + kappa x.^3 ; c_k, h quadratic (tables below)                */
@@ -442,6 +444,10 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *                            sweep TIME-PARALLEL over the sample's four SIMDs (solve_block_psw_kernel, csrc/psweep.h); status / iteration /
  *                            line-search counts as on every other path, values equal to rounding (~1e-15), not bit for bit          (1)
  *   psw_acl         0 / 1    ... its closed-loop rollouts in deviation form (3 MFMAs on the recursion's chain)                      (1)
+ *   psw_duo         0 / 1    ... with TWO workgroups (compute units) per sample while the batch leaves half the device dark (<= n_cu / 2
+ *                            samples): the policy evaluations as four-wave teams on one, every gain sweep as a four-wave team on the
+ *                            other, hand-overs through the XCD's L2 (counts identical, values to rounding: other segment cuts)         (1)
+ *   psw_duo_count   (read)   samples of this handle that have run that way so far (rat_debug_set clears it)
  *   psweep          0, 2..8  the batched sweep operators (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch) run the TIME-PARALLEL sweep:
  *                            that many wavefronts per trajectory over that many + 1 horizon segments (csrc/psweep.h); results agree with the
  *                            sequential sweep to rounding (not bit for bit)                                                        (0)

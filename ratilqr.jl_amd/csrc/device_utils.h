@@ -44,6 +44,20 @@ __device__ __forceinline__ double fast_rcp1(double p) {
     return fma(x, e, x);
 }
 
+// Loads of data ANOTHER COMPUTE UNIT may have written during this kernel (the two-workgroups-per-sample solve, kernels.hip: a partner
+// workgroup in the same XCD hands trajectories, gains and control words over through the XCD's L2).  A compute unit's vector L1 is
+// write-through but is not invalidated by another unit's stores, and the agent-scope acquire that would invalidate it (buffer_inv sc1) walks
+// the L2: 3.6 us each (tools/ubench/xwg_handoff.hip).  An agent-scope relaxed ATOMIC load carries sc1 and misses the L1 by definition --
+// a 13 KB hand-over costs ~1 us this way.  Only the translation unit of that kernel defines RAT_XC; everywhere else xld is a plain load.
+template <class T>
+__device__ __forceinline__ T xld(const T *p) {
+#ifdef RAT_XC
+    return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+
 // A per-sample index every lane loaded from the same address: telling the compiler it is wave-uniform (v_readfirstlane) moves the
 // slot / pointer arithmetic built on it, and the per-step address updates of the time loops, from the vector ALU to the scalar unit.
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

@@ -56,6 +56,9 @@ struct rat_handle_s {
     int block_mode = -1;             // workgroup-per-sample solve kernel (solve_block_kernel): -1 auto, 0 never, 1 whenever it is supported (RATILQR_BLOCK)
     int block_max_b = 512;           // auto, E = 1: used for batches up to this size (RATILQR_BLOCK_MAX_B)
     int n_cu = 256;                  // compute units of the device
+    long long *d_xw = nullptr;       // solve_block_psw_kernel, two workgroups per sample: [Bmax][XW_STRIDE] hand-over words (kernels.hip)
+    int *d_duo_count = nullptr;      // ... samples that ran as a pair so far
+    unsigned xepoch = 0;             // ... launches so far (the hand-over words carry it: nothing to clear between launches)
     int *d_census = nullptr;         // solve_block_kernel's per-CU workgroup tickets (two-wave geometry: which SIMD pair a workgroup keeps)
     bool block_shape = true;         // RATILQR_BLOCK_SHAPE=0: plain two-wave workgroups, placement left to the dispatcher
     bool block_helpers = true;       // RATILQR_BLOCK_HELPERS=0: no spare linearise waves at one workgroup per CU
@@ -125,6 +128,7 @@ struct rat_handle_s {
     int psweep = 0;                               // > 2: the batched sweep operators run the segment-parallel kernel with this many waves per trajectory
     int psw_hop = 120, psw_hop_e = 140, psw_comp = 125;   // its cost model (x 100, in ordinary steps): one hop (gain sweep / evaluation), one element step -- places the cuts
     bool psw_acl = true;                          // ... with its closed-loop rollouts in deviation form (rollacl_body: what block_acl is to solve_block_kernel)
+    bool psw_duo = true;                          // ... with two workgroups (compute units) per sample while the batch leaves half the device dark
     bool block_psw = true;                        // the workgroup-per-sample solve with time-parallel sweeps for batches of <= one sample per CU (solve_block_psw_kernel)
     uint64_t opts_serial = 0;                     // bumped by everything that can change what a solve returns without a new problem: rat_set_ileqg_opts,
                                                   // rat_debug_set, rat_set_path (the reference builds a fresh ILEQGSolver from the current options per evaluation)
@@ -202,6 +206,9 @@ static const DebugSwitch debug_switches[] = {
     {"psw_hop", [](rat_handle h, int64_t v) { h->psw_hop = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop; }},
     {"psw_hop_e", [](rat_handle h, int64_t v) { h->psw_hop_e = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop_e; }},
     {"block_psw", [](rat_handle h, int64_t v) { h->block_psw = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_psw; }},
+    {"psw_duo", [](rat_handle h, int64_t v) { h->psw_duo = (v != 0); }, [](rat_handle h) -> int64_t { return h->psw_duo; }},
+    {"psw_duo_count", [](rat_handle h, int64_t) { if (h->d_duo_count) { (void)hipStreamSynchronize(h->stream); (void)hipMemset(h->d_duo_count, 0, sizeof(int)); } },
+     [](rat_handle h) -> int64_t { int c = 0; if (h->d_duo_count) { (void)hipStreamSynchronize(h->stream); (void)hipMemcpy(&c, h->d_duo_count, sizeof(int), hipMemcpyDeviceToHost); } return c; }},
     {"psw_acl", [](rat_handle h, int64_t v) { h->psw_acl = (v != 0); }, [](rat_handle h) -> int64_t { return h->psw_acl; }},
     {"psw_comp", [](rat_handle h, int64_t v) { h->psw_comp = (int)std::max<int64_t>(100, v); }, [](rat_handle h) -> int64_t { return h->psw_comp; }},
 };
@@ -388,6 +395,8 @@ static rat_rc alloc_state(rat_handle h) {
     AL(st.status, B); AL(st.iter, B); AL(st.ls_active, B); AL(st.ls_count, B); AL(st.slot_nom, B); AL(st.n_ls, B); AL(st.hist_n, B);
     AL(st.value_c, (size_t)B * E); AL(st.d_c, (size_t)B * E); AL(st.flag_c, (size_t)B * E); AL(st.acc0, B);
     AL(st.counters, 2 * CTR_RING); AL(st.sink, (size_t)SINK_SLOTS * 64);
+    AL(h->d_xw, (size_t)B * XW_STRIDE); AL(h->d_duo_count, 1);
+    h->xepoch = 0;
     st.hist = nullptr; st.hist_cap = 0;
     AL(h->d_x0, XSTR); AL(h->d_u0, (size_t)N * USTR); AL(h->d_theta, B); AL(h->d_val, B);
     AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);
@@ -406,6 +415,8 @@ static rat_rc alloc_state(rat_handle h) {
     HIPCHK(hipMemsetAsync(st.spec_st, 0, (size_t)B * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(st.flag_c, 0, (size_t)B * E * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(st.acc0, 0, (size_t)B * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_xw, 0, (size_t)B * XW_STRIDE * sizeof(long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_duo_count, 0, sizeof(int), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return RAT_OK;
 }
@@ -413,6 +424,7 @@ static rat_rc alloc_state(rat_handle h) {
 // ---- problems beyond n <= 12, m <= 4: tables at their own size for wide.hip ---------------------------
 static rat_rc alloc_state_wide(rat_handle h) {
     free_list(h->st_allocs);
+    h->d_xw = nullptr; h->d_duo_count = nullptr;
     memset(&h->st, 0, sizeof(h->st));
     const int N = h->N, n = h->n, m = h->m, B = h->Bmax;
     h->st.B = B; h->st.E = h->E; h->st.N = N;
@@ -966,6 +978,10 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         fa.acl = h->block_acl ? 1 : 0;
         // one sample per compute unit, LQ family: the same solve with every sweep time-parallel over the sample's four SIMDs (psweep.h)
         const bool psw = path == PATH_BLOCK && h->block_psw && fa.helpers && !h->materialize && solve_block_psw_supported(fa);
+        fa.duo_stride = 0; fa.xepoch = 0; fa.xw = nullptr; fa.duo_count = nullptr;
+        if (psw && h->psw_duo && 2 * ((B + 7) & ~7) <= h->n_cu) {       // half the device would be dark: two workgroups (compute units) per sample
+            fa.duo_stride = (B + 7) & ~7; fa.xepoch = ++h->xepoch; fa.xw = h->d_xw; fa.duo_count = h->d_duo_count;
+        }
         if (psw) {
             fa.acl = (h->psw_acl || h->block_acl) ? 1 : 0;       // (this kernel's values agree with the sequential paths to rounding anyway)
             fa.psw2e = psweep_cuts(st.N, 2, h->psw_hop_e / 100.0, h->psw_comp / 100.0);

@@ -66,7 +66,14 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     // four-wave team (a sweep that has the compute unit to itself)
     PswCuts psw2e, psw2g, psw4e, psw4g;
     int psw_last;                      // solve_block_kernel, two-wave geometry: the evaluation that ends the solve by both waves, time-parallel (psw2e)
+    // solve_block_psw_kernel, two workgroups per sample (see the kernel): duo_stride = B rounded up to a multiple of 8 (0: one workgroup per
+    // sample), xw = [Bmax][XW_STRIDE] hand-over words, xepoch = this launch's number on the handle (> 0), duo_count = samples that ran as a pair
+    int duo_stride;
+    unsigned xepoch;
+    long long *xw;
+    int *duo_count;
 };
+#define XW_STRIDE 24                   /* 64-bit words per sample: [0] pair word, [8] role A's posts, [16] role B's posts (64 B apart) */
 #define CENSUS_SLOTS 4096              /* (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID / HW_REG_XCC_ID: 4 + 3 + 1 + 4 bits */
 
 struct LinArgs {

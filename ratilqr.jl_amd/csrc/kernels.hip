@@ -84,7 +84,7 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
                                           const double *__restrict__ Lp, const double *__restrict__ dlp, double mL, int g, int j,
                                           const FlyCtx *fc = nullptr, int t = 0) {
     if (FLY) {
-        tr.xj = fc->xh[(long)t * XSTR + ((j < 12) ? j : 11)];
+        tr.xj = xld(&fc->xh[(long)t * XSTR + ((j < 12) ? j : 11)]);
         if (FLY == 2) {
             const double *__restrict__ C = fc->ctab + (long)t * 256;
 #pragma unroll
@@ -98,10 +98,10 @@ __device__ __forceinline__ void load_tile(TileRegs &tr, const double *__restrict
         tr.c[0] = w2.x; tr.c[1] = w2.y; tr.c[2] = tp[r5];
         tr.c[3] = w1.y;
     }
-    tr.x = tp[TS_QR + lx];
+    tr.x = xld(&tp[TS_QR + lx]);
     tr.la = 0.0;
     if (HASL) {
-        tr.la = Lp[lq] * mL;                   // mL = 1 on lanes that hold a gain column (j < 12), else 0
+        tr.la = xld(&Lp[lq]) * mL;             // mL = 1 on lanes that hold a gain column (j < 12), else 0
         if (DUMP && dlp && j == 12) tr.la = dlp[g];      // operator form only (rat_dp_policy_eval with a dl_array)
     }
 }
@@ -129,10 +129,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
     int b, k = 0, slot, cidx = -1;
     if (a.mode == 1) { const int Ek = st.E - a.k_first; b = tid / Ek; k = a.k_first + (tid - b * Ek); } else b = tid;
     const int fidx = b * st.E + k;
-    const int v_act = st.ls_active[b], v_flag = st.flag_c[fidx], v_nom = st.slot_nom[b], v_stat = st.status[b], v_sel = st.lsel[b];
+    const int v_act = xld(&st.ls_active[b]), v_flag = xld(&st.flag_c[fidx]), v_nom = xld(&st.slot_nom[b]), v_stat = xld(&st.status[b]), v_sel = xld(&st.lsel[b]);
     const int s_act = wave_uniform(v_act), s_flag = wave_uniform(v_flag), s_nom = wave_uniform(v_nom), s_stat = wave_uniform(v_stat), sel = wave_uniform(v_sel);
-    const double theta = st.theta[b], mu_in = st.mu[b];
-    double delta = st.delta[b];
+    const double theta = xld(&st.theta[b]), mu_in = xld(&st.mu[b]);
+    double delta = xld(&st.delta[b]);
     if (a.mode == 1) {
         if (!s_act) return;
         cidx = fidx;
@@ -233,10 +233,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
             const int i = 4 * r + g;
             // (one unconditional load per register, the address selected per lane: conditional loads compile to a chain of divergent
             //  branches, each waiting for its own round trip -- 4.3 k cycles of prologue measured in the fused kernel)
-            const double te = tt[(j < 12) ? TT_Q + i * 12 + j : TT_QV + i];
+            const double te = xld(&tt[(j < 12) ? TT_Q + i * 12 + j : TT_QV + i]);
             v[r] = (j <= 12) ? te : 0.0;
         }
-        const double t3 = tt[(j < 12) ? TT_QV + j : TT_q];
+        const double t3 = xld(&tt[(j < 12) ? TT_QV + j : TT_q]);
         v[3] = (g == 0 && j <= 12) ? (j < 12 ? t3 : 2.0 * t3) : 0.0;
         racc = 0.0;
         rprod = 1.0;
@@ -495,10 +495,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
         } else {
             st.mu[b] = mu;
             st.delta[b] = delta;
-            st.iter[b] += 1;                                  // step!: iter_current += 1   (ileqg.jl:599)
+            st.iter[b] = xld(&st.iter[b]) + 1;                                  // step!: iter_current += 1   (ileqg.jl:599)
             if (fail) { st.status[b] = (fail == 1) ? 2 : 5; st.value[b] = INFINITY; }   // M_NOT_PD_GAIN / MU_DIVERGED
             else {                                            // line_search! starts at eps_init   (ileqg.jl:502)
-                st.ls_eps[b] = st.eps_init[b];
+                st.ls_eps[b] = xld(&st.eps_init[b]);
                 st.ls_count[b] = 0;
                 st.ls_active[b] = 1;
             }
@@ -1220,10 +1220,10 @@ __device__ __forceinline__ void rollin_body(const RolloutArgs &a, const int c, d
 // true when this sample takes part in the rollout phase MODE (both waves evaluate the same words: they agree)
 template <int MODE>
 __device__ __forceinline__ bool rollout_active(const StateDev &st, const int b, int &nom, int &lsel, double &eps_in) {
-    const int v_stat = st.status[b], v_act = st.ls_active[b], v_nom = st.slot_nom[b], v_lsel = st.lsel[b];
+    const int v_stat = xld(&st.status[b]), v_act = xld(&st.ls_active[b]), v_nom = xld(&st.slot_nom[b]), v_lsel = xld(&st.lsel[b]);
     const int s_stat = wave_uniform(v_stat), s_act = wave_uniform(v_act);
     nom = wave_uniform(v_nom); lsel = wave_uniform(v_lsel);
-    eps_in = st.ls_eps[b];
+    eps_in = xld(&st.ls_eps[b]);
     return (MODE == 0) ? (s_stat == ST_RUNNING) : (s_act != 0);
 }
 
@@ -1272,11 +1272,11 @@ __device__ __forceinline__ void rollrec_body(const RolloutArgs &a, const int b, 
         if (MODE == 1) {
             double tL[cL], tX[cX], tdl[cU];
 #pragma unroll
-            for (int q = 0; q < cL; ++q) { const int e = 64 * q + l; tL[q] = Lb[(e < N * LSTR) ? e : 0]; }
+            for (int q = 0; q < cL; ++q) { const int e = 64 * q + l; tL[q] = xld(&Lb[(e < N * LSTR) ? e : 0]); }
 #pragma unroll
             for (int q = 0; q < cX; ++q) { const int e = 64 * q + l; tX[q] = xbar[(e < (N + 1) * XSTR) ? e : 0]; }
 #pragma unroll
-            for (int q = 0; q < cU; ++q) { const int e = 64 * q + l; tdl[q] = dlb[(e < N * USTR) ? e : 0]; }
+            for (int q = 0; q < cU; ++q) { const int e = 64 * q + l; tdl[q] = xld(&dlb[(e < N * USTR) ? e : 0]); }
 #pragma unroll
             for (int q = 0; q < cL; ++q) sL[64 * q + l] = tL[q];
 #pragma unroll
@@ -1544,12 +1544,12 @@ __device__ __forceinline__ void stage_shared(const RolloutArgs &a, const int b, 
     const double *__restrict__ Lw = Lb + (long)part * LPER * 64;
     const int nl = (cL - part * LPER < LPER) ? cL - part * LPER : LPER;          // (wave-uniform)
 #pragma unroll
-    for (int q = 0; q < LPER; ++q) tL[q] = Lw[64 * q];
+    for (int q = 0; q < LPER; ++q) tL[q] = xld(&Lw[64 * q]);
     if (part == NP - 1) {
 #pragma unroll
         for (int q = 0; q < cX; ++q) tX[q] = xbar[64 * q];
 #pragma unroll
-        for (int q = 0; q < cU; ++q) { tl[q] = lnom[64 * q]; tdl[q] = dlb[64 * q]; }
+        for (int q = 0; q < cU; ++q) { tl[q] = lnom[64 * q]; tdl[q] = xld(&dlb[64 * q]); }
     }
     double *const sLw = sL + part * LPER * 64;
 #pragma unroll
@@ -2094,19 +2094,19 @@ __device__ __forceinline__ void init_state_body(const StateDev &st, const OptsDe
 // Start of the next step! (ileqg.jl:598-613) for a sample whose gain sweep has already been run speculatively:
 // iter += 1, adopt its gains / mu / Delta (or its failure), and enter line_search! at eps_init (:502).
 __device__ __forceinline__ bool commit_spec(const StateDev &st, int b) {
-    const int sp = st.spec_st[b];
+    const int sp = xld(&st.spec_st[b]);
     st.spec_st[b] = 0;
-    st.iter[b] += 1;                                       // :599
-    st.mu[b] = st.mu_spec[b];
-    st.delta[b] = st.delta_spec[b];
+    st.iter[b] = xld(&st.iter[b]) + 1;                     // :599
+    st.mu[b] = xld(&st.mu_spec[b]);
+    st.delta[b] = xld(&st.delta_spec[b]);
     if (sp != 1) {                                         // @assert isposdef(M) (:366) / mu-restart divergence
         st.status[b] = (sp == 2) ? 2 : 5;
         st.value[b] = INFINITY;
         st.ls_active[b] = 0;
         return false;
     }
-    st.lsel[b] ^= 1;                                       // ileqg.L_array <- L of the gain sweep (:380)
-    st.ls_eps[b] = st.eps_init[b];
+    st.lsel[b] = xld(&st.lsel[b]) ^ 1;                     // ileqg.L_array <- L of the gain sweep (:380)
+    st.ls_eps[b] = xld(&st.eps_init[b]);
     st.ls_count[b] = 0;
     st.ls_active[b] = 1;
     return true;
@@ -2114,8 +2114,8 @@ __device__ __forceinline__ bool commit_spec(const StateDev &st, int b) {
 
 // after initialize!: samples that survived the open-loop sweep start step! number 1 with the speculative gains
 __device__ __forceinline__ void commit_init_body(const StateDev &st, const int b) {
-    if (st.status[b] != ST_RUNNING) { st.spec_st[b] = 0; return; }
-    if (st.spec_st[b] != 0) commit_spec(st, b);
+    if (xld(&st.status[b]) != ST_RUNNING) { st.spec_st[b] = 0; return; }
+    if (xld(&st.spec_st[b]) != 0) commit_spec(st, b);
 }
 #if RAT_PART & PART_ROLL
 __global__ void commit_init_kernel(StateDev st) {
@@ -2156,13 +2156,13 @@ __device__ __forceinline__ bool ls_settled_within(const StateDev &st, const Opts
 __device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev &op, const int b, int *ctr) {
     // One lane runs this: every per-sample scalar it can need is fetched up front, so that the loads are in flight together (a
     // chain of a dozen dependent L2 round trips otherwise: ~10k cycles per line-search decision inside the fused solve).
-    const int active = st.ls_active[b];
+    const int active = xld(&st.ls_active[b]);
     const int c0 = b * st.E;
-    const double eps_in = st.ls_eps[b], cur = st.value[b], mu_b = st.mu[b];
-    const int count_in = st.ls_count[b], nls_in = st.n_ls[b], spec = st.spec_st[b], nom = st.slot_nom[b], iter_b = st.iter[b];
+    const double eps_in = xld(&st.ls_eps[b]), cur = xld(&st.value[b]), mu_b = xld(&st.mu[b]);
+    const int count_in = xld(&st.ls_count[b]), nls_in = xld(&st.n_ls[b]), spec = xld(&st.spec_st[b]), nom = xld(&st.slot_nom[b]), iter_b = xld(&st.iter[b]);
     const int hn_in = st.hist ? st.hist_n[b] : 0;
-    const int fl0 = st.flag_c[c0];
-    const double nv0 = st.value_c[c0], dc0 = st.d_c[c0];
+    const int fl0 = xld(&st.flag_c[c0]);
+    const double nv0 = xld(&st.value_c[c0]), dc0 = xld(&st.d_c[c0]);
     st.acc0[b] = 0;                                            // (the next round's candidates start unpruned)
     if (!active) return;
     double eps = eps_in;
@@ -2734,12 +2734,59 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
 // sequential ones to rounding (boundary values handed along the chain differ by ~1e-15), so values are NOT bit-identical to the other
 // paths -- identical status / iteration / line-search counts (tests/test_gpu_psweep.py), values to 1e-10.
 // =====================================================================================================
+// ---- two workgroups per sample ("duo"; FusedArgs.duo_stride > 0, batches of at most half a sample per CU) ----------------------------------------
+// At <= n_cu / 2 samples half the compute units are dark while every sample's gain team (two waves) is the long pole of both sweep phases.
+// The launch then carries TWO workgroups per sample, dealt so that partners land in one XCD (blocks i and i + 8 of a group of 16: workgroups go
+// to the 8 XCDs round-robin; checked at run time from HW_REG_XCC_ID) and therefore share an L2:
+//   role A (the solve)   everything solve_block_psw_kernel does except the gain sweeps; its policy evaluations as FOUR-wave teams
+//   role B (gain team)   every gain sweep of the sample as a four-wave team: initialize!'s speculative one (mode 5), the next step!'s beside
+//                        each candidate's evaluation (mode 4), the plain one after a rejected candidate (mode 0)
+// Hand-overs go through global memory: the producer's waves drain their stores (s_waitcnt vmcnt(0): the write-through L1 has delivered them to
+// the shared L2), a barrier, then ONE 64-bit word (launch epoch << 32 | sequence number) is stored; the consumer's leader polls it with
+// agent-scope relaxed loads, and every load of partner-written data is an sc1 load (xld, device_utils.h) that misses the consumer's L1.  No
+// agent-scope fence anywhere: buffer_wbl2 / buffer_inv sc1 walk the L2 (3.6 - 7 us per hand-over, tools/ubench/xwg_handoff.hip: more than
+// the second compute unit saves); this way a hand-over costs 0.5 - 2 us.
+// Co-residency is NOT assumed (an ordinary launch; hipLaunchCooperativeKernel costs +19 us): role B checks in with a CAS on the pair word and
+// role A -- dispatched earlier: workgroups start in order -- decides once, after initialize!'s copy, whether its partner is there (same XCD):
+// "duo", or "solo" = the one-workgroup schedule below, in which case a late partner leaves at once.  A resident role A never waits for a
+// partner that has not checked in, a role B only waits for a role A that is running: no deadlock whatever else shares the device.
+#define XW_EXIT 0x40000000ll
+#define XC_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+__device__ __forceinline__ long long xw_load(long long *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xw_store(long long *w, long long v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// all threads: drain, barrier, the leader posts
+__device__ __forceinline__ void xc_post(long long *w, const long long v) {
+    XC_DRAIN();
+    __syncthreads();
+    if (threadIdx.x == 0) xw_store(w, v);
+}
+// all threads: the leader polls until *w >= v (bounded: a protocol error must not hang the device), barrier; returns the word (0 on timeout)
+__device__ __forceinline__ long long xc_wait(long long *w, const long long v, long long *const bcast) {
+    if (threadIdx.x == 0) {
+        long long got = 0;
+        for (int polls = 0; polls < (1 << 22); ++polls) {
+            const long long x = xw_load(w);
+            if (x - v >= 0) { got = x; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *bcast = got;
+    }
+    __syncthreads();
+    const long long r = *bcast;
+    __syncthreads();
+    asm volatile("" ::: "memory");
+    return r;
+}
+
 template <bool CTV, int WM>
 __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     constexpr int FLYB = CTV ? 2 : 1;
-    const int b = blockIdx.x;
+    // duo launches: groups of 16 blocks = 8 samples x {role A, role B}, partners 8 blocks apart (one XCD)
+    const int role = (fa.duo_stride > 0) ? ((blockIdx.x >> 3) & 1) : 0;
+    const int b = (fa.duo_stride > 0) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const StateDev &st = fa.sw.st;
+    if (b >= st.B) return;
     __shared__ double wls_all[4][WLS_PSW];
     __shared__ double shxu_all[4][16];
     __shared__ double stg[STG_DOUBLES];
@@ -2747,6 +2794,7 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     __shared__ double aclring[ACL_DOUBLES];
     __shared__ int prog, pprog, lpool;
     __shared__ unsigned long long d_acc[2];
+    __shared__ long long xbc;                    // xc_wait's broadcast; the duo decision
     __shared__ PswShared psh[3];                 // [0] the evaluation team, [1] the gain team, [2] the four-wave team (a team's barrier counter
                                                  // stays a multiple of ITS size)
     int epoch = 0;
@@ -2756,11 +2804,55 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     double *const wls = wls_all[wave], *const shxu = shxu_all[wave];
     const bool leader = (wave == 0) && ((threadIdx.x & 63) == 0);
     const int team = wave & 1, tw = wave >> 1;          // evaluations: waves {0, 2}; gain sweeps: waves {1, 3}
+    long long *const xw = fa.xw ? fa.xw + (long)b * XW_STRIDE : nullptr;
+    const long long xep = (long long)fa.xepoch << 32;
+    int seqA = 0, seqB = 0;
+    if (role == 1) {
+        // ---- role B: check in, then every gain sweep of the sample ------------------------------------------------------------------------
+        if (threadIdx.x == 0) {
+            const long long mine = xep | 1 | ((long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 8);
+            long long code = 0;
+            for (int tries = 0; tries < 64; ++tries) {
+                long long old = xw_load(xw);
+                if ((old >> 32) == (xep >> 32)) { code = old & 0xff; break; }          // (role A was here first: solo)
+                if (__hip_atomic_compare_exchange_strong(xw, &old, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { code = 1; break; }
+            }
+            // role A is running (it was dispatched before this workgroup): its decision comes within its initialisation
+            for (int polls = 0; code == 1 && polls < (1 << 22); ++polls) {
+                const long long x = xw_load(xw);
+                if ((x & 0xff) != 1) code = x & 0xff; else __builtin_amdgcn_s_sleep(1);
+            }
+            xbc = code;
+        }
+        __syncthreads();
+        const bool duo_b = (xbc == 4);
+        __syncthreads();
+        if (!duo_b) return;
+        SweepArgs sa = fa.sw;
+        int mode = 5;                                // initialize!'s trajectory: the first step!'s gain sweep, speculatively
+        for (int guard = 0; guard <= fa.max_rounds; ++guard) {
+            sa.mode = mode;
+            psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
+            xc_post(xw + 16, xep | ++seqB);
+            while (true) {                           // role A's next post says what to sweep next
+                const long long got = xc_wait(xw + 8, xep | ++seqA, &xbc);
+                if (got == 0 || (got & XW_EXIT)) return;
+                const int v_stat = xld(&st.status[b]), v_act = xld(&st.ls_active[b]), v_it = xld(&st.iter[b]);
+                const double v_dc = xld(&st.d_c[b]), v_mu = xld(&st.mu[b]);
+                if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) return;
+                if (!__builtin_amdgcn_readfirstlane(v_act)) { mode = 0; break; }
+                const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
+                const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
+                if (!ends) { mode = 4; break; }      // (accepting would end solve!: nothing consumes a gain sweep; role A decides alone)
+            }
+        }
+        return;
+    }
 #ifdef RAT_DIAG_PHASES
     const unsigned long long dg_t0 = __builtin_readcyclecounter();
     int dg_pi = 0;
-#define BPSW_MARK() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8 && fa.sw.dump && dg_pi < 40 && wave < 2) \
-        fa.sw.dump[1024 + blockIdx.x * 80 + (wave ? 40 : 0) + dg_pi] = (double)(__builtin_readcyclecounter() - dg_t0); ++dg_pi; } while (0)
+#define BPSW_MARK() do { if ((threadIdx.x & 63) == 0 && b < 8 && fa.sw.dump && dg_pi < 40 && wave < 2) \
+        fa.sw.dump[1024 + b * 80 + (wave ? 40 : 0) + dg_pi] = (double)(__builtin_readcyclecounter() - dg_t0); ++dg_pi; } while (0)
 #else
 #define BPSW_MARK() do {} while (0)
 #endif
@@ -2780,24 +2872,59 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         __syncthreads();
         BPSW_MARK();
     }
+    bool duo = false;
+    if (fa.duo_stride > 0) {                     // is the partner there (and in this XCD)?  Decided once; the word doubles as "initialised"
+        XC_DRAIN();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const long long myx = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15);
+            long long code = 2;
+            for (int polls = 0; polls < 16; ++polls) {          // (a short bounded grace: the partner starts a few workgroups behind)
+                long long old = xw_load(xw);
+                if ((old >> 32) == (xep >> 32) && (old & 0xff) == 1) { code = (((old >> 8) & 0xff) == myx) ? 4 : 2; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (code == 2) {                                    // solo -- unless the partner checks in at this very moment
+                long long old = xw_load(xw);
+                while (true) {
+                    if ((old >> 32) == (xep >> 32) && (old & 0xff) == 1) { code = (((old >> 8) & 0xff) == myx) ? 4 : 2; break; }
+                    if (__hip_atomic_compare_exchange_strong(xw, &old, xep | 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                }
+            }
+            xw_store(xw, xep | code);
+            if (code == 4 && fa.duo_count) atomicAdd(fa.duo_count, 1);
+            xbc = code;
+        }
+        __syncthreads();
+        duo = (xbc == 4);
+        __syncthreads();
+    }
     {                                            // open-loop policy evaluation (:234) || the first step!'s gain sweep on the same trajectory
         SweepArgs sa = fa.sw;
-        if (team == 0) { sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
+        if (duo) { sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave); }
+        else if (team == 0) { sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
         else { sa.mode = 5; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[1], fa.psw2g, tw); }
     }
     BPSW_MARK();
     __syncthreads();
     BPSW_MARK();
-    if (leader) commit_init_body(st, b);
+    bool lost = false;                           // (a hand-over that timed out: a protocol error; the sample ends with status 8)
+    if (duo) lost = xc_wait(xw + 16, xep | ++seqB, &xbc) == 0;
+    if (leader && !lost) commit_init_body(st, b);
     BPSW_MARK();
     __syncthreads();
     BPSW_MARK();
-    for (int guard = 0; guard < fa.max_rounds; ++guard) {
+    for (int guard = 0; guard < fa.max_rounds && !lost; ++guard) {
         const int v_stat = __atomic_load_n(&st.status[b], __ATOMIC_RELAXED), v_act = __atomic_load_n(&st.ls_active[b], __ATOMIC_RELAXED);
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp! with no valid speculative sweep  (ileqg.jl:598-613)
-            SweepArgs sa = fa.sw; sa.mode = 0;
-            psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
+            if (duo) {
+                xc_post(xw + 8, xep | ++seqA);
+                lost = xc_wait(xw + 16, xep | ++seqB, &xbc) == 0;
+            } else {
+                SweepArgs sa = fa.sw; sa.mode = 0;
+                psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
+            }
             BPSW_MARK();
     __syncthreads();
     BPSW_MARK();
@@ -2828,6 +2955,7 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
             epoch += st.N + 2;
         }
         BPSW_MARK();
+        if (duo) XC_DRAIN();                                 // (the candidate's trajectory is about to be handed to the partner)
         __syncthreads();
         BPSW_MARK();
         // d of the candidate, gathered by the linearise waves in LDS (d_acc): to where the accept rule reads it (ordered before select by the
@@ -2840,24 +2968,30 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
         const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
         const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
+        if (duo) xc_post(xw + 8, xep | ++seqA);              // the partner reads the same words, forms the same `ends`, sweeps unless it holds
         {
             SweepArgs sa = fa.sw;
-            if (ends) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave); }
+            if (ends || duo) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave); }
             else if (team == 0) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
             else { sa.mode = 4; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[1], fa.psw2g, tw); }
         }
         BPSW_MARK();
     __syncthreads();
     BPSW_MARK();
-        if (leader) ls_select_body(st, fa.sw.op, b, nullptr);
+        if (duo && !ends) lost = xc_wait(xw + 16, xep | ++seqB, &xbc) == 0;
+        if (leader && !lost) ls_select_body(st, fa.sw.op, b, nullptr);
         BPSW_MARK();
     __syncthreads();
     BPSW_MARK();
     }
     BPSW_MARK();
+    if (duo) xc_post(xw + 8, xep | XW_EXIT | ++seqA);        // (always: the partner must not be left waiting)
     __syncthreads();
     BPSW_MARK();
-    if (leader) gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
+    if (leader) {
+        if (lost) { st.status[b] = 8; st.value[b] = INFINITY; }
+        gather_body(st, b, fa.out_value, fa.out_status, fa.out_iters, fa.out_ls, fa.out_cost, fa.kl_bound);
+    }
 }
 
 #undef BPSW_MARK
@@ -2870,7 +3004,8 @@ bool solve_block_psw_supported(const FusedArgs &fa) {
 }
 void launch_solve_block_psw(const FusedArgs &fa, hipStream_t s) {
     if (fa.sw.st.B <= 0) return;
-    const dim3 grid(fa.sw.st.B), block(256);
+    // duo (two workgroups per sample, FusedArgs.duo_stride): groups of 16 blocks = 8 samples x {role A, role B}
+    const dim3 grid(fa.duo_stride > 0 ? 2 * fa.duo_stride : fa.sw.st.B), block(256);
 #define BPSW_LAUNCH(C) do { if (fa.sw.pb.W_diag) hipLaunchKernelGGL((solve_block_psw_kernel<C, 2>), grid, block, 0, s, fa); \
                             else hipLaunchKernelGGL((solve_block_psw_kernel<C, 0>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.cost_tv) BPSW_LAUNCH(true); else BPSW_LAUNCH(false);
@@ -2954,13 +3089,13 @@ void launch_ls_select(const StateDev &st, const OptsDev &op, int slot, hipStream
 // the outputs of sample b: value (Inf for failures), status, iters, ls_evals, cost = value + kl / theta (cross_entropy...jl:193)
 __device__ __forceinline__ void gather_body(const StateDev &st, const int b, double *value, int *status, int *iters, int *ls_evals,
                                             double *cost, double kl_bound) {
-    const int s = st.status[b];
-    const double v = (s == 0 || s == 3) ? st.value[b] : INFINITY;
+    const int s = xld(&st.status[b]);
+    const double v = (s == 0 || s == 3) ? xld(&st.value[b]) : INFINITY;
     if (value) value[b] = v;
     if (status) status[b] = s;
-    if (iters) iters[b] = st.iter[b];
-    if (ls_evals) ls_evals[b] = st.n_ls[b];
-    if (cost) cost[b] = v + kl_bound / st.theta[b];
+    if (iters) iters[b] = xld(&st.iter[b]);
+    if (ls_evals) ls_evals[b] = xld(&st.n_ls[b]);
+    if (cost) cost[b] = v + kl_bound / xld(&st.theta[b]);
 }
 #if RAT_PART & PART_ROLL
 __global__ void gather_kernel(StateDev st, double *value, int *status, int *iters, int *ls_evals, double *cost, double kl_bound) {

@@ -74,10 +74,10 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     int b, k = 0, slot, cidx = -1;
     if (a.mode == 1) { const int Ek = st.E - a.k_first; b = tid / Ek; k = a.k_first + (tid - b * Ek); } else b = tid;
     const int fidx = b * st.E + k;
-    const int v_act = st.ls_active[b], v_flag = st.flag_c[fidx], v_nom = st.slot_nom[b], v_stat = st.status[b], v_sel = st.lsel[b];
+    const int v_act = xld(&st.ls_active[b]), v_flag = xld(&st.flag_c[fidx]), v_nom = xld(&st.slot_nom[b]), v_stat = xld(&st.status[b]), v_sel = xld(&st.lsel[b]);
     const int s_act = wave_uniform(v_act), s_flag = wave_uniform(v_flag), s_nom = wave_uniform(v_nom), s_stat = wave_uniform(v_stat), sel = wave_uniform(v_sel);
-    const double theta = st.theta[b], mu_in = st.mu[b];
-    double delta = st.delta[b];
+    const double theta = xld(&st.theta[b]), mu_in = xld(&st.mu[b]);
+    double delta = xld(&st.delta[b]);
     // (the same words decide for every wave of the workgroup: they leave together)
     if (a.mode == 1) {
         if (!s_act) return;
@@ -386,10 +386,10 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int i = 4 * r + g;
-                const double te = tt[(j < 12) ? TT_Q + i * 12 + j : TT_QV + i];
+                const double te = xld(&tt[(j < 12) ? TT_Q + i * 12 + j : TT_QV + i]);
                 v[r] = (j <= 12) ? te : 0.0;
             }
-            const double t3 = tt[(j < 12) ? TT_QV + j : TT_q];
+            const double t3 = xld(&tt[(j < 12) ? TT_QV + j : TT_q]);
             v[3] = (g == 0 && j <= 12) ? (j < 12 ? t3 : 2.0 * t3) : 0.0;
             thi = N; tlo = pc.cut[P - 1]; tmid = pc.cut[P];
         } else {
@@ -542,10 +542,10 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
         } else {
             st.mu[b] = mu;
             st.delta[b] = delta;
-            st.iter[b] += 1;
+            st.iter[b] = xld(&st.iter[b]) + 1;
             if (fail) { st.status[b] = (fail == 1) ? 2 : 5; st.value[b] = INFINITY; }
             else {
-                st.ls_eps[b] = st.eps_init[b];
+                st.ls_eps[b] = xld(&st.eps_init[b]);
                 st.ls_count[b] = 0;
                 st.ls_active[b] = 1;
             }

@@ -110,7 +110,7 @@ def test_time_varying_noise_covariance():
     prob = rat.LQRiskSensitiveProblem(A, B, Q=spd(n, 1.0), R=spd(m, 0.2), N=N, W=W, Qf=spd(n, 1.0), kappa=0.02)
     u = 0.1 * rng.standard_normal((N, m))
     check(prob, x0, u, np.array([0.2, 1.0, 3.0, 8.0]))
-    (v0, s0, i0, l0), (v1, s1, i1, l1) = _solve_both(prob, x0, u, np.array([0.0, 0.5, 2.0, 6.0, 400.0]))
+    (v0, s0, i0, l0), (v1, s1, i1, l1) = _solve_both(prob, x0, u, np.array([0.0, 0.5, 2.0, 6.0, 400.0]), psw_kernel=False)
     assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1)
     fin = np.isfinite(v0)
     assert np.array_equal(fin, np.isfinite(v1)) and rel(v1[fin], v0[fin]) < 1e-9
@@ -145,17 +145,28 @@ def test_no_state_cost_falls_back_to_the_sequential_sweep():
         assert np.array_equal(g["st"], ref["st"]) and np.array_equal(g["L"], ref["L"]) and np.array_equal(g["dl"], ref["dl"])
 
 
-def _solve_both(prob, x0, u, theta, opts=None, **kw):
+def _solve_both(prob, x0, u, theta, opts=None, psw_kernel=True, **kw):
+    """(sequential-sweep kernel, time-parallel kernel as it runs by default); for batches that leave half the device dark the default is TWO
+    workgroups per sample (switch psw_duo): the one-workgroup schedule (psw_duo = 0) is held to the same bar on the way."""
     out = []
-    for psw in (0, 1):
+    for psw, duo in ((0, 0), (1, 0), (1, 1)):
         ctx = rat.Context(prob, opts, max_batch=len(theta), spec_eps=1, **kw)
         ctx.debug_set("block_psw", psw)
+        ctx.debug_set("psw_duo", duo)
         ctx.profile(True)
         val, st, it, ls = ctx.solve_batch(x0, u, theta)
         kinds = [k for k, v in ctx.profile_get().items() if v["launches"]]
         assert kinds == ["solve_block"], kinds
+        if psw and duo and psw_kernel and len(theta) <= 128 and prob.N >= 8:
+            assert ctx.debug_get("psw_duo_count") == len(theta)              # (an idle device: every sample found its partner workgroup)
+        else:
+            assert ctx.debug_get("psw_duo_count") == 0
         out.append((val, st, it, ls))
-    return out
+    (v0, s0, i0, l0), (v1, s1, i1, l1), (v2, s2, i2, l2) = out
+    assert np.array_equal(s1, s2) and np.array_equal(i1, i2) and np.array_equal(l1, l2), (s1, s2, i1, i2, l1, l2)
+    fin = np.isfinite(v1)
+    assert np.array_equal(fin, np.isfinite(v2)) and (not fin.any() or rel(v2[fin], v1[fin]) < 1e-10)
+    return out[0], out[2]
 
 
 @pytest.mark.parametrize("case", ["lq", "cubic", "small", "indefinite", "short"])
