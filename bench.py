@@ -621,10 +621,16 @@ def rank_main(args):
         k8 = next((k for k in ("solve_fused", "solve_block") if p8all[k]["launches"] > 0), "sweep_eval")
         p8 = p8all[k8]
         a = algo_bytes()
-        # algorithmic bytes of the E = 8 batch: every line-search round evaluates 8 candidates per sample (7.08 MB/solve)
+        # spec_eps is an UPPER BOUND on the speculation width (include/ratilqr.h): by default the handle runs the sequential rule, so the
+        # candidates EVALUATED -- what the byte model prices (a fraction above 1 means the timed kernels are not doing
+        # the priced work) -- are the E = 1 solve's.  Under spec_force every line-search round evaluates 8 candidates per sample
+        # (7.08 MB/solve), minus the evaluations the pruning stops -- that leg is reported below without a byte-model fraction.
+        width8 = int(ctx8.debug_get("spec_width"))
         rounds = float(np.sum(np.ceil(ls_h / 1.0)))          # E = 1 accepted-candidate count = number of rounds on this workload
-        bytes8 = float(B) * a["init"] + float(np.sum(it_h)) * a["sweep_gain"] + 8.0 * rounds * a["candidate"]
-        second = {"spec_eps": 8, "value": B * K8 / e8, "unit": "solves/s", "ms_per_step": e8 / K8 * 1e3, "steps": K8,
+        bytes8 = float(B) * a["init"] + float(np.sum(it_h)) * a["sweep_gain"] + float(width8) * rounds * a["candidate"]
+        second = {"spec_eps": 8, "spec_width_run": width8,
+                  "policy": "spec_eps is an upper bound: the sequential line-search rule on the E = 1 kernels unless spec_force (identical results)",
+                  "value": B * K8 / e8, "unit": "solves/s", "ms_per_step": e8 / K8 * 1e3, "steps": K8,
                   "values_identical_to_primary": bool(torch.equal(v8, value)),
                   "algorithmic_GBps": bytes8 * K8 / e8 / 1e9, "algorithmic_bytes_per_solve": bytes8 / B,
                   "kernel_ms_per_step": {k: v["ms"] / K8 for k, v in p8all.items() if v["launches"]},
@@ -644,6 +650,19 @@ def rank_main(args):
                               "issue_frac_sweep_eval": (sq_for(f"sweep_eval_E8_B{B}") or {}).get("issue_frac")}
         second["hbm_traffic_per_batch"] = tb8
         second["hbm_traffic_per_solve"] = tb8 / B if tb8 else None
+        # the same handle forced to its requested width (the speculative kernels: round-based path, pruned): for the record
+        ctx8.debug_set("spec_force", 1)
+        ctx8.set_initial(x0, u0)
+        for _ in range(3):
+            ctx8.solve_batch_dev(theta.data_ptr(), B, v8.data_ptr())
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        for _ in range(K8):
+            ctx8.solve_batch_dev(theta.data_ptr(), B, v8.data_ptr())
+        torch.cuda.synchronize()
+        e8f = time.perf_counter() - t8
+        second["forced_width"] = {"spec_width_run": int(ctx8.debug_get("spec_width")), "path": ctx8.get_path(B), "value": B * K8 / e8f, "unit": "solves/s",
+                                  "ms_per_step": e8f / K8 * 1e3, "values_identical_to_primary": bool(torch.equal(v8, value))}
         del ctx8
 
     if world == 1 and not args.no_second:
@@ -769,8 +788,20 @@ def rank_main(args):
             c8s.compute_cost_enqueue(th8.data_ptr(), 128, 0.1, co8.data_ptr())
         torch.cuda.synchronize()
         e8s = (time.perf_counter() - t8s) / K8s
-        e8_shard = {"what": "config 3's per-GPU shard at 8 GPUs: 128 samples x 8 speculative step sizes", "ms_per_batch": e8s * 1e3, "steps": K8s,
-                    "path": c8s.get_path(128), "costs_identical_to_primary": bool(torch.equal(co8, w.cost[:128]))}
+        e8_shard = {"what": "config 3's per-GPU shard at 8 GPUs: 128 samples, handle created with 8 speculative step sizes (an upper bound: the "
+                            "sequential rule runs unless spec_force)", "spec_width_run": int(c8s.debug_get("spec_width")), "ms_per_batch": e8s * 1e3, "steps": K8s,
+                    "path": c8s.get_path(128), "costs_identical_to_primary": bool(torch.equal(co8, w.cost[:128])),
+                    "costs_match_primary_1e-12": bool(torch.allclose(co8, w.cost[:128], rtol=1e-12, atol=0.0))}
+        c8s.debug_set("spec_force", 1)                        # the speculative workgroup-per-sample kernel (E = 8 in one launch), for the record
+        c8s.set_initial(x0, u0)
+        for _ in range(3):
+            c8s.compute_cost_dev(th8.data_ptr(), 128, 0.1, co8.data_ptr())
+        torch.cuda.synchronize()
+        t8s = time.perf_counter()
+        for _ in range(K8s):
+            c8s.compute_cost_enqueue(th8.data_ptr(), 128, 0.1, co8.data_ptr())
+        torch.cuda.synchronize()
+        e8_shard["forced_width_ms_per_batch"] = (time.perf_counter() - t8s) / K8s * 1e3
         del c8s
 
     shard_lat = pets_sec = nm_sec = wide_sec = None
@@ -988,7 +1019,9 @@ def rank_main(args):
         flat = {
             "contract_solves_per_s": contract["value"] if contract else None,
             "e8_solves_per_s": second["value"] if second else None,
+            "e8_forced_solves_per_s": second["forced_width"]["value"] if second else None,
             "e8_shard128_ms": e8_shard["ms_per_batch"] if e8_shard else None,
+            "e8_forced_shard128_ms": e8_shard["forced_width_ms_per_batch"] if e8_shard else None,
             "nonlinear_solves_per_s": nonlin["value"] if nonlin else None,
             "shard512_ms": shard_lat["512"]["ms_per_batch"] if shard_lat else None,
             "shard256_ms": shard_lat["256"]["ms_per_batch"] if shard_lat else None,

@@ -98,8 +98,11 @@ void        rat_default_ileqg_opts(rat_ileqg_opts *o);                      /* d
 
 /* Create a solver context on HIP device `device`.
  *   max_batch : largest number of theta-samples one batch call will carry (device buffers are sized once)
- *   spec_eps  : E >= 1, number of line-search step sizes eps_k = eps*lambda^k evaluated speculatively
- *               per (sample, iteration); results are identical for every E.
+ *   spec_eps  : E >= 1, the LARGEST number of line-search step sizes eps_k = eps*lambda^k the library may evaluate
+ *               speculatively per (sample, iteration); results are identical for every E.
+ *               Speculation only pays where SIMDs would otherwise idle; on this device the sequential rule (E = 1) is at
+ *               least as fast at every batch size, so a handle runs E = 1 unless the switch
+ *               spec_force = 1 (rat_debug_set / RATILQR_SPEC_FORCE) asks for the requested width (the E > 1 kernels).
  * Replaces the ILEQGSolver constructor (ileqg.jl:191-208); option ranges are validated as its @asserts. */
 rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int32_t spec_eps, int32_t device, rat_handle *out);
 void   rat_destroy(rat_handle h);
@@ -419,6 +422,9 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   fused_dual      0 / 1    policy evaluation + following gain sweep as two recursions of one wavefront                 (1)
  *   fused_occ2      B0       batches of >= B0 samples: the 256-register one-recursion kernel, two samples per SIMD       (0 = never;
  *                            -1, the default: LQ-family batches of more samples than the device has SIMDs)
+ *   spec_force      0 / 1    run the speculation width rat_create was given (kernels for E = 2, 4, 8 in one launch, any E on the
+ *                            round-based path) instead of the sequential rule; re-lays the handle's state like `fused`         (0)
+ *   spec_width      (read)   the width the handle runs: 1, or rat_create's spec_eps under spec_force
  *   prune           0 / 1    round-based path, E > 1, tile-free candidates: the evaluations of candidates 1 .. E-1 of a sample stop once
  *                            candidate 0 is known to be the line search's choice (identical outputs)                      (1)
  *   wide16          0 / 1    general sizes with 12 <= n <= 16, m <= 4 (beyond the 12 + 4 tile): sweeps and rollouts of the solve kernel in

@@ -128,6 +128,8 @@ struct rat_handle_s {
     int psweep = 0;                               // > 2: the batched sweep operators run the segment-parallel kernel with this many waves per trajectory
     int psw_hop = 120, psw_hop_e = 140, psw_comp = 125;   // its cost model (x 100, in ordinary steps): one hop (gain sweep / evaluation), one element step -- places the cuts
     bool psw_acl = true;                          // ... with its closed-loop rollouts in deviation form (rollacl_body: what block_acl is to solve_block_kernel)
+    int E_req = 1;                                // the speculation width the caller asked for (rat_create's spec_eps); E is what the handle runs
+    bool spec_force = false;                      // switch spec_force: run E_req speculative candidates per line-search round (the E > 1 kernels)
     bool psw_duo = true;                          // ... with two workgroups (compute units) per sample while the batch leaves half the device dark
     bool block_psw = true;                        // the workgroup-per-sample solve with time-parallel sweeps for batches of <= one sample per CU (solve_block_psw_kernel)
     uint64_t opts_serial = 0;                     // bumped by everything that can change what a solve returns without a new problem: rat_set_ileqg_opts,
@@ -205,6 +207,8 @@ static const DebugSwitch debug_switches[] = {
     {"psweep", [](rat_handle h, int64_t v) { h->psweep = (v < 2 || v > PSW_MAXP) ? 0 : (int)v; }, [](rat_handle h) -> int64_t { return h->psweep; }},
     {"psw_hop", [](rat_handle h, int64_t v) { h->psw_hop = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop; }},
     {"psw_hop_e", [](rat_handle h, int64_t v) { h->psw_hop_e = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop_e; }},
+    {"spec_force", [](rat_handle h, int64_t v) { h->spec_force = (v != 0); }, [](rat_handle h) -> int64_t { return h->spec_force; }},
+    {"spec_width", [](rat_handle, int64_t) {}, [](rat_handle h) -> int64_t { return h->E; }},
     {"block_psw", [](rat_handle h, int64_t v) { h->block_psw = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_psw; }},
     {"psw_duo", [](rat_handle h, int64_t v) { h->psw_duo = (v != 0); }, [](rat_handle h) -> int64_t { return h->psw_duo; }},
     {"psw_duo_count", [](rat_handle h, int64_t) { if (h->d_duo_count) { (void)hipStreamSynchronize(h->stream); (void)hipMemset(h->d_duo_count, 0, sizeof(int)); } },
@@ -214,6 +218,12 @@ static const DebugSwitch debug_switches[] = {
 };
 // what the requests amount to on this handle (speculation width, forced pairings)
 static void finish_switches(rat_handle h) {
+    // spec_eps is an UPPER BOUND on the speculation width: evaluating line-search candidates ahead of the sequential rule
+    // is result-identical and pays only where SIMDs would otherwise idle -- and since the time-parallel sweeps (round 5) and the second
+    // compute unit per sample (round 6) the sequential rule is at least as fast at every batch size measured on this device (DESIGN.md
+    // section 3).  So a handle runs its samples with E = 1 unless the switch spec_force asks for the requested width.
+    h->E = (h->spec_force || h->E_req < 1) ? std::max(h->E_req, 1) : 1;
+    if (!h->dual_forced) h->dual = h->E > 1;     // E > 1: candidate 0 in paired wavefronts beside the other candidates' evaluation (+3.5 % at E = 8)
     h->fused = h->fused_req && !(h->speculate || h->dual || h->E != 1);
     h->block_mode = h->rounds_only ? 0 : h->block_req;       // fused = 0 is "the round-based path": no single-launch solve at all
 }
@@ -241,7 +251,7 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     if (device < 0 || device >= ndev) return fail(RAT_ERR_ARG, "rat_create: bad device index");
     HIPCHK(hipSetDevice(device));
     rat_handle h = new rat_handle_s();
-    h->device = device; h->opts = o; h->Bmax = max_batch; h->E = spec_eps;
+    h->device = device; h->opts = o; h->Bmax = max_batch; h->E_req = spec_eps; h->E = spec_eps;
     set_opd(h);
     memset(&h->st, 0, sizeof(h->st));
     memset(&h->pb, 0, sizeof(h->pb));
@@ -258,7 +268,6 @@ extern "C" rat_rc rat_create(const rat_ileqg_opts *opts, int32_t max_batch, int3
     // (ev_a / ev_b order the handle's two streams on ONE device: no system-scope fence)
     CREATECHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming | hipEventDisableSystemFence));
     CREATECHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming | hipEventDisableSystemFence));
-    h->dual = spec_eps > 1;          // E > 1: candidate 0 in paired wavefronts beside the other candidates' evaluation (+3.5 % at E = 8)
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     // E = 1 batches beyond one sample per SIMD: two samples per SIMD in 256 registers each, one recursion per pass (solve_fused_kernel<.., OCC2>).
     // Tile-free like the paired kernel since round 5 (its rollouts fetch their operands step by step, the sweeps form their tiles from x_t): no
@@ -415,6 +424,7 @@ static rat_rc alloc_state(rat_handle h) {
     HIPCHK(hipMemsetAsync(st.spec_st, 0, (size_t)B * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(st.flag_c, 0, (size_t)B * E * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(st.acc0, 0, (size_t)B * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_dump, 0, (size_t)(N + 1) * DUMP_STRIDE * sizeof(double), h->stream));      // (diagnostic builds count into it)
     HIPCHK(hipMemsetAsync(h->d_xw, 0, (size_t)B * XW_STRIDE * sizeof(long long), h->stream));
     HIPCHK(hipMemsetAsync(h->d_duo_count, 0, sizeof(int), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -862,8 +872,9 @@ extern "C" int32_t rat_get_path(rat_handle h, int64_t B) {
 // handle between them re-lays its state, so the initial trajectory has to be given again (rat_set_initial; the batch entry points that
 // take x0 / u0 do it themselves).
 static rat_rc alloc_state(rat_handle h);
-static rat_rc relayout_if_needed(rat_handle h, bool was_alias) {
-    if (h->have_problem && !h->wide && was_alias != h->fused) {      // re-laid only when the aliasing mode really changes
+static rat_rc relayout_if_needed(rat_handle h, bool was_alias, int was_E = -1) {
+    if (was_E < 0) was_E = h->E;
+    if (h->have_problem && !h->wide && (was_alias != h->fused || was_E != h->E)) {      // re-laid only when the aliasing mode or the speculation width really changes
         rat_rc rc = alloc_state(h);
         if (rc) return rc;
         h->have_initial = false; h->init_traj_valid = false; h->x0_host.clear(); h->u0_host.clear();
@@ -894,13 +905,16 @@ extern "C" rat_rc rat_debug_set(rat_handle h, const char *key, int64_t value) {
     for (const DebugSwitch &sw : debug_switches)
         if (!strcmp(sw.key, key)) {
             const bool was_alias = h->st.tile_alias != 0;
+            const int was_E = h->E;
             sw.set(h, value);
             h->opts_serial++;
             finish_switches(h);
             if (h->path_fixed != RAT_PATH_AUTO) {            // a fixed path keeps what rat_set_path derived
                 if (h->E == 1 && !h->speculate && !h->dual) h->fused = (h->path_fixed != RAT_PATH_ROUNDS);
             }
-            return relayout_if_needed(h, was_alias);
+            if (h->E != was_E && h->path_fixed != RAT_PATH_AUTO && !(h->path_fixed == RAT_PATH_ROUNDS || (h->path_fixed == RAT_PATH_FUSED ? h->E == 1 : solve_block_supported(h->E))))
+                h->path_fixed = RAT_PATH_AUTO;                 // (a fixed path that the new width has no kernel for)
+            return relayout_if_needed(h, was_alias, was_E);
         }
     return fail(RAT_ERR_ARG, std::string("rat_debug_set: unknown switch ") + key);
 }

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64 * MAXP) void psweep_kernel(SweepArgs a, PswCuts 
     __shared__ PswShared sh;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < PSW_MAXP) sh.flag[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { sh.bar = 0; sh.last_rc = 0; }
+    if (threadIdx.x == 0) { sh.bar = 0; sh.last_rc = 0; sh.lastP = 0; }
     __syncthreads();
     psweep_body<GAIN, WM, HASL, FLY>(a, blockIdx.x, wls[wave], &sh, pc, wave);
 }
@@ -2494,7 +2494,7 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
     constexpr bool PSW2 = SPLIT && !CTV && (WM != 1);
     __shared__ PswSharedT<PSW2 ? 2 : 1> psh2;
     __shared__ double wls_psw[PSW2 ? 2 : 1][PSW2 ? WLS_PSW : 1];
-    if (PSW2 && threadIdx.x == 0) { psh2.flag[0] = 0; psh2.flag[PSW2 ? 1 : 0] = 0; psh2.bar = 0; psh2.last_rc = 0; }
+    if (PSW2 && threadIdx.x == 0) { psh2.flag[0] = 0; psh2.flag[PSW2 ? 1 : 0] = 0; psh2.bar = 0; psh2.last_rc = 0; psh2.lastP = 0; }
     constexpr bool HELP = SPLIT && PAD4;         // fa.helpers: the two waves a padded workgroup does not need stay as linearise helpers
     int epoch = 0;
     if (threadIdx.x == 0) { prog = 0; pprog = 0; rdone = 0; }
@@ -2800,15 +2800,24 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     int epoch = 0;
     if (threadIdx.x == 0) { prog = 0; pprog = 0; }
     if (threadIdx.x < 3 * PSW_MAXP) psh[threadIdx.x / PSW_MAXP].flag[threadIdx.x % PSW_MAXP] = 0;
-    if (threadIdx.x < 3) { psh[threadIdx.x].bar = 0; psh[threadIdx.x].last_rc = 0; }
+    if (threadIdx.x < 3) { psh[threadIdx.x].bar = 0; psh[threadIdx.x].last_rc = 0; psh[threadIdx.x].lastP = 0; }
     double *const wls = wls_all[wave], *const shxu = shxu_all[wave];
     const bool leader = (wave == 0) && ((threadIdx.x & 63) == 0);
     const int team = wave & 1, tw = wave >> 1;          // evaluations: waves {0, 2}; gain sweeps: waves {1, 3}
     long long *const xw = fa.xw ? fa.xw + (long)b * XW_STRIDE : nullptr;
     const long long xep = (long long)fa.xepoch << 32;
     int seqA = 0, seqB = 0;
+#ifdef RAT_DIAG_PHASES
+    int dg_pi = 0;
+    // (role A: waves 0 and 1 at every barrier; role B: wave 0 around its check-in, sweeps and waits, in the area behind role A's)
+#define BPSW_MARK() do { if ((threadIdx.x & 63) == 0 && b < 8 && fa.sw.dump && dg_pi < 40 && wave < 2) \
+        fa.sw.dump[1024 + role * 640 + b * 80 + (wave ? 40 : 0) + dg_pi] = (double)(__builtin_amdgcn_s_memrealtime()); ++dg_pi; } while (0)
+#else
+#define BPSW_MARK() do {} while (0)
+#endif
     if (role == 1) {
         // ---- role B: check in, then every gain sweep of the sample ------------------------------------------------------------------------
+        BPSW_MARK();
         if (threadIdx.x == 0) {
             const long long mine = xep | 1 | ((long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 8);
             long long code = 0;
@@ -2828,14 +2837,17 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         const bool duo_b = (xbc == 4);
         __syncthreads();
         if (!duo_b) return;
+        BPSW_MARK();
         SweepArgs sa = fa.sw;
         int mode = 5;                                // initialize!'s trajectory: the first step!'s gain sweep, speculatively
         for (int guard = 0; guard <= fa.max_rounds; ++guard) {
             sa.mode = mode;
             psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
+            BPSW_MARK();
             xc_post(xw + 16, xep | ++seqB);
             while (true) {                           // role A's next post says what to sweep next
                 const long long got = xc_wait(xw + 8, xep | ++seqA, &xbc);
+                BPSW_MARK();
                 if (got == 0 || (got & XW_EXIT)) return;
                 const int v_stat = xld(&st.status[b]), v_act = xld(&st.ls_active[b]), v_it = xld(&st.iter[b]);
                 const double v_dc = xld(&st.d_c[b]), v_mu = xld(&st.mu[b]);
@@ -2848,14 +2860,6 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         }
         return;
     }
-#ifdef RAT_DIAG_PHASES
-    const unsigned long long dg_t0 = __builtin_readcyclecounter();
-    int dg_pi = 0;
-#define BPSW_MARK() do { if ((threadIdx.x & 63) == 0 && b < 8 && fa.sw.dump && dg_pi < 40 && wave < 2) \
-        fa.sw.dump[1024 + b * 80 + (wave ? 40 : 0) + dg_pi] = (double)(__builtin_readcyclecounter() - dg_t0); ++dg_pi; } while (0)
-#else
-#define BPSW_MARK() do {} while (0)
-#endif
     if (leader) init_state_body(st, fa.sw.op, fa.theta_in, b);
     if (fa.init_x) {                             // initialize!'s rollout was run once for the whole batch (FusedArgs.init_*): copied by another
         if (wave == 1) copy_initial(st, fa.init_x, fa.init_u, fa.init_t, b);          // wave while the leader writes the sample's control words
@@ -2910,6 +2914,7 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     BPSW_MARK();
     bool lost = false;                           // (a hand-over that timed out: a protocol error; the sample ends with status 8)
     if (duo) lost = xc_wait(xw + 16, xep | ++seqB, &xbc) == 0;
+    BPSW_MARK();
     if (leader && !lost) commit_init_body(st, b);
     BPSW_MARK();
     __syncthreads();
@@ -2979,6 +2984,7 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     __syncthreads();
     BPSW_MARK();
         if (duo && !ends) lost = xc_wait(xw + 16, xep | ++seqB, &xbc) == 0;
+        BPSW_MARK();
         if (leader && !lost) ls_select_body(st, fa.sw.op, b, nullptr);
         BPSW_MARK();
     __syncthreads();

@@ -38,6 +38,7 @@ struct PswSharedT {
     int hnotpd;                            // gain sweeps: H not PD in an ordinary step (mu restart)
     int last_rc;                           // (attempt << 2) | what ended the LAST segment's recursion early (1 M not PD, 2 H not PD): definite,
                                            // the sequential sweep meets it first; the other waves skip the rest of the attempt
+    int lastP;                             // diagnostic builds: the team size of the previous call on this area (0: none yet)
 };
 using PswShared = PswSharedT<PSW_MAXP>;
 
@@ -355,6 +356,15 @@ __device__ __forceinline__ void psweep_body(const SweepArgs &a, const int tid, d
     // Team barrier of the P waves (LDS counter; no s_barrier: inside solve_block_kernel two teams run different sweeps side by side).
     // sh->bar is a multiple of P whenever no wave of the team is inside this body: a PswShared serves teams of ONE size.
     int gen = wave_uniform(__hip_atomic_load(&sh->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) / P;
+#ifdef RAT_DIAG_PHASES
+    // diagnostic build: the invariant's sufficient condition, checked -- a barrier area serves teams of ONE size (a four-wave call after
+    // two-wave calls on the same counter released early and summed stale partials in round 5).  A violation is counted
+    // in the dump area: tools/gpu_phases_bpsw.py / gpu_phases_duo.py print the count.
+    if (wave == 0 && l_ == 0) {
+        if (sh->lastP != 0 && sh->lastP != P && a.dump && a.st.N >= 36) atomicAdd(&a.dump[4095], 1.0);
+        sh->lastP = P;
+    }
+#endif
     auto team_barrier = [&]() {
         WAVE_SYNC();
         ++gen;

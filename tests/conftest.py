@@ -22,3 +22,12 @@ def pytest_collection_modifyitems(config, items):
                 torch.cuda.init()
         except Exception:
             pass
+
+
+@pytest.fixture(autouse=True)
+def _speculation_forced(monkeypatch):
+    """spec_eps is an upper bound: by default a handle runs the sequential line-search rule (E = 1) whatever width it was created with
+    (include/ratilqr.h, switch spec_force).  The tests that create handles with spec_eps > 1 are there to hold the SPECULATIVE kernels to
+    the oracle, so the suite forces the requested width; the default policy has its own tests (test_gpu_parity.py::test_spec_eps_is_an_upper_bound,
+    test_gpu_ce.py::test_config3_full_size_ce_matches_the_oracle), which remove this variable."""
+    monkeypatch.setenv("RATILQR_SPEC_FORCE", "1")

@@ -256,6 +256,35 @@ def test_pruned_speculation_gives_the_same_batch(monkeypatch):
                 assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
 
 
+def test_spec_eps_is_an_upper_bound(monkeypatch):
+    """The DEFAULT policy (no RATILQR_SPEC_FORCE): a handle created with spec_eps = 8 runs the sequential line-search rule on the E = 1
+    kernels -- speculation is result-identical and does not pay on this device -- so its batches are the E = 1 handle's
+    bit for bit at every batch size, on the headline workload and on one whose line searches backtrack; spec_force = 1 on the live handle
+    re-lays it to the requested width (the speculative kernels), same results again."""
+    monkeypatch.delenv("RATILQR_SPEC_FORCE", raising=False)
+    monkeypatch.setenv("RATILQR_BLOCK_PSW", "0")            # (bit-identity across paths is a property of the sequential-sweep kernels)
+    for kappa in (0.06, 0.0):
+        prob, x0, u = rat.synthetic_lq_problem(kappa=kappa)
+        for B in (1024, 100):
+            theta = np.abs(1.0 + 2.0 * np.random.default_rng(3 + B).standard_normal(B)); theta[:3] = [0.0, 30.0, 5.9]
+            ref_ctx = rat.Context(prob, max_batch=B, spec_eps=1)
+            ref = ref_ctx.solve_batch(x0, u, theta)
+            ctx = rat.Context(prob, max_batch=B, spec_eps=8)
+            assert ctx.debug_get("spec_width") == 1 and ctx.debug_get("spec_force") == 0 and ctx.get_path(B) == ref_ctx.get_path(B)
+            got = ctx.solve_batch(x0, u, theta)
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b, equal_nan=True)
+            ctx.debug_set("spec_force", 1)                   # the requested width after all: E = 8 kernels on the same handle
+            assert ctx.debug_get("spec_width") == 8 and ctx.get_path(B) == ("rounds" if B == 1024 else "block")
+            forced = ctx.solve_batch(x0, u, theta)
+            for a, b in zip(forced, ref):
+                assert np.array_equal(a, b, equal_nan=True)
+            ctx.debug_set("spec_force", 0)
+            assert ctx.debug_get("spec_width") == 1
+            for a, b in zip(ctx.solve_batch(x0, u, theta), ref):
+                assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_api_misuse_is_reported():
     prob, x0, u = rat.synthetic_lq_problem()
     ctx = rat.Context(prob, max_batch=4)

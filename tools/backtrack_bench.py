@@ -4,6 +4,7 @@ every E (App. B.17); what changes is how many line-search evaluations run concur
   python tools/backtrack_bench.py [--kappa 0.06] [--theta 2 5] [--batch 1024]   (on an MI355X)"""
 import argparse
 import os
+os.environ.setdefault("RATILQR_SPEC_FORCE", "1")     # handles of width E > 1 run the speculative kernels here (spec_eps is otherwise an upper bound)
 import sys
 import time
 

@@ -1,5 +1,6 @@
 """ms per batch of an E-candidate shard through the user-facing batch call (host buffers):  python tools/e8_shard_time.py [B] [E]"""
 import os, sys, time
+os.environ.setdefault("RATILQR_SPEC_FORCE", "1")     # handles of width E > 1 run the speculative kernels here (spec_eps is otherwise an upper bound)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ratilqr.jl_amd as rat

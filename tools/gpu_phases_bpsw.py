@@ -43,3 +43,6 @@ for psw in (0, 1):
             print("      wave   start  element/recursion  boundary seen  hop posted  phase3 end  after barrier")
             for w in range(P):
                 print(f"      {w:4d} " + " ".join(f"{v:12.0f}" for v in r[w]))
+viol = np.zeros(1)
+lib.rat_diag_read_n(ctx.h, viol.ctypes.data_as(C.POINTER(C.c_double)), 4095, 1)
+print(f"team-barrier invariant violations counted by the diagnostic build (psweep.h): {int(viol[0])}")

@@ -4,6 +4,7 @@ headline LQ workload and on a workload whose line search backtracks.  Results ar
   python tools/path_sweep.py [--batches 128 256 512 1024 2048 4096] [--widths 1 2 4 8] [--reps 30]      (on an MI355X)"""
 import argparse
 import os
+os.environ.setdefault("RATILQR_SPEC_FORCE", "1")     # handles of width E > 1 run the speculative kernels here (spec_eps is otherwise an upper bound)
 import sys
 import time
 

@@ -6,6 +6,7 @@ line-search paths / an LU singularity in 1e120-scale arithmetic): no mismatch on
   SOAK_WIDE=16: n 13..16 with m 1..4 (the register sweeps and rollouts of wide16.h).
   SOAK_WIDE=1: shapes beyond the tile instead -- n 13..32 with m 1..32, or n 1..12 with m 5..32; N 1..30 (the general-size kernels of wide.hip)."""
 import sys, os, time
+os.environ.setdefault("RATILQR_SPEC_FORCE", "1")     # handles of width E > 1 run the speculative kernels here (spec_eps is otherwise an upper bound)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ratilqr.jl_amd as rat

@@ -6,6 +6,7 @@ four waves of a sample) and the two-wave kernel's time-parallel last evaluation 
 race shows as a wrong value or a hang, not as a rounding difference).
   STRESS_S=60 python tools/stress_block.py      (on an MI355X)"""
 import os
+os.environ.setdefault("RATILQR_SPEC_FORCE", "1")     # handles of width E > 1 run the speculative kernels here (spec_eps is otherwise an upper bound)
 import sys
 import time
 

@@ -3,6 +3,7 @@ time-varying cost and noise tables, cubic drift, the power-law family, horizons 
 (block kernel up to 512, paired fused kernel up to 1024, beyond it the two-samples-per-SIMD tile-free fused kernel for the LQ family).
   STRESS_S=120 python tools/stress_paths.py      (on an MI355X)"""
 import os
+os.environ.setdefault("RATILQR_SPEC_FORCE", "1")     # handles of width E > 1 run the speculative kernels here (spec_eps is otherwise an upper bound)
 import sys
 import time
 
