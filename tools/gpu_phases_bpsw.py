@@ -22,12 +22,17 @@ for psw in (0, 1):
         ctx.solve_batch(x0, u, np.full(B, 1.0))
     out = np.zeros(640)
     lib.rat_diag_read_n(ctx.h, out.ctypes.data_as(C.POINTER(C.c_double)), 1024, 640)
+    if psw:        # (round 6: this kernel's barrier marks are s_memrealtime stamps shared by its two workgroups: tools/gpu_phases_duo.py prints them)
+        ctx.debug_set("psw_duo", 0)
+        ctx.solve_batch(x0, u, np.full(B, 1.0))
+        print(f"block_psw = 1, B = {B}: barrier timeline in tools/gpu_phases_duo.py; the sweeps' own phases (one workgroup per sample):")
     t = out.reshape(8, 2, 40)
-    n = int(np.max(np.nonzero(t[0, 0])[0])) + 1
+    n = int(np.max(np.nonzero(t[0, 0])[0])) + 1 if not psw else 0
     arrive, leave = t[:, :, 0:n:2].mean(0), t[:, :, 1:n:2].mean(0)
-    print(f"block_psw = {psw}, B = {B}: total {t[:, 0, n - 1].mean():.0f} cycles")
+    if not psw:
+        print(f"block_psw = {psw}, B = {B}: total {t[:, 0, n - 1].mean():.0f} cycles")
     prev = np.zeros(2)
-    for i in range(arrive.shape[1]):
+    for i in range(min(arrive.shape[1], leave.shape[1])):
         nm = names[i] if i < len(names) else f"phase {i}"
         print(f"   {nm:22s} wave 0 busy {arrive[0, i] - prev[0]:8.0f}   wave 1 busy {arrive[1, i] - prev[1]:8.0f}   barrier released at {leave[0, i]:8.0f}")
         prev = leave[:, i]

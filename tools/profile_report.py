@@ -8,11 +8,11 @@ sys.path.insert(0, ROOT)
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-RND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 O = os.path.join(ROOT, "gpurun_out", RND, "prof")
 # (seq128 before block128, paired_4096 before fused_4096: both map to one key of profiles/traffic.json, the default kernel keeps it)
-CFG = {"fused": (1, 1024), "contract": (1, 1024), "seq128": (1, 128), "block128": (1, 128), "block256": (1, 256), "block512": (1, 512),
-       "e8_1024": (8, 1024), "e8_128": (8, 128), "paired_4096": (1, 4096), "fused_4096": (1, 4096)}
+CFG = {"fused": (1, 1024), "contract": (1, 1024), "seq128": (1, 128), "solo128": (1, 128), "block128": (1, 128), "block256": (1, 256), "block512": (1, 512),
+       "e8_1024": (8, 1024), "e8f_1024": (8, 1024), "e8_128": (8, 128), "paired_4096": (1, 4096), "fused_4096": (1, 4096)}
 # kernel-name pattern -> the key bench.py uses (traffic_for(f"{kind}_E{E}_B{B}")); first match wins
 KINDS = [("solve_fused_kernel", "solve_fused"), ("solve_block_psw_kernel", "solve_block"), ("solve_block_kernel", "solve_block"), ("sweep_dual_kernel", "sweep_dual"), ("sweep_cand0_kernel", "sweep_cand0"),
          ("rollin_multi_kernel", "rollout_multi"), ("rollin_stage_kernel", "rollout"), ("rollin_kernel", "rollout_init"),
@@ -83,7 +83,8 @@ for name, (E, B) in CFG.items():
             traffic[f"{k}_E{E}_B{B}"] = t
         alg = None
         if k in ("solve_fused", "solve_block", "solve_fused_mat"):
-            alg = B * (1537256 if E == 1 else 368312 + 2 * 188864 + 2 * E * 395608)
+            # (a handle of width 8 under the default policy runs the sequential rule: the E = 1 solve's bytes)
+            alg = B * (1537256 if (E == 1 or name == "e8_1024") else 368312 + 2 * 188864 + 2 * E * 395608)
         elif k == "sweep_eval":
             alg = a["sweep_eval"] * B * (E - 1 if ("sweep_dual" in rows or "sweep_cand0" in rows) else E)
         elif k in ("sweep_dual", "sweep_cand0"):
