@@ -97,14 +97,14 @@ for name, (E, B) in CFG.items():
             alg = (a["rollout_init"] + a["linearise"]) * B
         md.append(f"| {name}: B = {B}, E = {E} | `{kname[:70]}` | {calls} | {avg:.1f} | {t / 1e6:.1f} | {alg / 1e6 if alg else float('nan'):.1f} |"
                   if t is not None else f"| {name}: B = {B}, E = {E} | `{kname[:70]}` | {calls} | {avg:.1f} | - | {alg / 1e6 if alg else float('nan'):.1f} |")
-        if E > 1 and k not in ("solve_block",):
+        if E > 1 and k not in ("solve_block",) and "solve_fused" not in rows:
             # batches in the run: one copy of the shared initialize! trajectory per batch (the rollin_kernel launch is then the ONE
             # rollout per rat_set_initial); before round 3's sharing: one initial rollout per batch
             runs = runs or rows.get("copy_initial", rows.get("rollout_init", rows.get("sweep_dual")))[1]
             if not (k == "rollout_init" and "copy_initial" in rows):
                 per_batch += avg * calls
                 per_batch_t += (t or 0.0) * calls
-    if E > 1 and runs and "solve_block" not in rows:
+    if E > 1 and runs and "solve_block" not in rows and "solve_fused" not in rows:
         batches = runs
         traffic[f"batch_E{E}_B{B}"] = per_batch_t / batches
         md.append(f"| {name}: per batch (all kernels) | | {batches} batches | {per_batch / batches:.1f} | {per_batch_t / batches / 1e6:.1f} | "
