@@ -117,6 +117,7 @@ struct rat_handle_s {
     double *h_pzc = nullptr; size_t cap_pzc = 0;            // ... pinned: the injected control normals of a whole solve! | mu | Sigma | error word on the way back
     bool prune = true;               // round-based path, E > 1, tile-free candidates: evaluations of candidates 1 .. E-1 stop once candidate 0 is the line search's choice
     hipStream_t stream_lo = nullptr; // ... their stream: the lowest priority the device offers
+    bool wide32 = true;              // every other general size (n <= 32, m <= 32): the same in block form (wide32.h)
     bool wide16 = true;              // general sizes with n <= 16, m <= 4: the sweeps of the solve kernel in registers on the matrix pipe (wide16.h)
     bool pets_device = true;                                // switch pets_device
     double *h_pcost = nullptr; size_t cap_hpcost = 0;       // pinned landing zone of the sample costs of the synchronous call (zero-copy)
@@ -197,6 +198,10 @@ static const DebugSwitch debug_switches[] = {
          // EFFECTIVE: with a problem set, whether its solves run the register form (launch_wide_solve's own gate: 12 <= n <= 16, m <= 4)
          if (!h->have_problem) return h->wide16;
          return h->wide16 && h->wide && h->wpb.n >= 12 && h->wpb.n <= 16 && h->wpb.m <= 4; }},
+    {"wide32", [](rat_handle h, int64_t v) { h->wide32 = v != 0; }, [](rat_handle h) -> int64_t {
+         if (!h->have_problem) return h->wide32;
+         const bool s16 = h->wide16 && h->wpb.n >= 12 && h->wpb.n <= 16 && h->wpb.m <= 4;
+         return h->wide32 && h->wide && !s16; }},
     {"prune", [](rat_handle h, int64_t v) { h->prune = v != 0; }, [](rat_handle h) -> int64_t { return h->prune; }},
     {"wdiag", [](rat_handle h, int64_t v) { h->wdiag = (v != 0); }, [](rat_handle h) -> int64_t { return h->wdiag; }},
     {"materialize", [](rat_handle h, int64_t v) { h->materialize = (v != 0); }, [](rat_handle h) -> int64_t { return h->materialize; }},
@@ -496,10 +501,46 @@ static rat_rc problem_set_wide(rat_handle h, const rat_problem_desc *d) {
         sym_upper(n, wi.data(), &Winv[k * n2]);
     }
     h->hW = W; h->W_tv = wp.W_tv;
+    // register images of the tables for the block form (wide32.h; layout: wide.h)
+    const int NTi = (n <= 16 && m <= 16) ? 1 : 2, MTi = (m <= 16) ? 1 : 2;
+    wp.img_nt = NTi; wp.img_mt = MTi;
+    // element(i, jj) of a rows x cols block of RT x CT tiles; outside the matrix: `pad` on the diagonal, zero elsewhere
+    auto image = [](int RT, int CT, int rows, int cols, double pad, auto element, double *dst) {
+        for (int a = 0; a < RT; ++a) for (int b = 0; b < CT; ++b) for (int r = 0; r < 4; ++r) for (int l = 0; l < 64; ++l) {
+            const int g = l >> 4, j = l & 15, i = 16 * a + 4 * r + g, jj = 16 * b + j;
+            dst[(((size_t)a * CT + b) * 4 + r) * 64 + l] = (i < rows && jj < cols) ? element(i, jj) : ((i == jj) ? pad : 0.0);
+        }
+    };
+    const size_t sNN = (size_t)NTi * NTi * WIDE_IMG_TILE, sMN = (size_t)MTi * NTi * WIDE_IMG_TILE, sMM = (size_t)MTi * MTi * WIDE_IMG_TILE,
+                 sN1 = (size_t)NTi * WIDE_IMG_TILE, sM1 = (size_t)MTi * WIDE_IMG_TILE;
+    std::vector<double> tA(sNN), tAT(sNN), tB(sMN), tBT(sMN), tQ(Nc * sNN), tP(Nc * sMN), tPT(Nc * sMN), tR(Nc * sMM), tqv(Nc * sN1), trv(Nc * sM1),
+        tQf(sNN), tqvf(sN1), tWinv(Nw * sNN), tW(Nw * sNN);
+    image(NTi, NTi, n, n, 0.0, [&](int i, int jj) { return A[i + n * jj]; }, tA.data());
+    image(NTi, NTi, n, n, 0.0, [&](int i, int jj) { return A[jj + n * i]; }, tAT.data());
+    image(NTi, MTi, n, m, 0.0, [&](int i, int jj) { return B[i + n * jj]; }, tB.data());
+    image(MTi, NTi, m, n, 0.0, [&](int i, int jj) { return B[jj + n * i]; }, tBT.data());
+    image(NTi, NTi, n, n, 0.0, [&](int i, int jj) { return Qf[i + n * jj]; }, tQf.data());
+    image(NTi, 1, n, 1, 0.0, [&](int i, int) { return qvf[i]; }, tqvf.data());
+    for (int k = 0; k < Nc; ++k) {
+        const double *Qk = &Q[k * n2], *Pk = &P[k * nm], *Rk = &R[k * mm];
+        image(NTi, NTi, n, n, 0.0, [&](int i, int jj) { return Qk[i + n * jj]; }, &tQ[k * sNN]);
+        image(MTi, NTi, m, n, 0.0, [&](int i, int jj) { return Pk[i + m * jj]; }, &tP[k * sMN]);
+        image(NTi, MTi, n, m, 0.0, [&](int i, int jj) { return Pk[jj + m * i]; }, &tPT[k * sMN]);
+        image(MTi, MTi, m, m, 1.0, [&](int i, int jj) { return Rk[i + m * jj]; }, &tR[k * sMM]);
+        image(NTi, 1, n, 1, 0.0, [&](int i, int) { return qv[(size_t)k * n + i]; }, &tqv[k * sN1]);
+        image(MTi, 1, m, 1, 0.0, [&](int i, int) { return rv[(size_t)k * m + i]; }, &trv[k * sM1]);
+    }
+    for (int k = 0; k < Nw; ++k) {
+        const double *Wk = &W[k * n2], *Wik = &Winv[k * n2];
+        image(NTi, NTi, n, n, 1.0, [&](int i, int jj) { return Wik[i + n * jj]; }, &tWinv[k * sNN]);
+        image(NTi, NTi, n, n, 0.0, [&](int i, int jj) { return Wk[i + n * jj]; }, &tW[k * sNN]);
+    }
     rat_rc rc;
 #define UP(field, vec) if ((rc = dev_upload(h, h->pb_allocs, &wp.field, vec))) return rc
     UP(A, A); UP(B, B); UP(Q, Q); UP(R, R); UP(P, P); UP(qv, qv); UP(rv, rv); UP(q0, q0); UP(Qf, Qf); UP(qvf, qvf);
     UP(W, W); UP(Winv, Winv); UP(ldW, ldW);
+    UP(tA, tA); UP(tAT, tAT); UP(tB, tB); UP(tBT, tBT); UP(tQ, tQ); UP(tP, tP); UP(tPT, tPT); UP(tR, tR); UP(tqv, tqv); UP(trv, trv);
+    UP(tQf, tQf); UP(tqvf, tqvf); UP(tWinv, tWinv); UP(tW, tW);
 #undef UP
     const bool realloc_state = !h->have_problem || !h->wide || h->N != N || h->n != n || h->m != m;
     memset(&h->pb, 0, sizeof(h->pb));
@@ -949,7 +990,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
     const Path path = pick_path(h, B);
     if (path == PATH_WIDE) {
         WideArgs wa;
-        wa.pb = h->wpb; wa.op = h->opd; wa.B = B; wa.fast16 = h->wide16 ? 1 : 0;
+        wa.pb = h->wpb; wa.op = h->opd; wa.B = B; wa.fast16 = h->wide16 ? 1 : 0; wa.fast32 = h->wide32 ? 1 : 0;
         wa.x0 = h->d_x0; wa.u0 = h->d_u0; wa.theta = theta_dev;
         wa.xs = h->w_xs; wa.us = h->w_us; wa.L = h->w_L; wa.dl = h->w_dl; wa.nom = h->w_nom;
         wa.out_value = out.value; wa.out_status = out.status; wa.out_iters = out.iters; wa.out_ls = out.ls;

@@ -17,13 +17,25 @@ struct WideProblemDev {
     const double *qv, *rv, *q0;      // [Nc][n], [Nc][m], [Nc]
     const double *Qf, *qvf;          // [n*n] Symmetric, [n]
     const double *W, *Winv, *ldW;    // [Nw][n*n], [Nw][n*n] Symmetric(inv(W)), [Nw] logdet W(k)
+    // The same tables as REGISTER IMAGES for the block form of wide32.h: a block of RT x CT tiles is (RT CT 4) runs of 64 doubles -- tile (a, b),
+    // register r, lane (g, j) = element (16 a + 4 r + g, 16 b + j), zero outside the matrix (unit diagonal where noted) -- so a load is one
+    // coalesced instruction with an immediate offset: no address clamps, no 0 / 1 masks (which the compiler would otherwise hoist out of the
+    // time loop and keep, four per tile, in registers).  NT = tiles of the states, MT = of the controls, as launch_wide_solve picks them.
+    int img_nt, img_mt;
+    const double *tA, *tAT, *tB, *tBT;     // [NT NT], A' [NT NT], [NT MT], B' natural rows [MT NT]
+    const double *tQ, *tP, *tPT, *tR;      // [Nc][NT NT], P natural rows [Nc][MT NT], P' [Nc][NT MT], [Nc][MT MT] unit diagonal beyond m
+    const double *tqv, *trv;               // [Nc][NT] / [Nc][MT] one-column blocks (column 0)
+    const double *tQf, *tqvf;              // [NT NT], [NT]
+    const double *tWinv, *tW;              // [Nw][NT NT] unit diagonal beyond n; [Nw][NT NT]
 };
+#define WIDE_IMG_TILE 256            /* doubles per tile image */
 
 struct WideArgs {
     WideProblemDev pb;
     OptsDev op;
     int B;
     int fast16;                      // n <= 16, m <= 4: sweeps in registers on the matrix pipe (wide16.h); 0 = the general sweep (A/B, tests)
+    int fast32;                      // every other size: sweeps and rollouts in registers in block form (wide32.h); 0 = the general LDS sweep
     const double *x0, *u0, *theta;   // [n], [N*m] column-major (time slowest), [B]
     // per-sample scratch (the solver object of one theta-sample: x_array, l_array and their candidates, L_array, dl)
     double *xs, *us;                 // [B][2][(N+1)*n], [B][2][N*m]
@@ -61,3 +73,4 @@ struct WideOpArgs {
 size_t wide_lds_bytes(int n, int m);
 hipError_t launch_wide_op(const WideOpArgs &a, hipStream_t s);
 hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s);
+bool wide32_applies(const WideArgs &a);

@@ -29,6 +29,10 @@
 #include "device_utils.h"
 #include "rat_normal.h"
 
+#ifndef WIDE_PART
+#define WIDE_PART 3
+#endif
+
 namespace {
 
 // Every matrix of a step lives in LDS, and the pointers say so: through plain `double *` members the compiler can only emit FLAT
@@ -470,6 +474,7 @@ __device__ int sweep(const WideProblemDev &pb_in, const Ws &w_in, const Tiles &t
 }
 
 #include "wide16.h"
+#include "wide32.h"
 
 // simulate_dynamics(problem, x_0, u_array)  (ileqg.jl:18-38) into (xo, uo)
 __device__ void rollout_open(const WideProblemDev &pb, Ws &w, const double *x0, const double *u0, double *xo, double *uo) {
@@ -559,14 +564,21 @@ __device__ inline void carve(Ws &w, ldsd *p, const int n, const int m) {        
 }
 
 
+// NT, MT > 0: every sweep and rollout in registers in the block form of wide32.h (n <= 16 NT, m <= 16 MT; the workgroup's LDS holds only the
+// rounds' 0 / 1 tables: four workgroups -- one wavefront per SIMD -- per CU at every size); NT = 0: the general LDS sweeps, or wide16.h's form
+template <int NT, int MT>
 __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     extern __shared__ double lds[];
+    constexpr bool s32 = NT > 0;
+    constexpr int NT_ = s32 ? NT : 1, MT_ = s32 ? MT : 1;
     const WideProblemDev &pb = a.pb;
     const OptsDev &op = a.op;
     const int n = pb.n, m = pb.m, N = pb.N, nm = n * m, lane = threadIdx.x, b = blockIdx.x;
-    Ws w;
-    carve(w, (ldsd *)lds, n, m);
-    for (int e = lane; e < nm; e += 64) w.Bm[e % n + (n | 1) * (e / n)] = pb.B[e];
+    Ws w = {};
+    if (!s32) {
+        carve(w, (ldsd *)lds, n, m);
+        for (int e = lane; e < nm; e += 64) w.Bm[e % n + (n | 1) * (e / n)] = pb.B[e];
+    }
     const size_t xstr = (size_t)(N + 1) * n, ustr = (size_t)N * m;
     double *const xs = a.xs + (size_t)b * 2 * xstr, *const us = a.us + (size_t)b * 2 * ustr;
     double *const Lg = a.L + (size_t)b * N * nm, *const dlg = a.dl + (size_t)b * N * m;
@@ -578,16 +590,20 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     for (size_t e = lane; e < (size_t)N * nm; e += 64) Lg[e] = 0.0;                         // :230-232
     Tiles tl = {};
     // n <= 16, m <= 4: the sweeps run in registers on the matrix pipe (wide16.h); the exchange area of its gain solve is T's place in LDS
-    const bool s16 = a.fast16 && n >= 12 && n <= 16 && m <= 4;
-    ldsd *const tab16 = (ldsd *)lds + wide_lds_doubles(n, m);                             // (its tables: behind the general kernel's area)
-    if (s16) setup16(pb, tab16);
-    if (s16) rollout16<false>(pb, a.x0, a.u0, nullptr, nullptr, 0.0, xs, us);               // :225, :228
+    const bool s16 = !s32 && a.fast16 && n >= 12 && n <= 16 && m <= 4;
+    ldsd *const tab16 = s32 ? (ldsd *)lds : (ldsd *)lds + wide_lds_doubles(n, m);        // (its tables: behind the general kernel's area)
+    if (s16 || s32) setup16(pb, tab16);
+    if constexpr (s32) rollout32<false, NT_, MT_>(pb, a.x0, a.u0, nullptr, nullptr, 0.0, xs, us);
+    else if (s16) rollout16<false>(pb, a.x0, a.u0, nullptr, nullptr, 0.0, xs, us);          // :225, :228
     else rollout_open(pb, w, a.x0, a.u0, xs, us);
     auto run_sweep = [&](const double *xt, const double *ut, const double mu_, auto gain_c, auto zero_c, double &val) -> int {
         constexpr bool gain = decltype(gain_c)::value, zeroL = decltype(zero_c)::value;
-        if (s16) return sweep16<gain, zeroL>(pb, w.T, tab16, xt, ut, theta, mu_, Lg, dlg, val);
-        tl.x = xt; tl.u = ut;
-        return sweep(pb, w, tl, theta, mu_, gain, zeroL, Lg, dlg, nullptr, nullptr, val);
+        if constexpr (s32) return sweep32<gain, zeroL, NT_, MT_>(pb, tab16, xt, ut, theta, mu_, Lg, dlg, val);
+        else {
+            if (s16) return sweep16<gain, zeroL>(pb, w.T, tab16, xt, ut, theta, mu_, Lg, dlg, val);
+            tl.x = xt; tl.u = ut;
+            return sweep(pb, w, tl, theta, mu_, gain, zeroL, Lg, dlg, nullptr, nullptr, val);
+        }
     };
     const std::integral_constant<bool, true> yes;
     const std::integral_constant<bool, false> no;
@@ -619,7 +635,9 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
             count++;                                                                        // :505
             if (count > 4000) { status = 7; break; }                                        // (App. B.5)
             n_ls++;
-            const double d_new = s16 ? rollout16<true>(pb, xn, un, dlg, Lg, eps, xc, uc) : rollout_closed(pb, w, xn, un, dlg, Lg, eps, xc, uc);       // :509-517
+            double d_new;                                                                   // :509-517
+            if constexpr (s32) d_new = rollout32<true, NT_, MT_>(pb, xn, un, dlg, Lg, eps, xc, uc);
+            else d_new = s16 ? rollout16<true>(pb, xn, un, dlg, Lg, eps, xc, uc) : rollout_closed(pb, w, xn, un, dlg, Lg, eps, xc, uc);
             double newv;
             const int rc = run_sweep(xc, uc, mu, no, no, newv);                      // :520-528
             if (rc) { eps *= op.lambda; continue; }                                         // :529-535
@@ -711,6 +729,7 @@ __device__ double terminal_cost(const WideProblemDev &pb, Ws &w) {
     return wsum(part) + pb.q0f;
 }
 
+#if WIDE_PART & 1
 __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
     extern __shared__ double lds[];
     const WideProblemDev &pb = a.pb;
@@ -842,19 +861,41 @@ __global__ __launch_bounds__(64) void wide_op_kernel(const WideOpArgs a) {
     }
 }
 
+#endif  // WIDE_PART & 1
 }  // namespace
 
+#if WIDE_PART & 1
 size_t wide_lds_bytes(int n, int m) { return sizeof(double) * wide_lds_doubles(n, m); }
+#endif
 
 
+// The file is compiled in two parts (Makefile: WIDE_PART): 1 = the general kernel, wide16.h's form and the operator kernels; 2 = the block-form
+// kernels of wide32.h -- their own unit because they are built WITHOUT -amdgpu-mfma-vgpr-form (with it clang 22's "Rewrite AGPR-Copy-MFMA" pass
+// crashes on kernels that spill, and the <2, 2> instantiation does).
+hipError_t launch_wide32_solve(const WideArgs &a, hipStream_t s);
+#if WIDE_PART & 2
+hipError_t launch_wide32_solve(const WideArgs &a, hipStream_t s) {       // the LDS holds only the rounds' 0 / 1 tables
+    const size_t lds32 = sizeof(double) * W16_LDS;
+    if (a.pb.img_nt == 1 && a.pb.img_mt == 1) hipLaunchKernelGGL((wide_solve_kernel<1, 1>), dim3(a.B), dim3(64), lds32, s, a);
+    else if (a.pb.img_mt == 1) hipLaunchKernelGGL((wide_solve_kernel<2, 1>), dim3(a.B), dim3(64), lds32, s, a);
+    else hipLaunchKernelGGL((wide_solve_kernel<2, 2>), dim3(a.B), dim3(64), lds32, s, a);
+    return hipGetLastError();
+}
+#endif
+#if WIDE_PART & 1
+bool wide32_applies(const WideArgs &a) {
+    const bool s16 = a.fast16 && a.pb.n >= 12 && a.pb.n <= 16 && a.pb.m <= 4;
+    return a.fast32 && !s16;
+}
 hipError_t launch_wide_solve(const WideArgs &a, hipStream_t s) {
     const bool s16 = a.fast16 && a.pb.n >= 12 && a.pb.n <= 16 && a.pb.m <= 4;
+    if (wide32_applies(a)) return launch_wide32_solve(a, s);            // every other size: the block form in registers (wide32.h)
     const size_t lds = wide_lds_bytes(a.pb.n, a.pb.m) + (s16 ? sizeof(double) * W16_LDS : 0);
     if (lds > 64 * 1024) {               // (per device: set on every launch that needs it, the call is cheap)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wide_solve_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(wide_solve_kernel, dim3(a.B), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((wide_solve_kernel<0, 0>), dim3(a.B), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -867,3 +908,4 @@ hipError_t launch_wide_op(const WideOpArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(wide_op_kernel, dim3((unsigned)a.count), dim3(64), lds, s, a);
     return hipGetLastError();
 }
+#endif  // WIDE_PART & 1
