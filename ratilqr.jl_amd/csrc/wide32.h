@@ -140,21 +140,24 @@ __device__ __forceinline__ void elim32_round(Blk<TT, TT> &M, const ldsd *const m
 #pragma unroll
         for (int b = 0; b < TT; ++b) M.t[a][b] = MFMA(t[a], nu[b], M.t[a][b]);
 }
+// (rounds whose pivot rows lie beyond the matrix -- unit diagonal, nothing coupled -- are skipped: what they would leave there, -1 instead of
+//  1 on the padded diagonal, only ever meets zero rows)
 template <int KB, int TT>
-__device__ __forceinline__ void elim32_rounds(Blk<TT, TT> &M, const ldsd *const mk, const double (&es)[4], const bool odd, int &pdmin, double &rprod, int &rexp) {
-    elim32_round<KB, TT>(M, mk, es, odd, pdmin, rprod);
+__device__ __forceinline__ void elim32_rounds(Blk<TT, TT> &M, const ldsd *const mk, const double (&es)[4], const bool odd, int &pdmin, double &rprod, int &rexp,
+                                              const int size) {
+    if (2 * KB < size) elim32_round<KB, TT>(M, mk, es, odd, pdmin, rprod);
     if constexpr (KB % 8 == 7) {                             // (the determinant product is renormalised once per row tile)
         if (rprod * 0.0 == 0.0) { rexp += __builtin_amdgcn_frexp_exp(rprod); rprod = __builtin_amdgcn_frexp_mant(rprod); }
     }
     W32_FENCE();
-    if constexpr (KB + 1 < 8 * TT) elim32_rounds<KB + 1, TT>(M, mk, es, odd, pdmin, rprod, rexp);
+    if constexpr (KB + 1 < 8 * TT) elim32_rounds<KB + 1, TT>(M, mk, es, odd, pdmin, rprod, rexp, size);
 }
 
 // solve_approximate_dp (GAIN = false, :412-465) / one pass of solve_approximate_dp! (GAIN = true, :341-406) over the trajectory (x, u) of an
 // LQ-family problem with n <= 16 NT, m <= 16 MT.  Returns 0, 2 (M not positive definite) or -1 (H not positive definite: the caller raises
 // mu and restarts).  tab: the 0 / 1 tables of setup16 in LDS (the rounds' masks depend on the position inside a tile only).
 template <bool GAIN, bool ZEROL, int NT, int MT>
-__device__ __forceinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *const tab, const double *const x_, const double *const u_,
+__device__ __noinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *const tab, const double *const x_, const double *const u_,
                                        const double theta, const double mu, double *const Lg_, double *const dlg_out, double &value) {
     const WideProblemDev pb = pb_in;
     const gbld *const x = (const gbld *)x_, *const u = (const gbld *)u_;
@@ -195,9 +198,10 @@ __device__ __forceinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *
     // over the horizon first, the two would meet at fifty times the magnitude and lose its rounding -- which -1 / (2 theta) then amplifies
     double racc = 0.0, rprod = 1.0, lsum = 0.0;
     int rexp = 0;
-    // (x_t, u_t) and, for a policy evaluation, L_t of the step after this one are fetched while this one runs (raw values: masked where consumed)
-    double xr_n[NT][4], ur_n[MT][4], Lr_n[MT][NT][4];
-    auto fetch = [&](const int t, const int g, const int j) {
+    // (x_t, u_t) of the step after this one are fetched while this one runs (raw values: masked where consumed); a policy evaluation's L_t is
+    // fetched inside its own step, two phases ahead of its use -- nothing dynamic is carried across the elimination
+    double xr_n[NT][4], ur_n[MT][4];
+    auto fetch = [&](const int t, const int g) {
         const gbld *const xt = x + (size_t)t * n, *const ut = u + (size_t)t * m;
 #pragma unroll
         for (int a = 0; a < NT; ++a)
@@ -207,106 +211,97 @@ __device__ __forceinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *
         for (int c = 0; c < MT; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ur_n[c][r] = ut[min(16 * c + 4 * r + g, m - 1)];
-        if (!GAIN && !ZEROL) {
-            const gbld *const Lt = Lg + (size_t)t * nm;
-#pragma unroll
-            for (int c = 0; c < MT; ++c)
-#pragma unroll
-                for (int b = 0; b < NT; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Lr_n[c][b][r] = Lt[min(16 * c + 4 * r + g, m - 1) + m * min(16 * b + j, n - 1)];
-        }
     };
-    fetch(N - 1, g, j);
+    fetch(N - 1, g);
     const int g_ = g, j_ = j;
     for (int t = N - 1; t >= 0; --t) {
         // (opaque per-step copies of the lane indices: the 0 / 1 masks and clamped offsets of the step's dynamic loads and stores are formed
         //  where they are used instead of being kept, four per tile, as loop invariants)
         int g = g_, j = j_;
         asm volatile("" : "+v"(g), "+v"(j));
-        // this step's (x_t, u_t, L_t): x_t on every lane of its rows (f_x's diagonal), and as one-column blocks
-        double xrow[NT][4];
-        Blk<NT, 1> xv;
-        Blk<MT, 1> uv;
-        Blk<MT, NT> L;
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                xrow[a][r] = xr_n[a][r] * ((16 * a + 4 * r + g < n) ? 1.0 : 0.0);
-                xv.t[a][0][r] = (j == 0) ? xrow[a][r] : 0.0;
-            }
-#pragma unroll
-        for (int c = 0; c < MT; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) uv.t[c][0][r] = ur_n[c][r] * ((j == 0 && 16 * c + 4 * r + g < m) ? 1.0 : 0.0);
-#pragma unroll
-        for (int c = 0; c < MT; ++c)
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    L.t[c][b][r] = (!GAIN && !ZEROL) ? Lr_n[c][b][r] * ((16 * c + 4 * r + g < m && 16 * b + j < n) ? 1.0 : 0.0) : 0.0;
-        fetch(t > 0 ? t - 1 : 0, g, j);
         const int kc = pb.cost_tv ? t : 0, kw = pb.W_tv ? t : 0;
         const double *const tQk = pb.tQ + (size_t)kc * (NT * NT * WIDE_IMG_TILE), *const tPk = pb.tP + (size_t)kc * (MT * NT * WIDE_IMG_TILE),
                      *const tRk = pb.tR + (size_t)kc * (MT * MT * WIDE_IMG_TILE);
-        W32_FENCE();
+        // this step's x_t on every lane of its rows (f_x's diagonal)
+        double xrow[NT][4];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xrow[a][r] = xr_n[a][r] * ((16 * a + 4 * r + g < n) ? 1.0 : 0.0);
         // approximate_model at (x_t, u_t) (:294-313): q_vec = Q x + P'u + q_vec, r_vec = R u + P x + r_vec, c
         Blk<NT, 1> qvt;
         Blk<MT, 1> rvt;
         {
-            Blk<NT, NT> Q;
-            Blk<NT, 1> qx, qvc;
-            ld_img(Q, tQk, l);
-            ld_img(qvc, pb.tqv + (size_t)kc * (NT * WIDE_IMG_TILE), l);
-            blk_zero(qx);
-            pmm(Q, xv, qx);
-            qvt = qx;
-            Blk<MT, NT> Pm;                                     // P, natural rows (m x n)
-            ld_img(Pm, tPk, l);
-            pmm(Pm, uv, qvt);                                   // + P'u
+            Blk<NT, 1> xv;
+            Blk<MT, 1> uv;
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { qvt.t[a][0][r] += qvc.t[a][0][r]; acc += xv.t[a][0][r] * (0.5 * qx.t[a][0][r] + qvc.t[a][0][r]); }
-        }
-        W32_FENCE();
-        {
-            Blk<MT, MT> R;
-            Blk<NT, MT> PT;                                     // P' (n x m)
-            Blk<MT, 1> ru, px, rvc;
-            ld_img(R, tRk, l);                                  // unit diagonal beyond m
-            ld_img(PT, pb.tPT + (size_t)kc * (MT * NT * WIDE_IMG_TILE), l);
-            ld_img(rvc, pb.trv + (size_t)kc * (MT * WIDE_IMG_TILE), l);
-            blk_zero(ru); blk_zero(px);
-            pmm(R, uv, ru);
-            pmm(PT, xv, px);
+                for (int r = 0; r < 4; ++r) xv.t[a][0][r] = (j == 0) ? xrow[a][r] : 0.0;
 #pragma unroll
             for (int c = 0; c < MT; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    rvt.t[c][0][r] = (ru.t[c][0][r] + px.t[c][0][r]) + rvc.t[c][0][r];
-                    acc += uv.t[c][0][r] * (0.5 * ru.t[c][0][r] + px.t[c][0][r] + rvc.t[c][0][r]);
-                }
+                for (int r = 0; r < 4; ++r) uv.t[c][0][r] = ur_n[c][r] * ((j == 0 && 16 * c + 4 * r + g < m) ? 1.0 : 0.0);
+            {
+                Blk<NT, NT> Q;
+                Blk<NT, 1> qx, qvc;
+                ld_img(Q, tQk, l);
+                ld_img(qvc, pb.tqv + (size_t)kc * (NT * WIDE_IMG_TILE), l);
+                blk_zero(qx);
+                pmm(Q, xv, qx);
+                qvt = qx;
+                Blk<MT, NT> Pm;                                     // P, natural rows (m x n)
+                ld_img(Pm, tPk, l);
+                pmm(Pm, uv, qvt);                                   // + P'u
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qvt.t[a][0][r] += qvc.t[a][0][r]; acc += xv.t[a][0][r] * (0.5 * qx.t[a][0][r] + qvc.t[a][0][r]); }
+            }
+            W32_FENCE();
+            {
+                Blk<MT, MT> R;
+                Blk<NT, MT> PT;                                     // P' (n x m)
+                Blk<MT, 1> ru, px, rvc;
+                ld_img(R, tRk, l);                                  // unit diagonal beyond m
+                ld_img(PT, pb.tPT + (size_t)kc * (MT * NT * WIDE_IMG_TILE), l);
+                ld_img(rvc, pb.trv + (size_t)kc * (MT * WIDE_IMG_TILE), l);
+                blk_zero(ru); blk_zero(px);
+                pmm(R, uv, ru);
+                pmm(PT, xv, px);
+#pragma unroll
+                for (int c = 0; c < MT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        rvt.t[c][0][r] = (ru.t[c][0][r] + px.t[c][0][r]) + rvc.t[c][0][r];
+                        acc += uv.t[c][0][r] * (0.5 * ru.t[c][0][r] + px.t[c][0][r] + rvc.t[c][0][r]);
+                    }
+            }
         }
         W32_FENCE();
-        // f_x = A + 3 kappa diag(x^2), f_u = B
-        Blk<NT, NT> Ad;
-        Blk<NT, MT> Z2;
-        ld_img(Ad, pb.tA, l);
-        ld_img(Z2, pb.tB, l);
+        // f_x = A + 3 kappa diag(x^2), f_u = B: fetched where they are used (twice: a block of four tiles is 32 registers across the elimination)
+        auto load_fx = [&](Blk<NT, NT> &Ad) {
+            ld_img(Ad, pb.tA, l);
 #pragma unroll
-        for (int a = 0; a < NT; ++a)
+            for (int a = 0; a < NT; ++a)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ad.t[a][a][r] = fma((4 * r + g == j) ? 1.0 : 0.0, k3 * (xrow[a][r] * xrow[a][r]), Ad.t[a][a][r]);
+                for (int r = 0; r < 4; ++r) Ad.t[a][a][r] = fma((4 * r + g == j) ? 1.0 : 0.0, k3 * (xrow[a][r] * xrow[a][r]), Ad.t[a][a][r]);
+        };
         // T = (D S)[A | B | S^-1 s_vec]
         Blk<NT, NT> T1;
         Blk<NT, MT> TB;
         Blk<NT, 1> Ta = sv;
         blk_zero(T1); blk_zero(TB);
-        pmm(S, Ad, T1);                                         // X = S [A | B] + [0 | s_vec]
-        pmm(S, Z2, TB);
+        {
+            Blk<NT, NT> Ad;
+            load_fx(Ad);
+            pmm(S, Ad, T1);                                     // X = S [A | B] + [0 | s_vec]
+        }
+        {
+            Blk<NT, MT> Z2;
+            ld_img(Z2, pb.tB, l);
+            pmm(S, Z2, TB);
+        }
         W32_FENCE();
         if (theta != 0.0) {
             Blk<NT, NT> M;
@@ -318,7 +313,7 @@ __device__ __forceinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *
 #pragma unroll
                     for (int r = 0; r < 4; ++r) M.t[a][b][r] = fma(nth, S.t[a][b][r], M.t[a][b][r]);       // M = Symmetric(inv(W) - theta S)   (:365)
             int pdmin = 1;
-            elim32_rounds<0, NT>(M, mk, es, odd, pdmin, rprod, rexp);
+            elim32_rounds<0, NT>(M, mk, es, odd, pdmin, rprod, rexp, n);
             if (!(pdmin > 0) || !(rprod * 0.0 == 0.0)) return 2;               // @assert isposdef(M)  (:366 / :440)
             lsum += ((const gbld *)pb.ldW)[kw] + (log(rprod) + (double)rexp * 0.6931471805599453094);      // logdet(W M)   (:387)
             rprod = 1.0; rexp = 0;
@@ -373,33 +368,55 @@ __device__ __forceinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *
             if (__ballot(nf != nf) != 0ull) return 2;
         }
         W32_FENCE();
+        // (S is dead from here: its registers take the new value function)
+        // a policy evaluation's gains: fetched now, consumed two phases on
+        double Lr[MT][NT][4];
+        if (!GAIN && !ZEROL) {
+            const gbld *const Lt = Lg + (size_t)t * nm;
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Lr[c][b][r] = Lt[min(16 * c + 4 * r + g, m - 1) + m * min(16 * b + j, n - 1)];
+        }
         // F = [A | B]'T + the step's cost model
         Blk<NT, NT> F11;
+        Blk<NT, 1> F1a = qvt;
         Blk<MT, NT> G;
         Blk<MT, MT> H;
-        ld_img(F11, tQk, l);
-        pmm(Ad, T1, F11);                                       // Q + A'(D S)A   (:390)
-        Blk<NT, 1> F1a = qvt;
-        pmm(Ad, Ta, F1a);                                       // q_vec + A'D s_vec   (:389)
-        W32_FENCE();
-        ld_img(G, tPk, l);
-        pmm(Z2, T1, G);                                         // P + B'(D S)A   (:369)
-        ld_img(H, tRk, l);
-#pragma unroll
-        for (int c = 0; c < MT; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) H.t[c][c][r] += (4 * r + g == j) ? mu : 0.0;
-        pmm(Z2, TB, H);                                         // R + B'(D S)B + mu I   (:370)
         Blk<MT, 1> gv = rvt;
-        pmm(Z2, Ta, gv);                                        // r + B'D s_vec   (:368)
+        {
+            Blk<NT, NT> Ad;
+            load_fx(Ad);
+            ld_img(F11, tQk, l);
+            pmm(Ad, T1, F11);                                   // Q + A'(D S)A   (:390)
+            pmm(Ad, Ta, F1a);                                   // q_vec + A'D s_vec   (:389)
+        }
         W32_FENCE();
+        {
+            Blk<NT, MT> Z2;
+            ld_img(Z2, pb.tB, l);
+            ld_img(G, tPk, l);
+            pmm(Z2, T1, G);                                     // P + B'(D S)A   (:369)
+            ld_img(H, tRk, l);
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) H.t[c][c][r] += (4 * r + g == j) ? mu : 0.0;
+            pmm(Z2, TB, H);                                     // R + B'(D S)B + mu I   (:370)
+            pmm(Z2, Ta, gv);                                    // r + B'D s_vec   (:368)
+        }
+        W32_FENCE();
+        fetch(t > 0 ? t - 1 : 0, g);                            // the next step's (x, u): two phases ahead of their use
+        Blk<MT, NT> L;
         Blk<MT, 1> dl;
         blk_zero(dl);
         if (GAIN) {
             Blk<MT, MT> Hi = H;
             int pdh = 1, hexp = 0;
             double hprod = 1.0;
-            elim32_rounds<0, MT>(Hi, mk, es, odd, pdh, hprod, hexp);
+            elim32_rounds<0, MT>(Hi, mk, es, odd, pdh, hprod, hexp, m);
             if (!(pdh > 0) || !(hprod * 0.0 == 0.0)) return -1;                 // isposdef(H) fails   (:372)
             blk_zero(L);
             pmm(Hi, G, L);                                      // [L | dl] = -H \ [G | g]   (:379-382)
@@ -419,6 +436,14 @@ __device__ __forceinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *
                     if (j == 0 && ci < m) (dlg + (size_t)t * m)[ci] = dl.t[c][0][r];
                 }
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        L.t[c][b][r] = ZEROL ? 0.0 : Lr[c][b][r] * ((16 * c + 4 * r + g < m && 16 * b + j < n) ? 1.0 : 0.0);
         }
         W32_FENCE();
         // S = Q + A'(D S)A + L'(H L + G) + G'L,  s_vec = q_vec + A'D s_vec + L'(H dl + g) + G'dl   (:389-391)
@@ -458,7 +483,7 @@ __device__ __forceinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *
 // CLOSED = false: simulate_dynamics(problem, x_0, u_array) (:18-38): xbar_ = x_0, l_ = u_array, no gains.  The operands of step t + 1 are
 // fetched at the top of step t.  Returns maximum(norm.(l .- u_new)) (:539).
 template <bool CLOSED, int NT, int MT>
-__device__ __forceinline__ double rollout32(const WideProblemDev &pb_in, const double *const xbar_, const double *const l_, const double *const dl_,
+__device__ __noinline__ double rollout32(const WideProblemDev &pb_in, const double *const xbar_, const double *const l_, const double *const dl_,
                                             const double *const L_, const double eps, double *const xo_, double *const uo_) {
     const WideProblemDev pb = pb_in;
     const int n = pb.n, m = pb.m, N = pb.N, nm = n * m;
