@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak (one datapath, profiles/r01_ubench_fp64_pipe.md)
 # every file a counter figure of profiles/traffic.json depends on (tile / general-size / PETS / CE kernels and what they include)
-KERNEL_SOURCES = ("kernels.hip", "psweep.h", "sweep_dual.h", "sweep_dual.hip", "device_utils.h", "layout.h", "kernels.h", "wide.hip", "wide.h", "wide16.h",
+KERNEL_SOURCES = ("kernels.hip", "psweep.h", "sweep_dual.h", "sweep_dual.hip", "device_utils.h", "layout.h", "kernels.h", "wide.hip", "wide.h", "wide16.h", "wide32.h",
                   "ce_device.hip", "ce_device.h", "rat_pow.h", "rat_normal.h")
 
 
@@ -931,10 +931,10 @@ def rank_main(args):
                   "sequential_ileqg_solves_replaced": n_seq, "theta_opt": th_nm, "objective": val_nm,
                   "ms_per_sequential_solve": enm * 1e3 / max(n_seq, 1)}
 
-        # general sizes (wide.hip; ileqg.jl:229 takes the dimensions from the arrays): CE batch of 1024 at 16 x 4 and 32 x 32
+        # general sizes (wide.hip; ileqg.jl:229 takes the dimensions from the arrays): CE batch of 1024 at 16 x 4 (wide16.h), 24 x 8 and 32 x 32 (wide32.h)
         wide_sec = {"workload": "rat_ileqg_solve_batch, LQ-plus-noise problems of the headline recipe beyond the 12 + 4 tile, N = 50, CE batch 1024, "
                                 "host arrays in and out", "runs": {}}
-        for n_, m_ in ((16, 4), (32, 32)):
+        for n_, m_ in ((16, 4), (24, 8), (32, 32)):
             wprob, wx0, wu = rat.synthetic_lq_problem(n=n_, m=m_, N=50)
             wth = np.abs(1.0 + 2.0 * np.random.default_rng(1).standard_normal(1024)) * 0.2
             wctx = rat.Context(wprob, max_batch=1024, device=D.local_rank)
@@ -1030,6 +1030,7 @@ def rank_main(args):
             "compute_cost_host_ms": host_sec["ms_per_call"] if host_sec else None,
             "nm_ms_per_solve": nm_sec["ms_per_solve"] if nm_sec else None,
             "wide_16x4_solves_per_s": wide_sec["runs"]["16x4"]["solves_per_s"] if wide_sec else None,
+            "wide_24x8_solves_per_s": wide_sec["runs"]["24x8"]["solves_per_s"] if wide_sec else None,
             "wide_32x32_solves_per_s": wide_sec["runs"]["32x32"]["solves_per_s"] if wide_sec else None,
             "pets_traj_per_s": pets_sec["value"] if pets_sec else None,
             "pets_1m_traj_per_s": pets_sec["runs"]["1000x1000"]["trajectories_per_s"] if pets_sec else None,

@@ -430,6 +430,8 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   wide16          0 / 1    general sizes with 12 <= n <= 16, m <= 4 (beyond the 12 + 4 tile): sweeps and rollouts of the solve kernel in
  *                            registers on the matrix pipe (wide16.h); 0 = the general LDS sweep.  rat_debug_get: 1 only where the
  *                            problem set on the handle really runs that form                                              (1)
+ *   wide32          0 / 1    every other general size (n <= 32, m <= 32): the same in block form on 16 x 16 tiles, tables as register images
+ *                            (wide32.h: one wavefront per SIMD instead of one per compute unit); 0 = the general LDS sweep      (1)
  *   init_share      0 / 1    initialize!'s rollout (independent of theta) rolled out once per (x_0, u_array) and copied   (1)
  *   materialize     0 / 1    one-wavefront-per-sample kernel, LQ family, time-invariant cost: tile records written by the
  *                            rollouts and loaded by the sweeps (SURVEY 8d's wording) instead of formed in registers      (0)

@@ -127,6 +127,56 @@ def test_register_sweep_sizes_match_the_oracle_and_the_general_sweep(n, m, N, se
         assert np.abs(r1[k] - o).max() <= VT * (1 + np.abs(o).max()), k
 
 
+@pytest.mark.parametrize("n,m,N,seed,kappa,tv", [
+    (20, 6, 30, 31, 0.0, False),       # two state tiles, one control tile
+    (24, 8, 20, 32, 0.02, True),       # cubic drift, time-varying cost tables and W(k)
+    (32, 32, 8, 33, 0.0, False),       # two by two: every tile full
+    (17, 17, 12, 34, 0.01, True),      # one row / column into the second tiles: the odd pivot block pairs a state with a padded unit row
+    (8, 6, 25, 35, 0.0, False),        # only the controls exceed the 12 + 4 tile: one tile each
+    (5, 20, 10, 36, 0.0, False),       # few states, two control tiles
+    (32, 1, 10, 37, 0.02, False),
+])
+def test_block_form_sizes_match_the_oracle_and_the_general_sweep(n, m, N, seed, kappa, tv, monkeypatch):
+    """Every general size beyond wide16.h's runs its sweeps and rollouts in registers on blocks of 16 x 16 tiles (wide32.h: elimination with
+    2 x 2 block pivots over the blocks for M and for H, tables as register images).  Same bar against the oracle as every wide size, and the
+    general LDS sweep (switch wide32 = 0) must agree on every count and to 1e-10 on the values; single solve: trajectory, controls, gains."""
+    prob, x0, u = wide_problem(n, m, N, seed, kappa, tv)
+    P = orc.Problem(prob)
+    theta = theta_grid(P, x0, u)
+    ctx = rat.Context(prob, max_batch=theta.size)
+    assert ctx.debug_get("wide32") == 1 and ctx.debug_get("wide16") == 0
+    vg, sg = check_batch(ctx, P, x0, u, theta)
+    assert sg[0] == 0 and (sg[-2:] != 0).all() and (sg[1:-2] == 0).sum() >= 5
+    _, _, ig, lg = ctx.solve_batch(x0, u, theta)
+    monkeypatch.setenv("RATILQR_WIDE32", "0")
+    ref = rat.Context(prob, max_batch=theta.size)
+    monkeypatch.delenv("RATILQR_WIDE32")
+    assert ref.debug_get("wide32") == 0
+    vr, sr, ir, lr = ref.solve_batch(x0, u, theta)
+    assert np.array_equal(sg, sr) and np.array_equal(ig, ir) and np.array_equal(lg, lr)
+    fin = np.isfinite(vr)
+    assert np.all(np.abs(vg[fin] - vr[fin]) <= 1e-10 * np.abs(vr[fin]))
+    th = float(theta[3])
+    r1, r0 = ctx.solve(x0, u, th), ref.solve(x0, u, th)
+    assert rel(r1["x"], r0["x"]) < 1e-10 and rel(r1["l"], r0["l"]) < 1e-10 and rel(r1["L"], r0["L"]) < 1e-9
+    so = orc.ILEQGSolver(P)
+    assert so.solve(x0, u, th) == 0 and r1["status"] == 0 and r1["iters"] == so.s.iter_current
+    for k, o in (("x", so.x_array), ("l", so.l_array), ("L", so.L_array)):
+        assert np.abs(r1[k] - o).max() <= VT * (1 + np.abs(o).max()), k
+
+
+def test_block_form_regularisation_restarts():
+    """wide32.h: an indefinite c_uu -- the elimination of H meets a non-positive leading minor, mu and Delta are raised and the sweep restarts
+    (ileqg.jl:372-378) -- at a size with two control tiles"""
+    prob, x0, u = wide_problem(18, 20, 8, 92)
+    prob.R = prob.R - 0.9 * np.eye(20) * np.linalg.eigvalsh(prob.R).max()
+    P = orc.Problem(prob)
+    theta = np.array([0.0, 0.05, 0.2])
+    ctx = rat.Context(prob, max_batch=3)
+    assert ctx.debug_get("wide32") == 1
+    check_batch(ctx, P, x0, u, theta)
+
+
 def test_register_sweep_regularisation_restarts_and_backtracking():
     """wide16.h: an indefinite c_uu (H loses positive definiteness: mu, Delta raised, the sweep restarts, ileqg.jl:372-378) and cubic drift
     with rejected step sizes"""
