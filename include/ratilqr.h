@@ -433,6 +433,9 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   wide32          0 / 1    every other general size (n <= 32, m <= 32): the same in block form on 16 x 16 tiles, tables as register images
  *                            (wide32.h: one wavefront per SIMD instead of one per compute unit); 0 = the general LDS sweep      (1)
  *   init_share      0 / 1    initialize!'s rollout (independent of theta) rolled out once per (x_0, u_array) and copied   (1)
+ *   init_lazy       0 / 1    ... except for the FIRST batch on a new (x_0, u_array) while a sample has a compute unit to itself (<= n_cu samples):
+ *                            the samples roll it out inside the solve kernel and the shared rollout's launch (19 us) stays off the
+ *                            critical path of one-shot callers -- receding-horizon solves, a single rat_ileqg_solve               (1)
  *   materialize     0 / 1    one-wavefront-per-sample kernel, LQ family, time-invariant cost: tile records written by the
  *                            rollouts and loaded by the sweeps (SURVEY 8d's wording) instead of formed in registers      (0)
  *   fly             0 / 1    round-based path, E > 1: line-search candidates without tile records                         (1)

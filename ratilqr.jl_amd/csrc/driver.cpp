@@ -95,6 +95,8 @@ struct rat_handle_s {
     // initialize!'s open-loop trajectory of the current (x_0, u_array), shared by every sample of every batch (FusedArgs.init_*)
     double *d_init_x = nullptr, *d_init_u = nullptr, *d_init_t = nullptr;
     bool init_traj_valid = false;
+    bool init_lazy = true;           // switch init_lazy: the first small batch on a new (x_0, u_array) rolls initialize! out inside its own kernel
+    int init_batches = 0;            // batches run on the current (x_0, u_array) so far (the first small batch rolls initialize! out in its own kernel)
     bool init_share = true;          // RATILQR_INIT_SHARE=0: every sample rolls initialize!'s trajectory out for itself (A/B and test override)
     int pred_rounds = 1;             // rounds the previous batch needed: that many are enqueued before the host first polls
     // profiling
@@ -191,6 +193,7 @@ static const DebugSwitch debug_switches[] = {
     {"block_helpers", [](rat_handle h, int64_t v) { h->block_helpers = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_helpers; }},
     {"block_acl", [](rat_handle h, int64_t v) { h->block_acl = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_acl; }},
     {"init_share", [](rat_handle h, int64_t v) { h->init_share = (v != 0); }, [](rat_handle h) -> int64_t { return h->init_share; }},
+    {"init_lazy", [](rat_handle h, int64_t v) { h->init_lazy = (v != 0); }, [](rat_handle h) -> int64_t { return h->init_lazy; }},
     {"fly", [](rat_handle h, int64_t v) { h->fly = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly; }},
     {"fly_multi", [](rat_handle h, int64_t v) { h->fly_multi = (v != 0); }, [](rat_handle h) -> int64_t { return h->fly_multi; }},
     {"fused_occ2", [](rat_handle h, int64_t v) { h->fused_occ2 = (int)v; }, [](rat_handle h) -> int64_t { return h->fused_occ2; }},
@@ -416,7 +419,7 @@ static rat_rc alloc_state(rat_handle h) {
     AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);
     AL(h->d_opout, 2); AL(h->d_dump, (size_t)(N + 1) * DUMP_STRIDE); AL(h->d_dlin, (size_t)N * USTR);
     AL(h->d_init_x, (size_t)st.x_stride); AL(h->d_init_u, (size_t)st.u_stride); AL(h->d_init_t, (size_t)st.tile_stride);
-    h->init_traj_valid = false;
+    h->init_traj_valid = false; h->init_batches = 0;
 #undef AL
     // padded lanes of the slot pools must be exact zeros
     HIPCHK(hipMemsetAsync(st.xs, 0, slots * st.x_stride * sizeof(double), h->stream));
@@ -546,7 +549,7 @@ static rat_rc problem_set_wide(rat_handle h, const rat_problem_desc *d) {
     memset(&h->pb, 0, sizeof(h->pb));
     h->pb.model = d->model; h->pb.n = n; h->pb.m = m; h->pb.N = N;
     h->wpb = wp; h->n = n; h->m = m; h->N = N;
-    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false; h->problem_serial++;
+    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false; h->init_batches = 0; h->problem_serial++;
     if (realloc_state && (rc = alloc_state_wide(h))) return rc;
     return RAT_OK;
 }
@@ -653,7 +656,7 @@ extern "C" rat_rc rat_problem_set(rat_handle h, const rat_problem_desc *d) {
     // control step) keeps its buffers: every live lane is rewritten by the next solve.
     const bool realloc_state = !h->have_problem || h->wide || h->N != N || h->n != n || h->m != m;
     h->pb = pb; h->n = n; h->m = m; h->N = N;
-    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false; h->problem_serial++;
+    h->have_problem = true; h->have_initial = false; h->init_traj_valid = false; h->init_batches = 0; h->problem_serial++;
     if (realloc_state && (rc = alloc_state(h))) return rc;
     return RAT_OK;
 }
@@ -918,7 +921,7 @@ static rat_rc relayout_if_needed(rat_handle h, bool was_alias, int was_E = -1) {
     if (h->have_problem && !h->wide && (was_alias != h->fused || was_E != h->E)) {      // re-laid only when the aliasing mode or the speculation width really changes
         rat_rc rc = alloc_state(h);
         if (rc) return rc;
-        h->have_initial = false; h->init_traj_valid = false; h->x0_host.clear(); h->u0_host.clear();
+        h->have_initial = false; h->init_traj_valid = false; h->init_batches = 0; h->x0_host.clear(); h->u0_host.clear();
     }
     return RAT_OK;
 }
@@ -1021,10 +1024,6 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         // initialize!'s rollout is the same for every sample of every batch on this (x_0, u_array): rolled out once (the per-phase kernel,
         // one wavefront) into a slot of its own; the tile-free kernels copy it instead of repeating it per sample
         fa.init_x = fa.init_u = fa.init_t = nullptr;
-        if (h->init_share && h->pb.model == 1 && st.N <= ROLLIN_NST) {
-            ensure_init_traj(h, ra, theta_dev);
-            fa.init_x = h->d_init_x; fa.init_u = h->d_init_u; fa.init_t = h->d_init_t;
-        }
         // two-wave workgroups padded to one wave per SIMD (ticketed SIMD pairs): only while two workgroups per CU hold the batch -- the
         // register slots of the two waves that exit at once stay charged to the workgroup until it ends, so a third padded workgroup
         // per CU would have to wait for a whole solve (measured: 768 samples 0.515 ms padded, 0.420 ms plain)
@@ -1037,6 +1036,16 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         if (psw && h->psw_duo && 2 * ((B + 7) & ~7) <= h->n_cu) {       // half the device would be dark: two workgroups (compute units) per sample
             fa.duo_stride = (B + 7) & ~7; fa.xepoch = ++h->xepoch; fa.xw = h->d_xw; fa.duo_count = h->d_duo_count;
         }
+        // ... except for the FIRST batch on a new (x_0, u_array) when a sample has a compute unit to itself: there the samples roll it out
+        // themselves inside the solve (one recursion wave + three linearising waves: a few us, on compute units that would idle anyway) and the
+        // 19 us launch of the shared rollout stays off the critical path of one-shot callers -- a Nelder-Mead solve!, a single rat_ileqg_solve, the
+        // final solve of a fresh handle; a second batch on the same initial trajectory rolls the shared copy out for all that follow
+        const bool own_init = psw && h->init_lazy && !h->init_traj_valid && h->init_batches == 0;
+        if (h->init_share && h->pb.model == 1 && st.N <= ROLLIN_NST && !own_init) {
+            ensure_init_traj(h, ra, theta_dev);
+            fa.init_x = h->d_init_x; fa.init_u = h->d_init_u; fa.init_t = h->d_init_t;
+        }
+        h->init_batches++;
         if (psw) {
             fa.acl = (h->psw_acl || h->block_acl) ? 1 : 0;       // (this kernel's values agree with the sequential paths to rounding anyway)
             fa.psw2e = psweep_cuts(st.N, 2, h->psw_hop_e / 100.0, h->psw_comp / 100.0);
@@ -1130,7 +1139,7 @@ extern "C" rat_rc rat_set_initial(rat_handle h, const double *x0, const double *
     }
     // (the bilevel drivers pass the same x_0 / u_array for every batch of a solve: upload only what changed)
     if (h->have_initial && xp == h->x0_host && up == h->u0_host) return RAT_OK;
-    h->init_traj_valid = false;
+    h->init_traj_valid = false; h->init_batches = 0;
     HIPCHK(hipMemcpyAsync(h->d_x0, xp.data(), xp.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_u0, up.data(), up.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
