@@ -51,8 +51,9 @@
 #define PART_MISC 128     /* PETS and noisy Monte-Carlo rollouts */
 #define PART_PSW 256      /* psweep_kernel: the segment-parallel sweep (psweep.h) */
 #define PART_BPSW 512     /* solve_block_psw_kernel: the workgroup-per-sample solve with segment-parallel sweeps */
+#define PART_BPSW1 1024   /* ... its time-varying-W(k) instantiations (built without -amdgpu-mfma-vgpr-form: see launch_solve_block_psw_tv) */
 #ifndef RAT_PART
-#define RAT_PART 1023
+#define RAT_PART 2047
 #endif
 
 #ifndef OCC2_PREFETCH
@@ -2781,6 +2782,9 @@ __device__ __forceinline__ long long xc_wait(long long *w, const long long v, lo
 template <bool CTV, int WM>
 __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     constexpr int FLYB = CTV ? 2 : 1;
+    // (SEQ4: the evaluation and the gain sweep one after the other as four-wave teams instead of side by side as two-wave teams -- a
+    //  diagnostic of the W(k) miscompile, see launch_solve_block_psw_tv; off)
+    constexpr bool SEQ4 = false;
     // duo launches: groups of 16 blocks = 8 samples x {role A, role B}, partners 8 blocks apart (one XCD)
     const int role = (fa.duo_stride > 0) ? ((blockIdx.x >> 3) & 1) : 0;
     const int b = (fa.duo_stride > 0) ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : blockIdx.x;
@@ -2906,6 +2910,11 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     {                                            // open-loop policy evaluation (:234) || the first step!'s gain sweep on the same trajectory
         SweepArgs sa = fa.sw;
         if (duo) { sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave); }
+        else if (SEQ4) {                             // W(k): one four-wave team, the evaluation and then the gain sweep (see SEQ4)
+            sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave);
+            __syncthreads();
+            sa.mode = 5; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
+        }
         else if (team == 0) { sa.mode = 2; psweep_body<false, WM, false, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
         else { sa.mode = 5; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[1], fa.psw2g, tw); }
     }
@@ -2977,6 +2986,11 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         {
             SweepArgs sa = fa.sw;
             if (ends || duo) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave); }
+            else if (SEQ4) {
+                sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave);
+                __syncthreads();
+                sa.mode = 4; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
+            }
             else if (team == 0) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[0], fa.psw2e, tw); }
             else { sa.mode = 4; psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[1], fa.psw2g, tw); }
         }
@@ -3001,23 +3015,34 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
 }
 
 #undef BPSW_MARK
+void launch_solve_block_psw_tv(const FusedArgs &fa, const dim3 grid, hipStream_t s);
 #if RAT_PART & PART_BPSW
 bool solve_block_psw_supported(const FusedArgs &fa) {
-    // (a time-varying W(k) runs solve_block_kernel.  Tried: with W_tv tables -- even constant ones -- the elements / hops of this kernel's
-    //  fly sweeps come out wrong (negative pivots in the ordinary pass behind a hop), while the sweep operators with W_tv on materialised
-    //  tiles pass their parity tests for 2 ... 8 waves; the instantiation <fly, W_tv> is not understood yet, so not enabled)
-    return fa.sw.st.E == 1 && fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST && !fa.sw.pb.W_tv && fa.sw.st.N >= 8;
+    return fa.sw.st.E == 1 && fa.sw.pb.model == 1 && fa.sw.st.N <= ROLLIN_NST && fa.sw.st.N >= 8;
 }
 void launch_solve_block_psw(const FusedArgs &fa, hipStream_t s) {
     if (fa.sw.st.B <= 0) return;
     // duo (two workgroups per sample, FusedArgs.duo_stride): groups of 16 blocks = 8 samples x {role A, role B}
     const dim3 grid(fa.duo_stride > 0 ? 2 * fa.duo_stride : fa.sw.st.B), block(256);
+    if (fa.sw.pb.W_tv) { launch_solve_block_psw_tv(fa, grid, s); return; }
 #define BPSW_LAUNCH(C) do { if (fa.sw.pb.W_diag) hipLaunchKernelGGL((solve_block_psw_kernel<C, 2>), grid, block, 0, s, fa); \
                             else hipLaunchKernelGGL((solve_block_psw_kernel<C, 0>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.cost_tv) BPSW_LAUNCH(true); else BPSW_LAUNCH(false);
 #undef BPSW_LAUNCH
 }
 #endif  // PART_BPSW
+// Time-varying W(k): the same kernel's <.., W_tv> instantiations, in a translation-unit part of their own that is built WITHOUT
+// -amdgpu-mfma-vgpr-form.  With that flag clang 22 miscompiles them: the gain sweeps of a workgroup that also runs evaluations come out wrong
+// (negative pivots behind a hop: every line-search candidate then fails), while the identical source is right without the flag, right with it
+// when the gain sweeps have a workgroup to themselves (role B of the two-workgroup launch), and right in psweep_kernel.  Round 5 had this down
+// as "the <fly, W_tv> instantiation is not understood"; tools/wtv_probe.py is the reproducer.  The flag's pass is the one that crashes on
+// kernels that spill (wide.hip); the instantiations built with it are the ones the parity suite, soaks and race hunts hold to the oracle.
+#if RAT_PART & PART_BPSW1
+void launch_solve_block_psw_tv(const FusedArgs &fa, const dim3 grid, hipStream_t s) {
+    if (fa.sw.pb.cost_tv) hipLaunchKernelGGL((solve_block_psw_kernel<true, 1>), grid, dim3(256), 0, s, fa);
+    else hipLaunchKernelGGL((solve_block_psw_kernel<false, 1>), grid, dim3(256), 0, s, fa);
+}
+#endif  // PART_BPSW1
 
 template <int NW, bool GW>
 static void launch_solve_block_n(const FusedArgs &fa, hipStream_t s) {

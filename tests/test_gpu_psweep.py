@@ -96,7 +96,8 @@ def test_general_noise_covariance_and_time_varying_cost():
 
 def test_time_varying_noise_covariance():
     """W(k) time-varying: every step loads its own inv(W), W and pivots; the element step and the hop are the same formulas (sweep
-    operators).  The whole solve keeps the sequential-sweep kernel for such problems: same results whatever the switch says."""
+    operators).  The whole solve runs the time-parallel kernel's W(k) instantiations since round 6 (round 5's "wrong elements" were a
+    miscompile under -amdgpu-mfma-vgpr-form: that part of kernels.hip is built without the flag; tools/wtv_probe.py)."""
     rng = np.random.default_rng(12)
     n, m, N = 9, 3, 41
     Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
@@ -110,10 +111,12 @@ def test_time_varying_noise_covariance():
     prob = rat.LQRiskSensitiveProblem(A, B, Q=spd(n, 1.0), R=spd(m, 0.2), N=N, W=W, Qf=spd(n, 1.0), kappa=0.02)
     u = 0.1 * rng.standard_normal((N, m))
     check(prob, x0, u, np.array([0.2, 1.0, 3.0, 8.0]))
-    (v0, s0, i0, l0), (v1, s1, i1, l1) = _solve_both(prob, x0, u, np.array([0.0, 0.5, 2.0, 6.0, 400.0]), psw_kernel=False)
+    (v0, s0, i0, l0), (v1, s1, i1, l1) = _solve_both(prob, x0, u, np.array([0.0, 0.5, 2.0, 6.0, 400.0]))
     assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1)
     fin = np.isfinite(v0)
     assert np.array_equal(fin, np.isfinite(v1)) and rel(v1[fin], v0[fin]) < 1e-9
+    vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, np.array([0.0, 0.5, 2.0, 6.0, 400.0]), nthreads=8)
+    assert np.array_equal(so, s1) and np.array_equal(io, i1) and np.array_equal(lo, l1) and rel(v1[fin], vo[fin]) < 1e-9
 
 
 def test_mu_regularisation_restarts():
