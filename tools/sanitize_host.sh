@@ -13,7 +13,7 @@ CS=$R/ratilqr.jl_amd/csrc
 FLAGS="-std=c++17 -O1 -g -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include"
 g++ $FLAGS -c "$CS/driver.cpp" -o "$O/driver_asan.o"
 g++ $FLAGS -c "$CS/multi.cpp" -o "$O/multi_asan.o"
-g++ -shared -fsanitize=address,undefined -o "$O/libratilqr_hip_asan.so" "$CS"/kernels_{sweep,roll,fused,b2,b3,b5,b8,misc,psw,bpsw}.o "$CS/sweep_dual.o" "$CS/wide.o" \
+g++ -shared -fsanitize=address,undefined -o "$O/libratilqr_hip_asan.so" "$CS"/kernels_{sweep,roll,fused,b2,b3,b5,b8,misc,psw,bpsw,bpsw1}.o "$CS/sweep_dual.o" "$CS/wide.o" "$CS/wide32.o" \
     "$CS/ce_device.o" "$O/driver_asan.o" "$O/multi_asan.o" \
     -L/opt/rocm/lib -lamdhip64 -ldl -Wl,-rpath,/opt/rocm/lib
 gcc -O1 -g -fPIC -std=c11 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fopenmp -fno-fast-math -ffp-contract=off -shared \
