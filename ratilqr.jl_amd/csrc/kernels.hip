@@ -2743,7 +2743,8 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
 //   role B (gain team)   every gain sweep of the sample as a four-wave team: initialize!'s speculative one (mode 5), the next step!'s beside
 //                        each candidate's evaluation (mode 4), the plain one after a rejected candidate (mode 0)
 // Hand-overs go through global memory: the producer's waves drain their stores (s_waitcnt vmcnt(0): the write-through L1 has delivered them to
-// the shared L2), a barrier, then ONE 64-bit word (launch epoch << 32 | sequence number) is stored; the consumer's leader polls it with
+// the shared L2), a barrier, then ONE 64-bit word (launch epoch << 32 | sequence number; role A's posts also carry what they ask of role B) is
+// stored; the consumer's leader polls it with
 // agent-scope relaxed loads, and every load of partner-written data is an sc1 load (xld, device_utils.h) that misses the consumer's L1.  No
 // agent-scope fence anywhere: buffer_wbl2 / buffer_inv sc1 walk the L2 (3.6 - 7 us per hand-over, tools/ubench/xwg_handoff.hip: more than
 // the second compute unit saves); this way a hand-over costs 0.5 - 2 us.
@@ -2751,7 +2752,6 @@ __global__ __launch_bounds__(PAD4 ? 256 : 64 * NW, 2) void solve_block_kernel(Fu
 // role A -- dispatched earlier: workgroups start in order -- decides once, after initialize!'s copy, whether its partner is there (same XCD):
 // "duo", or "solo" = the one-workgroup schedule below, in which case a late partner leaves at once.  A resident role A never waits for a
 // partner that has not checked in, a role B only waits for a role A that is running: no deadlock whatever else shares the device.
-#define XW_EXIT 0x40000000ll
 #define XC_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 __device__ __forceinline__ long long xw_load(long long *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void xw_store(long long *w, long long v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2849,17 +2849,22 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
             psweep_body<true, WM, false, FLYB>(sa, b, wls, &psh[2], fa.psw4g, wave);
             BPSW_MARK();
             xc_post(xw + 16, xep | ++seqB);
-            while (true) {                           // role A's next post says what to sweep next
-                const long long got = xc_wait(xw + 8, xep | ++seqA, &xbc);
+            // Role A's posts carry what they ask for in their two low bits (word = epoch | sequence number << 2 | request): 0 nothing (accepting
+            // the candidate would end solve!: nothing consumes a gain sweep), 1 the plain gain sweep (mode 0), 2 the speculative one on the
+            // candidate (mode 4), 3 the solve is over.  The request travels WITH the post, not in the sample's state words: after a post that
+            // asks for nothing role A does not wait, so by the time this workgroup looks the state words may already be the next round's (a
+            // late reader would sweep that round twice and run one post ahead: found by tests/test_cpu_duo_protocol.py, not by the device).
+            // A post that asks for a sweep is answered before role A moves on, so what the sweep reads is stable.
+            while (true) {
+                const long long want = ++seqA;
+                const long long got = xc_wait(xw + 8, xep | (want << 2), &xbc);
                 BPSW_MARK();
-                if (got == 0 || (got & XW_EXIT)) return;
-                const int v_stat = xld(&st.status[b]), v_act = xld(&st.ls_active[b]), v_it = xld(&st.iter[b]);
-                const double v_dc = xld(&st.d_c[b]), v_mu = xld(&st.mu[b]);
-                if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) return;
-                if (!__builtin_amdgcn_readfirstlane(v_act)) { mode = 0; break; }
-                const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
-                const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
-                if (!ends) { mode = 4; break; }      // (accepting would end solve!: nothing consumes a gain sweep; role A decides alone)
+                if (got == 0) return;                                                   // (timed out: role A reports it)
+                const int code = (int)(got & 3);
+                if (code == 3) return;                                                  // over (every post before it asked for nothing or was answered)
+                if (((got - xep) >> 2) > want || code == 0) continue;                   // this post asked for nothing
+                mode = (code == 1) ? 0 : 4;
+                break;
             }
         }
         return;
@@ -2933,7 +2938,7 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp! with no valid speculative sweep  (ileqg.jl:598-613)
             if (duo) {
-                xc_post(xw + 8, xep | ++seqA);
+                xc_post(xw + 8, xep | ((long long)++seqA << 2) | 1);                       // the plain gain sweep, please
                 lost = xc_wait(xw + 16, xep | ++seqB, &xbc) == 0;
             } else {
                 SweepArgs sa = fa.sw; sa.mode = 0;
@@ -2982,7 +2987,7 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
         const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
         const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
-        if (duo) xc_post(xw + 8, xep | ++seqA);              // the partner reads the same words, forms the same `ends`, sweeps unless it holds
+        if (duo) xc_post(xw + 8, xep | ((long long)++seqA << 2) | (ends ? 0 : 2));      // the speculative gain sweep on this candidate -- unless accepting it ends the solve
         {
             SweepArgs sa = fa.sw;
             if (ends || duo) { sa.mode = 1; psweep_body<false, WM, true, FLYB>(sa, b, wls, &psh[2], fa.psw4e, wave); }
@@ -3005,7 +3010,7 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     BPSW_MARK();
     }
     BPSW_MARK();
-    if (duo) xc_post(xw + 8, xep | XW_EXIT | ++seqA);        // (always: the partner must not be left waiting)
+    if (duo) xc_post(xw + 8, xep | ((long long)++seqA << 2) | 3);       // over (always: the partner must not be left waiting)
     __syncthreads();
     BPSW_MARK();
     if (leader) {
