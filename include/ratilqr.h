@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RAT_VERSION 500
+#define RAT_VERSION 600
 
 /* ---- return codes (API level) ---------------------------------------------------------------- */
 typedef int32_t rat_rc;

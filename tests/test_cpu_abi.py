@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/ratilqr.h but not exported"
     assert declared == set(nv.EXPORTS)
-    assert lib.rat_version() == 500
+    assert lib.rat_version() == 600
 
 
 def test_defaults_match_reference_constructor():                    # ileqg.jl:191-194, ce.jl:100-116
