@@ -78,6 +78,7 @@ struct rat_handle_s {
     bool wide = false;
     WideProblemDev wpb;
     double *w_xs = nullptr, *w_us = nullptr, *w_L = nullptr, *w_dl = nullptr;
+    double *w_gq = nullptr, *w_gr = nullptr, *w_gc = nullptr;      // block form: cost gradients of a trajectory, formed 16 steps per product behind its rollout
     int *w_nom = nullptr, *w_hn = nullptr;
     std::vector<void *> pb_allocs, st_allocs;
     std::vector<double> hW;          // host copy of W (col-major, N entries) for rat_approximate_model
@@ -451,6 +452,7 @@ static rat_rc alloc_state_wide(rat_handle h) {
 #define AL(ptr, cnt) if ((rc = dev_alloc(h->st_allocs, &(ptr), (cnt)))) return rc
     AL(h->w_xs, (size_t)B * 2 * (N + 1) * n); AL(h->w_us, (size_t)B * 2 * N * m);
     AL(h->w_L, (size_t)B * N * n * m); AL(h->w_dl, (size_t)B * N * m); AL(h->w_nom, B); AL(h->w_hn, 1);
+    AL(h->w_gq, (size_t)B * 2 * N * n); AL(h->w_gr, (size_t)B * 2 * N * m); AL(h->w_gc, (size_t)B * 2 * 64);
     AL(h->d_x0, n); AL(h->d_u0, (size_t)N * m); AL(h->d_theta, B); AL(h->d_val, B);
     AL(h->d_ist, B); AL(h->d_iit, B); AL(h->d_ils, B);
     AL(h->d_opout, 2); AL(h->d_dump, 1); AL(h->d_dlin, 1);
@@ -996,6 +998,7 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
         wa.pb = h->wpb; wa.op = h->opd; wa.B = B; wa.fast16 = h->wide16 ? 1 : 0; wa.fast32 = h->wide32 ? 1 : 0;
         wa.x0 = h->d_x0; wa.u0 = h->d_u0; wa.theta = theta_dev;
         wa.xs = h->w_xs; wa.us = h->w_us; wa.L = h->w_L; wa.dl = h->w_dl; wa.nom = h->w_nom;
+        wa.gq = h->w_gq; wa.gr = h->w_gr; wa.gc = h->w_gc;
         wa.out_value = out.value; wa.out_status = out.status; wa.out_iters = out.iters; wa.out_ls = out.ls;
         wa.out_cost = out.cost; wa.kl_bound = out.kl_bound;
         wa.hist = h->st.hist; wa.hist_cap = h->st.hist_cap; wa.hist_n = h->w_hn;

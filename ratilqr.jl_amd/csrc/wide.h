@@ -40,6 +40,8 @@ struct WideArgs {
     // per-sample scratch (the solver object of one theta-sample: x_array, l_array and their candidates, L_array, dl)
     double *xs, *us;                 // [B][2][(N+1)*n], [B][2][N*m]
     double *L, *dl;                  // [B][N*m*n] (m x n column-major per step), [B][N*m]
+    double *gq, *gr, *gc;            // block form (wide32.h), time-invariant cost: [B][2][N*n] c_x, [B][2][N*m] c_u of the slots' trajectories and
+                                     // [B][2][64] the lanes' parts of their summed stage costs (grad32, once per rollout instead of per sweep step)
     int *nom;                        // [B] which of the two (x, u) slots holds x_array / l_array when the solve ends
     // outputs (any may be null)
     double *out_value; int *out_status, *out_iters, *out_ls;

@@ -593,12 +593,23 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
     const bool s16 = !s32 && a.fast16 && n >= 12 && n <= 16 && m <= 4;
     ldsd *const tab16 = s32 ? (ldsd *)lds : (ldsd *)lds + wide_lds_doubles(n, m);        // (its tables: behind the general kernel's area)
     if (s16 || s32) setup16(pb, tab16);
-    if constexpr (s32) rollout32<false, NT_, MT_>(pb, a.x0, a.u0, nullptr, nullptr, 0.0, xs, us);
+    // block form, time-invariant cost: the cost gradients of a slot's trajectory are formed behind its rollout, 16 steps per product (grad32)
+    double *const gqs = s32 ? a.gq + (size_t)b * 2 * N * n : nullptr, *const grs = s32 ? a.gr + (size_t)b * 2 * N * m : nullptr;
+    double *const gcs = s32 ? a.gc + (size_t)b * 2 * 64 : nullptr;
+    auto grads = [&](const int slot) {
+        if constexpr (s32) {
+            if (!pb.cost_tv) grad32<NT_, MT_>(pb, xs + (size_t)slot * xstr, us + (size_t)slot * ustr, gqs + (size_t)slot * N * n, grs + (size_t)slot * N * m, gcs + slot * 64);
+        }
+    };
+    if constexpr (s32) { rollout32<false, NT_, MT_>(pb, a.x0, a.u0, nullptr, nullptr, 0.0, xs, us); grads(0); }
     else if (s16) rollout16<false>(pb, a.x0, a.u0, nullptr, nullptr, 0.0, xs, us);          // :225, :228
     else rollout_open(pb, w, a.x0, a.u0, xs, us);
     auto run_sweep = [&](const double *xt, const double *ut, const double mu_, auto gain_c, auto zero_c, double &val) -> int {
         constexpr bool gain = decltype(gain_c)::value, zeroL = decltype(zero_c)::value;
-        if constexpr (s32) return sweep32<gain, zeroL, NT_, MT_>(pb, tab16, xt, ut, theta, mu_, Lg, dlg, val);
+        if constexpr (s32) {
+            const int slot = (xt == xs) ? 0 : 1;
+            return sweep32<gain, zeroL, NT_, MT_>(pb, tab16, xt, ut, theta, mu_, Lg, dlg, val, gqs + (size_t)slot * N * n, grs + (size_t)slot * N * m, gcs + slot * 64);
+        }
         else {
             if (s16) return sweep16<gain, zeroL>(pb, w.T, tab16, xt, ut, theta, mu_, Lg, dlg, val);
             tl.x = xt; tl.u = ut;
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(64) void wide_solve_kernel(const WideArgs a) {
             if (count > 4000) { status = 7; break; }                                        // (App. B.5)
             n_ls++;
             double d_new;                                                                   // :509-517
-            if constexpr (s32) d_new = rollout32<true, NT_, MT_>(pb, xn, un, dlg, Lg, eps, xc, uc);
+            if constexpr (s32) { d_new = rollout32<true, NT_, MT_>(pb, xn, un, dlg, Lg, eps, xc, uc); grads(nom ^ 1); }
             else d_new = s16 ? rollout16<true>(pb, xn, un, dlg, Lg, eps, xc, uc) : rollout_closed(pb, w, xn, un, dlg, Lg, eps, xc, uc);
             double newv;
             const int rc = run_sweep(xc, uc, mu, no, no, newv);                      // :520-528

@@ -153,12 +153,91 @@ __device__ __forceinline__ void elim32_rounds(Blk<TT, TT> &M, const ldsd *const 
     if constexpr (KB + 1 < 8 * TT) elim32_rounds<KB + 1, TT>(M, mk, es, odd, pdmin, rprod, rexp, size);
 }
 
+// approximate_model's cost gradients (:294-313) of a whole trajectory, SIXTEEN steps per product: with the steps as the columns of a tile,
+// c_x = Q X + P'U + q_vec and c_u = R U + P X + r_vec are four block products per 16 steps instead of four one-column products (which use 1 / 16
+// of a tile) per step of every sweep that reads the trajectory.  Time-invariant cost tables only (the caller checks).  gq [N][n], gr [N][m]:
+// the gradients; gc [64]: the lanes' parts of sum_t c(x_t, u_t) - q0 (the sweeps add them to their own per-lane sums).
+template <int NT, int MT>
+__device__ __noinline__ void grad32(const WideProblemDev &pb_in, const double *const x_, const double *const u_, double *const gq_, double *const gr_,
+                                    double *const gc_) {
+    const WideProblemDev pb = pb_in;
+    const gbld *const x = (const gbld *)x_, *const u = (const gbld *)u_;
+    gbld *const gq = (gbld *)gq_, *const gr = (gbld *)gr_;
+    const int n = pb.n, m = pb.m, N = pb.N;
+    const int l = threadIdx.x, g = l >> 4, j = l & 15;
+    double acc = 0.0;
+    for (int t0 = 0; t0 < N; t0 += 16) {
+        const int t = t0 + j, tc = min(t, N - 1);
+        const bool tin = t < N;
+        Blk<NT, 1> Xb, qx, qvb;
+        Blk<MT, 1> Ub, ru, px, rvb;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * a + 4 * r + g;
+                const bool in = tin && i < n;
+                Xb.t[a][0][r] = (x + (size_t)tc * n)[min(i, n - 1)] * (in ? 1.0 : 0.0);
+                qvb.t[a][0][r] = ((const gbld *)pb.qv)[min(i, n - 1)] * (in ? 1.0 : 0.0);
+            }
+#pragma unroll
+        for (int c = 0; c < MT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * c + 4 * r + g;
+                const bool in = tin && i < m;
+                Ub.t[c][0][r] = (u + (size_t)tc * m)[min(i, m - 1)] * (in ? 1.0 : 0.0);
+                rvb.t[c][0][r] = ((const gbld *)pb.rv)[min(i, m - 1)] * (in ? 1.0 : 0.0);
+            }
+        blk_zero(qx); blk_zero(ru); blk_zero(px);
+        {
+            Blk<NT, NT> Q;
+            ld_img(Q, pb.tQ, l);
+            pmm(Q, Xb, qx);
+        }
+        Blk<NT, 1> cq = qx;
+        {
+            Blk<MT, NT> Pm;
+            ld_img(Pm, pb.tP, l);
+            pmm(Pm, Ub, cq);
+        }
+        {
+            Blk<MT, MT> R;
+            ld_img(R, pb.tR, l);
+            pmm(R, Ub, ru);                                     // (unit diagonal beyond m: times u = 0 there)
+        }
+        {
+            Blk<NT, MT> PT;
+            ld_img(PT, pb.tPT, l);
+            pmm(PT, Xb, px);
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * a + 4 * r + g;
+                acc += Xb.t[a][0][r] * (0.5 * qx.t[a][0][r] + qvb.t[a][0][r]);
+                if (tin && i < n) (gq + (size_t)t * n)[i] = cq.t[a][0][r] + qvb.t[a][0][r];
+            }
+#pragma unroll
+        for (int c = 0; c < MT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * c + 4 * r + g;
+                acc += Ub.t[c][0][r] * (0.5 * ru.t[c][0][r] + px.t[c][0][r] + rvb.t[c][0][r]);
+                if (tin && i < m) (gr + (size_t)t * m)[i] = (ru.t[c][0][r] + px.t[c][0][r]) + rvb.t[c][0][r];
+            }
+    }
+    ((gbld *)gc_)[l] = acc;
+}
+
 // solve_approximate_dp (GAIN = false, :412-465) / one pass of solve_approximate_dp! (GAIN = true, :341-406) over the trajectory (x, u) of an
 // LQ-family problem with n <= 16 NT, m <= 16 MT.  Returns 0, 2 (M not positive definite) or -1 (H not positive definite: the caller raises
 // mu and restarts).  tab: the 0 / 1 tables of setup16 in LDS (the rounds' masks depend on the position inside a tile only).
 template <bool GAIN, bool ZEROL, int NT, int MT>
 __device__ __noinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *const tab, const double *const x_, const double *const u_,
-                                       const double theta, const double mu, double *const Lg_, double *const dlg_out, double &value) {
+                                       const double theta, const double mu, double *const Lg_, double *const dlg_out, double &value,
+                                       const double *const gq_, const double *const gr_, const double *const gc_) {
     const WideProblemDev pb = pb_in;
     const gbld *const x = (const gbld *)x_, *const u = (const gbld *)u_;
     gbld *const Lg = (gbld *)Lg_, *const dlg = (gbld *)dlg_out;
@@ -228,10 +307,21 @@ __device__ __noinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *con
         for (int a = 0; a < NT; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xrow[a][r] = xr_n[a][r] * ((16 * a + 4 * r + g < n) ? 1.0 : 0.0);
-        // approximate_model at (x_t, u_t) (:294-313): q_vec = Q x + P'u + q_vec, r_vec = R u + P x + r_vec, c
+        // approximate_model at (x_t, u_t) (:294-313): q_vec = Q x + P'u + q_vec, r_vec = R u + P x + r_vec, c -- read back from grad32's pass over
+        // the trajectory (time-invariant cost), or formed here as one-column products (time-varying tables)
         Blk<NT, 1> qvt;
         Blk<MT, 1> rvt;
-        {
+        if (!pb.cost_tv) {
+            const gbld *const gqt = (const gbld *)gq_ + (size_t)t * n, *const grt = (const gbld *)gr_ + (size_t)t * m;
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int i = 16 * a + 4 * r + g; qvt.t[a][0][r] = gqt[min(i, n - 1)] * ((j == 0 && i < n) ? 1.0 : 0.0); }
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int i = 16 * c + 4 * r + g; rvt.t[c][0][r] = grt[min(i, m - 1)] * ((j == 0 && i < m) ? 1.0 : 0.0); }
+        } else {
             Blk<NT, 1> xv;
             Blk<MT, 1> uv;
 #pragma unroll
@@ -473,6 +563,7 @@ __device__ __noinline__ int sweep32(const WideProblemDev &pb_in, const ldsd *con
         S = F11; sv = F1a;
         W32_FENCE();
     }
+    if (!pb.cost_tv) acc += ((const gbld *)gc_)[l];            // the stage costs of the trajectory (grad32)
     double tot = acc + 0.5 * racc;
     tot = wsum(tot) + usum;
     if (theta != 0.0) tot += coef * lsum;                                                           // -(logdet W + logdet M) / (2 theta)
