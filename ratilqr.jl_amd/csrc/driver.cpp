@@ -134,6 +134,9 @@ struct rat_handle_s {
     bool psw_acl = true;                          // ... with its closed-loop rollouts in deviation form (rollacl_body: what block_acl is to solve_block_kernel)
     int E_req = 1;                                // the speculation width the caller asked for (rat_create's spec_eps); E is what the handle runs
     bool spec_force = false;                      // switch spec_force: run E_req speculative candidates per line-search round (the E > 1 kernels)
+    bool psw_prl = true;                          // ... its closed-loop rollouts time-parallel over the four waves (kappa == 0, time-invariant cost)
+    int prl_elem = 45, prl_hop = 90, prl_epi = 100;   // the cut model of that rollout, in hundredths of an ordinary step: one element step, one hop, the terminal tile
+    int64_t prl_last = 0;                         // the cuts of the last launch that ran it (cut_1 | cut_2 << 16 | cut_3 << 32; 0 = did not apply)
     bool psw_duo = true;                          // ... with two workgroups (compute units) per sample while the batch leaves half the device dark
     bool block_psw = true;                        // the workgroup-per-sample solve with time-parallel sweeps for batches of <= one sample per CU (solve_block_psw_kernel)
     uint64_t opts_serial = 0;                     // bumped by everything that can change what a solve returns without a new problem: rat_set_ileqg_opts,
@@ -220,6 +223,11 @@ static const DebugSwitch debug_switches[] = {
     {"spec_width", [](rat_handle, int64_t) {}, [](rat_handle h) -> int64_t { return h->E; }},
     {"block_psw", [](rat_handle h, int64_t v) { h->block_psw = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_psw; }},
     {"psw_duo", [](rat_handle h, int64_t v) { h->psw_duo = (v != 0); }, [](rat_handle h) -> int64_t { return h->psw_duo; }},
+    {"psw_prl", [](rat_handle h, int64_t v) { h->psw_prl = (v != 0); }, [](rat_handle h) -> int64_t { return h->psw_prl; }},
+    {"prl_elem", [](rat_handle h, int64_t v) { h->prl_elem = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->prl_elem; }},
+    {"prl_hop", [](rat_handle h, int64_t v) { h->prl_hop = (int)std::max<int64_t>(0, v); }, [](rat_handle h) -> int64_t { return h->prl_hop; }},
+    {"prl_epi", [](rat_handle h, int64_t v) { h->prl_epi = (int)std::max<int64_t>(0, v); }, [](rat_handle h) -> int64_t { return h->prl_epi; }},
+    {"prl_cuts", [](rat_handle, int64_t) {}, [](rat_handle h) -> int64_t { return h->prl_last; }},
     {"psw_duo_count", [](rat_handle h, int64_t) { if (h->d_duo_count) { (void)hipStreamSynchronize(h->stream); (void)hipMemset(h->d_duo_count, 0, sizeof(int)); } },
      [](rat_handle h) -> int64_t { int c = 0; if (h->d_duo_count) { (void)hipStreamSynchronize(h->stream); (void)hipMemcpy(&c, h->d_duo_count, sizeof(int), hipMemcpyDeviceToHost); } return c; }},
     {"psw_acl", [](rat_handle h, int64_t v) { h->psw_acl = (v != 0); }, [](rat_handle h) -> int64_t { return h->psw_acl; }},
@@ -770,6 +778,38 @@ static PswCuts psweep_cuts(int N, int P, double hop, double comp) {
     for (int s = P; s >= 1; --s) pc.cut[s] = std::min(pc.cut[s], pc.cut[s + 1] - 1);
     return pc;
 }
+// Segment cuts of the time-parallel rollout (kernels.hip: rollprl_body).  Wave 0 runs the ordinary rollout over n_0 steps at once; wave w >= 1
+// first builds the element of segment w - 1 (e ordinary steps per step), hops (h steps; w - 1 of them are chained in front of it), then runs its
+// own n_w steps.  All four finish together when  n_0 = e n_0 + n_1 = e n_1 + h + n_2 = e n_2 + 2 h + n_3  and  n_0 + ... + n_3 = N.
+static PrlCuts rollprl_cuts(int N, double e, double h, double epi) {
+    // Cost model in units of one ordinary rollout step: an element step costs e, a hop (box taken, Phi dx + c, box posted) h, the terminal
+    // tile epi (last wave).  Wave 0 runs n_0 steps; wave w >= 1 builds the element of segment w - 1 (e n_{w-1}), takes the deviation of
+    // wave w - 1 (posted at T_{w-1}; T_0 = 0), hops (T_w = max(e n_{w-1}, T_{w-1}) + h) and runs n_w steps.  All waves end together at F:
+    // n_w = F - T_w (- epi for the last); F by bisection on sum n_w = N.
+    auto lens = [&](double F, double *n) {
+        double T = 0.0;
+        n[0] = F;
+        for (int w = 1; w < PRL_WAVES; ++w) {
+            T = std::max(e * n[w - 1], T) + h;
+            n[w] = std::max(F - T - (w == PRL_WAVES - 1 ? epi : 0.0), 1.0);
+        }
+        double sum = 0.0;
+        for (int w = 0; w < PRL_WAVES; ++w) sum += n[w];
+        return sum;
+    };
+    double n[PRL_WAVES], lo = 1.0, hi = (double)N;
+    for (int it = 0; it < 60; ++it) { const double mid = 0.5 * (lo + hi); (lens(mid, n) < (double)N ? lo : hi) = mid; }
+    lens(hi, n);
+    PrlCuts pc;
+    double t = 0.0;
+    pc.cut[0] = 0;
+    for (int w = 0; w < PRL_WAVES; ++w) { t += n[w]; pc.cut[w + 1] = (int)(t + 0.5); }
+    pc.cut[PRL_WAVES] = N;
+    for (int w = 1; w <= PRL_WAVES; ++w) pc.cut[w] = std::max(pc.cut[w], pc.cut[w - 1] + 1);
+    pc.cut[PRL_WAVES] = N;
+    for (int w = PRL_WAVES - 1; w >= 1; --w) pc.cut[w] = std::min(pc.cut[w], pc.cut[w + 1] - 1);
+    return pc;
+}
 // sweep launches of the batched operators: the segment-parallel kernel when the handle asks for it (switch psweep) and it covers the case
 static void launch_sweep_or_psweep(rat_handle h, const SweepArgs &a, int ntraj, bool gain) {
     if (h->psweep >= 2 && psweep_supported(a, gain)) {
@@ -1049,6 +1089,16 @@ static rat_rc run_batch(rat_handle h, const double *theta_dev, int B, const Batc
             fa.init_x = h->d_init_x; fa.init_u = h->d_init_u; fa.init_t = h->d_init_t;
         }
         h->init_batches++;
+        fa.prl = 0;
+        h->prl_last = 0;
+        if (psw) {
+            fa.acl = (h->psw_acl || h->block_acl) ? 1 : 0;
+            if (fa.acl && h->psw_prl && h->pb.kappa == 0.0 && !h->pb.cost_tv && st.N >= 4 * PRL_WAVES) {
+                fa.prl = 1;
+                fa.prl_cut = rollprl_cuts(st.N, h->prl_elem / 100.0, h->prl_hop / 100.0, h->prl_epi / 100.0);
+                h->prl_last = (int64_t)fa.prl_cut.cut[1] | (int64_t)fa.prl_cut.cut[2] << 16 | (int64_t)fa.prl_cut.cut[3] << 32;
+            }
+        }
         if (psw) {
             fa.acl = (h->psw_acl || h->block_acl) ? 1 : 0;       // (this kernel's values agree with the sequential paths to rounding anyway)
             fa.psw2e = psweep_cuts(st.N, 2, h->psw_hop_e / 100.0, h->psw_comp / 100.0);

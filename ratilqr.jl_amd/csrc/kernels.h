@@ -27,6 +27,10 @@ struct SweepArgs {
 #define PSW_MAXP 8
 struct PswCuts { int P; int cut[PSW_MAXP + 2]; };     // cut[0] = 0 < cut[1] < ... < cut[P + 1] = N
 
+// the time-parallel closed-loop rollout (kernels.hip: rollprl_body): four waves over four horizon segments [cut[w], cut[w+1])
+#define PRL_WAVES 4
+struct PrlCuts { int cut[PRL_WAVES + 1]; };
+
 struct RolloutArgs {
     StateDev st;
     ProblemDev pb;
@@ -68,6 +72,8 @@ struct FusedArgs {         // solve_fused_kernel: one persistent wavefront per s
     int psw_last;                      // solve_block_kernel, two-wave geometry: the evaluation that ends the solve by both waves, time-parallel (psw2e)
     // solve_block_psw_kernel, two workgroups per sample (see the kernel): duo_stride = B rounded up to a multiple of 8 (0: one workgroup per
     // sample), xw = [Bmax][XW_STRIDE] hand-over words, xepoch = this launch's number on the handle (> 0), duo_count = samples that ran as a pair
+    int prl;                           // solve_block_psw_kernel: closed-loop rollouts time-parallel over the workgroup's four waves (rollprl_body;
+    PrlCuts prl_cut;                   //  kappa == 0, time-invariant cost; switch psw_prl) and their segment cuts
     int duo_stride;
     unsigned xepoch;
     long long *xw;

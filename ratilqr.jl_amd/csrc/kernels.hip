@@ -1704,6 +1704,223 @@ __device__ __forceinline__ void rollacl_body(const RolloutArgs &a, const double 
     __hip_atomic_store(prog, epoch + N + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// =====================================================================================================
+// rollprl_body: the closed-loop rollout of ONE candidate TIME-PARALLEL over the four wavefronts of its workgroup (solve_block_psw_kernel;
+// LQ family with kappa == 0, time-invariant cost, operands staged in LDS by stage_shared; switch psw_prl).  simulate_dynamics (ileqg.jl:62-87)
+// is a chain of N dependent steps that ONE wavefront walks (rollacl_body) while three others linearise behind it; but for kappa == 0 the
+// DEVIATION dx_t = x_t - xbar_t obeys an affine recursion, dx_{t+1} = (A + B L_t) dx_t + eps B dl_t (xbar is a trajectory of the same
+// dynamics), and affine maps compose.  The horizon is cut into four segments [cut_w, cut_w+1):
+//   wave 0          runs the ordinary rollout (recursion + linearisation, rollin_body's step) over segment 0 from x_0 at once;
+//   wave w >= 1     first builds the ELEMENT of segment w - 1 -- the map dx_start -> dx_end = Phi dx_start + c -- by running the deviation
+//                   recursion on THIRTEEN columns at once: in B-form a vector is replicated over the 16 columns of the MFMA's B operand and
+//                   every column is computed on its own, so columns 0..11 carry the unit vectors (they become Phi) and column 12 the affine
+//                   input (it becomes c): the recursion's own seven MFMAs per step, no linearisation, ~half an ordinary step;
+//                   takes the deviation at the start of segment w - 1 from wave w - 1 (zero for w = 1), "hops" to its own start
+//                   (dx by column through three MFMAs, then Phi dx + c by a row sum: ~400 cycles), hands that on, and runs the ordinary
+//                   rollout over segment w from x = xbar + dx.
+// Every x_t, u_t, cost row and step norm comes from the ordinary step's own arithmetic on a start state that differs from the sequential
+// one by rounding (the hop): results agree with the sequential rollout to ~1e-16, like everything else on this path.  Critical path: with
+// the cuts balanced (rollprl_cuts) ~0.35 N ordinary steps instead of N recursion steps followed by the linearising pool's tail.
+// =====================================================================================================
+struct PrlShared { double box[PRL_WAVES][192]; int flag[PRL_WAVES]; };
+
+__device__ __forceinline__ void rollprl_body(const RolloutArgs &a, const int b, const int nom, const double eps, const double *const stg, double *const shxu,
+                                             PrlShared *const ps, const int epoch, const int wave, const PrlCuts &pc, unsigned long long *const d_acc) {
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));
+    const int l = lane_, j = l & 15, g = l >> 4;
+    const StateDev &st = a.st;
+    const ProblemDev &pb = a.pb;
+    const int N = st.N;
+    const int slot_o = cand_slot(b, 0, nom, st.E);
+    double *__restrict__ xo = st.xs + (long)slot_o * st.x_stride;
+    double *__restrict__ uo = st.us + (long)slot_o * st.u_stride;
+    double *__restrict__ tile0 = st.tiles + tile_slot(st, b, slot_o) * st.tile_stride;
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    constexpr int cL = STG_CL, cX = STG_CX, cU = STG_CU;
+    const double *const sL = stg, *const sX = stg + cL * 64, *const sl = sX + cX * 64, *const sdl = sl + cU * 64;
+    // per-lane constants of rollin_body (LQ family, time-invariant cost)
+    double zA[4], cf[4], es[4], lin4[4];
+    const double mq = (j < 12) ? 1.0 : 0.0;
+    const int jx = (j < 12) ? j : 11, j3 = j & 3;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        es[s] = (j == 4 * s + g) ? 1.0 : 0.0;
+        zA[s] = pb.Zt[jx * 16 + 4 * s + g] * mq;
+        cf[s] = pb.Ctab[64 * s + l];
+        lin4[s] = pb.lin[4 * s + g];
+    }
+    const double cq00 = pb.q0[0];
+    const double pm[4] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0, j == 3 ? 1.0 : 0.0};
+    double *const pxu = (j < 3) ? xo + 4 * j + g : (j == 3 ? uo + g : tile0 + TS_PAD);
+    const long sxu = (j < 3) ? XSTR : (j == 3 ? USTR : TSTRIDE);
+    const int t_lo = pc.cut[wave], t_hi = pc.cut[wave + 1];
+#ifdef RAT_DIAG_PHASES
+#define PRL_STAMP(i_) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0 && b < 8 && a.dump) \
+        a.dump[3072 + b * 64 + wave * 16 + (i_)] = (double)__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PRL_STAMP(i_) do {} while (0)
+#endif
+    PRL_STAMP(0);
+    // the terminal tile's constants are requested now (their L2 round trips pass under the segment): wave 0 copies Qf after its segment,
+    // the last wave holds its row of Qf for Qf x_N
+    double *__restrict__ tp = tile0 + (long)N * TSTRIDE;
+    double qfc[3] = {0.0, 0.0, 0.0}, qfr[12], qvf = 0.0;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) qfr[q] = 0.0;
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) qfc[q] = pb.Qf[(l + 64 * q < 144) ? l + 64 * q : 0];
+    } else if (wave == PRL_WAVES - 1) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) qfr[q] = pb.Qf[jx * 12 + q];
+        qvf = pb.qvf[jx];
+    }
+    // ---- waves 1..3: the element of the segment before their own, then the hop ----------------------------------------------------------
+    double dx[3] = {0.0, 0.0, 0.0};                             // deviation at this wave's first step, B-form
+    if (wave >= 1) {
+        double D[3] = {es[0], es[1], es[2]};                    // columns 0..11: unit vectors; column 12: zero (the affine part)
+        const double m12 = (j == 12) ? eps : 0.0;
+        // Five MFMAs per step, three of them in the chain: Acl_t' = A' + L_t' B' in the accumulator layout IS the A operand of Acl_t (.)
+        // slice by slice (rollprod_body's product), and the affine column's input B (eps dl_t) starts the accumulator -- both independent of D
+        // (an f64 MFMA holds the datapath for 64 cycles whatever it computes: the count is the cost, profiles/r01_ubench_fp64_pipe.md).
+        d4 cA;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) cA[s] = zA[s];              // (zA[s] on lane (g, j) = A[j][4 s + g] = A'[4 s + g][j])
+        cA[3] = 0.0;
+        const double bop = zA[3];                               // B' as the B operand: lane (g, j) = B[j][g]
+        const int loff = g * 12 + jx;
+        for (int t = pc.cut[wave - 1]; t < t_lo; ++t) {
+            const double la = sL[t * LSTR + loff] * mq;         // natural rows of L_t: lane (g, j) = L_t[g][j]
+            const double dlt = sdl[t * USTR + g];
+            const d4 acl = MFMA(la, bop, cA);
+            d4 xa = MFMA(zA[3], m12 * dlt, zero4);
+            xa = MFMA(acl[0], D[0], xa);
+            xa = MFMA(acl[1], D[1], xa);
+            xa = MFMA(acl[2], D[2], xa);
+            D[0] = xa[0]; D[1] = xa[1]; D[2] = xa[2];
+        }
+        PRL_STAMP(1);
+        double xin[3] = {0.0, 0.0, 0.0};
+        if (wave >= 2) {                                        // the deviation at the start of that segment, from the wave before
+            // (bounded: the producer is a wave of this workgroup that cannot fail to post; a protocol error must not hang the device)
+            for (int polls = 0; polls < (1 << 24) &&
+                 __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ps->flag[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - (epoch + 1) < 0; ++polls)
+                __builtin_amdgcn_s_sleep(1);
+            WAVE_SYNC();
+#pragma unroll
+            for (int s = 0; s < 3; ++s) xin[s] = ps->box[wave - 1][64 * s + l];
+        }
+        PRL_STAMP(2);
+        // hop: dx_out = Phi dx_in + c.  dx_in by column (lane (., j) <- component j): three MFMAs against the unit slices; Phi's column j times
+        // it, the affine column added, summed over the row's sixteen lanes: component 4 s + g on every lane of row g -- B-form again
+        d4 tj = MFMA(xin[0], es[0], zero4);
+        tj = MFMA(xin[1], es[1], tj);
+        tj = MFMA(xin[2], es[2], tj);
+        const double c12 = (j == 12) ? 1.0 : 0.0;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dx[s] = row_sum16(fma(D[s], tj[0], D[s] * c12));
+        if (wave < PRL_WAVES - 1) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) ps->box[wave][64 * s + l] = dx[s];
+            WAVE_SYNC();
+            if (l == 0) __hip_atomic_store(&ps->flag[wave], epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    PRL_STAMP(3);
+    // ---- the ordinary rollout over [t_lo, t_hi) (rollin_body's closed-loop step: staged operands, no tile records, cost rows of five steps per
+    //      set of four MFMAs) from x = xbar + dx ------------------------------------------------------------------------------------------------
+    double xb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) xb[s] = sX[t_lo * XSTR + 4 * s + g] + dx[s];
+    double xq[4] = {0.0, 0.0, 0.0, 0.0};
+    double dmax = 0.0;
+    bool dnan = false;
+    constexpr int RD = 5;
+    auto step = [&](const int t, const int d, const bool last) {
+        const double c_l = sl[t * USTR + g], c_dl = sdl[t * USTR + g];
+        const double xb0 = sX[t * XSTR + g], xb1 = sX[t * XSTR + 4 + g], xb2 = sX[t * XSTR + 8 + g];
+        const double La0 = sL[t * LSTR + j3 * 12 + g], La1 = sL[t * LSTR + j3 * 12 + 4 + g], La2 = sL[t * LSTR + j3 * 12 + 8 + g];
+        d4 xa = MFMA(zA[0], xb[0], zero4);
+        xa = MFMA(zA[1], xb[1], xa);
+        xa = MFMA(zA[2], xb[2], xa);
+        d4 fb = MFMA(La0, xb[0] - xb0, zero4);                  // L_t (x_t - xbar_t)   (:82)
+        fb = MFMA(La1, xb[1] - xb1, fb);
+        fb = MFMA(La2, xb[2] - xb2, fb);
+        const double lnew = c_l + eps * c_dl;                   // l + eps dl           (:509)
+        const double u = lnew + fb[0];
+        const double du = c_l - u, dsq = du * du;
+        const double dn2 = ((readlane_f64(dsq, 0) + readlane_f64(dsq, 16)) + readlane_f64(dsq, 32)) + readlane_f64(dsq, 48);
+        dnan |= (dn2 != dn2);
+        dmax = (dn2 > dmax) ? dn2 : dmax;
+        xa = MFMA(zA[3], u, xa);
+        const double pk = ((xb[0] * pm[0] + xb[1] * pm[1]) + xb[2] * pm[2]) + u * pm[3];
+        pxu[(long)t * sxu] = pk;
+        const bool me = (j == d) || (last && j > d);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) xq[s] = me ? xb[s] : xq[s];
+        xq[3] = me ? u : xq[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xb[r] = xa[r];              // (kappa == 0: no cubic term)
+    };
+    auto flush = [&](const int t0, const int cnt) {
+        d4 cx = MFMA(cf[0], xq[0], zero4);                      // C [x;u] of every step of the group
+        cx = MFMA(cf[1], xq[1], cx);
+        cx = MFMA(cf[2], xq[2], cx);
+        cx = MFMA(cf[3], xq[3], cx);
+        double *__restrict__ rp = tile0 + (long)(t0 + ((j < cnt) ? j : cnt - 1)) * TSTRIDE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rp[TS_QR + 4 * s + g] = cx[s] + lin4[s];                    // [c_x | c_u] = C [x;u] + [qv;rv]  (:297,:299)
+        const double a0 = cost_term(xq[0], cx[0], lin4[0]), a1 = cost_term(xq[1], cx[1], lin4[1]);
+        const double a2 = cost_term(xq[2], cx[2], lin4[2]), a3 = cost_term(xq[3], cx[3], lin4[3]);
+        double wr[4];
+        rows_bcast((a0 + a2) + (a1 + a3), wr);
+        const double part = ((wr[0] + wr[1]) + wr[2]) + wr[3];
+        rp[(g == 0) ? TS_q : TS_PAD + (g & 1)] = (g == 0) ? part + cq00 : 0.0;
+    };
+    int t0 = t_lo;
+    for (; t0 + RD <= t_hi; t0 += RD) {
+#pragma unroll
+        for (int d = 0; d < RD; ++d) step(t0 + d, d, d == RD - 1);
+        flush(t0, RD);
+    }
+    {
+        const int nt = t_hi - t0;
+#pragma unroll
+        for (int d = 0; d < RD - 1; ++d)
+            if (d < nt) step(t0 + d, d, d == nt - 1);
+        if (nt > 0) flush(t0, nt);
+    }
+    PRL_STAMP(4);
+    if (l == 0) {
+        atomicMax(&d_acc[0], (unsigned long long)__double_as_longlong(dmax));     // doubles >= +0 order like their bit patterns
+        if (dnan) atomicOr(&d_acc[1], 1ull);
+    }
+    // ---- wave 0: Qf into the terminal tile; the last wave: x_N and the rest of that tile (rollin_body's epilogue) --------------------------
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (l + 64 * q < 144) tp[TT_Q + l + 64 * q] = qfc[q];
+    }
+    if (wave == PRL_WAVES - 1) {
+        d4 tj = MFMA(xb[0], es[0], zero4);
+        tj = MFMA(xb[1], es[1], tj);
+        tj = MFMA(xb[2], es[2], tj);
+        const double x = tj[0];
+        if (l < 12) { xo[(long)N * XSTR + l] = x; shxu[l] = x; }
+        WAVE_SYNC();
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) acc = fma(qfr[q], shxu[q], acc);
+        if (l < 12) tp[TT_QV + l] = acc + qvf;
+        const double part = row_sum16((j < 12) ? cost_term(shxu[jx], acc, qvf) : 0.0);
+        if (l == 0) tp[TT_q] = part + pb.q0f;
+        WAVE_SYNC();
+    }
+    PRL_STAMP(5);
+#undef PRL_STAMP
+}
+
 #if RAT_PART & PART_ROLL
 template <int MODEL, int MODE, bool CTV, bool SEP>
 __global__ __launch_bounds__(64) void rollin_kernel(RolloutArgs a) {
@@ -2799,10 +3016,12 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     __shared__ int prog, pprog, lpool;
     __shared__ unsigned long long d_acc[2];
     __shared__ long long xbc;                    // xc_wait's broadcast; the duo decision
+    __shared__ PrlShared prl;                    // the time-parallel rollout's hand-over boxes (rollprl_body)
     __shared__ PswShared psh[3];                 // [0] the evaluation team, [1] the gain team, [2] the four-wave team (a team's barrier counter
                                                  // stays a multiple of ITS size)
     int epoch = 0;
     if (threadIdx.x == 0) { prog = 0; pprog = 0; }
+    if (threadIdx.x < PRL_WAVES) prl.flag[threadIdx.x] = 0;
     if (threadIdx.x < 3 * PSW_MAXP) psh[threadIdx.x / PSW_MAXP].flag[threadIdx.x % PSW_MAXP] = 0;
     if (threadIdx.x < 3) { psh[threadIdx.x].bar = 0; psh[threadIdx.x].last_rc = 0; psh[threadIdx.x].lastP = 0; }
     double *const wls = wls_all[wave], *const shxu = shxu_all[wave];
@@ -2962,9 +3181,13 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
             __syncthreads();
             BPSW_MARK();
             if (act) {
-                if (wave == 0) rollacl_body(ra, eps_, stg, aclring, xu, &pprog, &prog, epoch);
-                else if (wave == 1) rollprod_body(ra, stg, aclring, &pprog, &prog, epoch);
-                rolllin_body<1, CTV, true, true, true>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc, stg, eps_, &lpool, wave == 0 ? 1 : 0);
+                if (!CTV && fa.prl) {                        // kappa == 0, time-invariant cost: the rollout time-parallel over the four waves
+                    rollprl_body(ra, b, nom_, eps_, stg, shxu, &prl, epoch, wave, fa.prl_cut, d_acc);
+                } else {
+                    if (wave == 0) rollacl_body(ra, eps_, stg, aclring, xu, &pprog, &prog, epoch);
+                    else if (wave == 1) rollprod_body(ra, stg, aclring, &pprog, &prog, epoch);
+                    rolllin_body<1, CTV, true, true, true>(ra, b, shxu, xu, &prog, epoch, 0, 1, d_acc, stg, eps_, &lpool, wave == 0 ? 1 : 0);
+                }
             }
             epoch += st.N + 2;
         } else {                                             // the candidate of this line-search round  (ileqg.jl:504-521)
