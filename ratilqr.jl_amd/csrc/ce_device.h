@@ -24,5 +24,7 @@ void launch_ce_step(CeDev *s, const double *z, long long z_avail, double *theta,
 // PETS step! bookkeeping on the device (ce_device.hip): control sequences from (mu_t, Sigma_t) and the elite / smoothed update
 #define PETS_DEV_MAX_S 1024     /* one workgroup sorts the sample costs */
 // one launch between two rollout launches: elites + smoothed update on the finished rollouts (do_update), the next control sequences (do_sample)
+struct PetsStage3 { const double *src[3]; double *dst[3]; long n[3]; int *zero_word; };      // three copies (and one word zeroed) in one launch
+void launch_pets_stage3(const PetsStage3 &a, hipStream_t st);
 void launch_pets_step(double *mu, double *Sigma, double *controls, const double *cost, long S, int ne, int N, int m, double sf, const double *zc,
                       unsigned long long seed, int it, int do_update, int do_sample, int *err, hipStream_t st);

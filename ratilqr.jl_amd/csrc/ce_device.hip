@@ -246,14 +246,19 @@ __device__ __forceinline__ void pd_philox(unsigned c0, unsigned c1, unsigned c2,
 }
 __device__ __forceinline__ double pd_u01(unsigned hi, unsigned lo) { return (double)((((unsigned long long)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0); }
 
-// ONE bookkeeping launch between two rollout launches (one workgroup of 1024 threads; the sort runs over CT slots, CT = the power of two
-// >= S, at least 64 -- a batch of 100 control samples needs 28 of the 55 stages of the 1024-slot network, one of them through LDS):
+// ONE bookkeeping launch between two rollout launches.  Round 6: a GRID of workgroups, each owning a slice of the horizon (one time step per
+// workgroup up to 64 of them) -- everything below is independent per time step except the ranking of the sample costs, which every
+// workgroup repeats for itself (1024 threads; the sort runs over CT slots, CT = the power of two >= S, at least 64 -- a batch of 100
+// control samples needs 28 of the 55 stages of the 1024-slot network, one of them through LDS).  A workgroup reads and writes the controls
+// of ITS time steps only (reads before writes, behind its own barrier), so the update and the next draw stay in place:
 //   do_update: get_elite_samples + compute_new_distribution (pets.jl:159-191) on the sample costs of the finished rollouts -- elites by the
-//              bitonic network of ce_update under (isless(cost), index), over CT slots only; then a thread per (t, a): mean and unbiased
-//              variance over the elites in sorted order, smoothed update of mu_t and of the diagonal covariance;
+//              bitonic network of ce_update under (isless(cost), index), over CT slots only; then per time step of the slice: the elites'
+//              controls pulled into LDS by all threads at once, a thread per control a: mean and unbiased variance over the elites in
+//              sorted order (sequential sums: the reference's order), smoothed update of mu_t and of the diagonal covariance;
 //   do_sample: the next iteration's control sequences, controls[ii][t][0..3] = mu_t + chol(Sigma_t) z  (rand(rng, MvNormal(mu_t, Sigma_t)),
-//              :206-216), padded to four controls: the N covariances are factorised by a thread per time step (m <= 4), then (ii, t) pairs
-//              in strides of CT.  zc: injected standard normals [S][N][m] of that iteration, or nullptr: Philox keyed by (seed, iteration).
+//              :206-216), padded to four controls: the slice's covariances are factorised by a thread per time step (m <= 4), then its
+//              (ii, t) pairs in strides of 1024.  zc: injected standard normals [S][N][m] of that iteration, or nullptr: Philox keyed by
+//              (seed, iteration).
 template <int CT>
 __global__ __launch_bounds__(CE_T) void pets_step_kernel(double *__restrict__ mu, double *__restrict__ Sigma, double *__restrict__ controls,
                                                        const double *__restrict__ cost, long S, int ne, int N, int m, double sf,
@@ -261,8 +266,10 @@ __global__ __launch_bounds__(CE_T) void pets_step_kernel(double *__restrict__ mu
 #pragma clang fp contract(off)
     __shared__ unsigned long long k_sh[CT];
     __shared__ int idx_sh[CT];
-    extern __shared__ double Lsh[];                          // [N][16]
+    extern __shared__ double Lsh[];                          // [N][16] Cholesky factors | [ne][4] the elites' controls of one time step
+    double *const v_sh = Lsh + (size_t)N * 16;
     const int tid = threadIdx.x;
+    const int t_lo = (int)((long)blockIdx.x * N / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * N / gridDim.x), nt = t_hi - t_lo;
     if (do_update) {
         const bool sorter = tid < CT;                        // (whole wavefronts: CT is a multiple of 64)
         const double c = (tid < S) ? cost[tid] : NAN;        // (pad slots: NaN cost, index >= S: after every sample)
@@ -291,38 +298,30 @@ __global__ __launch_bounds__(CE_T) void pets_step_kernel(double *__restrict__ mu
         __syncthreads();
         if (sorter) idx_sh[tid] = id;                        // position tid of the sorted sequence
         __syncthreads();
-        for (int e_ = tid; e_ < N * m; e_ += CE_T) {
-            const int t = e_ / m, a = e_ - t * m;
-            // (the elites' loads are independent of the running sums: eight in flight at a time; the sums stay sequential, in sorted order)
-            double mean = 0.0;
-            for (int e0 = 0; e0 < ne; e0 += 8) {
-                double v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = controls[((long)idx_sh[(e0 + q < ne) ? e0 + q : 0] * N + t) * 4 + a];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) if (e0 + q < ne) mean += v[q];
+        for (int t = t_lo; t < t_hi; ++t) {
+            for (int q = tid; q < ne * 4; q += CE_T) v_sh[q] = controls[((long)idx_sh[q >> 2] * N + t) * 4 + (q & 3)];
+            __syncthreads();
+            if (tid < m) {
+                const int a = tid;
+                double mean = 0.0;
+                for (int e0 = 0; e0 < ne; ++e0) mean += v_sh[e0 * 4 + a];
+                mean /= (double)ne;                                                    // :183
+                double var = 0.0;
+                for (int e0 = 0; e0 < ne; ++e0) { const double d = v_sh[e0 * 4 + a] - mean; var += d * d; }
+                var /= (double)(ne - 1);                                               // var = unbiased :184
+                mu[t * m + a] = (1.0 - sf) * mean + sf * mu[t * m + a];                 // :186
+                for (int b = 0; b < m; ++b) {                                          // Diagonal(var) :184, smoothing :187
+                    double *Sg = &Sigma[(long)t * m * m + a + m * b];
+                    *Sg = (1.0 - sf) * (a == b ? var : 0.0) + sf * *Sg;
+                }
             }
-            mean /= (double)ne;                                                    // :183
-            double var = 0.0;
-            for (int e0 = 0; e0 < ne; e0 += 8) {
-                double v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = controls[((long)idx_sh[(e0 + q < ne) ? e0 + q : 0] * N + t) * 4 + a];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) if (e0 + q < ne) { const double d = v[q] - mean; var += d * d; }
-            }
-            var /= (double)(ne - 1);                                               // var = unbiased :184
-            mu[t * m + a] = (1.0 - sf) * mean + sf * mu[t * m + a];                 // :186
-            for (int b = 0; b < m; ++b) {                                          // Diagonal(var) :184, smoothing :187
-                double *Sg = &Sigma[(long)t * m * m + a + m * b];
-                *Sg = (1.0 - sf) * (a == b ? var : 0.0) + sf * *Sg;
-            }
+            __syncthreads();
         }
         __threadfence_block();
         __syncthreads();                                     // (the sampling below reads the mu / Sigma just written, and overwrites the controls)
     }
     if (!do_sample) return;
-    for (int t = tid; t < N; t += CE_T) {                    // host_chol_lower, column-major m x m
+    for (int t = t_lo + tid; t < t_hi; t += CE_T) {          // host_chol_lower, column-major m x m
         const double *A = Sigma + (long)t * m * m;
         double *Lo = Lsh + t * 16;
         for (int q = 0; q < 16; ++q) Lo[q] = 0.0;
@@ -341,9 +340,9 @@ __global__ __launch_bounds__(CE_T) void pets_step_kernel(double *__restrict__ mu
         if (!ok) atomicExch(err, 1);                         // Sigma_t is not positive definite (MvNormal would throw)
     }
     __syncthreads();
-    for (long e = tid; e < S * N; e += CE_T) {
-        const long ii = e / N;
-        const int t = (int)(e - ii * N);
+    for (long e = tid; e < S * nt; e += CE_T) {
+        const long ii = e / nt;
+        const int t = t_lo + (int)(e - ii * nt);
         double z[4] = {0.0, 0.0, 0.0, 0.0};
         if (zc) {
             for (int b = 0; b < m; ++b) z[b] = zc[(ii * N + t) * m + b];
@@ -368,14 +367,32 @@ __global__ __launch_bounds__(CE_T) void pets_step_kernel(double *__restrict__ mu
     }
 }
 
+// Up to three copies in ONE launch (x0 | mu | Sigma in from the pinned area; mu | Sigma | error word back out): a launch behind a launch
+// costs ~2-4 us on the stream, and the device-resident loop is ~20 of them around 0.2 ms of rollouts.
+__global__ __launch_bounds__(256) void pets_stage3_kernel(PetsStage3 a) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && a.zero_word) *a.zero_word = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (i >= 0 && i < a.n[k]) a.dst[k][i] = a.src[k][i];
+        i -= a.n[k];
+    }
+}
+void launch_pets_stage3(const PetsStage3 &a, hipStream_t st) {
+    const long total = a.n[0] + a.n[1] + a.n[2];
+    if (total <= 0) return;
+    hipLaunchKernelGGL(pets_stage3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+}
+
 void launch_pets_step(double *mu, double *Sigma, double *controls, const double *cost, long S, int ne, int N, int m, double sf, const double *zc,
                       unsigned long long seed, int it, int do_update, int do_sample, int *err, hipStream_t st) {
-    const size_t lds = (size_t)N * 16 * sizeof(double);
+    const size_t lds = ((size_t)N * 16 + (size_t)ne * 4) * sizeof(double);
+    const int nblk = N < 64 ? N : 64;                        // one time step per workgroup up to 64 workgroups, slices beyond
     // beyond 64 KB of LDS (static ~12 KB + 128 B per time step: horizons above ~400) a launch needs the attribute raised first, as
     // launch_wide_solve does; a failure here surfaces through hipGetLastError at the caller's check like a failed launch
 #define PSTEP(CT) do { if (lds + 16 * 1024 > 64 * 1024) \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pets_step_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((pets_step_kernel<CT>), dim3(1), dim3(CE_T), lds, st, mu, Sigma, controls, cost, S, ne, N, m, sf, zc, seed, it, do_update, do_sample, err); } while (0)
+        hipLaunchKernelGGL((pets_step_kernel<CT>), dim3(nblk), dim3(CE_T), lds, st, mu, Sigma, controls, cost, S, ne, N, m, sf, zc, seed, it, do_update, do_sample, err); } while (0)
     if (S <= 64) PSTEP(64); else if (S <= 128) PSTEP(128); else if (S <= 256) PSTEP(256); else if (S <= 512) PSTEP(512); else PSTEP(1024);
 #undef PSTEP
 }

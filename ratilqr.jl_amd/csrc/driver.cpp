@@ -2954,7 +2954,7 @@ static rat_rc pets_solve_device(rat_handle h, rat_pets_solver *s, const double *
     if ((rc = grow(&h->d_pcost, &h->cap_cost, (size_t)S))) return rc;
     if ((rc = grow(&h->d_pmu, &h->cap_pmu, nmu))) return rc;
     if ((rc = grow(&h->d_psig, &h->cap_psig, nsg))) return rc;
-    if (!h->d_perr) HIPCHK(hipMalloc((void **)&h->d_perr, sizeof(int)));
+    if (!h->d_perr) { HIPCHK(hipMalloc((void **)&h->d_perr, sizeof(double))); HIPCHK(hipMemset(h->d_perr, 0, sizeof(double))); }
     // pinned: [x0 (XSTR) | mu | Sigma | error word (as a double slot) | control normals of all iterations]
     const size_t off_mu = XSTR, off_sg = off_mu + nmu, off_err = off_sg + nsg, off_zc = off_err + 2, need = off_zc + (zc ? nzc * (size_t)IT : 0);
     if (need > h->cap_pzc) {
@@ -2971,16 +2971,20 @@ static rat_rc pets_solve_device(rat_handle h, rat_pets_solver *s, const double *
     if (zc) memcpy(hp + off_zc, zc, nzc * (size_t)IT * 8);
     const double *hp_dev = nullptr;
     HIPCHK(hipHostGetDevicePointer((void **)&hp_dev, hp, 0));
-    HIPCHK(hipMemsetAsync(h->d_perr, 0, sizeof(int), h->stream));
     const double *zc_dev = nullptr;
     if (zc) {                                                                         // the injected control normals: pulled over the link by one parallel launch
         if ((rc = grow(&h->d_pzu, &h->cap_zu, nzc * (size_t)IT))) return rc;          // (the rollouts draw their noise on the device: d_pzu is free)
         launch_pets_stage(hp_dev + off_zc, h->d_pzu, (long)(nzc * (size_t)IT), h->stream);
         zc_dev = h->d_pzu;
     }
-    launch_pets_stage(hp_dev, h->d_pin, (long)XSTR, h->stream);                       // x0
-    launch_pets_stage(hp_dev + off_mu, h->d_pmu, (long)nmu, h->stream);
-    launch_pets_stage(hp_dev + off_sg, h->d_psig, (long)nsg, h->stream);
+    {                                                                                 // x0 | mu | Sigma in one launch, the error word zeroed by it
+        PetsStage3 sa;
+        sa.src[0] = hp_dev; sa.dst[0] = h->d_pin; sa.n[0] = (long)XSTR;
+        sa.src[1] = hp_dev + off_mu; sa.dst[1] = h->d_pmu; sa.n[1] = (long)nmu;
+        sa.src[2] = hp_dev + off_sg; sa.dst[2] = h->d_psig; sa.n[2] = (long)nsg;
+        sa.zero_word = h->d_perr;
+        launch_pets_stage3(sa, h->stream);
+    }
     PetsArgs a;
     a.g = h->gen; a.x0 = h->d_pin; a.controls = h->d_pin + XSTR; a.S = S; a.K = K; a.use_true = use_true_model ? 1 : 0;
     a.zn = nullptr; a.zu = nullptr; a.traj0 = 0; a.traj_cost = h->d_ptraj; a.cost = h->d_pcost; a.wave16 = h->pets_wave16;
@@ -3005,9 +3009,14 @@ static rat_rc pets_solve_device(rat_handle h, rat_pets_solver *s, const double *
     // results back into the pinned area by the same pull kernel, the other way (device -> pinned host)
     double *hp_w = nullptr;
     HIPCHK(hipHostGetDevicePointer((void **)&hp_w, hp, 0));
-    launch_pets_stage(h->d_pmu, hp_w + off_mu, (long)nmu, h->stream);
-    launch_pets_stage(h->d_psig, hp_w + off_sg, (long)nsg, h->stream);
-    HIPCHK(hipMemcpyAsync(hp + off_err, h->d_perr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    {                                                                                 // mu | Sigma | the error word (an 8-byte slot) by one launch
+        PetsStage3 sa;
+        sa.src[0] = h->d_pmu; sa.dst[0] = hp_w + off_mu; sa.n[0] = (long)nmu;
+        sa.src[1] = h->d_psig; sa.dst[1] = hp_w + off_sg; sa.n[1] = (long)nsg;
+        sa.src[2] = reinterpret_cast<const double *>(h->d_perr); sa.dst[2] = hp_w + off_err; sa.n[2] = 1;
+        sa.zero_word = nullptr;
+        launch_pets_stage3(sa, h->stream);
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     int err = 0;
     memcpy(&err, hp + off_err, sizeof(int));
