@@ -2996,6 +2996,21 @@ __device__ __forceinline__ long long xc_wait(long long *w, const long long v, lo
     return r;
 }
 
+typedef int kw_v16i __attribute__((ext_vector_type(16)));
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    kw_v16i sink;
+    static_assert(BYTES % 64 == 0 && BYTES <= 2048, "whole lines, immediate offsets");
+#define KW_LD(off_) do { if ((off_) < BYTES) asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(sink) : "s"(kp), "n"(off_) : "memory"); } while (0)
+#define KW_LD4(o_) KW_LD(o_); KW_LD((o_) + 64); KW_LD((o_) + 128); KW_LD((o_) + 192)
+    KW_LD4(0); KW_LD4(256); KW_LD4(512); KW_LD4(768); KW_LD4(1024); KW_LD4(1280); KW_LD4(1536); KW_LD4(1792);
+#undef KW_LD4
+#undef KW_LD
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" :: "s"(sink));
+}
+
 template <bool CTV, int WM>
 __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     constexpr int FLYB = CTV ? 2 : 1;
@@ -3008,6 +3023,10 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const StateDev &st = fa.sw.st;
     if (b >= st.B) return;
+    // The kernel arguments are 1.5 KB (24 lines) that the phases below load piece by piece into scalar registers, each piece for the first time
+    // on the critical path: a cold round trip to device memory of ~2 us (4.4 us measured in front of the first rollout alone).  Wave 3, which
+    // starts with nothing to do, pulls the whole block through the scalar cache once.
+    if (wave == 3) kernarg_warm<sizeof(FusedArgs)>();
     __shared__ double wls_all[4][WLS_PSW];
     __shared__ double shxu_all[4][16];
     __shared__ double stg[STG_DOUBLES];
@@ -3172,7 +3191,10 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
             RolloutArgs ra = fa.ro; ra.mode = 1;
             int nom_, lsel_;
             double eps_;
+            BPSW_MARK();
             const bool act = rollout_active<1>(st, b, nom_, lsel_, eps_);       // (every wave reads the same words)
+            asm volatile("" :: "s"(nom_), "s"(lsel_));
+            BPSW_MARK();
             if (act) {
                 if (leader) { d_acc[0] = 0ull; d_acc[1] = 0ull; lpool = 0; }
                 stage_shared<4>(ra, b, nom_, lsel_, stg, wave);

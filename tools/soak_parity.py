@@ -12,6 +12,8 @@ import numpy as np
 import ratilqr.jl_amd as rat
 from oracle import oracle as orc
 bad = 0
+DUMP = os.environ.get('SOAK_DUMP')              # SOAK_DUMP=file.npz: every problem's device results, for bit-wise comparison between two builds
+dump = {}                                       # (tools/novf_diff.sh)
 t0 = time.time()
 NS = int(os.environ.get('SOAK_N', '240'))
 S0 = int(os.environ.get('SOAK_SEED0', '0'))     # first problem seed: SOAK_SEED0=3000 SOAK_N=3000 runs problems 3000..5999
@@ -69,10 +71,14 @@ for seed in range(S0, S0 + NS):
     if not os.environ.get('SOAK_WIDE') and seed % 2 == 1 and not os.environ.get('SOAK_E'):
         ctx.set_path("rounds")                 # E > 1: candidates without tile records (fly sweeps, all candidates of a sample in one rollout wave)
     vg, sg, ig, lg = ctx.solve_batch(x0, u, theta)
+    if DUMP:
+        dump[f"v{seed}"], dump[f"s{seed}"], dump[f"i{seed}"], dump[f"l{seed}"] = vg, sg, ig, lg
     fin = np.isfinite(vo)
     ok = np.array_equal(sg, so) and np.array_equal(ig, io) and np.array_equal(lg, lo) and np.array_equal(fin, np.isfinite(vg)) \
         and (not fin.any() or np.all(np.abs(vg[fin] - vo[fin]) <= 1e-9 * np.abs(vo[fin])))
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, (n, m, N), tv, kappa, E, kw, so.tolist(), sg.tolist(), io.tolist(), ig.tolist(), lo.tolist(), lg.tolist())
+if DUMP:
+    np.savez(DUMP, **dump)
 print("soak done:", NS, "problems,", bad, "mismatches,", round(time.time() - t0, 1), "s")
