@@ -419,7 +419,8 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *   block_helpers   0 / 1    spare waves of a padded workgroup linearise (one workgroup per CU)                          (1)
  *   block_acl       0 / 1    E = 1 workgroup-per-sample kernel: closed-loop rollouts in deviation form (3 MFMAs on the recursion's
  *                            chain; values agree with the other paths to rounding, ~1e-15, not bit for bit; opt-in)      (0)
- *   fused_dual      0 / 1    policy evaluation + following gain sweep as two recursions of one wavefront                 (1)
+ *   fused_dual      (read)   policy evaluation + following gain sweep as two recursions of one wavefront: always on (the separate-sweep
+ *                            instantiations of rounds 1-5 were retired in round 6; writes are ignored)                    (1)
  *   fused_occ2      B0       batches of >= B0 samples: the 256-register one-recursion kernel, two samples per SIMD       (0 = never;
  *                            -1, the default: LQ-family batches of more samples than the device has SIMDs)
  *   spec_force      0 / 1    run the speculation width rat_create was given (kernels for E = 2, 4, 8 in one launch, any E on the
@@ -459,9 +460,16 @@ int32_t rat_get_path(rat_handle h, int64_t B);
  *                            samples): the policy evaluations as four-wave teams on one, every gain sweep as a four-wave team on the
  *                            other, hand-overs through the XCD's L2 (counts identical, values to rounding: other segment cuts)         (1)
  *   psw_duo_count   (read)   samples of this handle that have run that way so far (rat_debug_set clears it)
- *   psweep          0, 2..8  the batched sweep operators (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch) run the TIME-PARALLEL sweep:
+ *   psw_prl         0 / 1    ... and the candidate's closed-loop rollout (simulate_dynamics, ileqg.jl:62-87) TIME-PARALLEL over the four
+ *                            wavefronts where the deviation from the nominal trajectory is affine (kappa == 0, time-invariant cost,
+ *                            N >= 16): four segments, the deviation at each cut from the composed maps of the segments before it
+ *                            (rollprl_body; counts identical, values to ~1e-15 against the one-wave recursion)                         (1)
+ *   prl_elem, prl_hop, prl_epi   its cost model in hundredths of an ordinary rollout step -- one step of a segment map, one hop, the
+ *                            terminal tile: where the three cuts go (any model gives the same results)                      (45, 90, 100)
+ *   prl_cuts        (read)   the cuts of the last launch that ran it: cut_1 | cut_2 << 16 | cut_3 << 32 (0: it did not apply)
+ *   psweep          0, 2..4  the batched sweep operators (rat_dp_gain_sweep_batch / rat_dp_policy_eval_batch) run the TIME-PARALLEL sweep:
  *                            that many wavefronts per trajectory over that many + 1 horizon segments (csrc/psweep.h); results agree with the
- *                            sequential sweep to rounding (not bit for bit)                                                        (0)
+ *                            sequential sweep to rounding (not bit for bit); values above 4 mean 4 (one wave per SIMD)             (0)
  *   psw_hop, psw_hop_e, psw_comp   its cost model in hundredths of an ordinary step -- one hop of a gain sweep, one hop of an evaluation, one
  *                            element step: where the segment cuts go                                                      (120, 140, 125)
  *   wdiag           0 / 1    diagonal time-invariant W: inv(W) folded into M^-1's operand (takes effect at the next rat_problem_set) (1) */

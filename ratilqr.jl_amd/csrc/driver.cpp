@@ -190,7 +190,7 @@ static const DebugSwitch debug_switches[] = {
     {"speculate", [](rat_handle h, int64_t v) { h->speculate = (v == 1); }, [](rat_handle h) -> int64_t { return h->speculate; }},
     {"dual", [](rat_handle h, int64_t v) { h->dual = (v == 1); h->dual_forced = true; }, [](rat_handle h) -> int64_t { return h->dual; }},
     {"fused", [](rat_handle h, int64_t v) { h->fused_req = (v != 0); h->rounds_only = (v == 0); }, [](rat_handle h) -> int64_t { return h->fused; }},
-    {"fused_dual", [](rat_handle h, int64_t v) { h->fused_dual = (v != 0); }, [](rat_handle h) -> int64_t { return h->fused_dual; }},
+    {"fused_dual", [](rat_handle, int64_t) {}, [](rat_handle h) -> int64_t { return h->fused_dual; }},   // (retired in round 6: always paired)
     {"block", [](rat_handle h, int64_t v) { h->block_req = (v == 1) ? 1 : (v == 0 ? 0 : -1); }, [](rat_handle h) -> int64_t { return h->block_mode; }},
     {"block_max_b", [](rat_handle h, int64_t v) { h->block_max_b = (int)v; }, [](rat_handle h) -> int64_t { return h->block_max_b; }},
     {"block_shape", [](rat_handle h, int64_t v) { h->block_shape = (v != 0); }, [](rat_handle h) -> int64_t { return h->block_shape; }},
@@ -216,7 +216,7 @@ static const DebugSwitch debug_switches[] = {
     {"pets_wave16", [](rat_handle h, int64_t v) { h->pets_wave16 = (v < 0 || v > 3) ? 1 : (int)v; }, [](rat_handle h) -> int64_t { return h->pets_wave16; }},
     {"ce_device", [](rat_handle h, int64_t v) { h->ce_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->ce_device; }},
     {"pets_device", [](rat_handle h, int64_t v) { h->pets_device = (v != 0); }, [](rat_handle h) -> int64_t { return h->pets_device; }},
-    {"psweep", [](rat_handle h, int64_t v) { h->psweep = (v < 2 || v > PSW_MAXP) ? 0 : (int)v; }, [](rat_handle h) -> int64_t { return h->psweep; }},
+    {"psweep", [](rat_handle h, int64_t v) { h->psweep = (v < 2) ? 0 : (int)std::min<int64_t>(v, 4); }, [](rat_handle h) -> int64_t { return h->psweep; }},
     {"psw_hop", [](rat_handle h, int64_t v) { h->psw_hop = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop; }},
     {"psw_hop_e", [](rat_handle h, int64_t v) { h->psw_hop_e = (int)std::max<int64_t>(1, v); }, [](rat_handle h) -> int64_t { return h->psw_hop_e; }},
     {"spec_force", [](rat_handle h, int64_t v) { h->spec_force = (v != 0); }, [](rat_handle h) -> int64_t { return h->spec_force; }},

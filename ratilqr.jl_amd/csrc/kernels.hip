@@ -518,7 +518,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int tid, do
 // One workgroup of pc.P wavefronts per trajectory (psweep.h).  The modes are sweep_kernel's (0 gain sweep, 1 policy evaluation of candidates,
 // 2 initialize!'s evaluation, 4 / 5 speculative gain sweeps); results agree with sweep_kernel's to rounding (tests/test_gpu_psweep.py).
 // MAXP = 4: one wavefront per SIMD, each may hold 512 registers (256 + 256 accumulation registers as spill space of the gain element's
-// 4 x 4 factors); MAXP = 8: two per SIMD, 256 each.
+// 4 x 4 factors).
 template <bool GAIN, int WM, bool HASL, int FLY, int MAXP>
 __global__ __launch_bounds__(64 * MAXP) void psweep_kernel(SweepArgs a, PswCuts pc) {
     __shared__ double wls[MAXP][WLS_PSW];
@@ -538,14 +538,14 @@ bool psweep_supported(const SweepArgs &a, bool gain) {
 
 void launch_psweep(const SweepArgs &a, int ntraj, bool gain, const PswCuts &pc, hipStream_t s) {
     if (ntraj <= 0) return;
+    if (pc.P > 4) return;                                    // (not reachable: psweep_cuts is asked for at most four waves)
     const dim3 grid(ntraj), block(64 * pc.P);
     const int wm = a.pb.W_tv ? 1 : (a.pb.W_diag ? 2 : 0);
-#define PSW_LAUNCH(G, H, F) do { if (pc.P <= 4) { if (wm == 2) hipLaunchKernelGGL((psweep_kernel<G, 2, H, F, 4>), grid, block, 0, s, a, pc); \
-                                                   else if (wm == 1) hipLaunchKernelGGL((psweep_kernel<G, 1, H, F, 4>), grid, block, 0, s, a, pc); \
-                                                   else hipLaunchKernelGGL((psweep_kernel<G, 0, H, F, 4>), grid, block, 0, s, a, pc); } \
-                                 else { if (wm == 2) hipLaunchKernelGGL((psweep_kernel<G, 2, H, F, 8>), grid, block, 0, s, a, pc); \
-                                        else if (wm == 1) hipLaunchKernelGGL((psweep_kernel<G, 1, H, F, 8>), grid, block, 0, s, a, pc); \
-                                        else hipLaunchKernelGGL((psweep_kernel<G, 0, H, F, 8>), grid, block, 0, s, a, pc); } } while (0)
+    // (teams of up to four waves, one per SIMD: the eight-wave instantiations of rounds 4-5 -- two waves per SIMD, 256 registers each, gain
+    //  elements spilling to scratch -- never won a measurement and were retired in round 6; the switch psweep is clamped to 4 on the host)
+#define PSW_LAUNCH(G, H, F) do { if (wm == 2) hipLaunchKernelGGL((psweep_kernel<G, 2, H, F, 4>), grid, block, 0, s, a, pc); \
+                                 else if (wm == 1) hipLaunchKernelGGL((psweep_kernel<G, 1, H, F, 4>), grid, block, 0, s, a, pc); \
+                                 else hipLaunchKernelGGL((psweep_kernel<G, 0, H, F, 4>), grid, block, 0, s, a, pc); } while (0)
     if (gain) { if (a.fly) PSW_LAUNCH(true, false, 1); else PSW_LAUNCH(true, false, 0); }
     else if (a.mode == 2) { if (a.fly) PSW_LAUNCH(false, false, 1); else PSW_LAUNCH(false, false, 0); }
     else { if (a.fly) PSW_LAUNCH(false, true, 1); else PSW_LAUNCH(false, true, 0); }
@@ -2632,8 +2632,7 @@ void launch_solve_fused(const FusedArgs &fa, hipStream_t s) {
         if (fa.occ2) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false, true>), grid, block, 0, s, fa); \
         else if (fa.mat && fa.dual && stg && M == 1 && !C) hipLaunchKernelGGL((solve_fused_kernel<1, false, W, true, true, false, true>), grid, block, 0, s, fa); \
         else if (fa.dual && stg && M == 1) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, M == 1>), grid, block, 0, s, fa); \
-        else if (fa.dual) hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, false>), grid, block, 0, s, fa); \
-        else hipLaunchKernelGGL((solve_fused_kernel<M, C, W, false, false>), grid, block, 0, s, fa); } while (0)
+        else hipLaunchKernelGGL((solve_fused_kernel<M, C, W, true, false>), grid, block, 0, s, fa); } while (0)
     if (fa.sw.pb.model == 1) {
         if (fa.sw.pb.cost_tv) { if (wm == 1) FUSED_LAUNCH(1, true, 1); else if (wm == 2) FUSED_LAUNCH(1, true, 2); else FUSED_LAUNCH(1, true, 0); }
         else { if (wm == 1) FUSED_LAUNCH(1, false, 1); else if (wm == 2) FUSED_LAUNCH(1, false, 2); else FUSED_LAUNCH(1, false, 0); }
@@ -3191,10 +3190,7 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
             RolloutArgs ra = fa.ro; ra.mode = 1;
             int nom_, lsel_;
             double eps_;
-            BPSW_MARK();
             const bool act = rollout_active<1>(st, b, nom_, lsel_, eps_);       // (every wave reads the same words)
-            asm volatile("" :: "s"(nom_), "s"(lsel_));
-            BPSW_MARK();
             if (act) {
                 if (leader) { d_acc[0] = 0ull; d_acc[1] = 0ull; lpool = 0; }
                 stage_shared<4>(ra, b, nom_, lsel_, stg, wave);

@@ -26,6 +26,10 @@ for duo in (0, 1):
         t0 = a[0]
         na = int(np.max(np.nonzero(a)[0])) + 1
         print(f"  sample {smp}: role A wave 0 marks (us from its first): " + " ".join(f"{(v - t0) / 100:.1f}" for v in a[:na]))
+        a1 = t[0, smp, 1]
+        if os.environ.get("WAVE1") and a1.any():
+            n1 = int(np.max(np.nonzero(a1)[0])) + 1
+            print(f"  sample {smp}: role A wave 1 marks (us, same origin):  " + " ".join(f"{(v - t0) / 100:.1f}" for v in a1[:n1]))
         if duo and bb.any():
             nb = int(np.max(np.nonzero(bb)[0])) + 1
             print(f"  sample {smp}: role B wave 0 marks (us, same origin):  " + " ".join(f"{(v - t0) / 100:.1f}" for v in bb[:nb]))
