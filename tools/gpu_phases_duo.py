@@ -22,6 +22,8 @@ for duo in (0, 1):
     t = out.reshape(2, 8, 2, 40)
     print(f"psw_duo = {duo}, B = {B}; pairs formed: {ctx.debug_get('psw_duo_count')}")
     for smp in (0, 5):
+        if smp >= B:
+            continue
         a = t[0, smp, 0]; bb = t[1, smp, 0]
         t0 = a[0]
         na = int(np.max(np.nonzero(a)[0])) + 1
@@ -44,6 +46,8 @@ if int(os.environ.get("PRL", "1")):
     c = ctx.debug_get("prl_cuts")
     print(f"  rollprl cuts: 0 {c & 0xffff} {(c >> 16) & 0xffff} {(c >> 32) & 0xffff} {prob.N}")
     for smp in (0, 5):
+        if smp >= B:
+            continue
         o = pr[smp, 0, 0]
         for w in range(4):
             print(f"  sample {smp} rollprl wave {w} (us from wave 0's entry): " + " ".join(f"{(v - o) / 100:.2f}" for v in pr[smp, w, :6]))
