@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import ratilqr.jl_amd as rat
 from oracle import oracle as orc
 from psweep_time import Harness, approx_of, rel
+import rollprl_model
 
 pytestmark = pytest.mark.gpu
 WAVES = (2, 3, 4)            # (teams of up to four waves: one per SIMD; the eight-wave instantiations were retired in round 6)
@@ -265,7 +266,7 @@ def test_time_parallel_rollout_equals_the_one_wave_rollout_and_the_oracle(n, m, 
     rng = np.random.default_rng(N)
     theta = np.concatenate([[0.0], np.abs(1.0 + 2.0 * rng.standard_normal(28)), [40.0, 300.0]])
     (v0, s0, i0, l0), (v1, s1, i1, l1), cuts = _prl_pair(prob, x0, u, theta, duo=duo)
-    assert 0 < cuts[0] < cuts[1] < cuts[2] < N, cuts
+    assert 0 < cuts[0] < cuts[1] < cuts[2] < N and list(cuts) == rollprl_model.cuts(N)[1:4], cuts
     assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1), (s0, s1, i0, i1, l0, l1)
     fin = np.isfinite(v0)
     assert fin.sum() >= 8 and np.array_equal(fin, np.isfinite(v1)) and rel(v1[fin], v0[fin]) < 1e-12
@@ -305,6 +306,7 @@ def test_time_parallel_rollout_cut_models_and_where_it_does_not_apply():
     for e, h, epi in ((45, 90, 100), (1, 0, 0), (400, 0, 0), (10, 2000, 0), (45, 90, 1500), (99, 300, 300)):
         r0, r1, cuts = _prl_pair(prob, x0, u, theta, prl_elem=e, prl_hop=h, prl_epi=epi)
         assert 0 < cuts[0] < cuts[1] < cuts[2] < 21, cuts
+        assert list(cuts) == rollprl_model.cuts(21, e / 100.0, h / 100.0, epi / 100.0)[1:4]      # (the host's cut model = tests/rollprl_model.py's)
         seen.add(cuts)
         base = base or r0
         for a, b in zip(r0[1:], r1[1:]):
