@@ -488,7 +488,7 @@ rat_rc  rat_debug_get(rat_handle h, const char *key, int64_t *value);      /* th
 #define RAT_K_SOLVE_BLOCK 8  /* one workgroup per sample runs the whole solve!: a wavefront per line-search candidate + a gain-sweep wavefront */
 #define RAT_K_SOLVE_WIDE  9  /* general-size solve kernel (n <= 32, m <= 32 beyond the 12 + 4 tile): a workgroup per sample, whole solve! */
 #define RAT_K_PETS       10  /* PETS stochastic rollouts (pets_rollout_kernel + the per-sample mean) */
-#define RAT_K_CE         11  /* draw + update kernels of the device-resident Cross-Entropy loop of rat_ce_solve (one workgroup each) */
+#define RAT_K_CE         11  /* draw + update kernels of the device-resident Cross-Entropy loops: rat_ce_solve (one workgroup each), rat_pets_solve (one per time step) */
 #define RAT_K_COUNT     12
 /* When enabled, kernel launches are bracketed by HIP events on the handle's stream.
  * on = 0: off; on = 1: every kernel kind; otherwise on = (mask << 1) | 1 with bit k of mask selecting kind RAT_K_k.

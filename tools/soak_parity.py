@@ -17,7 +17,8 @@ dump = {}                                       # (tools/novf_diff.sh)
 t0 = time.time()
 NS = int(os.environ.get('SOAK_N', '240'))
 S0 = int(os.environ.get('SOAK_SEED0', '0'))     # first problem seed: SOAK_SEED0=3000 SOAK_N=3000 runs problems 3000..5999
-for seed in range(S0, S0 + NS):
+SEEDS = [int(v) for v in os.environ['SOAK_SEEDS'].split(',')] if os.environ.get('SOAK_SEEDS') else range(S0, S0 + NS)   # SOAK_SEEDS=4228,6308: those problems only
+for seed in SEEDS:
     rng = np.random.default_rng(5000 + seed)
     n, m, N = int(rng.integers(1, 13)), int(rng.integers(1, 5)), int(rng.integers(1, 61))
     if os.environ.get('SOAK_WIDE') == '1':
@@ -79,6 +80,9 @@ for seed in range(S0, S0 + NS):
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, (n, m, N), tv, kappa, E, kw, so.tolist(), sg.tolist(), io.tolist(), ig.tolist(), lo.tolist(), lg.tolist())
+        if os.environ.get('SOAK_SEEDS'):     # diagnosis: where the two differ, with the values
+            for i in np.nonzero((so != sg) | (io != ig) | (lo != lg) | ~((vo == vg) | (np.abs(vo - vg) <= 1e-9 * np.abs(vo)) | (~np.isfinite(vo) & ~np.isfinite(vg))))[0]:
+                print(f"   sample {i} theta {theta[i]:.6g}: oracle value {vo[i]:.15g} status {so[i]} iters {io[i]} ls {lo[i]} | device value {vg[i]:.15g} status {sg[i]} iters {ig[i]} ls {lg[i]}")
 if DUMP:
     np.savez(DUMP, **dump)
 print("soak done:", NS, "problems,", bad, "mismatches,", round(time.time() - t0, 1), "s")
