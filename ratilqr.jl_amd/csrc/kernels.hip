@@ -2311,20 +2311,28 @@ __device__ __forceinline__ void init_state_body(const StateDev &st, const OptsDe
 
 // Start of the next step! (ileqg.jl:598-613) for a sample whose gain sweep has already been run speculatively:
 // iter += 1, adopt its gains / mu / Delta (or its failure), and enter line_search! at eps_init (:502).
-__device__ __forceinline__ bool commit_spec(const StateDev &st, int b) {
-    const int sp = xld(&st.spec_st[b]);
+// The words a commit reads, fetched by its caller together with whatever else it needs (one lane runs this: every dependent load is an L2
+// round trip of ~0.7 us on the sample's critical path)
+struct CommitWords { int sp, iter, lsel; double mu_spec, delta_spec, eps_init; };
+__device__ __forceinline__ CommitWords commit_words(const StateDev &st, int b) {
+    CommitWords w;
+    w.sp = xld(&st.spec_st[b]); w.iter = xld(&st.iter[b]); w.lsel = xld(&st.lsel[b]);
+    w.mu_spec = xld(&st.mu_spec[b]); w.delta_spec = xld(&st.delta_spec[b]); w.eps_init = xld(&st.eps_init[b]);
+    return w;
+}
+__device__ __forceinline__ bool commit_spec(const StateDev &st, int b, const CommitWords &w) {
     st.spec_st[b] = 0;
-    st.iter[b] = xld(&st.iter[b]) + 1;                     // :599
-    st.mu[b] = xld(&st.mu_spec[b]);
-    st.delta[b] = xld(&st.delta_spec[b]);
-    if (sp != 1) {                                         // @assert isposdef(M) (:366) / mu-restart divergence
-        st.status[b] = (sp == 2) ? 2 : 5;
+    st.iter[b] = w.iter + 1;                               // :599
+    st.mu[b] = w.mu_spec;
+    st.delta[b] = w.delta_spec;
+    if (w.sp != 1) {                                       // @assert isposdef(M) (:366) / mu-restart divergence
+        st.status[b] = (w.sp == 2) ? 2 : 5;
         st.value[b] = INFINITY;
         st.ls_active[b] = 0;
         return false;
     }
-    st.lsel[b] = xld(&st.lsel[b]) ^ 1;                     // ileqg.L_array <- L of the gain sweep (:380)
-    st.ls_eps[b] = xld(&st.eps_init[b]);
+    st.lsel[b] = w.lsel ^ 1;                               // ileqg.L_array <- L of the gain sweep (:380)
+    st.ls_eps[b] = w.eps_init;
     st.ls_count[b] = 0;
     st.ls_active[b] = 1;
     return true;
@@ -2332,8 +2340,10 @@ __device__ __forceinline__ bool commit_spec(const StateDev &st, int b) {
 
 // after initialize!: samples that survived the open-loop sweep start step! number 1 with the speculative gains
 __device__ __forceinline__ void commit_init_body(const StateDev &st, const int b) {
-    if (xld(&st.status[b]) != ST_RUNNING) { st.spec_st[b] = 0; return; }
-    if (xld(&st.spec_st[b]) != 0) commit_spec(st, b);
+    const int stat = xld(&st.status[b]);
+    const CommitWords w = commit_words(st, b);             // (in flight with the status word)
+    if (stat != ST_RUNNING) { st.spec_st[b] = 0; return; }
+    if (w.sp != 0) commit_spec(st, b, w);
 }
 #if RAT_PART & PART_ROLL
 __global__ void commit_init_kernel(StateDev st) {
@@ -2377,7 +2387,9 @@ __device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev
     const int active = xld(&st.ls_active[b]);
     const int c0 = b * st.E;
     const double eps_in = xld(&st.ls_eps[b]), cur = xld(&st.value[b]), mu_b = xld(&st.mu[b]);
-    const int count_in = xld(&st.ls_count[b]), nls_in = xld(&st.n_ls[b]), spec = xld(&st.spec_st[b]), nom = xld(&st.slot_nom[b]), iter_b = xld(&st.iter[b]);
+    const int count_in = xld(&st.ls_count[b]), nls_in = xld(&st.n_ls[b]), nom = xld(&st.slot_nom[b]);
+    CommitWords cw = commit_words(st, b);                      // (what commit_spec would otherwise fetch behind the decision: a second round trip)
+    const int spec = cw.sp, iter_b = cw.iter;
     const int hn_in = st.hist ? st.hist_n[b] : 0;
     const int fl0 = xld(&st.flag_c[c0]);
     const double nv0 = xld(&st.value_c[c0]), dc0 = xld(&st.d_c[c0]);
@@ -2426,16 +2438,17 @@ __device__ __forceinline__ void ls_select_body(const StateDev &st, const OptsDev
     st.slot_nom[b] = (chosen < nom) ? chosen : chosen + 1;     // x_array, l_array (and their tiles) <- candidate
     st.ls_active[b] = 0;
     if (op.adaptive) {                                         // :582-591
-        if (count == 1) st.eps_init[b] = fmin(op.eps_init, eps / op.lambda);
+        if (count == 1) cw.eps_init = fmin(op.eps_init, eps / op.lambda);
         else {
             while (eps < op.eps_min) eps = eps / op.lambda;
-            st.eps_init[b] = eps;
+            cw.eps_init = eps;
         }
+        st.eps_init[b] = cw.eps_init;
     }
     if (op.d > d_new && mu_b <= op.mu_min) { st.status[b] = 0; st.spec_st[b] = 0; }                         // converged  (:642)
     else if (iter_b == op.iter_max) { st.status[b] = 3; st.spec_st[b] = 0; }                                // iter_max   (:648)
     else if (chosen == 0 && spec != 0) {
-        if (commit_spec(st, b) && ctr) atomicAdd(&ctr[1], 1);  // next step! already has its gain sweep: straight to line search
+        if (commit_spec(st, b, cw) && ctr) atomicAdd(&ctr[1], 1);  // next step! already has its gain sweep: straight to line search
     } else {
         st.spec_st[b] = 0;
         if (ctr) atomicAdd(&ctr[1], 1);                        // next round runs the plain gain sweep for this sample
@@ -3171,7 +3184,13 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
     __syncthreads();
     BPSW_MARK();
     for (int guard = 0; guard < fa.max_rounds && !lost; ++guard) {
+        // the round's control words in ONE batch (every wave reads the same words; rollout_active's three ride along: a dependent load is an
+        // L2 round trip of ~0.7 us on the critical path)
         const int v_stat = __atomic_load_n(&st.status[b], __ATOMIC_RELAXED), v_act = __atomic_load_n(&st.ls_active[b], __ATOMIC_RELAXED);
+        const int v_nom = xld(&st.slot_nom[b]), v_lsel = xld(&st.lsel[b]);
+        const double v_eps = xld(&st.ls_eps[b]);
+        const double v_mu = xld(&st.mu[b]);                  // (mu and the iteration count of the "would accepting end the solve" test behind the
+        const int v_it = xld(&st.iter[b]);                   //  rollout: nothing writes them in between)
         if (__builtin_amdgcn_readfirstlane(v_stat) != ST_RUNNING) break;
         if (!__builtin_amdgcn_readfirstlane(v_act)) {        // step!: solve_approximate_dp! with no valid speculative sweep  (ileqg.jl:598-613)
             if (duo) {
@@ -3188,9 +3207,9 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         }
         if (fa.acl) {                                        // the candidate of this line-search round in deviation form (rollacl_body; switch block_acl)
             RolloutArgs ra = fa.ro; ra.mode = 1;
-            int nom_, lsel_;
-            double eps_;
-            const bool act = rollout_active<1>(st, b, nom_, lsel_, eps_);       // (every wave reads the same words)
+            const int nom_ = wave_uniform(v_nom), lsel_ = wave_uniform(v_lsel);         // (rollout_active<1>'s words: read at the loop top)
+            const double eps_ = v_eps;
+            const bool act = true;
             if (act) {
                 if (leader) { d_acc[0] = 0ull; d_acc[1] = 0ull; lpool = 0; }
                 stage_shared<4>(ra, b, nom_, lsel_, stg, wave);
@@ -3224,8 +3243,6 @@ __global__ __launch_bounds__(256, 1) void solve_block_psw_kernel(FusedArgs fa) {
         const double v_dc = da1 ? NAN : sqrt(__longlong_as_double((long long)da0));
         if (threadIdx.x == 64) { st.d_c[b] = v_dc; st.flag_c[b] = 0; }
         // would accepting this candidate end solve! (:642-653)?  Then nothing consumes a speculative gain sweep: all four waves evaluate.
-        const double v_mu = *(const volatile double *)&st.mu[b];
-        const int v_it = __atomic_load_n(&st.iter[b], __ATOMIC_RELAXED);
         const double dc = readlane_f64(v_dc, 0), mu = readlane_f64(v_mu, 0);
         const bool ends = (fa.sw.op.d > dc && mu <= fa.sw.op.mu_min) || __builtin_amdgcn_readfirstlane(v_it) == fa.sw.op.iter_max;
         if (duo) xc_post(xw + 8, xep | ((long long)++seqA << 2) | (ends ? 0 : 2));      // the speculative gain sweep on this candidate -- unless accepting it ends the solve
