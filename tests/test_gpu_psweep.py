@@ -318,3 +318,29 @@ def test_time_parallel_rollout_cut_models_and_where_it_does_not_apply():
         p2, x2, u2 = rat.synthetic_lq_problem(seed=3, **kw)
         _, _, cuts = _prl_pair(p2, x2, u2, theta)
         assert cuts == (0, 0, 0)
+
+
+def test_time_parallel_rollout_in_the_noise_covariance_instantiations():
+    """W(k) with a time-invariant cost and kappa = 0: the W(k) instantiations of the latency kernel (their own translation-unit part, built
+    without -amdgpu-mfma-vgpr-form) run the time-parallel rollout too -- against the one-wave recursion and the oracle."""
+    rng = np.random.default_rng(12)
+    n, m, N = 9, 3, 41
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A, B, x0 = 0.85 * Qo, rng.standard_normal((n, m)) / np.sqrt(n), rng.standard_normal(n)
+
+    def spd(k, scale):
+        G = rng.standard_normal((k, k))
+        return scale * (np.eye(k) + 0.2 * G @ G.T / k)
+
+    W = np.stack([spd(n, 1e-3 * (0.5 + rng.random())) for _ in range(N)])
+    prob = rat.LQRiskSensitiveProblem(A, B, Q=spd(n, 1.0), R=spd(m, 0.2), N=N, W=W, Qf=spd(n, 1.0), kappa=0.0)
+    u = 0.1 * rng.standard_normal((N, m))
+    theta = np.array([0.0, 0.5, 2.0, 6.0, 400.0])
+    for duo in (1, 0):
+        (v0, s0, i0, l0), (v1, s1, i1, l1), cuts = _prl_pair(prob, x0, u, theta, duo=duo)
+        assert list(cuts) == rollprl_model.cuts(N)[1:4]
+        assert np.array_equal(s0, s1) and np.array_equal(i0, i1) and np.array_equal(l0, l1)
+        fin = np.isfinite(v0)
+        assert fin.sum() >= 3 and np.array_equal(fin, np.isfinite(v1)) and rel(v1[fin], v0[fin]) < 1e-12
+        vo, so, io, lo = orc.compute_value_batch(orc.Problem(prob), x0, u, theta, nthreads=8)
+        assert np.array_equal(so, s1) and np.array_equal(io, i1) and np.array_equal(lo, l1) and rel(v1[fin], vo[fin]) < 1e-9
